@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REFERENCE implementation.
+
+Run in the build container only (it needs /root/reference, which never travels to the GPU box):
+
+    python tests/golden/make_golden.py
+
+It imports the reference's own modules *unmodified* (models/heads.py, models/loss.py standalone;
+models/tformer.py and models/vformer.py through a synthetic package whose __path__ is the
+reference's models/ directory, with an empty stub registered for the absent ``torchvision``,
+which the classes used here never touch) and records inputs, parameters, outputs and gradients
+as fp32 ``.npz`` files.  The fixtures are data only; no reference source text is stored.
+
+Fixture list: G1 attention, G2 feed-forward, G3 transformer at config C1,
+G4 transformer with inner != dim at N in {12, 17, 49}, G5 AU_former (eval), G6 tformer_AU_head
+(emb 64), G7 TFormer, G8 AULoss with/without ignored rows, G9 tiny pipeline TFormer -> AU_former
+-> AULoss with gradients, G10 tanh-GELU on a grid.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+REF = os.environ.get("AVF_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _load_standalone(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load_reference():
+    # torchvision is imported at the top of tformer/vformer but unused by the classes we need
+    for n in ("torchvision", "torchvision.models"):
+        if n not in sys.modules:
+            sys.modules[n] = types.ModuleType(n)
+    sys.modules["torchvision"].models = sys.modules["torchvision.models"]
+    pkg = types.ModuleType("refmodels")
+    pkg.__path__ = [os.path.join(REF, "models")]
+    sys.modules["refmodels"] = pkg
+    heads = _load_standalone("refmodels.heads", os.path.join(REF, "models", "heads.py"))
+    loss = _load_standalone("refmodels.loss", os.path.join(REF, "models", "loss.py"))
+    tformer = _load_standalone("refmodels.tformer", os.path.join(REF, "models", "tformer.py"))
+    vformer = _load_standalone("refmodels.vformer", os.path.join(REF, "models", "vformer.py"))
+    return heads, loss, tformer, vformer
+
+
+def npify(d):
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **npify(arrays))
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def module_io(mod, x, loss_fn, prefix_params="p.", prefix_grads="g."):
+    """Forward + backward; returns dict with params, grads, y, dx."""
+    x = x.clone().requires_grad_(True)
+    y = mod(x)
+    if isinstance(y, tuple):
+        y_main = y[0]
+    else:
+        y_main = y
+    loss = loss_fn(y_main)
+    loss.backward()
+    out = {"x": x.detach(), "y": y_main.detach(), "dx": x.grad, "loss": loss.detach()}
+    if isinstance(y, tuple):
+        for i, extra in enumerate(y[1:]):
+            out[f"y_extra{i}"] = extra.detach()
+    for k, v in mod.state_dict().items():
+        out[prefix_params + k] = v
+    for k, p in mod.named_parameters():
+        if p.grad is not None:
+            out[prefix_grads + k] = p.grad
+    return out
+
+
+def main():
+    heads, loss_mod, tformer, vformer = load_reference()
+    sq = lambda y: y.pow(2).mean()
+
+    # G1: one Attention (dim 32, 4 heads x 8)
+    torch.manual_seed(1001)
+    att = heads.Attention(dim=32, heads=4, dim_head=8)
+    save("g1_attention", heads=4, dim_head=8, **module_io(att, torch.randn(2, 7, 32), sq))
+
+    # G2: one FeedForward (32 -> 64 -> 32)
+    torch.manual_seed(1002)
+    ff = heads.FeedForward(32, 64)
+    save("g2_feedforward", **module_io(ff, torch.randn(2, 7, 32), sq))
+
+    # G3: Transformer at BASELINE config C1 (B4 N64 D128 L2 H8 dh32 M256)
+    torch.manual_seed(1003)
+    tr = heads.Transformer(128, 2, 8, 32, 256)
+    save("g3_transformer_c1", dim=128, depth=2, heads=8, dim_head=32, mlp_dim=256,
+         **module_io(tr, torch.randn(4, 64, 128), sq))
+
+    # G4: inner != dim, N in {12, 17, 49}
+    for n, (dim, depth, h, dh, mlp) in {12: (64, 2, 8, 32, 128), 17: (32, 2, 8, 64, 64),
+                                        49: (48, 1, 8, 32, 96)}.items():
+        torch.manual_seed(1004 + n)
+        tr = heads.Transformer(dim, depth, h, dh, mlp)
+        save(f"g4_transformer_n{n}", dim=dim, depth=depth, heads=h, dim_head=dh, mlp_dim=mlp,
+             **module_io(tr, torch.randn(3, n, dim), sq))
+
+    # G5: AU_former(input_dim=64, emb_dim=32) in eval mode (running stats perturbed so BN is not
+    # the identity)
+    torch.manual_seed(1005)
+    auf = heads.AU_former(input_dim=64, emb_dim=32)
+    auf.AU_BN1.running_mean.normal_(0, 0.5)
+    auf.AU_BN1.running_var.uniform_(0.5, 2.0)
+    auf.eval()
+    save("g5_au_former", input_dim=64, emb_dim=32, **module_io(auf, torch.randn(5, 64), sq))
+
+    # G6: tformer_AU_head(emb_dim=64) eval  (the stand-in for avformer's missing former_AU_head,
+    # which avformer.py:87 instantiates with emb_dim=256; 64 keeps the fixture small)
+    torch.manual_seed(1006)
+    hd = tformer.tformer_AU_head(emb_dim=64)
+    hd.eval()
+    save("g6_au_head", emb_dim=64, **module_io(hd, torch.randn(3, 12, 64), sq))
+
+    # G7: TFormer(num_patches=16, dim=64, depth=2, heads=8, mlp 128, dim_head 32)
+    torch.manual_seed(1007)
+    tf = vformer.TFormer(num_patches=16, dim=64, depth=2, heads=8, mlp_dim=128, dim_head=32)
+    save("g7_tformer", num_patches=16, dim=64, depth=2, heads=8, dim_head=32, mlp_dim=128,
+         **module_io(tf, torch.randn(3, 16, 64), sq))
+
+    # G8: AULoss with and without ignored (-1) rows.  The ctor calls torch.cuda.current_device()
+    # (loss.py:73); on a CPU-only host we let it return 'cpu'.
+    torch.cuda.current_device = lambda: "cpu"
+    crit = loss_mod.AULoss()
+    torch.manual_seed(1008)
+    z = torch.randn(16, 12) * 3
+    y = (torch.rand(16, 12) > 0.5).float()
+    out = {}
+    for tag, yy in (("all", y.clone()), ("ign", y.clone())):
+        if tag == "ign":
+            yy[3] = -1
+            yy[7] = -1
+            yy[8, 0] = -1          # only the first label decides (loss.py:85-88)
+            yy[9, 5] = -1          # a -1 elsewhere does NOT drop the row (its BCE target is -1)
+        zz = z.clone().requires_grad_(True)
+        l = crit(zz, yy)
+        l.backward()
+        out.update({f"{tag}.z": z, f"{tag}.y": yy, f"{tag}.loss": l.detach(), f"{tag}.dz": zz.grad})
+    save("g8_au_loss", **out)
+
+    # G9: tiny pipeline  [B,T,D] -> TFormer -> AU_former(eval) -> AULoss, all gradients
+    torch.manual_seed(1009)
+    tf = vformer.TFormer(num_patches=8, dim=32, depth=1, heads=8, mlp_dim=64, dim_head=32)
+    auf = heads.AU_former(input_dim=32, emb_dim=32)
+    auf.AU_BN1.running_mean.normal_(0, 0.3)
+    auf.AU_BN1.running_var.uniform_(0.7, 1.5)
+    auf.eval()
+    x = torch.randn(6, 8, 32, requires_grad=True)
+    labels = (torch.rand(6, 12) > 0.5).float()
+    labels[2] = -1
+    feat = tf(x)
+    logits, tokens = auf(feat)
+    l = crit(logits, labels)
+    l.backward()
+    out = {"x": x.detach(), "labels": labels, "feat": feat.detach(), "logits": logits.detach(),
+           "tokens": tokens.detach(), "loss": l.detach(), "dx": x.grad}
+    for k, v in tf.state_dict().items():
+        out["p.tf." + k] = v
+    for k, v in auf.state_dict().items():
+        out["p.au." + k] = v
+    for k, p in tf.named_parameters():
+        out["g.tf." + k] = p.grad
+    for k, p in auf.named_parameters():
+        if p.grad is not None:
+            out["g.au." + k] = p.grad
+    save("g9_pipeline", **out)
+
+    # G10: tanh-GELU on a grid incl. large magnitudes, with its derivative
+    g = heads.GELU()
+    u = torch.cat([torch.linspace(-12, 12, 481), torch.tensor([-60.0, -30.0, 30.0, 60.0, 0.0, 1e-4, -1e-4])])
+    u = u.clone().requires_grad_(True)
+    yv = g(u)
+    yv.sum().backward()
+    save("g10_gelu", u=u.detach(), y=yv.detach(), dy_du=u.grad)
+
+
+if __name__ == "__main__":
+    main()
