@@ -1,0 +1,146 @@
+/* avformer_hip.h - C ABI of libavformer_hip.so (gfx950 / MI355X).
+ *
+ * The drop-in boundary for the transformer hot path of
+ * ColinWine/Multi-modal-Multi-label-Facial-Action-Unit-Detection-with-Transformer.
+ * The reference has no native layer of its own (pure PyTorch eager), so there is no FFI to mirror;
+ * each entry point below cites the reference Python it replaces (paths relative to the reference
+ * repository root).  Conventions:
+ *
+ *   - every function returns 0 on success, non-zero on error; avf_last_error() returns a
+ *     thread-local message for the last failure.  Nothing throws across the boundary.
+ *   - all data pointers are CALLER-OWNED DEVICE pointers (PyTorch allocates inputs, outputs,
+ *     saved activations and workspaces); the library allocates nothing persistent.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).
+ *     All work is enqueued on it; no entry point synchronises the device (graph-capture safe).
+ *   - activations are row-major [rows = batch*tokens, features]; the residual stream is fp32;
+ *     `dtype` selects the compute/storage type of the non-residual activations:
+ *     AVF_F32 (parity mode: fp32 MFMA / fp32 VALU) or AVF_BF16 (throughput mode: bf16 MFMA,
+ *     fp32 accumulate, fp32 LayerNorm/softmax statistics).
+ */
+#ifndef AVFORMER_HIP_H
+#define AVFORMER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AVF_F32 0
+#define AVF_BF16 1
+
+/* GEMM epilogues (avf_gemm) */
+#define AVF_EPI_NONE 0      /* C = acc (+bias if given)                                           */
+#define AVF_EPI_BIAS_RES 1  /* C(f32) = acc + bias + residual(f32)        heads.py:175,238,196    */
+#define AVF_EPI_BIAS_GELU 2 /* aux = acc + bias ; C = tanh-GELU(aux)      heads.py:166,191-192    */
+#define AVF_EPI_DGELU 3     /* C = acc * dGELU/du(aux)                    backward of heads.py:166 */
+
+typedef struct avf_layer_cfg {
+  int32_t batch;       /* clips B                                                              */
+  int32_t tokens;      /* tokens per clip N                                                    */
+  int32_t dim;         /* D      - Transformer(dim, ...)                  heads.py:243          */
+  int32_t heads;       /* H                                               heads.py:204          */
+  int32_t dim_head;    /* dh ; inner I = H*dh                             heads.py:206          */
+  int32_t mlp_dim;     /* M                                               heads.py:189          */
+  int32_t dtype;       /* AVF_F32 | AVF_BF16                                                    */
+  int32_t project_out; /* 0 iff heads==1 && dim_head==dim (nn.Identity)   heads.py:207          */
+  float ln_eps;        /* nn.LayerNorm default 1e-5                       heads.py:181          */
+  float dropout_p;     /* must be 0 in this version (eval()/p=0 semantics) heads.py:194-196,216 */
+} avf_layer_cfg;
+
+/* fp32 master parameters of one layer, in state_dict order:
+ * layers.{i}.0.fn.norm.{weight,bias}, .0.fn.fn.to_qkv.weight [3I,D], .0.fn.fn.to_out.0.{weight [D,I],bias},
+ * layers.{i}.1.fn.norm.{weight,bias}, .1.fn.fn.net.0.{weight [M,D],bias}, .1.fn.fn.net.3.{weight [D,M],bias} */
+typedef struct avf_layer_params {
+  const float *ln1_w, *ln1_b, *w_qkv, *w_out, *b_out, *ln2_w, *ln2_b, *w1, *b1, *w2, *b2;
+} avf_layer_params;
+
+/* gradients, same shapes; every non-null pointer is OVERWRITTEN (not accumulated) */
+typedef struct avf_layer_grads {
+  float *ln1_w, *ln1_b, *w_qkv, *w_out, *b_out, *ln2_w, *ln2_b, *w1, *b1, *w2, *b2;
+} avf_layer_grads;
+
+int avf_version(void);
+const char* avf_last_error(void);
+/* 1 if a gfx950 device is usable by this process */
+int avf_device_ok(void);
+
+/* ---- per-operator entry points --------------------------------------------------------- */
+
+/* nn.LayerNorm(dim) forward - heads.py:178-185.  x fp32 [rows,dim] -> y (y_dtype) ; mean/rstd fp32 [rows]. */
+int avf_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype,
+                      float* mean, float* rstd, int64_t rows, int dim, float eps, void* stream);
+
+/* LayerNorm backward.  dx = dres (nullable) + LN'(dy); optional low-precision copy dx_lo (bf16, nullable);
+ * dgamma/dbeta [dim]; dcolsum (nullable) = column sums of dx (bias gradient of the Linear that produced x).
+ * workspace >= avf_layernorm_bwd_workspace_bytes(rows, dim). */
+size_t avf_layernorm_bwd_workspace_bytes(int64_t rows, int dim);
+int avf_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean,
+                      const float* rstd, const float* dres, float* dx, void* dx_lo, float* dgamma,
+                      float* dbeta, float* dcolsum, void* workspace, int64_t rows, int dim, void* stream);
+
+/* column sums (bias gradients): out[c] = sum_r in[r,c].  workspace >= avf_colsum_workspace_bytes. */
+size_t avf_colsum_workspace_bytes(int64_t rows, int cols);
+int avf_colsum(const void* in, int in_dtype, int64_t rows, int cols, int64_t ld, float* out, void* workspace,
+               void* stream);
+
+/* fp32 -> bf16 cast (n elements) */
+int avf_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
+/* fp32 weight [rows,cols] -> bf16 copy [rows,cols] and bf16 transpose [cols,rows] (either may be null) */
+int avf_prep_weight_bf16(const float* w, void* w_lo, void* w_t_lo, int rows, int cols, void* stream);
+
+/* GEMM  C[M,N] = op(A)[M,K] * op(B)[K,N]  with fused epilogue.
+ *   transA = 0: A stored [M,K] (lda)      transA = 1: A stored [K,M] (lda)
+ *   transB = 0: B stored [K,N] (ldb)      transB = 1: B stored [N,K] (ldb)   (nn.Linear weight layout)
+ * dtype AVF_F32: every form, any sizes.  dtype AVF_BF16: (transA=0,transB=1) "NT" with K%8==0, and
+ * (transA=1,transB=0) "TN" (weight gradients, fp32 output, M%8==0, N%8==0).
+ * c_dtype: storage type of C (and aux).  workspace only for bf16 TN split-K (avf_gemm_workspace_bytes). */
+size_t avf_gemm_workspace_bytes(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K);
+int avf_gemm(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+             const void* B, int64_t ldb, void* C, int64_t ldc, int c_dtype, int epilogue, const float* bias,
+             const float* residual, int64_t ldres, void* aux, int64_t ldaux, void* workspace, void* stream);
+
+/* Multi-head self-attention core - heads.py:222-237.  qkv [B*N, 3I] (q|k|v, head-major columns),
+ * o [B*N, I], lse2 fp32 [B,H,N] = log2-domain log-sum-exp of the scaled scores (saved for backward). */
+int avf_attn_fwd(int dtype, const void* qkv, void* o, float* lse2, int batch, int tokens, int heads,
+                 int dim_head, void* stream);
+/* backward: dqkv [B*N,3I] from do [B*N,I].  workspace >= avf_attn_bwd_workspace_bytes (holds delta [B,H,N]). */
+size_t avf_attn_bwd_workspace_bytes(int batch, int tokens, int heads, int dim_head);
+int avf_attn_bwd(int dtype, const void* qkv, const void* o, const void* d_o, const float* lse2, void* dqkv,
+                 void* workspace, int batch, int tokens, int heads, int dim_head, void* stream);
+
+/* AULoss - loss.py:63-103.  logits/labels fp32 [rows, 12] (ld given); rows whose FIRST label == ignore
+ * are dropped; loss[0] = mean over kept rows x 12 of BCE-with-logits(pos_weight); grad_unit [rows,12]
+ * (contiguous) = d loss / d logits.  All rows dropped => NaN (as the reference). */
+int avf_au_loss(const float* logits, int64_t ld_logits, const float* labels, int64_t ld_labels, const float* pos_weight,
+                float ignore, int rows, int ncls, float* loss, float* grad_unit, void* stream);
+
+/* ---- one transformer layer (heads.py:246-255), forward and backward ------------------------ */
+size_t avf_layer_saved_bytes(const avf_layer_cfg* cfg);     /* activations kept for backward        */
+size_t avf_layer_lowp_bytes(const avf_layer_cfg* cfg);      /* bf16 weight copies (+transposes)     */
+size_t avf_layer_workspace_bytes(const avf_layer_cfg* cfg); /* scratch, reusable across layers      */
+
+/* refresh the bf16 weight copies from the fp32 masters (no-op in AVF_F32 mode) */
+int avf_layer_prepare_weights(const avf_layer_cfg* cfg, const avf_layer_params* p, void* lowp, void* stream);
+
+/* x_out = layer(x_in); x_in, x_out fp32 [B*N, D] (may not alias). */
+int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p, const void* lowp, const float* x_in,
+                  float* x_out, void* saved, void* workspace, void* stream);
+
+/* dx_in (fp32) and all parameter gradients from dx_out (fp32).  dx_out_lo: optional bf16 copy of dx_out
+ * (null => made internally); dx_in_lo: optional bf16 copy of dx_in to hand to the previous layer.
+ * dx_in may alias dx_out. */
+int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p, const void* lowp, const float* x_in,
+                  const void* saved, const float* dx_out, const void* dx_out_lo, float* dx_in, void* dx_in_lo,
+                  const avf_layer_grads* g, void* workspace, void* stream);
+
+/* ---- hardware self-tests used by tests/ (MFMA fragment maps, transposed LDS read) ----------- */
+int avf_selftest_mfma_bf16(const void* a_bf16_16x32, const void* b_bf16_32x16, float* c_16x16, void* stream);
+int avf_selftest_mfma_f32(const float* a_16x4, const float* b_4x16, float* c_16x16, void* stream);
+int avf_selftest_tr16(const void* tile_bf16_32x16, void* out_bf16_64x8, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVFORMER_HIP_H */

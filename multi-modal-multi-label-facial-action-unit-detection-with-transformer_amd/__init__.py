@@ -1,0 +1,17 @@
+"""MI355X-native implementation of the aural-visual transformer hot path of
+ColinWine/Multi-modal-Multi-label-Facial-Action-Unit-Detection-with-Transformer.
+
+The compute lives in ``lib/libavformer_hip.so`` (hand-written HIP for gfx950, C ABI in
+``include/avformer_hip.h``); this package is the host-side mirror of the reference's
+``Transformer`` / head / loss / model-registry surface.
+"""
+from . import _build, _lib, ops  # noqa: F401
+from .heads import AU_former, TFormer, former_AU_head, tformer_AU_head  # noqa: F401
+from .loss import AULoss  # noqa: F401
+from .models import (MODEL_REGISTRY, AudioFormer, SyntheticAVFormer, TwoStreamAuralVisualFormer,  # noqa: F401
+                     VisualFormer, build_model)
+from .transformer import Transformer  # noqa: F401
+
+__all__ = ["Transformer", "AU_former", "tformer_AU_head", "former_AU_head", "TFormer", "AULoss",
+           "TwoStreamAuralVisualFormer", "SyntheticAVFormer", "AudioFormer", "VisualFormer", "MODEL_REGISTRY",
+           "build_model", "ops"]

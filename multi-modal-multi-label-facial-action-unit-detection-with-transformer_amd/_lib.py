@@ -1,0 +1,112 @@
+"""ctypes binding of libavformer_hip.so (the C ABI declared in include/avformer_hip.h).
+
+The product path has NO fallback: if the shared library is missing or cannot be loaded, every
+entry point raises.  (The CPU oracle under /oracle is test infrastructure and is never imported
+from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+from . import _build
+
+F32, BF16 = 0, 1
+EPI_NONE, EPI_BIAS_RES, EPI_BIAS_GELU, EPI_DGELU = 0, 1, 2, 3
+
+_vp = C.c_void_p
+_i64 = C.c_int64
+_int = C.c_int
+_f = C.c_float
+_sz = C.c_size_t
+
+
+class LayerCfg(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("tokens", C.c_int32), ("dim", C.c_int32), ("heads", C.c_int32),
+                ("dim_head", C.c_int32), ("mlp_dim", C.c_int32), ("dtype", C.c_int32), ("project_out", C.c_int32),
+                ("ln_eps", C.c_float), ("dropout_p", C.c_float)]
+
+
+PARAM_FIELDS = ("ln1_w", "ln1_b", "w_qkv", "w_out", "b_out", "ln2_w", "ln2_b", "w1", "b1", "w2", "b2")
+
+
+class LayerPtrs(C.Structure):
+    """avf_layer_params / avf_layer_grads: 11 device pointers in state_dict order."""
+    _fields_ = [(n, _vp) for n in PARAM_FIELDS]
+
+
+# name -> (restype, argtypes); every symbol declared in include/avformer_hip.h
+SIGNATURES = {
+    "avf_version": (_int, []),
+    "avf_last_error": (C.c_char_p, []),
+    "avf_device_ok": (_int, []),
+    "avf_layernorm_fwd": (_int, [_vp, _vp, _vp, _vp, _int, _vp, _vp, _i64, _int, _f, _vp]),
+    "avf_layernorm_bwd_workspace_bytes": (_sz, [_i64, _int]),
+    "avf_layernorm_bwd": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp]),
+    "avf_colsum_workspace_bytes": (_sz, [_i64, _int]),
+    "avf_colsum": (_int, [_vp, _int, _i64, _int, _i64, _vp, _vp, _vp]),
+    "avf_cast_f32_to_bf16": (_int, [_vp, _vp, _i64, _vp]),
+    "avf_prep_weight_bf16": (_int, [_vp, _vp, _vp, _int, _int, _vp]),
+    "avf_gemm_workspace_bytes": (_sz, [_int, _int, _int, _i64, _i64, _i64]),
+    "avf_gemm": (_int, [_int, _int, _int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _int, _int, _vp, _vp,
+                        _i64, _vp, _i64, _vp, _vp]),
+    "avf_attn_fwd": (_int, [_int, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
+    "avf_attn_bwd_workspace_bytes": (_sz, [_int, _int, _int, _int]),
+    "avf_attn_bwd": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
+    "avf_au_loss": (_int, [_vp, _i64, _vp, _i64, _vp, _f, _int, _int, _vp, _vp, _vp]),
+    "avf_layer_saved_bytes": (_sz, [C.POINTER(LayerCfg)]),
+    "avf_layer_lowp_bytes": (_sz, [C.POINTER(LayerCfg)]),
+    "avf_layer_workspace_bytes": (_sz, [C.POINTER(LayerCfg)]),
+    "avf_layer_prepare_weights": (_int, [C.POINTER(LayerCfg), C.POINTER(LayerPtrs), _vp, _vp]),
+    "avf_layer_fwd": (_int, [C.POINTER(LayerCfg), C.POINTER(LayerPtrs), _vp, _vp, _vp, _vp, _vp, _vp]),
+    "avf_layer_bwd": (_int, [C.POINTER(LayerCfg), C.POINTER(LayerPtrs), _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                             C.POINTER(LayerPtrs), _vp, _vp]),
+    "avf_selftest_mfma_bf16": (_int, [_vp, _vp, _vp, _vp]),
+    "avf_selftest_mfma_f32": (_int, [_vp, _vp, _vp, _vp]),
+    "avf_selftest_tr16": (_int, [_vp, _vp, _vp]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load(build_if_missing: bool = False):
+    """Load (once) and return the ctypes handle.  Raises HipLibraryError if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = _build.lib_path()
+        if not os.path.exists(path):
+            if build_if_missing:
+                _build.build()
+            else:
+                raise HipLibraryError(
+                    f"{path} not found - build it first (python __graft_entry__.py or "
+                    f"python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+        try:
+            lib = C.CDLL(path)
+        except OSError as e:  # pragma: no cover - environment dependent
+            raise HipLibraryError(f"cannot load {path}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as e:
+                raise HipLibraryError(f"{path} does not export {name}") from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().avf_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libavformer_hip: {what} failed (rc={rc}): {msg}")

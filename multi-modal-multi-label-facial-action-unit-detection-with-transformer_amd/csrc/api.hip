@@ -1,0 +1,177 @@
+// api.hip - extern "C" surface of libavformer_hip.so (see include/avformer_hip.h), error plumbing,
+// and the hardware self-tests that pin the MFMA fragment maps / transposed LDS read semantics the
+// bf16 kernels rely on.
+#include <stdarg.h>
+
+#include "common.hpp"
+
+namespace avf {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return 2;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// self-tests
+// ---------------------------------------------------------------------------------------------
+// C[16x16] = A[16x32] * B[32x16] with one v_mfma_f32_16x16x32_bf16, operands fetched with the
+// lane maps the kernels use: A[i=l&15][k=8(l>>4)+j], B[k=8(l>>4)+j][n=l&15]; C col=l&15,row=4(l>>4)+r.
+__global__ void selftest_mfma_bf16_kernel(const bf16* a, const bf16* b, float* c) {
+  const int l = threadIdx.x, li = l & 15, lg = l >> 4;
+  bf16x8_t fa, fb;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    fa[j] = __builtin_bit_cast(__bf16, a[li * 32 + 8 * lg + j].x);
+    fb[j] = __builtin_bit_cast(__bf16, b[(8 * lg + j) * 16 + li].x);
+  }
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c[(4 * lg + r) * 16 + li] = acc[r];
+}
+
+__global__ void selftest_mfma_f32_kernel(const float* a, const float* b, float* c) {
+  const int l = threadIdx.x, li = l & 15, lg = l >> 4;
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[li * 4 + lg], b[lg * 16 + li], acc, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c[(4 * lg + r) * 16 + li] = acc[r];
+}
+
+// ds_read_b64_tr_b16 on a [32 rows][16 cols] bf16 tile (32-byte rows): lane l (i=l&15, g=l>>4) issues two
+// reads with row blocks 4g.. (h=0) and 16+4g.. (h=1), address = &T[blk + (i>>2)][4*(i&3)], and stores
+// its 8 received values: out[l][h*4 + e].  Expected (kernels' assumption): out[l][h*4+e] = T[16h+4g+e][i].
+__global__ void selftest_tr16_kernel(const bf16* tile, bf16* out) {
+  __shared__ __attribute__((aligned(16))) bf16 T[32 * 16];
+  const int l = threadIdx.x, li = l & 15, lg = l >> 4;
+  for (int i = l; i < 32 * 16; i += 64) T[i] = tile[i];
+  __syncthreads();
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const bf16* src = &T[(16 * h + 4 * lg + (li >> 2)) * 16 + 4 * (li & 3)];
+    s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)src);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out[l * 8 + h * 4 + e].x = (uint16_t)v[e];
+  }
+}
+
+}  // namespace avf
+
+using namespace avf;
+
+extern "C" int avf_version(void) { return 1; }
+extern "C" const char* avf_last_error(void) { return g_err; }
+
+extern "C" int avf_device_ok(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    set_error("no HIP device visible");
+    return 0;
+  }
+  hipDeviceProp_t prop;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+    set_error("cannot query HIP device");
+    return 0;
+  }
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    set_error("device arch %s is not gfx950", prop.gcnArchName);
+    return 0;
+  }
+  return 1;
+}
+
+extern "C" int avf_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype,
+                                 float* mean, float* rstd, int64_t rows, int dim, float eps, void* stream) {
+  AVF_REQUIRE(x && gamma && beta && y && mean && rstd, "layernorm_fwd: null pointer");
+  return layernorm_fwd(x, gamma, beta, y, y_dtype, mean, rstd, rows, dim, eps, (hipStream_t)stream);
+}
+extern "C" size_t avf_layernorm_bwd_workspace_bytes(int64_t rows, int dim) { return layernorm_bwd_ws(rows, dim); }
+extern "C" int avf_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean,
+                                 const float* rstd, const float* dres, float* dx, void* dx_lo, float* dgamma,
+                                 float* dbeta, float* dcolsum, void* workspace, int64_t rows, int dim, void* stream) {
+  AVF_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && workspace, "layernorm_bwd: null pointer");
+  return layernorm_bwd(dy, dy_dtype, x, gamma, mean, rstd, dres, dx, dx_lo, dgamma, dbeta, dcolsum, workspace, rows,
+                       dim, (hipStream_t)stream);
+}
+extern "C" size_t avf_colsum_workspace_bytes(int64_t rows, int cols) { return colsum_ws(rows, cols); }
+extern "C" int avf_colsum(const void* in, int in_dtype, int64_t rows, int cols, int64_t ld, float* out,
+                          void* workspace, void* stream) {
+  return colsum(in, in_dtype, rows, cols, ld, out, workspace, (hipStream_t)stream);
+}
+extern "C" int avf_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream) {
+  AVF_REQUIRE(in && out, "cast: null pointer");
+  return cast_f32_to_bf16(in, out, n, (hipStream_t)stream);
+}
+extern "C" int avf_prep_weight_bf16(const float* w, void* w_lo, void* w_t_lo, int rows, int cols, void* stream) {
+  AVF_REQUIRE(w, "prep_weight: null pointer");
+  return prep_weight_bf16(w, w_lo, w_t_lo, rows, cols, (hipStream_t)stream);
+}
+
+extern "C" size_t avf_gemm_workspace_bytes(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K) {
+  return gemm_ws(dtype, transA, transB, M, N, K);
+}
+extern "C" int avf_gemm(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+                        const void* B, int64_t ldb, void* C, int64_t ldc, int c_dtype, int epilogue, const float* bias,
+                        const float* residual, int64_t ldres, void* aux, int64_t ldaux, void* workspace, void* stream) {
+  AVF_REQUIRE(A && B && C, "gemm: null pointer");
+  GemmArgs a;
+  a.dtype = dtype; a.transA = transA; a.transB = transB;
+  a.M = M; a.N = N; a.K = K;
+  a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
+  a.c_dtype = c_dtype; a.epilogue = epilogue; a.bias = bias; a.residual = residual; a.ldres = ldres;
+  a.aux = aux; a.ldaux = ldaux; a.workspace = workspace;
+  return gemm(a, (hipStream_t)stream);
+}
+
+extern "C" int avf_attn_fwd(int dtype, const void* qkv, void* o, float* lse2, int batch, int tokens, int heads,
+                            int dim_head, void* stream) {
+  AVF_REQUIRE(qkv && o && lse2, "attn_fwd: null pointer");
+  if (dtype == AVF_F32)
+    return attn_fwd_f32((const float*)qkv, (float*)o, lse2, batch, tokens, heads, dim_head, (hipStream_t)stream);
+  if (dtype == AVF_BF16)
+    return attn_fwd_bf16((const bf16*)qkv, (bf16*)o, lse2, batch, tokens, heads, dim_head, (hipStream_t)stream);
+  AVF_REQUIRE(false, "attn_fwd: bad dtype %d", dtype);
+}
+extern "C" size_t avf_attn_bwd_workspace_bytes(int batch, int tokens, int heads, int dim_head) {
+  (void)dim_head;
+  return (size_t)batch * tokens * heads * sizeof(float);
+}
+extern "C" int avf_attn_bwd(int dtype, const void* qkv, const void* o, const void* d_o, const float* lse2, void* dqkv,
+                            void* workspace, int batch, int tokens, int heads, int dim_head, void* stream) {
+  AVF_REQUIRE(qkv && o && d_o && lse2 && dqkv && workspace, "attn_bwd: null pointer");
+  if (dtype == AVF_F32)
+    return attn_bwd_f32((const float*)qkv, (const float*)o, (const float*)d_o, lse2, (float*)dqkv, (float*)workspace,
+                        batch, tokens, heads, dim_head, (hipStream_t)stream);
+  if (dtype == AVF_BF16)
+    return attn_bwd_bf16((const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse2, (bf16*)dqkv, (float*)workspace,
+                         batch, tokens, heads, dim_head, (hipStream_t)stream);
+  AVF_REQUIRE(false, "attn_bwd: bad dtype %d", dtype);
+}
+
+extern "C" int avf_selftest_mfma_bf16(const void* a, const void* b, float* c, void* stream) {
+  selftest_mfma_bf16_kernel<<<1, 64, 0, (hipStream_t)stream>>>((const bf16*)a, (const bf16*)b, c);
+  return check_launch("selftest_mfma_bf16");
+}
+extern "C" int avf_selftest_mfma_f32(const float* a, const float* b, float* c, void* stream) {
+  selftest_mfma_f32_kernel<<<1, 64, 0, (hipStream_t)stream>>>(a, b, c);
+  return check_launch("selftest_mfma_f32");
+}
+extern "C" int avf_selftest_tr16(const void* tile, void* out, void* stream) {
+  selftest_tr16_kernel<<<1, 64, 0, (hipStream_t)stream>>>((const bf16*)tile, (bf16*)out);
+  return check_launch("selftest_tr16");
+}

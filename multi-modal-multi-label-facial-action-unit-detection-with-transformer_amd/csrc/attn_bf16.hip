@@ -1,0 +1,530 @@
+// attn_bf16.hip - throughput-mode attention core: LDS-tiled flash attention forward and backward on
+// v_mfma_f32_16x16x32_bf16, fp32 online-softmax statistics, bf16 operands.
+//
+// Reference: models/heads.py:222-237 (scores * dh^-0.5, softmax over keys, P v, head merge).  The
+// [B,H,N,N] score tensor the reference materialises never exists here.  q, k, v are read in place from
+// the QKV GEMM output [B*N, 3I] (absorbing 'b n (h d) -> b h n d'), o is written as [B*N, I]
+// ('b h n d -> b n (h d)').
+//
+// Orientation trick (the accumulator of one MFMA is the operand of the next, no LDS round trip):
+//   forward / dQ : S^T = K Q^T    -> lane owns a query column; P^T (or dS^T) packs straight into the
+//                  B operand of  O^T = V^T P^T  /  dQ^T = K^T dS^T ; V^T / K^T fragments come from
+//                  ds_read_b64_tr_b16 on the row-major tile.
+//   dK / dV      : S = Q K^T      -> lane owns a key column;  dV^T = dO^T P,  dK^T = Q^T dS.
+// k-slot map of a packed accumulator pair / transposed fragment (32 reduction rows per k-step):
+//   slot j of lane group g  <->  row 16*(j>>2) + 4*g + (j&3).
+#include "common.hpp"
+
+namespace avf {
+
+namespace {
+
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+template <int LD>
+__device__ __forceinline__ bf16x8_t tr_frag(const lds_char* tile, int row_base, int col_base, int li, int lg) {
+  const lds_char* p0 = tile + (row_base + 4 * lg + (li >> 2)) * LD + (col_base + 4 * (li & 3)) * 2;
+  s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
+  s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0 + 16 * LD));
+  s16x8_t r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+
+template <int LD>
+__device__ __forceinline__ bf16x8_t row_frag(const char* tile, int row, int col) {
+  return *reinterpret_cast<const bf16x8_t*>(tile + row * LD + col * 2);
+}
+
+__device__ __forceinline__ bf16x8_t pack_pair(const f32x4_t& a, const f32x4_t& b) {
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+  u32x4_t r = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+
+__device__ __forceinline__ bf16x8_t load_frag_global(const bf16* p, bool ok) {
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (ok) v = *reinterpret_cast<const uint4*>(p);
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// stage ROWS rows x DH bf16 from global (row stride ld elements) into an LDS tile with row stride LD bytes;
+// rows >= nvalid are zero-filled.  Split in issue (global -> regs) / commit (regs -> LDS).
+template <int DH, int ROWS>
+struct TileStager {
+  static constexpr int CPR = DH / 8;                    // 16-byte chunks per row
+  static constexpr int PER = (ROWS * CPR + 255) / 256;  // chunks per thread
+  uint4 r[PER];
+  __device__ __forceinline__ void issue(const bf16* src, int64_t ld, int row0, int nvalid, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx / CPR, c = idx - row * CPR;
+      r[i] = make_uint4(0, 0, 0, 0);
+      if (idx < ROWS * CPR && row < nvalid) r[i] = *reinterpret_cast<const uint4*>(src + (int64_t)(row0 + row) * ld + c * 8);
+    }
+  }
+  template <int LD>
+  __device__ __forceinline__ void commit(char* tile, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx / CPR, c = idx - row * CPR;
+      if (idx < ROWS * CPR) *reinterpret_cast<uint4*>(tile + row * LD + c * 16) = r[i];
+    }
+  }
+};
+
+// =============================================================================================
+// forward
+// =============================================================================================
+template <int DH>
+__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
+                                                            float* __restrict__ lse2, int B, int N, int H) {
+  constexpr int KS = DH / 32, DB = DH / 16;
+  constexpr int KLD = DH * 2 + 16;  // K tile: row reads (ds_read_b128)
+  constexpr int VLD = DH * 2 + 32;  // V tile: transposed reads, 8 consecutive rows -> 8 distinct bank windows
+  constexpr int STAGE = 64 * KLD + 64 * VLD;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  const int I = H * DH;
+  const int64_t ld = 3 * (int64_t)I;
+  const bf16* qbase = qkv + (int64_t)b * N * ld + h * DH;
+  const bf16* kbase = qbase + I;
+  const bf16* vbase = qbase + 2 * I;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const float c = LOG2E / sqrtf((float)DH);
+
+  bf16x8_t fq[2][KS];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int q = q0 + qb * 16 + li;
+      fq[qb][ks] = load_frag_global(qbase + (int64_t)q * ld + ks * 32 + 8 * lg, q < N);
+    }
+
+  f32x4_t ot[DB][2];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) ot[d][qb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.f, 0.f};
+
+  TileStager<DH, 64> sk, sv;
+  const int nt = (N + 63) / 64;
+  {
+    const int nv = N < 64 ? N : 64;
+    sk.issue(kbase, ld, 0, nv, tid);
+    sv.issue(vbase, ld, 0, nv, tid);
+    sk.template commit<KLD>(smem, tid);
+    sv.template commit<VLD>(smem + 64 * KLD, tid);
+  }
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nt) {
+      const int r0 = (t + 1) * 64;
+      const int nv = (N - r0) < 64 ? (N - r0) : 64;
+      sk.issue(kbase, ld, r0, nv, tid);
+      sv.issue(vbase, ld, r0, nv, tid);
+    }
+    const char* kt = smem + cur * STAGE;
+    const lds_char* vt = (const lds_char*)(smem + cur * STAGE + 64 * KLD);
+
+    // S^T[key][q] = K Q^T
+    f32x4_t st[4][2];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      st[kb][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      st[kb][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8_t fk = row_frag<KLD>(kt, kb * 16 + li, ks * 32 + 8 * lg);
+        st[kb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq[0][ks], st[kb][0], 0, 0, 0);
+        st[kb][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq[1][ks], st[kb][1], 0, 0, 0);
+      }
+    }
+    const bool partial = (t * 64 + 64 > N);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float s = st[kb][qb][r] * c;
+          if (partial && (t * 64 + kb * 16 + 4 * lg + r >= N)) s = -INFINITY;
+          st[kb][qb][r] = s;
+          tmax = fmaxf(tmax, s);
+        }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float mn = fmaxf(m[qb], tmax);
+      const float alpha = __builtin_amdgcn_exp2f(m[qb] - mn);
+      m[qb] = mn;
+      float ps = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(st[kb][qb][r] - mn);
+          st[kb][qb][r] = pv;
+          ps += pv;
+        }
+      lsum[qb] = lsum[qb] * alpha + ps;
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+        ot[d][qb][0] *= alpha; ot[d][qb][1] *= alpha; ot[d][qb][2] *= alpha; ot[d][qb][3] *= alpha;
+      }
+    }
+    // O^T[d][q] += V^T P^T
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bf16x8_t p0 = pack_pair(st[2 * s][0], st[2 * s + 1][0]);
+      const bf16x8_t p1 = pack_pair(st[2 * s][1], st[2 * s + 1][1]);
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+        const bf16x8_t fv = tr_frag<VLD>(vt, 32 * s, d * 16, li, lg);
+        ot[d][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, p0, ot[d][0], 0, 0, 0);
+        ot[d][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, p1, ot[d][1], 0, 0, 0);
+      }
+    }
+    if (t + 1 < nt) {
+      sk.template commit<KLD>(smem + (cur ^ 1) * STAGE, tid);
+      sv.template commit<VLD>(smem + (cur ^ 1) * STAGE + 64 * KLD, tid);
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    float l = lsum[qb];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const int q = q0 + qb * 16 + li;
+    if (q < N) {
+      const float inv = 1.0f / l;
+      bf16* orow = o + ((int64_t)b * N + q) * I + h * DH;
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+        store4<bf16>(orow + d * 16 + 4 * lg,
+                     make_float4(ot[d][qb][0] * inv, ot[d][qb][1] * inv, ot[d][qb][2] * inv, ot[d][qb][3] * inv));
+      if (lg == 0) lse2[(int64_t)bh * N + q] = m[qb] + log2f(l);
+    }
+  }
+}
+
+// =============================================================================================
+// backward: dQ  (query on the lane; sweeps key tiles)
+// =============================================================================================
+template <int DH>
+__global__ __launch_bounds__(256) void attn_dq_bf16_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
+                                                           const float* __restrict__ lse2,
+                                                           const float* __restrict__ delta, bf16* __restrict__ dqkv,
+                                                           int B, int N, int H) {
+  constexpr int KS = DH / 32, DB = DH / 16;
+  constexpr int KLD = DH * 2 + 32;  // K tile: row reads AND transposed reads
+  constexpr int VLD = DH * 2 + 16;  // V tile: row reads only
+  constexpr int STAGE = 64 * KLD + 64 * VLD;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  const int I = H * DH;
+  const int64_t ld = 3 * (int64_t)I;
+  const bf16* qbase = qkv + (int64_t)b * N * ld + h * DH;
+  const bf16* kbase = qbase + I;
+  const bf16* vbase = qbase + 2 * I;
+  const bf16* gbase = d_o + (int64_t)b * N * I + h * DH;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const float scale = 1.0f / sqrtf((float)DH);
+  const float c = LOG2E * scale;
+
+  bf16x8_t fq[2][KS], fg[2][KS];
+  float L[2], dl[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int q = q0 + qb * 16 + li;
+    const bool ok = q < N;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      fq[qb][ks] = load_frag_global(qbase + (int64_t)q * ld + ks * 32 + 8 * lg, ok);
+      fg[qb][ks] = load_frag_global(gbase + (int64_t)q * I + ks * 32 + 8 * lg, ok);
+    }
+    L[qb] = ok ? lse2[(int64_t)bh * N + q] : 0.f;
+    dl[qb] = ok ? delta[(int64_t)bh * N + q] : 0.f;
+  }
+  f32x4_t dqt[DB][2];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) dqt[d][qb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  TileStager<DH, 64> sk, sv;
+  const int nt = (N + 63) / 64;
+  {
+    const int nv = N < 64 ? N : 64;
+    sk.issue(kbase, ld, 0, nv, tid);
+    sv.issue(vbase, ld, 0, nv, tid);
+    sk.template commit<KLD>(smem, tid);
+    sv.template commit<VLD>(smem + 64 * KLD, tid);
+  }
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nt) {
+      const int r0 = (t + 1) * 64;
+      const int nv = (N - r0) < 64 ? (N - r0) : 64;
+      sk.issue(kbase, ld, r0, nv, tid);
+      sv.issue(vbase, ld, r0, nv, tid);
+    }
+    const char* kt = smem + cur * STAGE;
+    const char* vt = smem + cur * STAGE + 64 * KLD;
+    const bool partial = (t * 64 + 64 > N);
+
+    f32x4_t ds[4][2];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8_t fk = row_frag<KLD>(kt, kb * 16 + li, ks * 32 + 8 * lg);
+        const bf16x8_t fv = row_frag<VLD>(vt, kb * 16 + li, ks * 32 + 8 * lg);
+        s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq[0][ks], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq[1][ks], s1, 0, 0, 0);
+        p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, fg[0][ks], p0, 0, 0, 0);
+        p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, fg[1][ks], p1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool dead = partial && (t * 64 + kb * 16 + 4 * lg + r >= N);
+        const float e0 = dead ? 0.f : __builtin_amdgcn_exp2f(s0[r] * c - L[0]);
+        const float e1 = dead ? 0.f : __builtin_amdgcn_exp2f(s1[r] * c - L[1]);
+        ds[kb][0][r] = e0 * (p0[r] - dl[0]);
+        ds[kb][1][r] = e1 * (p1[r] - dl[1]);
+      }
+    }
+    // dQ^T[d][q] += K^T dS^T
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bf16x8_t a0 = pack_pair(ds[2 * s][0], ds[2 * s + 1][0]);
+      const bf16x8_t a1 = pack_pair(ds[2 * s][1], ds[2 * s + 1][1]);
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+        const bf16x8_t fkt = tr_frag<KLD>((const lds_char*)kt, 32 * s, d * 16, li, lg);
+        dqt[d][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fkt, a0, dqt[d][0], 0, 0, 0);
+        dqt[d][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fkt, a1, dqt[d][1], 0, 0, 0);
+      }
+    }
+    if (t + 1 < nt) {
+      sk.template commit<KLD>(smem + (cur ^ 1) * STAGE, tid);
+      sv.template commit<VLD>(smem + (cur ^ 1) * STAGE + 64 * KLD, tid);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int q = q0 + qb * 16 + li;
+    if (q < N) {
+      bf16* out = dqkv + ((int64_t)b * N + q) * ld + h * DH;
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+        store4<bf16>(out + d * 16 + 4 * lg, make_float4(dqt[d][qb][0] * scale, dqt[d][qb][1] * scale,
+                                                        dqt[d][qb][2] * scale, dqt[d][qb][3] * scale));
+    }
+  }
+}
+
+// =============================================================================================
+// backward: dK, dV  (key on the lane; sweeps query tiles)
+// =============================================================================================
+template <int DH>
+__global__ __launch_bounds__(256) void attn_dkv_bf16_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
+                                                            const float* __restrict__ lse2,
+                                                            const float* __restrict__ delta, bf16* __restrict__ dqkv,
+                                                            int B, int N, int H) {
+  constexpr int KS = DH / 32, DB = DH / 16;
+  constexpr int TLD = DH * 2 + 32;  // Q and dO tiles: row reads AND transposed reads
+  constexpr int STAGE = 2 * 64 * TLD + 2 * 64 * 4;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  const int I = H * DH;
+  const int64_t ld = 3 * (int64_t)I;
+  const bf16* qbase = qkv + (int64_t)b * N * ld + h * DH;
+  const bf16* kbase = qbase + I;
+  const bf16* vbase = qbase + 2 * I;
+  const bf16* gbase = d_o + (int64_t)b * N * I + h * DH;
+  const int k0 = blockIdx.x * 128 + wave * 32;
+  const float scale = 1.0f / sqrtf((float)DH);
+  const float c = LOG2E * scale;
+
+  bf16x8_t fk[2][KS], fv[2][KS];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int key = k0 + kb * 16 + li;
+      fk[kb][ks] = load_frag_global(kbase + (int64_t)key * ld + ks * 32 + 8 * lg, key < N);
+      fv[kb][ks] = load_frag_global(vbase + (int64_t)key * ld + ks * 32 + 8 * lg, key < N);
+    }
+  f32x4_t dvt[DB][2], dkt[DB][2];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      dvt[d][kb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      dkt[d][kb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+
+  TileStager<DH, 64> sq, sg;
+  float rl = 0.f, rd = 0.f;  // staged lse2 / delta (threads 0..63)
+  auto issue_stats = [&](int r0) {
+    if (tid < 64) {
+      const bool ok = r0 + tid < N;
+      rl = ok ? lse2[(int64_t)bh * N + r0 + tid] : INFINITY;  // 2^(x - inf) = 0 for padded queries
+      rd = ok ? delta[(int64_t)bh * N + r0 + tid] : 0.f;
+    }
+  };
+  auto commit_stats = [&](char* stage) {
+    if (tid < 64) {
+      reinterpret_cast<float*>(stage + 2 * 64 * TLD)[tid] = rl;
+      reinterpret_cast<float*>(stage + 2 * 64 * TLD + 256)[tid] = rd;
+    }
+  };
+  const int nt = (N + 63) / 64;
+  {
+    const int nv = N < 64 ? N : 64;
+    sq.issue(qbase, ld, 0, nv, tid);
+    sg.issue(gbase, I, 0, nv, tid);
+    issue_stats(0);
+    sq.template commit<TLD>(smem, tid);
+    sg.template commit<TLD>(smem + 64 * TLD, tid);
+    commit_stats(smem);
+  }
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nt) {
+      const int r0 = (t + 1) * 64;
+      const int nv = (N - r0) < 64 ? (N - r0) : 64;
+      sq.issue(qbase, ld, r0, nv, tid);
+      sg.issue(gbase, I, r0, nv, tid);
+      issue_stats(r0);
+    }
+    const char* qt = smem + cur * STAGE;
+    const char* gt = qt + 64 * TLD;
+    const float* Ls = reinterpret_cast<const float*>(qt + 2 * 64 * TLD);
+    const float* Ds = Ls + 64;
+
+    f32x4_t pm[4][2], dsm[4][2];  // P and dS, [q-block][key-block]
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+      f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8_t fqr = row_frag<TLD>(qt, qb * 16 + li, ks * 32 + 8 * lg);
+        const bf16x8_t fgr = row_frag<TLD>(gt, qb * 16 + li, ks * 32 + 8 * lg);
+        s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqr, fk[0][ks], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqr, fk[1][ks], s1, 0, 0, 0);
+        p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fgr, fv[0][ks], p0, 0, 0, 0);
+        p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fgr, fv[1][ks], p1, 0, 0, 0);
+      }
+      const float4 l4 = *reinterpret_cast<const float4*>(Ls + qb * 16 + 4 * lg);
+      const float4 d4 = *reinterpret_cast<const float4*>(Ds + qb * 16 + 4 * lg);
+      const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e0 = __builtin_amdgcn_exp2f(s0[r] * c - lv[r]);
+        const float e1 = __builtin_amdgcn_exp2f(s1[r] * c - lv[r]);
+        pm[qb][0][r] = e0;
+        pm[qb][1][r] = e1;
+        dsm[qb][0][r] = e0 * (p0[r] - dv[r]);
+        dsm[qb][1][r] = e1 * (p1[r] - dv[r]);
+      }
+    }
+    // dV^T[d][key] += dO^T P ; dK^T[d][key] += Q^T dS
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bf16x8_t pa0 = pack_pair(pm[2 * s][0], pm[2 * s + 1][0]);
+      const bf16x8_t pa1 = pack_pair(pm[2 * s][1], pm[2 * s + 1][1]);
+      const bf16x8_t da0 = pack_pair(dsm[2 * s][0], dsm[2 * s + 1][0]);
+      const bf16x8_t da1 = pack_pair(dsm[2 * s][1], dsm[2 * s + 1][1]);
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+        const bf16x8_t fgt = tr_frag<TLD>((const lds_char*)gt, 32 * s, d * 16, li, lg);
+        const bf16x8_t fqt = tr_frag<TLD>((const lds_char*)qt, 32 * s, d * 16, li, lg);
+        dvt[d][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fgt, pa0, dvt[d][0], 0, 0, 0);
+        dvt[d][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fgt, pa1, dvt[d][1], 0, 0, 0);
+        dkt[d][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqt, da0, dkt[d][0], 0, 0, 0);
+        dkt[d][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqt, da1, dkt[d][1], 0, 0, 0);
+      }
+    }
+    if (t + 1 < nt) {
+      char* nx = smem + (cur ^ 1) * STAGE;
+      sq.template commit<TLD>(nx, tid);
+      sg.template commit<TLD>(nx + 64 * TLD, tid);
+      commit_stats(nx);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    const int key = k0 + kb * 16 + li;
+    if (key < N) {
+      bf16* outk = dqkv + ((int64_t)b * N + key) * ld + I + h * DH;
+      bf16* outv = outk + I;
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+        store4<bf16>(outk + d * 16 + 4 * lg, make_float4(dkt[d][kb][0] * scale, dkt[d][kb][1] * scale,
+                                                         dkt[d][kb][2] * scale, dkt[d][kb][3] * scale));
+        store4<bf16>(outv + d * 16 + 4 * lg,
+                     make_float4(dvt[d][kb][0], dvt[d][kb][1], dvt[d][kb][2], dvt[d][kb][3]));
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int attn_fwd_bf16(const bf16* qkv, bf16* o, float* lse2, int B, int N, int H, int dh, hipStream_t s) {
+  AVF_REQUIRE(B > 0 && N > 0 && H > 0, "attn_fwd_bf16: bad shape");
+  AVF_REQUIRE((int64_t)B * H < 65536, "attn_fwd_bf16: batch*heads too large for grid");
+  AVF_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)o & 7) == 0, "attn_fwd_bf16: misaligned pointers");
+  dim3 grid((unsigned)ceil_div(N, 128), (unsigned)(B * H));
+  if (dh == 64) attn_fwd_bf16_kernel<64><<<grid, 256, 0, s>>>(qkv, o, lse2, B, N, H);
+  else if (dh == 32) attn_fwd_bf16_kernel<32><<<grid, 256, 0, s>>>(qkv, o, lse2, B, N, H);
+  else AVF_REQUIRE(false, "attention (bf16): unsupported dim_head %d (32 or 64)", dh);
+  return check_launch("attn_fwd_bf16_kernel");
+}
+
+int attn_bwd_bf16(const bf16* qkv, const bf16* o, const bf16* d_o, const float* lse2, bf16* dqkv, float* delta, int B,
+                  int N, int H, int dh, hipStream_t s) {
+  AVF_REQUIRE(B > 0 && N > 0 && H > 0, "attn_bwd_bf16: bad shape");
+  AVF_REQUIRE((int64_t)B * H < 65536, "attn_bwd_bf16: batch*heads too large for grid");
+  AVF_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)d_o & 15) == 0 && ((uintptr_t)dqkv & 7) == 0,
+              "attn_bwd_bf16: misaligned pointers");
+  AVF_TRY(attn_delta(AVF_BF16, o, d_o, delta, B, N, H, dh, s));
+  dim3 grid((unsigned)ceil_div(N, 128), (unsigned)(B * H));
+  if (dh == 64) {
+    attn_dq_bf16_kernel<64><<<grid, 256, 0, s>>>(qkv, d_o, lse2, delta, dqkv, B, N, H);
+    attn_dkv_bf16_kernel<64><<<grid, 256, 0, s>>>(qkv, d_o, lse2, delta, dqkv, B, N, H);
+  } else if (dh == 32) {
+    attn_dq_bf16_kernel<32><<<grid, 256, 0, s>>>(qkv, d_o, lse2, delta, dqkv, B, N, H);
+    attn_dkv_bf16_kernel<32><<<grid, 256, 0, s>>>(qkv, d_o, lse2, delta, dqkv, B, N, H);
+  } else {
+    AVF_REQUIRE(false, "attention (bf16): unsupported dim_head %d (32 or 64)", dh);
+  }
+  return check_launch("attn_bwd_bf16 kernels");
+}
+
+}  // namespace avf

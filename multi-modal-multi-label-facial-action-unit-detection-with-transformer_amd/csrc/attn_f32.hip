@@ -1,0 +1,285 @@
+// attn_f32.hip - parity-mode attention core (fp32 VALU, flash-style: never materialises [B,H,N,N]).
+//
+// Reference: models/heads.py:222-237 -  dots = q k^T * dh^-0.5 ; softmax(dim=-1) ; out = attn v ;
+// 'b h n d -> b n (h d)'.  No dropout on the probabilities, the mask branch is dead (no caller).
+// One lane owns one query (forward, dQ) or one key (dK, dV); the opposite operand is staged in
+// LDS and read as wave-wide broadcasts.  Scores are kept in the log2 domain:
+//   s2 = (q . k) * dh^-0.5 * log2(e),  p = 2^(s2 - lse2),  lse2 = m2 + log2(sum 2^(s2 - m2)).
+#include "common.hpp"
+
+namespace avf {
+
+namespace {
+
+constexpr int KT = 32;  // keys (or queries) staged per step
+constexpr float LOG2E = 1.4426950408889634f;
+
+template <int DH>
+__device__ __forceinline__ void stage_rows(float* dst, const float* src, int64_t ld, int row0, int nrows_valid) {
+  // KT rows x DH floats, 64 threads, float4 granules; rows >= nrows_valid are zero-filled
+  constexpr int V = DH / 4;
+  for (int i = threadIdx.x; i < KT * V; i += 64) {
+    const int r = i / V, c = (i - r * V) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < nrows_valid) v = *reinterpret_cast<const float4*>(src + (int64_t)(row0 + r) * ld + c);
+    *reinterpret_cast<float4*>(dst + r * DH + c) = v;
+  }
+}
+
+template <int DH>
+__global__ __launch_bounds__(64) void attn_fwd_f32_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+                                                          float* __restrict__ lse2, int B, int N, int H) {
+  __shared__ __attribute__((aligned(16))) float Ks[KT * DH];
+  __shared__ __attribute__((aligned(16))) float Vs[KT * DH];
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  const int I = H * DH;
+  const int64_t ld = 3 * (int64_t)I;
+  const float* base = qkv + (int64_t)b * N * ld + h * DH;
+  const int qi = blockIdx.x * 64 + threadIdx.x;
+  const bool valid = qi < N;
+  const float c = LOG2E / sqrtf((float)DH);
+  float q[DH], acc[DH];
+#pragma unroll
+  for (int d = 0; d < DH; d += 4) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) v = *reinterpret_cast<const float4*>(base + (int64_t)qi * ld + d);
+    q[d] = v.x * c; q[d + 1] = v.y * c; q[d + 2] = v.z * c; q[d + 3] = v.w * c;
+    acc[d] = acc[d + 1] = acc[d + 2] = acc[d + 3] = 0.f;
+  }
+  float m = -INFINITY, l = 0.f;
+  for (int kt = 0; kt < N; kt += KT) {
+    const int nk = (N - kt) < KT ? (N - kt) : KT;
+    stage_rows<DH>(Ks, base + I, ld, kt, nk);
+    stage_rows<DH>(Vs, base + 2 * I, ld, kt, nk);
+    __syncthreads();
+    float s[KT];
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) a = fmaf(q[d], Ks[j * DH + d], a);
+      s[j] = (j < nk) ? a : -INFINITY;
+      tmax = fmaxf(tmax, s[j]);
+    }
+    const float mn = fmaxf(m, tmax);
+    const float alpha = exp2f(m - mn);
+    l *= alpha;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) acc[d] *= alpha;
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+      const float pj = exp2f(s[j] - mn);
+      l += pj;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) acc[d] = fmaf(pj, Vs[j * DH + d], acc[d]);
+    }
+    m = mn;
+    __syncthreads();
+  }
+  if (valid) {
+    const float inv = 1.0f / l;
+    float* orow = o + ((int64_t)b * N + qi) * I + h * DH;
+#pragma unroll
+    for (int d = 0; d < DH; d += 4)
+      *reinterpret_cast<float4*>(orow + d) = make_float4(acc[d] * inv, acc[d + 1] * inv, acc[d + 2] * inv, acc[d + 3] * inv);
+    lse2[(int64_t)bh * N + qi] = m + log2f(l);
+  }
+}
+
+// dQ: one lane per query.  dS = P o (dP - delta),  dq = dS k * dh^-0.5
+template <int DH>
+__global__ __launch_bounds__(64) void attn_dq_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
+                                                         const float* __restrict__ lse2, const float* __restrict__ delta,
+                                                         float* __restrict__ dqkv, int B, int N, int H) {
+  __shared__ __attribute__((aligned(16))) float Ks[KT * DH];
+  __shared__ __attribute__((aligned(16))) float Vs[KT * DH];
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  const int I = H * DH;
+  const int64_t ld = 3 * (int64_t)I;
+  const float* base = qkv + (int64_t)b * N * ld + h * DH;
+  const int qi = blockIdx.x * 64 + threadIdx.x;
+  const bool valid = qi < N;
+  const float scale = 1.0f / sqrtf((float)DH);
+  const float c = LOG2E * scale;
+  float q[DH], g[DH], dq[DH];
+#pragma unroll
+  for (int d = 0; d < DH; d += 4) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f), w = v;
+    if (valid) {
+      v = *reinterpret_cast<const float4*>(base + (int64_t)qi * ld + d);
+      w = *reinterpret_cast<const float4*>(d_o + ((int64_t)b * N + qi) * I + h * DH + d);
+    }
+    q[d] = v.x * c; q[d + 1] = v.y * c; q[d + 2] = v.z * c; q[d + 3] = v.w * c;
+    g[d] = w.x; g[d + 1] = w.y; g[d + 2] = w.z; g[d + 3] = w.w;
+    dq[d] = dq[d + 1] = dq[d + 2] = dq[d + 3] = 0.f;
+  }
+  const float L = valid ? lse2[(int64_t)bh * N + qi] : 0.f;
+  const float dl = valid ? delta[(int64_t)bh * N + qi] : 0.f;
+  for (int kt = 0; kt < N; kt += KT) {
+    const int nk = (N - kt) < KT ? (N - kt) : KT;
+    stage_rows<DH>(Ks, base + I, ld, kt, nk);
+    stage_rows<DH>(Vs, base + 2 * I, ld, kt, nk);
+    __syncthreads();
+#pragma unroll 4
+    for (int j = 0; j < KT; ++j) {
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) {
+        s = fmaf(q[d], Ks[j * DH + d], s);
+        dp = fmaf(g[d], Vs[j * DH + d], dp);
+      }
+      const float pj = (j < nk) ? exp2f(s - L) : 0.f;
+      const float ds = pj * (dp - dl);
+#pragma unroll
+      for (int d = 0; d < DH; ++d) dq[d] = fmaf(ds, Ks[j * DH + d], dq[d]);
+    }
+    __syncthreads();
+  }
+  if (valid) {
+    float* out = dqkv + ((int64_t)b * N + qi) * ld + h * DH;
+#pragma unroll
+    for (int d = 0; d < DH; d += 4)
+      *reinterpret_cast<float4*>(out + d) =
+          make_float4(dq[d] * scale, dq[d + 1] * scale, dq[d + 2] * scale, dq[d + 3] * scale);
+  }
+}
+
+// dK / dV: one lane per key.  PASS 0: dv = P^T dO.  PASS 1: dk = dS^T q * dh^-0.5
+template <int DH, int PASS>
+__global__ __launch_bounds__(64) void attn_dkv_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
+                                                          const float* __restrict__ lse2,
+                                                          const float* __restrict__ delta, float* __restrict__ dqkv,
+                                                          int B, int N, int H) {
+  __shared__ __attribute__((aligned(16))) float Qs[KT * DH];
+  __shared__ __attribute__((aligned(16))) float Gs[KT * DH];
+  __shared__ float Ls[KT], Ds[KT];
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  const int I = H * DH;
+  const int64_t ld = 3 * (int64_t)I;
+  const float* base = qkv + (int64_t)b * N * ld + h * DH;
+  const int ki = blockIdx.x * 64 + threadIdx.x;
+  const bool valid = ki < N;
+  const float scale = 1.0f / sqrtf((float)DH);
+  const float c = LOG2E * scale;
+  float k[DH], v[PASS == 1 ? DH : 1], acc[DH];
+#pragma unroll
+  for (int d = 0; d < DH; d += 4) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) a = *reinterpret_cast<const float4*>(base + I + (int64_t)ki * ld + d);
+    k[d] = a.x * c; k[d + 1] = a.y * c; k[d + 2] = a.z * c; k[d + 3] = a.w * c;
+    if (PASS == 1) {
+      float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (valid) w = *reinterpret_cast<const float4*>(base + 2 * I + (int64_t)ki * ld + d);
+      v[d] = w.x; v[d + 1] = w.y; v[d + 2] = w.z; v[d + 3] = w.w;
+    }
+    acc[d] = acc[d + 1] = acc[d + 2] = acc[d + 3] = 0.f;
+  }
+  for (int qt = 0; qt < N; qt += KT) {
+    const int nq = (N - qt) < KT ? (N - qt) : KT;
+    stage_rows<DH>(Qs, base, ld, qt, nq);
+    stage_rows<DH>(Gs, d_o + (int64_t)b * N * I + h * DH, I, qt, nq);
+    if (threadIdx.x < KT) {
+      const bool ok = threadIdx.x < nq;
+      Ls[threadIdx.x] = ok ? lse2[(int64_t)bh * N + qt + threadIdx.x] : INFINITY;  // 2^(s - inf) = 0
+      Ds[threadIdx.x] = ok ? delta[(int64_t)bh * N + qt + threadIdx.x] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int j = 0; j < KT; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) s = fmaf(k[d], Qs[j * DH + d], s);
+      const float pj = exp2f(s - Ls[j]);
+      if (PASS == 0) {
+#pragma unroll
+        for (int d = 0; d < DH; ++d) acc[d] = fmaf(pj, Gs[j * DH + d], acc[d]);
+      } else {
+        float dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) dp = fmaf(Gs[j * DH + d], v[d], dp);
+        const float ds = pj * (dp - Ds[j]);
+#pragma unroll
+        for (int d = 0; d < DH; ++d) acc[d] = fmaf(ds, Qs[j * DH + d], acc[d]);
+      }
+    }
+    __syncthreads();
+  }
+  if (valid) {
+    const float f = PASS == 1 ? scale : 1.0f;
+    float* out = dqkv + ((int64_t)b * N + ki) * ld + (PASS == 1 ? I : 2 * I) + h * DH;
+#pragma unroll
+    for (int d = 0; d < DH; d += 4)
+      *reinterpret_cast<float4*>(out + d) = make_float4(acc[d] * f, acc[d + 1] * f, acc[d + 2] * f, acc[d + 3] * f);
+  }
+}
+
+// delta[b,h,n] = sum_d dO[b,n,h,d] * O[b,n,h,d]   (= rowsum(dP o P))
+template <typename T>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ d_o,
+                                                         float* __restrict__ delta, int B, int N, int H, int DH) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over (b, n, h)
+  const int64_t total = (int64_t)B * N * H;
+  if (idx >= total) return;
+  const int h = (int)(idx % H);
+  const int64_t bn = idx / H;
+  const int n = (int)(bn % N);
+  const int b = (int)(bn / N);
+  const T* po = o + bn * (int64_t)H * DH + (int64_t)h * DH;
+  const T* pg = d_o + bn * (int64_t)H * DH + (int64_t)h * DH;
+  float a = 0.f;
+  for (int d = 0; d < DH; d += 4) {
+    float4 x = load4<T>(po + d), y = load4<T>(pg + d);
+    a += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+  }
+  delta[((int64_t)b * H + h) * N + n] = a;
+}
+
+}  // namespace
+
+int attn_delta(int dtype, const void* o, const void* d_o, float* delta, int B, int N, int H, int dh, hipStream_t s) {
+  AVF_REQUIRE(dh % 4 == 0, "attn_delta: dim_head %d must be a multiple of 4", dh);
+  const int64_t total = (int64_t)B * N * H;
+  const unsigned grid = (unsigned)ceil_div(total, 256);
+  if (dtype == AVF_F32)
+    attn_delta_kernel<float><<<grid, 256, 0, s>>>((const float*)o, (const float*)d_o, delta, B, N, H, dh);
+  else
+    attn_delta_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)o, (const bf16*)d_o, delta, B, N, H, dh);
+  return check_launch("attn_delta_kernel");
+}
+
+#define AVF_DH_DISPATCH(dh, MACRO)                                                           \
+  switch (dh) {                                                                               \
+    case 8: MACRO(8); break;                                                                  \
+    case 16: MACRO(16); break;                                                                \
+    case 32: MACRO(32); break;                                                                \
+    case 64: MACRO(64); break;                                                                \
+    default: AVF_REQUIRE(false, "attention (fp32): unsupported dim_head %d (8,16,32,64)", dh); \
+  }
+
+int attn_fwd_f32(const float* qkv, float* o, float* lse2, int B, int N, int H, int dh, hipStream_t s) {
+  AVF_REQUIRE(B > 0 && N > 0 && H > 0, "attn_fwd_f32: bad shape");
+  AVF_REQUIRE((int64_t)B * H < 65536, "attn_fwd_f32: batch*heads too large for grid");
+  dim3 grid((unsigned)ceil_div(N, 64), (unsigned)(B * H));
+#define L(D) attn_fwd_f32_kernel<D><<<grid, 64, 0, s>>>(qkv, o, lse2, B, N, H)
+  AVF_DH_DISPATCH(dh, L)
+#undef L
+  return check_launch("attn_fwd_f32_kernel");
+}
+
+int attn_bwd_f32(const float* qkv, const float* o, const float* d_o, const float* lse2, float* dqkv, float* delta,
+                 int B, int N, int H, int dh, hipStream_t s) {
+  AVF_REQUIRE(B > 0 && N > 0 && H > 0, "attn_bwd_f32: bad shape");
+  AVF_REQUIRE((int64_t)B * H < 65536, "attn_bwd_f32: batch*heads too large for grid");
+  AVF_TRY(attn_delta(AVF_F32, o, d_o, delta, B, N, H, dh, s));
+  dim3 grid((unsigned)ceil_div(N, 64), (unsigned)(B * H));
+#define L(D)                                                                                 \
+  attn_dq_f32_kernel<D><<<grid, 64, 0, s>>>(qkv, d_o, lse2, delta, dqkv, B, N, H);           \
+  attn_dkv_f32_kernel<D, 0><<<grid, 64, 0, s>>>(qkv, d_o, lse2, delta, dqkv, B, N, H);       \
+  attn_dkv_f32_kernel<D, 1><<<grid, 64, 0, s>>>(qkv, d_o, lse2, delta, dqkv, B, N, H)
+  AVF_DH_DISPATCH(dh, L)
+#undef L
+  return check_launch("attn_bwd_f32 kernels");
+}
+
+}  // namespace avf

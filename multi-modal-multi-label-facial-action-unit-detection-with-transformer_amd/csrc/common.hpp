@@ -1,0 +1,168 @@
+// common.hpp - shared device/host helpers for libavformer_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/avformer_hip.h"
+
+namespace avf {
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing (nothing throws across the C ABI)
+// ---------------------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define AVF_REQUIRE(cond, ...)          \
+  do {                                  \
+    if (!(cond)) {                      \
+      ::avf::set_error(__VA_ARGS__);    \
+      return 1;                         \
+    }                                   \
+  } while (0)
+
+#define AVF_TRY(expr)            \
+  do {                           \
+    int _rc = (expr);            \
+    if (_rc != 0) return _rc;    \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// element types
+// ---------------------------------------------------------------------------------------------
+struct bf16 {
+  uint16_t x;
+};
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;  // MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // MFMA 16x16 accumulator
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+  // plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN stays NaN)
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+}
+
+template <typename T>
+__device__ __forceinline__ float to_f32(T v);
+template <>
+__device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ float to_f32<bf16>(bf16 v) { return bf16_bits_to_f32(v.x); }
+
+template <typename T>
+__device__ __forceinline__ T from_f32(float v);
+template <>
+__device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ bf16 from_f32<bf16>(float v) { bf16 r; r.x = f32_to_bf16_bits(v); return r; }
+
+// 4 consecutive elements
+template <typename T>
+__device__ __forceinline__ float4 load4(const T* p);
+template <>
+__device__ __forceinline__ float4 load4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <>
+__device__ __forceinline__ float4 load4<bf16>(const bf16* p) {
+  uint2 r = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                     __uint_as_float(r.y & 0xffff0000u));
+}
+template <typename T>
+__device__ __forceinline__ void store4(T* p, float4 v);
+template <>
+__device__ __forceinline__ void store4<float>(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+template <>
+__device__ __forceinline__ void store4<bf16>(bf16* p, float4 v) {
+  uint2 r;
+  r.x = pack_bf16x2(v.x, v.y);
+  r.y = pack_bf16x2(v.z, v.w);
+  *reinterpret_cast<uint2*>(p) = r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave (64 lanes) reductions
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// tanh-GELU exactly as models/heads.py:166 and its derivative
+__device__ __forceinline__ float gelu_tanh_f(float u) {
+  const float c = 0.7978845608028654f;  // sqrt(2/pi)
+  float inner = c * (u + 0.044715f * u * u * u);
+  return 0.5f * u * (1.0f + tanhf(inner));
+}
+__device__ __forceinline__ float dgelu_tanh_f(float u) {
+  const float c = 0.7978845608028654f;
+  float u2 = u * u;
+  float t = tanhf(c * (u + 0.044715f * u * u2));
+  return 0.5f * (1.0f + t) + 0.5f * u * (1.0f - t * t) * c * (1.0f + 3.0f * 0.044715f * u2);
+}
+
+__host__ __device__ static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------------------------
+// internal launchers shared between translation units (all return 0 / non-zero)
+// ---------------------------------------------------------------------------------------------
+int layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype, float* mean,
+                  float* rstd, int64_t rows, int dim, float eps, hipStream_t s);
+size_t layernorm_bwd_ws(int64_t rows, int dim);
+int layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean,
+                  const float* rstd, const float* dres, float* dx, void* dx_lo, float* dgamma, float* dbeta,
+                  float* dcolsum, void* ws, int64_t rows, int dim, hipStream_t s);
+size_t colsum_ws(int64_t rows, int cols);
+int colsum(const void* in, int in_dtype, int64_t rows, int cols, int64_t ld, float* out, void* ws, hipStream_t s);
+int cast_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t s);
+int prep_weight_bf16(const float* w, void* w_lo, void* w_t_lo, int rows, int cols, hipStream_t s);
+
+struct GemmArgs {
+  int dtype, transA, transB;
+  int64_t M, N, K;
+  const void* A;
+  int64_t lda;
+  const void* B;
+  int64_t ldb;
+  void* C;
+  int64_t ldc;
+  int c_dtype;
+  int epilogue;
+  const float* bias;
+  const float* residual;
+  int64_t ldres;
+  void* aux;
+  int64_t ldaux;
+  void* workspace;
+};
+size_t gemm_ws(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K);
+int gemm(const GemmArgs& a, hipStream_t s);
+int gemm_f32(const GemmArgs& a, hipStream_t s);
+int gemm_bf16_nt(const GemmArgs& a, hipStream_t s);
+int gemm_bf16_tn(const GemmArgs& a, hipStream_t s);
+size_t gemm_bf16_tn_ws(int64_t M, int64_t N, int64_t K);
+
+int attn_fwd_f32(const float* qkv, float* o, float* lse2, int B, int N, int H, int dh, hipStream_t s);
+int attn_bwd_f32(const float* qkv, const float* o, const float* d_o, const float* lse2, float* dqkv, float* delta,
+                 int B, int N, int H, int dh, hipStream_t s);
+int attn_fwd_bf16(const bf16* qkv, bf16* o, float* lse2, int B, int N, int H, int dh, hipStream_t s);
+int attn_bwd_bf16(const bf16* qkv, const bf16* o, const bf16* d_o, const float* lse2, bf16* dqkv, float* delta,
+                  int B, int N, int H, int dh, hipStream_t s);
+int attn_delta(int dtype, const void* o, const void* d_o, float* delta, int B, int N, int H, int dh, hipStream_t s);
+
+}  // namespace avf

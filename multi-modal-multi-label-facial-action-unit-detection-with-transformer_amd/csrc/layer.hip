@@ -1,0 +1,304 @@
+// layer.hip - host-side orchestration of one transformer layer (forward and backward) on a HIP stream.
+//
+// Reference: models/heads.py:246-255 - one (Residual(PreNorm(Attention)), Residual(PreNorm(FeedForward)))
+// pair; SURVEY.md appendix A gives the op order and the backward formulas.  Everything here is
+// enqueue-only (no allocation, no synchronisation) so a caller may capture it into a hipGraph.
+//
+// forward:   h1 = LN1(x)            -> qkv = h1 Wqkv^T          -> o = attn(qkv)
+//            x_mid = o Wo^T + bo + x -> h2 = LN2(x_mid)          -> u = h2 W1^T + b1, g = gelu(u)
+//            x_out = g W2^T + b2 + x_mid
+// backward:  du = (dx_out W2) o gelu'(u) ; dW2 = dx_out^T g ; db2 = colsum(dx_out)
+//            dh2 = du W1 ; dW1 = du^T h2 ; db1 = colsum(du)
+//            dx_mid = dx_out + LN2'(dh2) ; dgamma2, dbeta2 ; dbo = colsum(dx_mid)   [fused in LN bwd]
+//            do = dx_mid Wo ; dWo = dx_mid^T o ; dqkv = attn'(do) ; dWqkv = dqkv^T h1 ; dh1 = dqkv Wqkv
+//            dx_in = dx_mid + LN1'(dh1) ; dgamma1, dbeta1
+#include "common.hpp"
+
+namespace avf {
+
+namespace {
+
+struct Dims {
+  int64_t R;  // rows = batch * tokens
+  int D, H, dh, I, M, B, N;
+  int dt;     // compute dtype
+  size_t es;  // element size of compute dtype
+};
+
+int make_dims(const avf_layer_cfg* c, Dims* d) {
+  AVF_REQUIRE(c, "layer: null cfg");
+  AVF_REQUIRE(c->batch > 0 && c->tokens > 0 && c->dim > 0 && c->heads > 0 && c->dim_head > 0 && c->mlp_dim > 0,
+              "layer: non-positive shape in cfg");
+  AVF_REQUIRE(c->dtype == AVF_F32 || c->dtype == AVF_BF16, "layer: bad dtype %d", c->dtype);
+  AVF_REQUIRE(c->dropout_p == 0.0f, "layer: dropout_p=%g is not supported by this version (use eval()/p=0)",
+              (double)c->dropout_p);
+  AVF_REQUIRE(c->project_out == 1,
+              "layer: the nn.Identity to_out case (heads==1 && dim_head==dim, heads.py:207) is not supported");
+  d->B = c->batch; d->N = c->tokens; d->D = c->dim; d->H = c->heads; d->dh = c->dim_head;
+  d->I = c->heads * c->dim_head; d->M = c->mlp_dim; d->R = (int64_t)c->batch * c->tokens;
+  d->dt = c->dtype; d->es = c->dtype == AVF_BF16 ? 2 : 4;
+  if (c->dtype == AVF_BF16) {
+    AVF_REQUIRE(d->D % 8 == 0 && d->I % 8 == 0 && d->M % 8 == 0, "layer(bf16): dim, inner and mlp_dim must be multiples of 8");
+    AVF_REQUIRE(d->dh == 32 || d->dh == 64, "layer(bf16): dim_head must be 32 or 64 (got %d)", d->dh);
+  } else {
+    AVF_REQUIRE(d->D % 4 == 0 && d->I % 4 == 0 && d->M % 4 == 0, "layer(f32): dim, inner and mlp_dim must be multiples of 4");
+  }
+  return 0;
+}
+
+struct Carver {
+  char* base;
+  size_t off;
+  explicit Carver(void* b) : base((char*)b), off(0) {}
+  void* take(size_t bytes) {
+    void* p = base ? base + off : nullptr;
+    off += align_up(bytes, 256);
+    return p;
+  }
+};
+
+struct Saved {
+  void *h1, *qkv, *o, *h2, *u, *g;
+  float *mean1, *rstd1, *lse2, *x_mid, *mean2, *rstd2;
+};
+size_t carve_saved(const Dims& d, void* base, Saved* s) {
+  Carver c(base);
+  Saved t;
+  t.h1 = c.take(d.R * d.D * d.es);
+  t.mean1 = (float*)c.take(d.R * 4);
+  t.rstd1 = (float*)c.take(d.R * 4);
+  t.qkv = c.take(d.R * 3 * d.I * d.es);
+  t.o = c.take(d.R * d.I * d.es);
+  t.lse2 = (float*)c.take((size_t)d.B * d.H * d.N * 4);
+  t.x_mid = (float*)c.take(d.R * d.D * 4);
+  t.h2 = c.take(d.R * d.D * d.es);
+  t.mean2 = (float*)c.take(d.R * 4);
+  t.rstd2 = (float*)c.take(d.R * 4);
+  t.u = c.take(d.R * d.M * d.es);
+  t.g = c.take(d.R * d.M * d.es);
+  if (s) *s = t;
+  return c.off;
+}
+
+struct LowP {
+  void *wqkv, *wqkv_t, *wo, *wo_t, *w1, *w1_t, *w2, *w2_t;
+};
+size_t carve_lowp(const Dims& d, void* base, LowP* l) {
+  if (d.dt != AVF_BF16) {
+    if (l) memset(l, 0, sizeof(*l));
+    return 0;
+  }
+  Carver c(base);
+  LowP t;
+  t.wqkv = c.take((size_t)3 * d.I * d.D * 2);
+  t.wqkv_t = c.take((size_t)3 * d.I * d.D * 2);
+  t.wo = c.take((size_t)d.D * d.I * 2);
+  t.wo_t = c.take((size_t)d.D * d.I * 2);
+  t.w1 = c.take((size_t)d.M * d.D * 2);
+  t.w1_t = c.take((size_t)d.M * d.D * 2);
+  t.w2 = c.take((size_t)d.D * d.M * 2);
+  t.w2_t = c.take((size_t)d.D * d.M * 2);
+  if (l) *l = t;
+  return c.off;
+}
+
+struct Work {
+  void *du, *dh, *d_o, *dqkv, *dx_mid_lo, *dx_out_lo, *ln_ws, *cs_ws, *gemm_ws;
+  float *dx_mid, *delta;
+};
+size_t carve_work(const Dims& d, void* base, Work* w) {
+  Carver c(base);
+  Work t;
+  t.du = c.take(d.R * d.M * d.es);
+  t.dh = c.take(d.R * d.D * d.es);
+  t.d_o = c.take(d.R * d.I * d.es);
+  t.dqkv = c.take(d.R * 3 * d.I * d.es);
+  t.dx_mid = (float*)c.take(d.R * d.D * 4);
+  t.dx_mid_lo = c.take(d.dt == AVF_BF16 ? d.R * d.D * 2 : 0);
+  t.dx_out_lo = c.take(d.dt == AVF_BF16 ? d.R * d.D * 2 : 0);
+  t.delta = (float*)c.take((size_t)d.B * d.H * d.N * 4);
+  t.ln_ws = c.take(layernorm_bwd_ws(d.R, d.D));
+  const int maxc = d.M > d.D ? d.M : d.D;
+  t.cs_ws = c.take(colsum_ws(d.R, maxc));
+  size_t g = 0;
+  if (d.dt == AVF_BF16) {
+    size_t a = gemm_bf16_tn_ws(3 * d.I, d.D, d.R), b = gemm_bf16_tn_ws(d.D, d.I, d.R);
+    size_t e = gemm_bf16_tn_ws(d.M, d.D, d.R), f = gemm_bf16_tn_ws(d.D, d.M, d.R);
+    g = a > b ? a : b;
+    g = g > e ? g : e;
+    g = g > f ? g : f;
+  }
+  t.gemm_ws = c.take(g);
+  if (w) *w = t;
+  return c.off;
+}
+
+// C[R, out] = A[R, in] * W[out, in]^T  (nn.Linear forward)
+int linear_fwd(const Dims& d, const void* A, int in, const void* W, int out, void* C, int c_dtype, int epi,
+               const float* bias, const float* res, void* aux, hipStream_t s) {
+  GemmArgs a;
+  a.dtype = d.dt; a.transA = 0; a.transB = 1;
+  a.M = d.R; a.N = out; a.K = in;
+  a.A = A; a.lda = in; a.B = W; a.ldb = in;
+  a.C = C; a.ldc = out; a.c_dtype = c_dtype; a.epilogue = epi;
+  a.bias = bias; a.residual = res; a.ldres = out; a.aux = aux; a.ldaux = out; a.workspace = nullptr;
+  return gemm(a, s);
+}
+
+// dX[R, in] = dY[R, out] * W[out, in].  bf16 mode consumes the transposed copy Wt[in, out] as an NT GEMM.
+int linear_dx(const Dims& d, const void* dY, int out, const void* W_f32, const void* Wt_lo, int in, void* dX, int epi,
+              void* aux, hipStream_t s) {
+  GemmArgs a;
+  a.dtype = d.dt; a.transA = 0;
+  a.M = d.R; a.N = in; a.K = out;
+  a.A = dY; a.lda = out;
+  if (d.dt == AVF_BF16) { a.transB = 1; a.B = Wt_lo; a.ldb = out; }
+  else { a.transB = 0; a.B = W_f32; a.ldb = in; }
+  a.C = dX; a.ldc = in; a.c_dtype = d.dt; a.epilogue = epi;
+  a.bias = nullptr; a.residual = nullptr; a.ldres = 0; a.aux = aux; a.ldaux = in; a.workspace = nullptr;
+  return gemm(a, s);
+}
+
+// dW[out, in] = dY[R, out]^T * X[R, in]   (fp32 result)
+int linear_dw(const Dims& d, const void* dY, int out, const void* X, int in, float* dW, void* ws, hipStream_t s) {
+  GemmArgs a;
+  a.dtype = d.dt; a.transA = 1; a.transB = 0;
+  a.M = out; a.N = in; a.K = d.R;
+  a.A = dY; a.lda = out; a.B = X; a.ldb = in;
+  a.C = dW; a.ldc = in; a.c_dtype = AVF_F32; a.epilogue = AVF_EPI_NONE;
+  a.bias = nullptr; a.residual = nullptr; a.ldres = 0; a.aux = nullptr; a.ldaux = 0; a.workspace = ws;
+  return gemm(a, s);
+}
+
+}  // namespace
+
+size_t gemm_ws(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K) {
+  if (dtype == AVF_BF16 && transA == 1 && transB == 0) return gemm_bf16_tn_ws(M, N, K);
+  return 0;
+}
+
+int gemm(const GemmArgs& a, hipStream_t s) {
+  if (a.dtype == AVF_F32) return gemm_f32(a, s);
+  if (a.dtype == AVF_BF16) {
+    if (a.transA == 0 && a.transB == 1) return gemm_bf16_nt(a, s);
+    if (a.transA == 1 && a.transB == 0) return gemm_bf16_tn(a, s);
+    AVF_REQUIRE(false, "gemm(bf16): only NT (transA=0,transB=1) and TN (transA=1,transB=0) forms exist");
+  }
+  AVF_REQUIRE(false, "gemm: bad dtype %d", a.dtype);
+}
+
+}  // namespace avf
+
+using namespace avf;
+
+extern "C" size_t avf_layer_saved_bytes(const avf_layer_cfg* cfg) {
+  Dims d;
+  if (make_dims(cfg, &d)) return 0;
+  return carve_saved(d, nullptr, nullptr);
+}
+extern "C" size_t avf_layer_lowp_bytes(const avf_layer_cfg* cfg) {
+  Dims d;
+  if (make_dims(cfg, &d)) return 0;
+  return carve_lowp(d, nullptr, nullptr);
+}
+extern "C" size_t avf_layer_workspace_bytes(const avf_layer_cfg* cfg) {
+  Dims d;
+  if (make_dims(cfg, &d)) return 0;
+  return carve_work(d, nullptr, nullptr);
+}
+
+extern "C" int avf_layer_prepare_weights(const avf_layer_cfg* cfg, const avf_layer_params* p, void* lowp,
+                                         void* stream) {
+  Dims d;
+  AVF_TRY(make_dims(cfg, &d));
+  if (d.dt != AVF_BF16) return 0;
+  AVF_REQUIRE(p && lowp, "prepare_weights: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  LowP l;
+  carve_lowp(d, lowp, &l);
+  AVF_TRY(prep_weight_bf16(p->w_qkv, l.wqkv, l.wqkv_t, 3 * d.I, d.D, s));
+  AVF_TRY(prep_weight_bf16(p->w_out, l.wo, l.wo_t, d.D, d.I, s));
+  AVF_TRY(prep_weight_bf16(p->w1, l.w1, l.w1_t, d.M, d.D, s));
+  AVF_TRY(prep_weight_bf16(p->w2, l.w2, l.w2_t, d.D, d.M, s));
+  return 0;
+}
+
+extern "C" int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p, const void* lowp, const float* x_in,
+                             float* x_out, void* saved, void* workspace, void* stream) {
+  (void)workspace;
+  Dims d;
+  AVF_TRY(make_dims(cfg, &d));
+  AVF_REQUIRE(p && x_in && x_out && saved, "layer_fwd: null pointer");
+  AVF_REQUIRE(d.dt == AVF_F32 || lowp, "layer_fwd(bf16): lowp weights missing");
+  hipStream_t s = (hipStream_t)stream;
+  Saved sv;
+  carve_saved(d, saved, &sv);
+  LowP l;
+  carve_lowp(d, (void*)lowp, &l);
+  const bool lo = d.dt == AVF_BF16;
+  const void* wqkv = lo ? l.wqkv : (const void*)p->w_qkv;
+  const void* wo = lo ? l.wo : (const void*)p->w_out;
+  const void* w1 = lo ? l.w1 : (const void*)p->w1;
+  const void* w2 = lo ? l.w2 : (const void*)p->w2;
+
+  AVF_TRY(layernorm_fwd(x_in, p->ln1_w, p->ln1_b, sv.h1, d.dt, sv.mean1, sv.rstd1, d.R, d.D, cfg->ln_eps, s));
+  AVF_TRY(linear_fwd(d, sv.h1, d.D, wqkv, 3 * d.I, sv.qkv, d.dt, AVF_EPI_NONE, nullptr, nullptr, nullptr, s));
+  if (lo) AVF_TRY(attn_fwd_bf16((const bf16*)sv.qkv, (bf16*)sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s));
+  else AVF_TRY(attn_fwd_f32((const float*)sv.qkv, (float*)sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s));
+  AVF_TRY(linear_fwd(d, sv.o, d.I, wo, d.D, sv.x_mid, AVF_F32, AVF_EPI_BIAS_RES, p->b_out, x_in, nullptr, s));
+  AVF_TRY(layernorm_fwd(sv.x_mid, p->ln2_w, p->ln2_b, sv.h2, d.dt, sv.mean2, sv.rstd2, d.R, d.D, cfg->ln_eps, s));
+  AVF_TRY(linear_fwd(d, sv.h2, d.D, w1, d.M, sv.g, d.dt, AVF_EPI_BIAS_GELU, p->b1, nullptr, sv.u, s));
+  AVF_TRY(linear_fwd(d, sv.g, d.M, w2, d.D, x_out, AVF_F32, AVF_EPI_BIAS_RES, p->b2, sv.x_mid, nullptr, s));
+  return 0;
+}
+
+extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p, const void* lowp, const float* x_in,
+                             const void* saved, const float* dx_out, const void* dx_out_lo, float* dx_in,
+                             void* dx_in_lo, const avf_layer_grads* g, void* workspace, void* stream) {
+  Dims d;
+  AVF_TRY(make_dims(cfg, &d));
+  AVF_REQUIRE(p && x_in && saved && dx_out && dx_in && g && workspace, "layer_bwd: null pointer");
+  AVF_REQUIRE(d.dt == AVF_F32 || lowp, "layer_bwd(bf16): lowp weights missing");
+  hipStream_t s = (hipStream_t)stream;
+  Saved sv;
+  carve_saved(d, (void*)saved, &sv);
+  LowP l;
+  carve_lowp(d, (void*)lowp, &l);
+  Work w;
+  carve_work(d, workspace, &w);
+  const bool lo = d.dt == AVF_BF16;
+
+  // gradient of the layer output in the compute dtype (GEMM operand)
+  const void* gy = dx_out;
+  if (lo) {
+    if (dx_out_lo) gy = dx_out_lo;
+    else {
+      AVF_TRY(cast_f32_to_bf16(dx_out, w.dx_out_lo, d.R * d.D, s));
+      gy = w.dx_out_lo;
+    }
+  }
+  // ---- feed-forward half -------------------------------------------------------------------
+  AVF_TRY(colsum(dx_out, AVF_F32, d.R, d.D, d.D, g->b2, w.cs_ws, s));
+  AVF_TRY(linear_dw(d, gy, d.D, sv.g, d.M, g->w2, w.gemm_ws, s));
+  AVF_TRY(linear_dx(d, gy, d.D, p->w2, l.w2_t, d.M, w.du, AVF_EPI_DGELU, sv.u, s));
+  AVF_TRY(colsum(w.du, d.dt, d.R, d.M, d.M, g->b1, w.cs_ws, s));
+  AVF_TRY(linear_dw(d, w.du, d.M, sv.h2, d.D, g->w1, w.gemm_ws, s));
+  AVF_TRY(linear_dx(d, w.du, d.M, p->w1, l.w1_t, d.D, w.dh, AVF_EPI_NONE, nullptr, s));
+  AVF_TRY(layernorm_bwd(w.dh, d.dt, sv.x_mid, p->ln2_w, sv.mean2, sv.rstd2, dx_out, w.dx_mid,
+                        lo ? w.dx_mid_lo : nullptr, g->ln2_w, g->ln2_b, g->b_out, w.ln_ws, d.R, d.D, s));
+  // ---- attention half ----------------------------------------------------------------------
+  const void* gm = lo ? (const void*)w.dx_mid_lo : (const void*)w.dx_mid;
+  AVF_TRY(linear_dw(d, gm, d.D, sv.o, d.I, g->w_out, w.gemm_ws, s));
+  AVF_TRY(linear_dx(d, gm, d.D, p->w_out, l.wo_t, d.I, w.d_o, AVF_EPI_NONE, nullptr, s));
+  if (lo)
+    AVF_TRY(attn_bwd_bf16((const bf16*)sv.qkv, (const bf16*)sv.o, (const bf16*)w.d_o, sv.lse2, (bf16*)w.dqkv, w.delta,
+                          d.B, d.N, d.H, d.dh, s));
+  else
+    AVF_TRY(attn_bwd_f32((const float*)sv.qkv, (const float*)sv.o, (const float*)w.d_o, sv.lse2, (float*)w.dqkv,
+                         w.delta, d.B, d.N, d.H, d.dh, s));
+  AVF_TRY(linear_dw(d, w.dqkv, 3 * d.I, sv.h1, d.D, g->w_qkv, w.gemm_ws, s));
+  AVF_TRY(linear_dx(d, w.dqkv, 3 * d.I, p->w_qkv, l.wqkv_t, d.D, w.dh, AVF_EPI_NONE, nullptr, s));
+  AVF_TRY(layernorm_bwd(w.dh, d.dt, x_in, p->ln1_w, sv.mean1, sv.rstd1, w.dx_mid, dx_in, lo ? dx_in_lo : nullptr,
+                        g->ln1_w, g->ln1_b, nullptr, w.ln_ws, d.R, d.D, s));
+  return 0;
+}

@@ -1,0 +1,384 @@
+// norm_elem.hip - HBM-bound kernels of the hot path: LayerNorm fwd/bwd (wavefront reductions),
+// column sums (bias gradients), fp32->bf16 casts / weight transposes, AU loss.
+//
+// Reference math: models/heads.py:178-185 (PreNorm/nn.LayerNorm), models/loss.py:63-103 (AULoss).
+#include "common.hpp"
+
+namespace avf {
+
+// =============================================================================================
+// LayerNorm forward: one wavefront per row; fp32 statistics; output fp32 or bf16.
+// Algorithmic bytes per row: 4*D read + sizeof(out)*D written + 8 (mean, rstd).
+// =============================================================================================
+template <typename OutT>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, OutT* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd,
+                                                     int64_t rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * D;
+  OutT* yr = y + row * D;
+  float s = 0.f;
+  if ((D & 3) == 0) {
+    for (int c = lane * 4; c < D; c += 256) {
+      float4 v = *reinterpret_cast<const float4*>(xr + c);
+      s += (v.x + v.y) + (v.z + v.w);
+    }
+  } else {
+    for (int c = lane; c < D; c += 64) s += xr[c];
+  }
+  const float mu = wave_sum(s) / (float)D;
+  float q = 0.f;
+  if ((D & 3) == 0) {
+    for (int c = lane * 4; c < D; c += 256) {
+      float4 v = *reinterpret_cast<const float4*>(xr + c);
+      float a = v.x - mu, b = v.y - mu, cc = v.z - mu, d = v.w - mu;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  } else {
+    for (int c = lane; c < D; c += 64) {
+      float a = xr[c] - mu;
+      q += a * a;
+    }
+  }
+  const float var = wave_sum(q) / (float)D;
+  const float rs = 1.0f / sqrtf(var + eps);
+  if (lane == 0) {
+    mean[row] = mu;
+    rstd[row] = rs;
+  }
+  if ((D & 3) == 0) {
+    for (int c = lane * 4; c < D; c += 256) {
+      float4 v = *reinterpret_cast<const float4*>(xr + c);
+      float4 g = *reinterpret_cast<const float4*>(gamma + c);
+      float4 b = *reinterpret_cast<const float4*>(beta + c);
+      float4 o;
+      o.x = (v.x - mu) * rs * g.x + b.x;
+      o.y = (v.y - mu) * rs * g.y + b.y;
+      o.z = (v.z - mu) * rs * g.z + b.z;
+      o.w = (v.w - mu) * rs * g.w + b.w;
+      store4<OutT>(yr + c, o);
+    }
+  } else {
+    for (int c = lane; c < D; c += 64) yr[c] = from_f32<OutT>((xr[c] - mu) * rs * gamma[c] + beta[c]);
+  }
+}
+
+int layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype, float* mean,
+                  float* rstd, int64_t rows, int dim, float eps, hipStream_t s) {
+  AVF_REQUIRE(rows > 0 && dim > 0, "layernorm_fwd: bad shape rows=%lld dim=%d", (long long)rows, dim);
+  dim3 grid((unsigned)ceil_div(rows, 4)), block(256);
+  if (y_dtype == AVF_F32)
+    ln_fwd_kernel<float><<<grid, block, 0, s>>>(x, gamma, beta, (float*)y, mean, rstd, rows, dim, eps);
+  else if (y_dtype == AVF_BF16)
+    ln_fwd_kernel<bf16><<<grid, block, 0, s>>>(x, gamma, beta, (bf16*)y, mean, rstd, rows, dim, eps);
+  else
+    AVF_REQUIRE(false, "layernorm_fwd: bad dtype %d", y_dtype);
+  return check_launch("ln_fwd_kernel");
+}
+
+// =============================================================================================
+// LayerNorm backward.  One wavefront per row computes dx; the block accumulates the per-column sums
+// (dgamma, dbeta, and the column sum of dx = bias gradient of the producing Linear) in LDS with
+// ds_add_f32 and writes one partial per block; a second kernel folds the partials.
+//   xhat = (x-mu)*rstd ; g = dy*gamma ; dx = rstd*(g - mean(g) - xhat*mean(g*xhat)) + dres
+// =============================================================================================
+constexpr int LNB_ROWS_PER_BLOCK = 32;
+
+template <typename DyT, bool VEC>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const DyT* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ dres,
+                                                     float* __restrict__ dx, bf16* __restrict__ dx_lo,
+                                                     float* __restrict__ partial, int64_t rows, int D,
+                                                     int want_colsum) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [3][D]
+  float* s_dg = lds;
+  float* s_db = lds + D;
+  float* s_cs = lds + 2 * D;
+  for (int i = threadIdx.x; i < 3 * D; i += 256) lds[i] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t row0 = (int64_t)blockIdx.x * LNB_ROWS_PER_BLOCK;
+  const float invD = 1.0f / (float)D;
+  for (int rr = wave; rr < LNB_ROWS_PER_BLOCK; rr += 4) {
+    const int64_t row = row0 + rr;
+    if (row >= rows) break;
+    const float mu = mean[row], rs = rstd[row];
+    const DyT* dyr = dy + row * D;
+    const float* xr = x + row * D;
+    float s1 = 0.f, s2 = 0.f;
+    if (VEC) {
+      for (int c = lane * 4; c < D; c += 256) {
+        float4 d = load4<DyT>(dyr + c);
+        float4 v = *reinterpret_cast<const float4*>(xr + c);
+        float4 g = *reinterpret_cast<const float4*>(gamma + c);
+        float g0 = d.x * g.x, g1 = d.y * g.y, g2 = d.z * g.z, g3 = d.w * g.w;
+        s1 += (g0 + g1) + (g2 + g3);
+        s2 += (g0 * (v.x - mu) + g1 * (v.y - mu)) + (g2 * (v.z - mu) + g3 * (v.w - mu));
+      }
+    } else {
+      for (int c = lane; c < D; c += 64) {
+        float g0 = to_f32<DyT>(dyr[c]) * gamma[c];
+        s1 += g0;
+        s2 += g0 * (xr[c] - mu);
+      }
+    }
+    s1 = wave_sum(s1) * invD;
+    s2 = wave_sum(s2) * rs * invD;  // mean(g * xhat)
+    float* dxr = dx + row * D;
+    if (VEC) {
+      for (int c = lane * 4; c < D; c += 256) {
+        float4 d = load4<DyT>(dyr + c);
+        float4 v = *reinterpret_cast<const float4*>(xr + c);
+        float4 g = *reinterpret_cast<const float4*>(gamma + c);
+        float xh[4] = {(v.x - mu) * rs, (v.y - mu) * rs, (v.z - mu) * rs, (v.w - mu) * rs};
+        float dd[4] = {d.x, d.y, d.z, d.w};
+        float gg[4] = {g.x, g.y, g.z, g.w};
+        float r[4] = {0.f, 0.f, 0.f, 0.f};
+        if (dres) {
+          float4 t = *reinterpret_cast<const float4*>(dres + row * D + c);
+          r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+        }
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          o[j] = rs * (dd[j] * gg[j] - s1 - xh[j] * s2) + r[j];
+          atomicAdd(&s_dg[c + j], dd[j] * xh[j]);
+          atomicAdd(&s_db[c + j], dd[j]);
+          if (want_colsum) atomicAdd(&s_cs[c + j], o[j]);
+        }
+        *reinterpret_cast<float4*>(dxr + c) = make_float4(o[0], o[1], o[2], o[3]);
+        if (dx_lo) store4<bf16>(dx_lo + row * D + c, make_float4(o[0], o[1], o[2], o[3]));
+      }
+    } else {
+      for (int c = lane; c < D; c += 64) {
+        float d = to_f32<DyT>(dyr[c]);
+        float xh = (xr[c] - mu) * rs;
+        float o = rs * (d * gamma[c] - s1 - xh * s2) + (dres ? dres[row * D + c] : 0.f);
+        atomicAdd(&s_dg[c], d * xh);
+        atomicAdd(&s_db[c], d);
+        if (want_colsum) atomicAdd(&s_cs[c], o);
+        dxr[c] = o;
+        if (dx_lo) dx_lo[row * D + c] = from_f32<bf16>(o);
+      }
+    }
+  }
+  __syncthreads();
+  float* out = partial + (int64_t)blockIdx.x * 3 * D;
+  for (int i = threadIdx.x; i < 3 * D; i += 256) out[i] = lds[i];
+}
+
+// out[j] = sum_b partial[b][j], j in [0, width): 64 columns x 4 partial-groups per block
+__global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ partial, int nb, int width,
+                                                            float* __restrict__ o0, float* __restrict__ o1,
+                                                            float* __restrict__ o2, int seg) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;
+  float acc = 0.f;
+  if (col < width)
+    for (int b = grp; b < nb; b += 4) acc += partial[(int64_t)b * width + col];
+  red[grp][cl] = acc;
+  __syncthreads();
+  if (grp == 0 && col < width) {
+    float v = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    const int which = col / seg, c = col - which * seg;
+    float* dst = which == 0 ? o0 : (which == 1 ? o1 : o2);
+    if (dst) dst[c] = v;
+  }
+}
+
+size_t layernorm_bwd_ws(int64_t rows, int dim) {
+  return (size_t)ceil_div(rows, LNB_ROWS_PER_BLOCK) * 3 * dim * sizeof(float);
+}
+
+int layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean,
+                  const float* rstd, const float* dres, float* dx, void* dx_lo, float* dgamma, float* dbeta,
+                  float* dcolsum, void* ws, int64_t rows, int dim, hipStream_t s) {
+  AVF_REQUIRE(rows > 0 && dim > 0 && ws, "layernorm_bwd: bad arguments");
+  AVF_REQUIRE((size_t)3 * dim * sizeof(float) <= 64 * 1024, "layernorm_bwd: dim %d too large", dim);
+  const int nb = (int)ceil_div(rows, LNB_ROWS_PER_BLOCK);
+  const size_t lds = (size_t)3 * dim * sizeof(float);
+  float* partial = (float*)ws;
+  const bool vec = (dim & 3) == 0;
+  const int wc = dcolsum ? 1 : 0;
+#define LAUNCH(T, V)                                                                                            \
+  ln_bwd_kernel<T, V><<<nb, 256, lds, s>>>((const T*)dy, x, gamma, mean, rstd, dres, dx, (bf16*)dx_lo, partial, \
+                                           rows, dim, wc)
+  if (dy_dtype == AVF_F32) {
+    if (vec) LAUNCH(float, true); else LAUNCH(float, false);
+  } else if (dy_dtype == AVF_BF16) {
+    if (vec) LAUNCH(bf16, true); else LAUNCH(bf16, false);
+  } else {
+    AVF_REQUIRE(false, "layernorm_bwd: bad dtype %d", dy_dtype);
+  }
+#undef LAUNCH
+  AVF_TRY(check_launch("ln_bwd_kernel"));
+  const int width = 3 * dim;
+  fold_partials_kernel<<<(unsigned)ceil_div(width, 64), 256, 0, s>>>(partial, nb, width, dgamma, dbeta, dcolsum, dim);
+  return check_launch("fold_partials_kernel");
+}
+
+// =============================================================================================
+// column sums: out[c] = sum_r in[r, c]  (bias gradients - "db = sum_rows dY")
+// =============================================================================================
+constexpr int CS_ROW_CHUNKS = 128;
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ in, int64_t rows, int cols, int64_t ld,
+                                                     float* __restrict__ partial) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  const int64_t per = ceil_div(rows, (int64_t)gridDim.y);
+  const int64_t r0 = (int64_t)blockIdx.y * per;
+  const int64_t r1 = r0 + per < rows ? r0 + per : rows;
+  if (col >= cols) return;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int64_t r = r0;
+  for (; r + 3 < r1; r += 4) {
+    a0 += to_f32<T>(in[(r + 0) * ld + col]);
+    a1 += to_f32<T>(in[(r + 1) * ld + col]);
+    a2 += to_f32<T>(in[(r + 2) * ld + col]);
+    a3 += to_f32<T>(in[(r + 3) * ld + col]);
+  }
+  for (; r < r1; ++r) a0 += to_f32<T>(in[r * ld + col]);
+  partial[(int64_t)blockIdx.y * cols + col] = (a0 + a1) + (a2 + a3);
+}
+
+static int colsum_chunks(int64_t rows) {
+  int64_t c = ceil_div(rows, 64);
+  if (c > CS_ROW_CHUNKS) c = CS_ROW_CHUNKS;
+  if (c < 1) c = 1;
+  return (int)c;
+}
+size_t colsum_ws(int64_t rows, int cols) { return (size_t)colsum_chunks(rows) * cols * sizeof(float); }
+
+int colsum(const void* in, int in_dtype, int64_t rows, int cols, int64_t ld, float* out, void* ws, hipStream_t s) {
+  AVF_REQUIRE(rows > 0 && cols > 0 && ws && out, "colsum: bad arguments");
+  const int ch = colsum_chunks(rows);
+  dim3 grid((unsigned)ceil_div(cols, 256), ch);
+  if (in_dtype == AVF_F32)
+    colsum_kernel<float><<<grid, 256, 0, s>>>((const float*)in, rows, cols, ld, (float*)ws);
+  else if (in_dtype == AVF_BF16)
+    colsum_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)in, rows, cols, ld, (float*)ws);
+  else
+    AVF_REQUIRE(false, "colsum: bad dtype %d", in_dtype);
+  AVF_TRY(check_launch("colsum_kernel"));
+  fold_partials_kernel<<<(unsigned)ceil_div(cols, 64), 256, 0, s>>>((const float*)ws, ch, cols, out, nullptr, nullptr,
+                                                                     cols);
+  return check_launch("fold_partials_kernel");
+}
+
+// =============================================================================================
+// casts / weight preparation
+// =============================================================================================
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ in, bf16* __restrict__ out,
+                                                        int64_t n) {
+  int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+  for (; i + 3 < n; i += stride) store4<bf16>(out + i, *reinterpret_cast<const float4*>(in + i));
+  // tail (n not a multiple of 4): handled by the thread whose i lands on it
+  if (i < n && i + 3 >= n)
+    for (int64_t j = i; j < n; ++j) out[j] = from_f32<bf16>(in[j]);
+}
+
+int cast_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t s) {
+  AVF_REQUIRE(n > 0, "cast: n must be positive");
+  AVF_REQUIRE((((uintptr_t)in) & 15) == 0 && (((uintptr_t)out) & 7) == 0, "cast: pointers must be 16B/8B aligned");
+  int64_t blocks = ceil_div(n, 1024);
+  if (blocks > 2048) blocks = 2048;
+  cast_bf16_kernel<<<(unsigned)blocks, 256, 0, s>>>(in, (bf16*)out, n);
+  return check_launch("cast_bf16_kernel");
+}
+
+// w [R,C] fp32 -> w_lo [R,C] bf16 and w_t_lo [C,R] bf16, 32x32 tiles through LDS
+__global__ __launch_bounds__(256) void prep_weight_kernel(const float* __restrict__ w, bf16* __restrict__ w_lo,
+                                                          bf16* __restrict__ w_t, int R, int C) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int r = r0 + ty + 8 * i, c = c0 + tx;
+    float v = (r < R && c < C) ? w[(int64_t)r * C + c] : 0.f;
+    tile[ty + 8 * i][tx] = v;
+    if (w_lo && r < R && c < C) w_lo[(int64_t)r * C + c] = from_f32<bf16>(v);
+  }
+  __syncthreads();
+  if (w_t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int c = c0 + ty + 8 * i, r = r0 + tx;  // output row = c, output col = r
+      if (c < C && r < R) w_t[(int64_t)c * R + r] = from_f32<bf16>(tile[tx][ty + 8 * i]);
+    }
+  }
+}
+
+int prep_weight_bf16(const float* w, void* w_lo, void* w_t_lo, int rows, int cols, hipStream_t s) {
+  AVF_REQUIRE(rows > 0 && cols > 0, "prep_weight: bad shape");
+  dim3 grid((unsigned)ceil_div(cols, 32), (unsigned)ceil_div(rows, 32));
+  prep_weight_kernel<<<grid, 256, 0, s>>>(w, (bf16*)w_lo, (bf16*)w_t_lo, rows, cols);
+  return check_launch("prep_weight_kernel");
+}
+
+// =============================================================================================
+// AULoss (models/loss.py:75-103): one block; rows are few (a batch of clips).
+//   keep_b = (y[b,0] != ignore);  l = (1-y) z + (1 + (w-1) y) softplus(-z);  loss = mean over kept
+//   dl/dz = sigmoid(z) (1 - y + w y) - w y, scaled by 1/(ncls * kept), 0 for dropped rows.
+// =============================================================================================
+__global__ __launch_bounds__(256) void au_loss_kernel(const float* __restrict__ z, int64_t ldz,
+                                                      const float* __restrict__ y, int64_t ldy,
+                                                      const float* __restrict__ pw, float ignore, int rows, int ncls,
+                                                      float* __restrict__ loss, float* __restrict__ grad) {
+  __shared__ float red[4];
+  __shared__ int redc[4];
+  float acc = 0.f;
+  int kept = 0;
+  for (int r = threadIdx.x; r < rows; r += 256) kept += (y[(int64_t)r * ldy] != ignore) ? 1 : 0;
+  for (int i = threadIdx.x; i < rows * ncls; i += 256) {
+    const int r = i / ncls, c = i - r * ncls;
+    if (y[(int64_t)r * ldy] != ignore) {
+      const float zz = z[(int64_t)r * ldz + c], yy = y[(int64_t)r * ldy + c], w = pw[c];
+      // softplus(-z) = max(-z,0) + log1p(exp(-|z|))
+      const float sp = fmaxf(-zz, 0.f) + log1pf(expf(-fabsf(zz)));
+      acc += (1.f - yy) * zz + (1.f + (w - 1.f) * yy) * sp;
+    }
+  }
+  acc = wave_sum(acc);
+  for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o, 64);
+  if ((threadIdx.x & 63) == 0) {
+    red[threadIdx.x >> 6] = acc;
+    redc[threadIdx.x >> 6] = kept;
+  }
+  __syncthreads();
+  const float total = (red[0] + red[1]) + (red[2] + red[3]);
+  const int nk = redc[0] + redc[1] + redc[2] + redc[3];
+  const float denom = (float)nk * (float)ncls;
+  if (threadIdx.x == 0) loss[0] = total / denom;  // 0/0 -> NaN when every row is ignored (as the reference)
+  const float inv = 1.0f / denom;
+  for (int i = threadIdx.x; i < rows * ncls; i += 256) {
+    const int r = i / ncls, c = i - r * ncls;
+    float g = 0.f;
+    if (y[(int64_t)r * ldy] != ignore) {
+      const float zz = z[(int64_t)r * ldz + c], yy = y[(int64_t)r * ldy + c], w = pw[c];
+      const float sg = 1.0f / (1.0f + expf(-zz));
+      g = (sg * (1.f - yy + w * yy) - w * yy) * inv;
+    }
+    grad[i] = g;
+  }
+}
+
+}  // namespace avf
+
+extern "C" int avf_au_loss(const float* logits, int64_t ld_logits, const float* labels, int64_t ld_labels,
+                           const float* pos_weight, float ignore, int rows, int ncls, float* loss, float* grad_unit,
+                           void* stream) {
+  using namespace avf;
+  AVF_REQUIRE(rows > 0 && ncls > 0 && logits && labels && pos_weight && loss && grad_unit, "au_loss: bad arguments");
+  au_loss_kernel<<<1, 256, 0, (hipStream_t)stream>>>(logits, ld_logits, labels, ld_labels, pos_weight, ignore, rows,
+                                                     ncls, loss, grad_unit);
+  return check_launch("au_loss_kernel");
+}

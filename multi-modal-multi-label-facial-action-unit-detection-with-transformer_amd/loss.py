@@ -1,0 +1,47 @@
+"""``AULoss`` - pos-weighted BCE-with-logits over the 12 action units (reference models/loss.py:63-103),
+computed by one HIP kernel (forward value and the logits gradient in the same launch)."""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import ops
+
+# reference models/loss.py:73
+AU_POS_WEIGHT = (1., 1., 1., 1., 1., 1., 1., 3., 3., 3., 1., 2.)
+
+
+class _AULossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y_pred, y_true, pos_weight, ignore):
+        if y_pred.stride(-1) != 1:
+            y_pred = y_pred.contiguous()
+        if y_true.stride(-1) != 1 or y_true.dtype != torch.float32:
+            y_true = y_true.to(torch.float32).contiguous()
+        loss, grad = ops.au_loss(y_pred.to(torch.float32), y_true, pos_weight, ignore)
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None
+
+
+class AULoss(nn.Module):
+    """Rows whose FIRST label equals ``ignore`` are dropped (loss.py:85-88); the loss is the mean of
+    ``BCEWithLogits(reduction='none', pos_weight=[1,1,1,1,1,1,1,3,3,3,1,2])`` over kept rows x 12.
+    With every row dropped the result is NaN, exactly like the reference's mean over an empty tensor.
+    Unlike the reference ctor (loss.py:73) this does not need a current CUDA device at construction:
+    ``pos_weight`` is a buffer and follows ``.to(device)``."""
+
+    def __init__(self, ignore=-1):
+        super().__init__()
+        self.ignore = ignore
+        self.register_buffer("pos_weight", torch.tensor(AU_POS_WEIGHT, dtype=torch.float32), persistent=False)
+
+    def forward(self, y_pred, y_true):
+        if not y_pred.is_cuda:
+            raise RuntimeError("AULoss (HIP) needs its inputs on the MI355X; there is no CPU fallback")
+        pw = self.pos_weight if self.pos_weight.device == y_pred.device else self.pos_weight.to(y_pred.device)
+        return _AULossFn.apply(y_pred, y_true, pw, float(self.ignore))

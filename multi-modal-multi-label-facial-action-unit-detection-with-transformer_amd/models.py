@@ -1,0 +1,148 @@
+"""Task models and the model registry around the HIP transformer (reference train.py:292-315,
+models/avformer.py:37-123).
+
+``TwoStreamAuralVisualFormer`` keeps the reference's constructor signature, ``.modes`` / ``.task``
+attributes, ``forward(dict) -> [B,21]`` layout ([0:12] AU logits, [12:19] EX, [19:21] VA) and
+``get_*_loss`` methods, so the step loop of the reference's ``train.py:206-237`` runs on it
+unchanged.  Its CNN feature extractors (ResNet18 on mel-spectrograms, Former-DFER video model) are
+out of scope: ``AudioFormer`` / ``VisualFormer`` take a ``backbone``
+module and default to the identity, i.e. they consume per-clip feature vectors [B, 512].
+
+``SyntheticAVFormer`` is the BASELINE.json scale-up of the same block: video tokens [B,T_v,D] and
+audio tokens [B,T_a,D] fused on the SEQUENCE axis, + positional embedding -> Transformer(D, L) ->
+mean-pooled -> 12 AU logits -> AULoss.
+"""
+from __future__ import annotations
+
+import os
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from .heads import AU_former, TFormer, former_AU_head, tformer_AU_head  # noqa: F401
+from .loss import AULoss
+from .transformer import Transformer
+
+
+def load_pretrain(model, weight_path):
+    """reference avformer.py:28-35 - strips 'module.' prefixes, strict=False; a missing file is skipped
+    (the reference hard-codes K:\\ paths and would crash)."""
+    if not weight_path or not os.path.exists(weight_path):
+        return False
+    sd = torch.load(weight_path, map_location="cpu")
+    model.load_state_dict(OrderedDict((k.replace("module.", ""), v) for k, v in sd.items()), strict=False)
+    return True
+
+
+class AudioFormer(nn.Module):
+    def __init__(self, modality='A', audio_pretrained=False, task='EX', backbone=None, compute_dtype="bf16"):
+        super().__init__()
+        self.audio_model = backbone if backbone is not None else nn.Identity()
+        self.task = task
+        self.modes = ['audio_features']
+        self.au_head = AU_former(dropout=0.2, compute_dtype=compute_dtype)
+
+    def forward(self, x):
+        _, tokens = self.au_head(self.audio_model(x))
+        return tokens
+
+
+class VisualFormer(nn.Module):
+    def __init__(self, modality='A;V', video_pretrained=True, task='EX', backbone=None, in_features=512,
+                 compute_dtype="bf16"):
+        super().__init__()
+        self.video_model = backbone if backbone is not None else nn.Identity()
+        self.task = task
+        self.modes = ["clip"]
+        self.au_head = AU_former(input_dim=in_features, compute_dtype=compute_dtype)
+
+    def forward(self, x):
+        _, tokens = self.au_head(self.video_model(x))
+        return tokens
+
+
+class _TaskLossMixin:
+    def get_au_loss(self, y_pred, y_true):
+        return self.loss_AU(y_pred[:, :12], y_true)
+
+    def get_ex_loss(self, y_pred, y_true):
+        # EX / VA tasks are outside the hot path; plain PyTorch equivalents
+        return nn.functional.cross_entropy(y_pred[:, 12:19], y_true.view(-1), ignore_index=7)
+
+    def get_va_loss(self, y_pred, y_true):
+        def ccc_loss(p, t):
+            pm, tm = p.mean(), t.mean()
+            cov = ((p - pm) * (t - tm)).mean()
+            return 1 - 2 * cov / (p.var(unbiased=False) + t.var(unbiased=False) + (pm - tm) ** 2 + 1e-8)
+        v, a = torch.tanh(y_pred[:, 19]), torch.tanh(y_pred[:, 20])
+        return 2 * ccc_loss(v, y_true[:, 0]) + ccc_loss(a, y_true[:, 1])
+
+
+class TwoStreamAuralVisualFormer(nn.Module, _TaskLossMixin):
+    def __init__(self, modality='A;V;M', video_pretrained=True, audio_pretrained=True, task='EX',
+                 video_weights=None, audio_weights=None, compute_dtype="bf16"):
+        super().__init__()
+        self.audio_model = AudioFormer(compute_dtype=compute_dtype)
+        self.video_model = VisualFormer(compute_dtype=compute_dtype)
+        if video_pretrained and load_pretrain(self.video_model, video_weights):
+            for p in self.video_model.parameters():
+                p.requires_grad = False
+        if audio_pretrained and load_pretrain(self.audio_model, audio_weights):
+            for p in self.audio_model.parameters():
+                p.requires_grad = False
+        self.task = task
+        self.au_head = former_AU_head(emb_dim=256, dropout=0.2, compute_dtype=compute_dtype)
+        self.modes = ['clip', 'audio_features']
+        self.loss_AU = AULoss()
+
+    def forward(self, x):
+        audio_tok = self.audio_model(x['audio_features'])
+        video_tok = self.video_model(x['clip'])
+        features = torch.cat([audio_tok, video_tok], dim=2)  # fusion on the FEATURE axis, avformer.py:100
+        out = torch.zeros(features.shape[0], 21, device=features.device, dtype=features.dtype)
+        if self.task == 'AU':
+            out[:, :12] = self.au_head(features)
+        return out
+
+
+class SyntheticAVFormer(nn.Module, _TaskLossMixin):
+    """BASELINE.json configs C2-C5: one Transformer(dim, depth, heads, dim_head, mlp_dim) over the fused
+    [B, T_v + T_a, dim] token sequence, mean pooling, 12 AU logits in the reference's [B,21] layout."""
+
+    def __init__(self, dim=512, depth=6, heads=8, dim_head=64, mlp_dim=1024, t_video=196, t_audio=128, task='AU',
+                 compute_dtype="bf16"):
+        super().__init__()
+        self.task = task
+        self.modes = ['clip', 'audio_features']
+        self.t_video, self.t_audio = t_video, t_audio
+        self.pos_embedding = nn.Parameter(torch.randn(1, t_video + t_audio, dim) * 0.02)
+        self.transformer = Transformer(dim, depth, heads, dim_head, mlp_dim, 0.0, compute_dtype=compute_dtype)
+        self.au_fc = nn.Linear(dim, 12)
+        self.loss_AU = AULoss()
+
+    def forward(self, x):
+        tokens = torch.cat([x['clip'], x['audio_features']], dim=1)  # fusion on the SEQUENCE axis
+        tokens = tokens + self.pos_embedding[:, :tokens.shape[1]]
+        y = self.transformer(tokens)
+        logits = self.au_fc(y.mean(dim=1))
+        out = torch.zeros(y.shape[0], 21, device=y.device, dtype=logits.dtype)
+        out[:, :12] = logits
+        return out
+
+
+# name -> class, as the if/elif chain in the reference's train.py:292-315 does for --model_name
+MODEL_REGISTRY = {
+    'avformer': TwoStreamAuralVisualFormer,
+    'avformer_synthetic': SyntheticAVFormer,
+}
+
+
+def build_model(model_name: str, modality: str = 'A;V;M', task: str = 'AU', **kw) -> nn.Module:
+    if model_name not in MODEL_REGISTRY:
+        raise KeyError(f"model {model_name!r} is not provided by the MI355X hot-path build; available: "
+                       f"{sorted(MODEL_REGISTRY)} (the CNN-backbone models of the reference are out of scope)")
+    cls = MODEL_REGISTRY[model_name]
+    if cls is TwoStreamAuralVisualFormer:
+        return cls(modality=modality, task=task, **kw)
+    return cls(task=task, **kw)

@@ -1,0 +1,204 @@
+"""Tensor-level wrappers over the per-operator C entry points (used by the modules and by tests).
+
+All tensors must live on a CUDA(HIP) device; nothing here falls back to PyTorch math.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import BF16, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, EPI_NONE, F32  # noqa: F401
+
+_TORCH2AVF = {torch.float32: F32, torch.bfloat16: BF16}
+_AVF2TORCH = {F32: torch.float32, BF16: torch.bfloat16}
+
+
+def avf_dtype(dt) -> int:
+    if isinstance(dt, int):
+        return dt
+    if isinstance(dt, str):
+        return {"f32": F32, "fp32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16}[dt.lower()]
+    return _TORCH2AVF[dt]
+
+
+def torch_dtype(dt) -> torch.dtype:
+    return _AVF2TORCH[avf_dtype(dt)]
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("libavformer_hip operators need tensors on the MI355X (got a CPU tensor); "
+                               "there is no CPU fallback in the product path")
+
+
+def _bytes(n: int, device) -> torch.Tensor:
+    return torch.empty(max(int(n), 16), dtype=torch.uint8, device=device)
+
+
+def device_ok() -> bool:
+    return bool(_lib.load().avf_device_ok())
+
+
+# ------------------------------------------------------------------------------------------------
+def layernorm_fwd(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5,
+                  out_dtype=torch.float32) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """nn.LayerNorm(dim) forward (reference models/heads.py:178-185).  x fp32 [..., D]."""
+    _need_cuda(x, weight, bias)
+    lib = _lib.load()
+    x = x.contiguous()
+    D = x.shape[-1]
+    rows = x.numel() // D
+    y = torch.empty(x.shape, dtype=torch_dtype(out_dtype), device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _lib.check(lib.avf_layernorm_fwd(_ptr(x), _ptr(weight), _ptr(bias), _ptr(y), avf_dtype(out_dtype), _ptr(mean),
+                                     _ptr(rstd), rows, D, float(eps), _stream()), "layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, weight, mean, rstd, dres=None, want_lo=False, want_colsum=False):
+    """-> dx fp32, dx_lo (bf16 or None), dgamma, dbeta, colsum(dx) or None."""
+    _need_cuda(dy, x, weight, mean, rstd, dres)
+    lib = _lib.load()
+    dy = dy.contiguous()
+    x = x.contiguous()
+    D = x.shape[-1]
+    rows = x.numel() // D
+    dx = torch.empty_like(x)
+    dx_lo = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_lo else None
+    dg = torch.empty(D, dtype=torch.float32, device=x.device)
+    db = torch.empty(D, dtype=torch.float32, device=x.device)
+    cs = torch.empty(D, dtype=torch.float32, device=x.device) if want_colsum else None
+    ws = _bytes(lib.avf_layernorm_bwd_workspace_bytes(rows, D), x.device)
+    _lib.check(lib.avf_layernorm_bwd(_ptr(dy), avf_dtype(dy.dtype), _ptr(x), _ptr(weight), _ptr(mean), _ptr(rstd),
+                                     _ptr(dres.contiguous() if dres is not None else None), _ptr(dx), _ptr(dx_lo),
+                                     _ptr(dg), _ptr(db), _ptr(cs), _ptr(ws), rows, D, _stream()), "layernorm_bwd")
+    return dx, dx_lo, dg, db, cs
+
+
+def colsum(t: torch.Tensor) -> torch.Tensor:
+    _need_cuda(t)
+    lib = _lib.load()
+    t = t.contiguous()
+    cols = t.shape[-1]
+    rows = t.numel() // cols
+    out = torch.empty(cols, dtype=torch.float32, device=t.device)
+    ws = _bytes(lib.avf_colsum_workspace_bytes(rows, cols), t.device)
+    _lib.check(lib.avf_colsum(_ptr(t), avf_dtype(t.dtype), rows, cols, cols, _ptr(out), _ptr(ws), _stream()), "colsum")
+    return out
+
+
+def cast_bf16(t: torch.Tensor) -> torch.Tensor:
+    _need_cuda(t)
+    t = t.contiguous()
+    out = torch.empty(t.shape, dtype=torch.bfloat16, device=t.device)
+    _lib.check(_lib.load().avf_cast_f32_to_bf16(_ptr(t), _ptr(out), t.numel(), _stream()), "cast")
+    return out
+
+
+def prep_weight_bf16(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    _need_cuda(w)
+    w = w.contiguous()
+    r, c = w.shape
+    lo = torch.empty((r, c), dtype=torch.bfloat16, device=w.device)
+    lo_t = torch.empty((c, r), dtype=torch.bfloat16, device=w.device)
+    _lib.check(_lib.load().avf_prep_weight_bf16(_ptr(w), _ptr(lo), _ptr(lo_t), r, c, _stream()), "prep_weight")
+    return lo, lo_t
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = True, out_dtype=None,
+         epilogue: int = EPI_NONE, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+         aux: Optional[torch.Tensor] = None):
+    """C = op(A) op(B) with a fused epilogue.  Returns C (and aux for EPI_BIAS_GELU)."""
+    _need_cuda(a, b, bias, residual, aux)
+    lib = _lib.load()
+    a = a.contiguous()
+    b = b.contiguous()
+    assert a.dtype == b.dtype
+    dt = avf_dtype(a.dtype)
+    M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
+    N = b.shape[0] if trans_b else b.shape[1]
+    Kb = b.shape[1] if trans_b else b.shape[0]
+    assert K == Kb, (a.shape, b.shape, trans_a, trans_b)
+    cdt = torch_dtype(out_dtype) if out_dtype is not None else a.dtype
+    c = torch.empty((M, N), dtype=cdt, device=a.device)
+    made_aux = None
+    if epilogue == EPI_BIAS_GELU and aux is None:
+        made_aux = aux = torch.empty((M, N), dtype=cdt, device=a.device)
+    ws = _bytes(lib.avf_gemm_workspace_bytes(dt, int(trans_a), int(trans_b), M, N, K), a.device)
+    _lib.check(lib.avf_gemm(dt, int(trans_a), int(trans_b), M, N, K, _ptr(a), a.shape[1], _ptr(b), b.shape[1],
+                            _ptr(c), N, avf_dtype(cdt), epilogue, _ptr(bias),
+                            _ptr(residual.contiguous() if residual is not None else None), N,
+                            _ptr(aux), N, _ptr(ws), _stream()), "gemm")
+    if made_aux is not None:
+        return c, made_aux
+    return c
+
+
+def attn_fwd(qkv: torch.Tensor, batch: int, tokens: int, heads: int, dim_head: int):
+    """Attention core on the packed QKV projection [B*N, 3*H*dh] -> (o [B*N, H*dh], lse2 [B,H,N])."""
+    _need_cuda(qkv)
+    qkv = qkv.contiguous()
+    inner = heads * dim_head
+    assert qkv.shape == (batch * tokens, 3 * inner)
+    o = torch.empty((batch * tokens, inner), dtype=qkv.dtype, device=qkv.device)
+    lse2 = torch.empty((batch, heads, tokens), dtype=torch.float32, device=qkv.device)
+    _lib.check(_lib.load().avf_attn_fwd(avf_dtype(qkv.dtype), _ptr(qkv), _ptr(o), _ptr(lse2), batch, tokens, heads,
+                                        dim_head, _stream()), "attn_fwd")
+    return o, lse2
+
+
+def attn_bwd(qkv, o, d_o, lse2, batch: int, tokens: int, heads: int, dim_head: int) -> torch.Tensor:
+    _need_cuda(qkv, o, d_o, lse2)
+    lib = _lib.load()
+    qkv, o, d_o = qkv.contiguous(), o.contiguous(), d_o.contiguous()
+    dqkv = torch.empty_like(qkv)
+    ws = _bytes(lib.avf_attn_bwd_workspace_bytes(batch, tokens, heads, dim_head), qkv.device)
+    _lib.check(lib.avf_attn_bwd(avf_dtype(qkv.dtype), _ptr(qkv), _ptr(o), _ptr(d_o), _ptr(lse2), _ptr(dqkv), _ptr(ws),
+                                batch, tokens, heads, dim_head, _stream()), "attn_bwd")
+    return dqkv
+
+
+def au_loss(logits: torch.Tensor, labels: torch.Tensor, pos_weight: torch.Tensor, ignore: float = -1.0):
+    """-> (loss scalar tensor, dloss/dlogits [rows, ncls]).  Reference models/loss.py:75-103."""
+    _need_cuda(logits, labels, pos_weight)
+    assert logits.dim() == 2 and labels.dim() == 2 and logits.shape == labels.shape
+    assert logits.stride(1) == 1 and labels.stride(1) == 1 and logits.dtype == torch.float32
+    labels = labels.to(torch.float32)
+    rows, ncls = logits.shape
+    loss = torch.empty((), dtype=torch.float32, device=logits.device)
+    grad = torch.empty((rows, ncls), dtype=torch.float32, device=logits.device)
+    _lib.check(_lib.load().avf_au_loss(_ptr(logits), logits.stride(0), _ptr(labels), labels.stride(0), _ptr(pos_weight),
+                                       float(ignore), rows, ncls, _ptr(loss), _ptr(grad), _stream()), "au_loss")
+    return loss, grad
+
+
+# hardware self-tests -------------------------------------------------------------------------------
+def selftest_mfma_bf16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    c = torch.empty((16, 16), dtype=torch.float32, device=a.device)
+    _lib.check(_lib.load().avf_selftest_mfma_bf16(_ptr(a.contiguous()), _ptr(b.contiguous()), _ptr(c), _stream()), "selftest")
+    return c
+
+
+def selftest_mfma_f32(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    c = torch.empty((16, 16), dtype=torch.float32, device=a.device)
+    _lib.check(_lib.load().avf_selftest_mfma_f32(_ptr(a.contiguous()), _ptr(b.contiguous()), _ptr(c), _stream()), "selftest")
+    return c
+
+
+def selftest_tr16(tile: torch.Tensor) -> torch.Tensor:
+    out = torch.empty((64, 8), dtype=torch.bfloat16, device=tile.device)
+    _lib.check(_lib.load().avf_selftest_tr16(_ptr(tile.contiguous()), _ptr(out), _stream()), "selftest")
+    return out

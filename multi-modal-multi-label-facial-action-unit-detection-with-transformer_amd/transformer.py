@@ -1,0 +1,233 @@
+"""``Transformer`` - drop-in for the reference's pre-norm transformer stack, computed by HIP kernels.
+
+Mirrors ``Transformer(dim, depth, heads, dim_head, mlp_dim, dropout=0.)`` of the reference
+(models/heads.py:242-256 and its byte-identical copies in sformer.py/tformer.py/vformer.py/
+dual_sformer.py/vggformer.py): same constructor, same ``forward(x[B,N,dim], mask=None)``, same
+``state_dict`` keys and default initialisation (it instantiates the same ``nn.Linear`` /
+``nn.LayerNorm`` holders in the same order, so a given ``torch.manual_seed`` yields the weights
+the reference would get).  The holders only own parameters: all math runs in
+``libavformer_hip.so`` through one forward and one backward C call per layer.
+
+Extra keyword ``compute_dtype``: ``"bf16"`` (throughput mode: bf16 MFMA, fp32 accumulate / LayerNorm /
+softmax statistics / residual stream) or ``"f32"`` (parity mode: fp32 MFMA + fp32 attention; matches the
+fp32 CPU reference to ~1e-5).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, List, Optional
+
+import torch
+from torch import nn
+
+from . import _lib
+from .ops import avf_dtype
+
+PARAMS_PER_LAYER = 11
+
+
+class _Holder(nn.Module):
+    """Parameter container; mirrors the reference's wrapper nesting so state_dict keys match."""
+
+    def forward(self, *a, **k):  # pragma: no cover - never called
+        raise RuntimeError("parameter holder: the computation runs in the enclosing Transformer")
+
+
+def _make_layer(dim: int, heads: int, dim_head: int, mlp_dim: int, dropout: float) -> nn.ModuleList:
+    inner = heads * dim_head
+    project_out = not (heads == 1 and dim_head == dim)  # reference heads.py:207
+    # construction order == RNG order of the reference: to_qkv, to_out, (LayerNorm), net.0, net.3, (LayerNorm)
+    attn = _Holder()
+    attn.to_qkv = nn.Linear(dim, inner * 3, bias=False)
+    attn.to_out = nn.Sequential(nn.Linear(inner, dim), nn.Dropout(dropout)) if project_out else nn.Identity()
+    pre_a = _Holder()
+    pre_a.norm = nn.LayerNorm(dim)
+    pre_a.fn = attn
+    res_a = _Holder()
+    res_a.fn = pre_a
+    ff = _Holder()
+    ff.net = nn.Sequential(nn.Linear(dim, mlp_dim), nn.Identity(), nn.Dropout(dropout), nn.Linear(mlp_dim, dim),
+                           nn.Dropout(dropout))
+    pre_f = _Holder()
+    pre_f.norm = nn.LayerNorm(dim)
+    pre_f.fn = ff
+    res_f = _Holder()
+    res_f.fn = pre_f
+    return nn.ModuleList([res_a, res_f])
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class _StackFn(torch.autograd.Function):
+    """x -> L layers.  Saved activations live in per-layer byte buffers carved by the library."""
+
+    @staticmethod
+    def forward(ctx, x, mod, *params):
+        lib = _lib.load()
+        B, N, D = x.shape
+        dev = x.device
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        cfg = mod._cfg(B, N)
+        L = mod.depth
+        params = [p.detach() for p in params]
+        need_grad = any(ctx.needs_input_grad)  # (grad mode is off inside Function.forward)
+        saved_bytes = lib.avf_layer_saved_bytes(C.byref(cfg))
+        if saved_bytes == 0:
+            _lib.check(1, "layer configuration")
+        ws = mod._workspace(lib, cfg, dev)
+        lowps = mod._lowp(lib, cfg, params, dev, stream)
+        xs = [x.detach().contiguous().view(B * N, D)]
+        saved = []
+        shared = None
+        for l in range(L):
+            pp = mod._param_struct(params, l)
+            if need_grad:
+                sv = torch.empty(saved_bytes, dtype=torch.uint8, device=dev)
+            else:
+                shared = shared if shared is not None else torch.empty(saved_bytes, dtype=torch.uint8, device=dev)
+                sv = shared
+            x_out = torch.empty((B * N, D), dtype=torch.float32, device=dev)
+            _lib.check(lib.avf_layer_fwd(C.byref(cfg), C.byref(pp), _ptr(lowps[l]), _ptr(xs[-1]), _ptr(x_out), _ptr(sv),
+                                         _ptr(ws), stream), f"layer_fwd[{l}]")
+            saved.append(sv)
+            xs.append(x_out)
+        ctx.mod = mod
+        ctx.cfg = cfg
+        ctx.shape = (B, N, D)
+        ctx.xs = xs[:-1] if need_grad else None
+        ctx.saved_bufs = saved if need_grad else None
+        ctx.params = params
+        ctx.lowps = lowps
+        return xs[-1].view(B, N, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        mod = ctx.mod
+        cfg = ctx.cfg
+        B, N, D = ctx.shape
+        dev = dy.device
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L = mod.depth
+        ws = mod._workspace(lib, cfg, dev)
+        bf16 = cfg.dtype == _lib.BF16
+        dx = dy.contiguous().view(B * N, D).to(torch.float32)
+        if dx.data_ptr() == dy.data_ptr():
+            dx = dx.clone()  # layers write their input gradient in place
+        lo_a = torch.empty((B * N, D), dtype=torch.bfloat16, device=dev) if bf16 else None
+        lo_b = torch.empty((B * N, D), dtype=torch.bfloat16, device=dev) if bf16 else None
+        have_lo = False
+        grads: List[Optional[torch.Tensor]] = [None] * (L * PARAMS_PER_LAYER)
+        sizes = [p.numel() for p in ctx.params[:PARAMS_PER_LAYER]]
+        hook = mod._grad_hook
+        for l in reversed(range(L)):
+            flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+            views, off = [], 0
+            for i, n in enumerate(sizes):
+                views.append(flat[off:off + n].view_as(ctx.params[l * PARAMS_PER_LAYER + i]))
+                off += n
+            gp = _lib.LayerPtrs(*[v.data_ptr() for v in views])
+            pp = mod._param_struct(ctx.params, l)
+            _lib.check(lib.avf_layer_bwd(C.byref(cfg), C.byref(pp), _ptr(ctx.lowps[l]), _ptr(ctx.xs[l]),
+                                         _ptr(ctx.saved_bufs[l]), _ptr(dx), _ptr(lo_a) if have_lo else None, _ptr(dx),
+                                         _ptr(lo_b), C.byref(gp), _ptr(ws), stream), f"layer_bwd[{l}]")
+            lo_a, lo_b = lo_b, lo_a
+            have_lo = bf16
+            for i, v in enumerate(views):
+                grads[l * PARAMS_PER_LAYER + i] = v
+            if hook is not None:
+                hook(l, flat)  # e.g. launch this layer's gradient all-reduce while earlier layers still run
+        ctx.saved_bufs = None
+        ctx.xs = None
+        return (dx.view(B, N, D), None, *grads)
+
+
+class Transformer(nn.Module):
+    """MI355X-native ``Transformer`` (reference models/heads.py:242-256)."""
+
+    def __init__(self, dim, depth, heads, dim_head, mlp_dim, dropout=0., compute_dtype="bf16"):
+        super().__init__()
+        self.dim, self.depth, self.heads, self.dim_head, self.mlp_dim = dim, depth, heads, dim_head, mlp_dim
+        self.dropout = float(dropout)
+        self.compute_dtype = avf_dtype(compute_dtype)
+        self.project_out = not (heads == 1 and dim_head == dim)
+        self.layers = nn.ModuleList([_make_layer(dim, heads, dim_head, mlp_dim, dropout) for _ in range(depth)])
+        self._ws = None
+        self._lowp_bufs = None
+        self._lowp_versions = None
+        self._grad_hook: Optional[Callable[[int, torch.Tensor], None]] = None
+
+    # ---- parameter plumbing --------------------------------------------------------------------
+    def layer_parameters(self, l: int) -> List[torch.Tensor]:
+        """The 11 tensors of layer ``l`` in state_dict order."""
+        attn_w, ff_w = self.layers[l]
+        a, f = attn_w.fn, ff_w.fn
+        if not self.project_out:
+            raise NotImplementedError("heads==1 and dim_head==dim (nn.Identity to_out) is not supported by the HIP path")
+        return [a.norm.weight, a.norm.bias, a.fn.to_qkv.weight, a.fn.to_out[0].weight, a.fn.to_out[0].bias,
+                f.norm.weight, f.norm.bias, f.fn.net[0].weight, f.fn.net[0].bias, f.fn.net[3].weight, f.fn.net[3].bias]
+
+    def flat_parameters(self) -> List[torch.Tensor]:
+        out = []
+        for l in range(self.depth):
+            out += self.layer_parameters(l)
+        return out
+
+    def set_grad_hook(self, hook: Optional[Callable[[int, torch.Tensor], None]]):
+        """``hook(layer_index, flat_fp32_grad_of_that_layer)`` is called right after the layer's backward has
+        been enqueued (reverse layer order) - the data-parallel wrapper launches its all-reduce there."""
+        self._grad_hook = hook
+
+    def _cfg(self, B: int, N: int) -> _lib.LayerCfg:
+        p = self.dropout if self.training else 0.0
+        if p != 0.0:
+            raise NotImplementedError(
+                f"dropout={p} in training mode is not implemented by the HIP path yet; call .eval() or construct "
+                f"with dropout=0 (parity with the reference is defined at p=0 / eval, SURVEY.md section 7)")
+        return _lib.LayerCfg(B, N, self.dim, self.heads, self.dim_head, self.mlp_dim, self.compute_dtype,
+                             int(self.project_out), 1e-5, 0.0)
+
+    @staticmethod
+    def _param_struct(params, l) -> _lib.LayerPtrs:
+        return _lib.LayerPtrs(*[p.data_ptr() for p in params[l * PARAMS_PER_LAYER:(l + 1) * PARAMS_PER_LAYER]])
+
+    def _workspace(self, lib, cfg, dev):
+        need = lib.avf_layer_workspace_bytes(C.byref(cfg))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+        return self._ws
+
+    def _lowp(self, lib, cfg, params, dev, stream):
+        """bf16 weight copies (+ transposes), refreshed only when a master weight changed."""
+        if cfg.dtype != _lib.BF16:
+            return [None] * self.depth
+        need = lib.avf_layer_lowp_bytes(C.byref(cfg))
+        versions = [(p.data_ptr(), p._version) for p in params]
+        if (self._lowp_bufs is None or self._lowp_bufs[0].numel() < need or self._lowp_bufs[0].device != dev):
+            self._lowp_bufs = [torch.empty(need, dtype=torch.uint8, device=dev) for _ in range(self.depth)]
+            self._lowp_versions = None
+        if self._lowp_versions != versions:
+            for l in range(self.depth):
+                pp = self._param_struct(params, l)
+                _lib.check(lib.avf_layer_prepare_weights(C.byref(cfg), C.byref(pp), _ptr(self._lowp_bufs[l]), stream),
+                           f"prepare_weights[{l}]")
+            self._lowp_versions = versions
+        return self._lowp_bufs
+
+    # ---- forward -------------------------------------------------------------------------------
+    def forward(self, x, mask=None):
+        if mask is not None:
+            # dead branch in the reference (no caller passes a mask); not built.
+            raise NotImplementedError("mask is not supported by the HIP path (no reference caller uses it)")
+        if not x.is_cuda:
+            raise RuntimeError("Transformer (HIP) needs its input on the MI355X; there is no CPU fallback - "
+                               "use oracle/ only as a test checker")
+        if x.dim() != 3 or x.shape[-1] != self.dim:
+            raise ValueError(f"expected [B, N, {self.dim}], got {tuple(x.shape)}")
+        params = self.flat_parameters()
+        for p in params:
+            if p.dtype != torch.float32 or not p.is_cuda:
+                raise RuntimeError("Transformer (HIP): parameters must be fp32 tensors on the GPU (model.to('cuda'))")
+        return _StackFn.apply(x.to(torch.float32), self, *params)

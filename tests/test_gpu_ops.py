@@ -1,0 +1,240 @@
+"""-m gpu: every per-operator C entry point against a plain fp32 restatement of the same op.
+
+Tolerances: parity mode (f32) 2e-5 abs / 1e-4 rel on O(1) data; throughput mode (bf16 operands, fp32
+accumulate) is judged by relative Frobenius error <= 1e-2 per op (bf16 has 8 significant bits: 2^-9 = 2e-3
+per rounding)."""
+import math
+
+import pytest
+import torch
+
+import oracle
+from conftest import load_golden
+from gpu_util import max_abs, rel_fro
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import avformer_amd as A
+    assert A.ops.device_ok()
+    return A.ops
+
+
+def _close(a, b, atol=2e-5, rtol=1e-4):
+    if not torch.is_tensor(b):
+        b = torch.tensor(b)
+    torch.testing.assert_close(a.detach().float().cpu(), b.detach().float().cpu(), atol=atol, rtol=rtol)
+
+
+# ---------------------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("rows,D", [(7, 32), (100, 128), (37, 48), (64, 512), (5, 1536), (33, 30)])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_fwd(ops, rows, D, out_dtype):
+    g = torch.Generator().manual_seed(rows * 1000 + D)
+    x = torch.randn(rows, D, generator=g) * 2 + 0.5
+    w = torch.randn(D, generator=g)
+    b = torch.randn(D, generator=g)
+    y, mean, rstd = ops.layernorm_fwd(x.cuda(), w.cuda(), b.cuda(), 1e-5, out_dtype)
+    ref = oracle.layernorm(x, w, b)
+    if out_dtype == torch.float32:
+        _close(y, ref)
+    else:
+        assert rel_fro(y, ref) < 4e-3
+    _close(mean, x.mean(-1))
+    _close(rstd, 1 / torch.sqrt(x.var(-1, unbiased=False) + 1e-5), atol=1e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("rows,D", [(7, 32), (100, 128), (37, 48), (300, 512), (33, 30)])
+@pytest.mark.parametrize("dy_dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_bwd(ops, rows, D, dy_dtype):
+    g = torch.Generator().manual_seed(rows * 1000 + D + 1)
+    x = (torch.randn(rows, D, generator=g) * 2 + 0.5).requires_grad_(True)
+    w = torch.randn(D, generator=g).requires_grad_(True)
+    b = torch.randn(D, generator=g).requires_grad_(True)
+    dy = torch.randn(rows, D, generator=g).to(dy_dtype)
+    dres = torch.randn(rows, D, generator=g)
+    y = oracle.layernorm(x, w, b)
+    y.backward(dy.float())
+    _, mean, rstd = ops.layernorm_fwd(x.detach().cuda(), w.detach().cuda(), b.detach().cuda())
+    dx, dx_lo, dg, db, cs = ops.layernorm_bwd(dy.cuda(), x.detach().cuda(), w.detach().cuda(), mean, rstd,
+                                              dres=dres.cuda(), want_lo=True, want_colsum=True)
+    ref_dx = x.grad + dres
+    _close(dx, ref_dx, atol=5e-5)
+    _close(dg, w.grad, atol=2e-4, rtol=2e-4)
+    _close(db, b.grad, atol=2e-4, rtol=2e-4)
+    _close(cs, ref_dx.sum(0), atol=5e-4, rtol=2e-4)
+    assert rel_fro(dx_lo, ref_dx) < 4e-3
+
+
+def test_colsum_and_cast(ops):
+    g = torch.Generator().manual_seed(5)
+    t = torch.randn(1000, 200, generator=g)
+    _close(ops.colsum(t.cuda()), t.sum(0), atol=2e-4)
+    tb = t.to(torch.bfloat16)
+    _close(ops.colsum(tb.cuda()), tb.float().sum(0), atol=2e-4)
+    for n in (1, 3, 4, 1023, 4096 + 2):
+        v = torch.randn(n, generator=g)
+        assert torch.equal(ops.cast_bf16(v.cuda()).cpu(), v.to(torch.bfloat16))
+    w = torch.randn(70, 100, generator=g)
+    lo, lo_t = ops.prep_weight_bf16(w.cuda())
+    assert torch.equal(lo.cpu(), w.to(torch.bfloat16))
+    assert torch.equal(lo_t.cpu(), w.t().contiguous().to(torch.bfloat16))
+
+
+# ---------------------------------------------------------------------------------------------- GEMM
+def _gemm_ref(a, b, ta, tb):
+    A_ = a.t() if ta else a
+    B_ = b.t() if tb else b
+    return A_.double() @ B_.double()
+
+
+@pytest.mark.parametrize("M,N,K", [(5, 12, 8), (64, 64, 16), (130, 70, 52), (300, 256, 128), (257, 96, 260)])
+@pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False)])
+def test_gemm_f32_forms(ops, M, N, K, ta, tb):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn((K, M) if ta else (M, K), generator=g)
+    b = torch.randn((N, K) if tb else (K, N), generator=g)
+    c = ops.gemm(a.cuda(), b.cuda(), trans_a=ta, trans_b=tb)
+    _close(c, _gemm_ref(a, b, ta, tb).float(), atol=1e-4 * math.sqrt(K), rtol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_epilogues(ops, dtype):
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 200, 136, 96
+    a = torch.randn(M, K, generator=g).to(dtype)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype)
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    base = a.double() @ w.double().t() + bias.double()
+    tol = dict(atol=1e-4, rtol=1e-4) if dtype == torch.float32 else dict(atol=3e-2, rtol=2e-2)
+    # bias + residual -> fp32
+    c = ops.gemm(a.cuda(), w.cuda(), out_dtype=torch.float32, epilogue=ops.EPI_BIAS_RES, bias=bias.cuda(), residual=res.cuda())
+    _close(c, (base + res.double()).float(), atol=1e-4 if dtype == torch.float32 else 1e-3, rtol=1e-4)
+    # bias + GELU (aux = pre-activation)
+    c, aux = ops.gemm(a.cuda(), w.cuda(), epilogue=ops.EPI_BIAS_GELU, bias=bias.cuda())
+    _close(aux, base.float(), **tol)
+    _close(c, oracle.gelu_tanh(base.float()), **tol)
+    # dGELU: C = (A W^T) * gelu'(aux)
+    u = torch.randn(M, N, generator=g).to(dtype)
+    uu = u.float().clone().requires_grad_(True)
+    oracle.gelu_tanh(uu).sum().backward()
+    c = ops.gemm(a.cuda(), w.cuda(), epilogue=ops.EPI_DGELU, aux=u.cuda())
+    _close(c, ((a.double() @ w.double().t()) * uu.grad.double()).float(), **tol)
+
+
+@pytest.mark.parametrize("M,N,K", [(8, 8, 8), (64, 128, 64), (200, 136, 96), (384, 1536, 512), (1000, 48, 40)])
+def test_gemm_bf16_nt(ops, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    b = torch.randn(N, K, generator=g).to(torch.bfloat16)
+    ref = _gemm_ref(a, b, False, True)
+    c32 = ops.gemm(a.cuda(), b.cuda(), out_dtype=torch.float32)
+    # fp32 accumulation of exact bf16 products: only summation-order noise
+    _close(c32, ref.float(), atol=2e-5 * K, rtol=1e-5)
+    c16 = ops.gemm(a.cuda(), b.cuda())
+    assert rel_fro(c16, ref) < 4e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(8, 8, 8), (64, 128, 64), (136, 96, 200), (1536, 512, 2048), (48, 40, 1000),
+                                   (512, 512, 16384)])
+def test_gemm_bf16_tn(ops, M, N, K):
+    """weight-gradient form: C[M,N] = A[K,M]^T B[K,N] (reduction over tokens), incl. the split-K path"""
+    g = torch.Generator().manual_seed(M + N + K + 1)
+    a = torch.randn(K, M, generator=g).to(torch.bfloat16)
+    b = torch.randn(K, N, generator=g).to(torch.bfloat16)
+    ref = _gemm_ref(a, b, True, False)
+    c = ops.gemm(a.cuda(), b.cuda(), trans_a=True, trans_b=False, out_dtype=torch.float32)
+    _close(c, ref.float(), atol=2e-5 * K, rtol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------- attention
+def _attn_ref(qkv, B, N, H, dh, d_o=None):
+    """fp64 restatement of heads.py:222-237 on the packed projection."""
+    I = H * dh
+    qkv = qkv.double().clone().requires_grad_(True)
+    q, k, v = qkv.view(B, N, 3 * I).split(I, dim=-1)
+    sh = lambda t: t.reshape(B, N, H, dh).permute(0, 2, 1, 3)
+    q, k, v = sh(q), sh(k), sh(v)
+    s = (q @ k.transpose(-1, -2)) * dh ** -0.5
+    p = s.softmax(-1)
+    o = (p @ v).permute(0, 2, 1, 3).reshape(B * N, I)
+    lse2 = torch.logsumexp(s, dim=-1) * math.log2(math.e)
+    dqkv = None
+    if d_o is not None:
+        o.backward(d_o.double())
+        dqkv = qkv.grad
+    return o.detach(), lse2.detach(), dqkv
+
+
+@pytest.mark.parametrize("B,N,H,dh", [(2, 7, 4, 8), (1, 64, 2, 32), (2, 49, 8, 32), (3, 17, 8, 64), (2, 130, 3, 64),
+                                      (1, 324, 2, 64), (2, 12, 8, 16)])
+def test_attention_f32(ops, B, N, H, dh):
+    g = torch.Generator().manual_seed(B * 100 + N + dh)
+    qkv = torch.randn(B * N, 3 * H * dh, generator=g)
+    d_o = torch.randn(B * N, H * dh, generator=g)
+    o_ref, lse_ref, dqkv_ref = _attn_ref(qkv, B, N, H, dh, d_o)
+    o, lse2 = ops.attn_fwd(qkv.cuda(), B, N, H, dh)
+    _close(o, o_ref.float())
+    _close(lse2, lse_ref.float(), atol=1e-4)
+    dqkv = ops.attn_bwd(qkv.cuda(), o, d_o.cuda(), lse2, B, N, H, dh)
+    _close(dqkv, dqkv_ref.float(), atol=5e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,N,H,dh", [(1, 64, 2, 32), (2, 49, 8, 32), (3, 17, 8, 64), (2, 130, 3, 64), (1, 324, 2, 64),
+                                      (2, 12, 8, 32), (1, 512, 2, 64), (1, 200, 1, 32)])
+def test_attention_bf16(ops, B, N, H, dh):
+    g = torch.Generator().manual_seed(B * 100 + N + dh + 1)
+    qkv = torch.randn(B * N, 3 * H * dh, generator=g).to(torch.bfloat16)
+    d_o = torch.randn(B * N, H * dh, generator=g).to(torch.bfloat16)
+    o_ref, lse_ref, dqkv_ref = _attn_ref(qkv.float(), B, N, H, dh, d_o.float())
+    o, lse2 = ops.attn_fwd(qkv.cuda(), B, N, H, dh)
+    assert rel_fro(o, o_ref) < 1e-2, rel_fro(o, o_ref)
+    _close(lse2, lse_ref.float(), atol=2e-2, rtol=1e-3)
+    dqkv = ops.attn_bwd(qkv.cuda(), o, d_o.cuda(), lse2, B, N, H, dh)
+    I = H * dh
+    for name, sl in (("dq", slice(0, I)), ("dk", slice(I, 2 * I)), ("dv", slice(2 * I, 3 * I))):
+        e = rel_fro(dqkv[:, sl], dqkv_ref[:, sl])
+        assert e < 2e-2, (name, e)
+
+
+def test_attention_bf16_spiked_scores(ops):
+    """online-softmax rescale path: one key dominates late in the sequence (max jumps at a later tile)"""
+    B, N, H, dh = 1, 256, 1, 64
+    g = torch.Generator().manual_seed(3)
+    qkv = torch.randn(B * N, 3 * dh, generator=g)
+    qkv[200, dh:2 * dh] = qkv[5, 0:dh] * 6.0  # key 200 aligned with query 5 -> huge score in tile 3
+    qkv = qkv.to(torch.bfloat16)
+    o_ref, lse_ref, _ = _attn_ref(qkv.float(), B, N, H, dh)
+    o, lse2 = ops.attn_fwd(qkv.cuda(), B, N, H, dh)
+    assert rel_fro(o, o_ref) < 1e-2
+    assert max_abs(o, o_ref) < 5e-2
+    _close(lse2, lse_ref.float(), atol=5e-2, rtol=1e-3)
+
+
+# ---------------------------------------------------------------------------------------------- AU loss
+@pytest.mark.parametrize("tag", ["all", "ign"])
+def test_au_loss_golden(ops, tag):
+    import avformer_amd as A
+    g = load_golden("g8_au_loss")
+    crit = A.AULoss().cuda()
+    z = g[f"{tag}.z"].cuda().requires_grad_(True)
+    loss = crit(z, g[f"{tag}.y"].cuda())
+    loss.backward()
+    _close(loss, g[f"{tag}.loss"], atol=1e-6, rtol=1e-5)
+    _close(z.grad, g[f"{tag}.dz"], atol=1e-7, rtol=1e-5)
+
+
+def test_au_loss_strided_and_all_ignored(ops):
+    import avformer_amd as A
+    crit = A.AULoss().cuda()
+    g = torch.Generator().manual_seed(2)
+    out = torch.randn(9, 21, generator=g)
+    y = (torch.rand(9, 12, generator=g) > 0.5).float()
+    y[4] = -1
+    ref = oracle.au_loss(out[:, :12], y)
+    got = crit(out.cuda()[:, :12], y.cuda())  # strided view, as get_au_loss passes it (avformer.py:116)
+    _close(got, ref, atol=1e-6, rtol=1e-5)
+    assert torch.isnan(crit(out.cuda()[:, :12], -torch.ones(9, 12).cuda()))
