@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py - clips/sec (fwd+bwd) of the AV-former transformer hot path on synthetic (B,T,d) AV sequences.
+
+    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+
+One "step" = one training pass of the hot path over one resident synthetic batch on every rank:
+zero_grad -> SyntheticAVFormer forward (pos-emb + Transformer stack + AU logits) -> AULoss -> backward (hand-written
+HIP kernels) -> gradient all-reduce (RCCL, overlapped with backward; N>1 only) -> Adam step (as reference train.py:206-237).
+Workload at N=1: BASELINE.json configs[1] ("C2"): d=512, 6 layers, 8 heads x 64, mlp 1024, T_v=196 + T_a=128 = 324
+tokens, B=32 per GPU, bf16 MFMA compute with fp32 accumulate/residual.  Weak scaling: B=32 per GPU at every N.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel class, timed
+live with HIP events on the launch stream during the timed steps) and `cpu_baseline` (the CPU oracle - a port of the
+reference's math - timed on this host, rank 0, N=1 only, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: dim, depth, heads, dim_head, mlp, T_v, T_a, per-GPU batch
+    "c1": dict(dim=128, depth=2, heads=8, dim_head=32, mlp_dim=256, t_video=32, t_audio=32, batch=4),
+    "c2": dict(dim=512, depth=6, heads=8, dim_head=64, mlp_dim=1024, t_video=196, t_audio=128, batch=32),
+    "c3": dict(dim=512, depth=6, heads=8, dim_head=64, mlp_dim=1024, t_video=384, t_audio=128, batch=32),
+    "c4": dict(dim=768, depth=12, heads=12, dim_head=64, mlp_dim=1536, t_video=768, t_audio=256, batch=16),
+}
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def stack_flops_fwd(c, B):
+    D, L, H, dh, M = c["dim"], c["depth"], c["heads"], c["dim_head"], c["mlp_dim"]
+    N, I = c["t_video"] + c["t_audio"], c["heads"] * c["dim_head"]
+    return L * (2.0 * B * N * (3 * D * I + I * D + 2 * D * M) + 4.0 * B * N * N * I)
+
+
+def cpu_baseline(c, steps, threads):
+    """The oracle (a port of the reference's op sequence) fwd+bwd on the host CPU, same shapes."""
+    import torch
+    import oracle
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(123)
+    D, L, H, dh, M = c["dim"], c["depth"], c["heads"], c["dim_head"], c["mlp_dim"]
+    B, N = c["batch"], c["t_video"] + c["t_audio"]
+    sd = oracle.init_transformer_state(D, L, H, dh, M, generator=g)
+    sd = {k: v.requires_grad_(True) for k, v in sd.items()}
+    pos = (torch.randn(1, N, D, generator=g) * 0.02).requires_grad_(True)
+    w = (torch.randn(12, D, generator=g) * 0.04).requires_grad_(True)
+    b = torch.zeros(12, requires_grad=True)
+    x = torch.randn(B, N, D, generator=g)
+    labels = (torch.rand(B, 12, generator=g) > 0.5).float()
+
+    def one():
+        for t in list(sd.values()) + [pos, w, b]:
+            t.grad = None
+        y = oracle.transformer_forward(x + pos, sd, L, H)
+        loss = oracle.au_loss(y.mean(1) @ w.t() + b, labels)
+        loss.backward()
+
+    one()  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    dt = (time.perf_counter() - t0) / steps
+    return B / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--no-optimizer", action="store_true", help="time fwd+bwd(+all-reduce) only")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import avformer_amd as A
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with: python -m torch.distributed.run --nproc-per-node N "
+                             "--master-addr 127.0.0.1 bench.py --gpus N ...")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    A._lib.load()  # no fallback: fails here if the HIP library is missing
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    c = dict(CONFIGS[args.config])
+    if args.batch:
+        c["batch"] = args.batch
+    B, Tv, Ta = c["batch"], c["t_video"], c["t_audio"]
+    torch.manual_seed(123)  # identical weights on every rank (reference default seed, opts.py:19)
+    model = A.SyntheticAVFormer(c["dim"], c["depth"], c["heads"], c["dim_head"], c["mlp_dim"], Tv, Ta, task="AU",
+                                compute_dtype=args.dtype).to(dev)
+    g = torch.Generator().manual_seed(123 + rank)  # rank-distinct synthetic clips
+    clip = torch.randn(B, Tv, c["dim"], generator=g).to(dev)
+    audio = torch.randn(B, Ta, c["dim"], generator=g).to(dev)
+    labels = (torch.rand(B, 12, generator=g) > 0.5).float()
+    labels[::16] = -1  # 1/16 of the clips carry the ignore label
+    labels = labels.to(dev)
+    batch = {"clip": clip, "audio_features": audio}
+    opt = None
+    if not args.no_optimizer:
+        try:
+            opt = torch.optim.Adam(model.parameters(), lr=5e-4, weight_decay=5e-5, fused=True)
+        except Exception:
+            opt = torch.optim.Adam(model.parameters(), lr=5e-4, weight_decay=5e-5)
+    dp = A.dp.DataParallel(model) if world > 1 else None
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        out = model(batch)
+        loss = model.get_au_loss(out, labels)
+        loss.backward()
+        if dp is not None:
+            dp.finish()
+        if opt is not None:
+            opt.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    events = not args.no_kernel_events
+    if events:
+        A._lib.timing_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if events:
+        A._lib.timing_enable(False)
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = t.item()
+    ms_per_step = dt / args.steps * 1e3
+    clips_per_s = B * world * args.steps / dt
+
+    result = {
+        "metric": "clips/sec (fwd+bwd) on synthetic (B,T,d) AV sequences",
+        "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"BASELINE.json configs[{'1' if args.config == 'c2' else args.config}]: avformer "
+                               f"transformer stack d={c['dim']} L={c['depth']} H={c['heads']}x{c['dim_head']} "
+                               f"mlp={c['mlp_dim']}, T_v={Tv}+T_a={Ta} tokens, B={B}/GPU",
+                   "global_batch": B * world, "seq_len": Tv + Ta, "parallelism": f"dp{world}",
+                   "step": "zero_grad+fwd+AULoss+bwd" + ("+allreduce" if world > 1 else "") + ("+adam" if opt else ""),
+                   "loss": float(loss.item())},
+    }
+    if rank == 0:
+        flops_step = 3.0 * stack_flops_fwd(c, B)
+        result["stack_tflops_per_gpu"] = round(flops_step / (ms_per_step * 1e-3) / 1e12, 2)
+        if events:
+            tm = A._lib.timing_read()
+            mfma = {k: v for k, v in tm.items() if k.startswith("gemm") or k.startswith("attn")}
+            dom = max(mfma, key=lambda k: mfma[k]["ms"])
+            d = mfma[dom]
+            if d["launches"] > 0 and d["ms"] > 0:
+                ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+                peak = MFMA_PEAK_TFLOPS[args.dtype]
+                result["roofline"] = {
+                    "kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": None,
+                    "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2), "launches": d["launches"],
+                    "flops_per_launch": d["flops"] / d["launches"],
+                    "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
+                    "algorithmic_GBps": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1),
+                    "measured": "HIP events around every launch of this kernel class on the launch stream, timed steps",
+                }
+            result["kernel_classes"] = {
+                k: {"ms_per_step": round(v["ms"] / args.steps, 4), "launches_per_step": v["launches"] / args.steps,
+                    "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 and v["flops"] > 0 else None,
+                    "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None}
+                for k, v in tm.items() if v["launches"] > 0}
+        if world == 1 and not args.no_cpu_baseline:
+            threads = min(os.cpu_count() or 1, 16)
+            try:
+                threads = min(threads, len(os.sched_getaffinity(0)))
+            except Exception:
+                pass
+            cps, sec = cpu_baseline(c, args.cpu_steps, threads)
+            result["cpu_baseline"] = {
+                "value": round(cps, 3), "unit": "clips/s", "cores": threads, "kind": "port",
+                "sample": f"{args.cpu_steps} fwd+bwd steps (after 1 warm-up) of the same workload (B={B}) through "
+                          f"oracle/ (fp32 eager PyTorch ops, un-fused, as the reference), {sec:.2f} s/step"}
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

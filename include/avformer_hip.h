@@ -135,6 +135,12 @@ int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p, const voi
                   const void* saved, const float* dx_out, const void* dx_out_lo, float* dx_in, void* dx_in_lo,
                   const avf_layer_grads* g, void* workspace, void* stream);
 
+/* ---- optional HIP-event timing per kernel class (bench.py's roofline line) --------------------------
+ * classes: 0 gemm_bf16_nt, 1 gemm_bf16_tn(+fold), 2 gemm_f32, 3 attn_fwd, 4 attn_bwd, 5 layernorm.
+ * enable(1) resets the records; read() synchronises the recorded events and sums them. */
+int avf_timing_enable(int on);
+int avf_timing_read(int cls, double* total_ms, int64_t* launches, double* flops, double* bytes);
+
 /* ---- hardware self-tests used by tests/ (MFMA fragment maps, transposed LDS read) ----------- */
 int avf_selftest_mfma_bf16(const void* a_bf16_16x32, const void* b_bf16_32x16, float* c_16x16, void* stream);
 int avf_selftest_mfma_f32(const float* a_16x4, const float* b_4x16, float* c_16x16, void* stream);

@@ -62,6 +62,9 @@ SIGNATURES = {
     "avf_layer_fwd": (_int, [C.POINTER(LayerCfg), C.POINTER(LayerPtrs), _vp, _vp, _vp, _vp, _vp, _vp]),
     "avf_layer_bwd": (_int, [C.POINTER(LayerCfg), C.POINTER(LayerPtrs), _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                              C.POINTER(LayerPtrs), _vp, _vp]),
+    "avf_timing_enable": (_int, [_int]),
+    "avf_timing_read": (_int, [_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                               C.POINTER(C.c_double)]),
     "avf_selftest_mfma_bf16": (_int, [_vp, _vp, _vp, _vp]),
     "avf_selftest_mfma_f32": (_int, [_vp, _vp, _vp, _vp]),
     "avf_selftest_tr16": (_int, [_vp, _vp, _vp]),
@@ -104,6 +107,24 @@ def load(build_if_missing: bool = False):
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+KERNEL_CLASSES = ("gemm_bf16_nt", "gemm_bf16_tn", "gemm_f32", "attn_fwd", "attn_bwd", "layernorm")
+
+
+def timing_enable(on: bool):
+    check(load().avf_timing_enable(int(on)), "timing_enable")
+
+
+def timing_read():
+    """-> {class name: dict(ms, launches, flops, bytes)} for the launches recorded since timing_enable(True)."""
+    lib = load()
+    out = {}
+    for i, name in enumerate(KERNEL_CLASSES):
+        ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+        check(lib.avf_timing_read(i, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)), "timing_read")
+        out[name] = dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)
+    return out
 
 
 def check(rc: int, what: str = ""):

@@ -26,6 +26,32 @@ int check_launch(const char* what) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// event timing
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int TIMING_POOL = 32768;
+struct TimingRec { hipEvent_t start, stop; int cls; double flops, bytes; };
+bool g_timing_on = false;
+TimingRec* g_recs = nullptr;
+int g_created = 0, g_used = 0;
+}  // namespace
+
+TimingScope::TimingScope(int cls, double flops, double bytes, hipStream_t s) : slot(-1), stream(s) {
+  if (!g_timing_on || g_used >= TIMING_POOL) return;
+  if (!g_recs) g_recs = new TimingRec[TIMING_POOL];
+  if (g_used >= g_created) {
+    if (hipEventCreate(&g_recs[g_created].start) != hipSuccess || hipEventCreate(&g_recs[g_created].stop) != hipSuccess) return;
+    ++g_created;
+  }
+  slot = g_used++;
+  g_recs[slot].cls = cls; g_recs[slot].flops = flops; g_recs[slot].bytes = bytes;
+  (void)hipEventRecord(g_recs[slot].start, s);
+}
+TimingScope::~TimingScope() {
+  if (slot >= 0) (void)hipEventRecord(g_recs[slot].stop, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
 // self-tests
 // ---------------------------------------------------------------------------------------------
 // C[16x16] = A[16x32] * B[32x16] with one v_mfma_f32_16x16x32_bf16, operands fetched with the
@@ -74,6 +100,27 @@ __global__ void selftest_tr16_kernel(const bf16* tile, bf16* out) {
 using namespace avf;
 
 extern "C" int avf_version(void) { return 1; }
+
+extern "C" int avf_timing_enable(int on) {
+  g_timing_on = on != 0;
+  if (on) g_used = 0;
+  return 0;
+}
+extern "C" int avf_timing_read(int cls, double* total_ms, int64_t* launches, double* flops, double* bytes) {
+  AVF_REQUIRE(cls >= 0 && cls < KC_COUNT && total_ms && launches && flops && bytes, "timing_read: bad arguments");
+  double ms = 0, fl = 0, by = 0;
+  int64_t n = 0;
+  for (int i = 0; i < g_used; ++i) {
+    if (g_recs[i].cls != cls) continue;
+    float t = 0.f;
+    hipError_t e = hipEventSynchronize(g_recs[i].stop);
+    if (e == hipSuccess) e = hipEventElapsedTime(&t, g_recs[i].start, g_recs[i].stop);
+    AVF_REQUIRE(e == hipSuccess, "timing_read: %s", hipGetErrorString(e));
+    ms += t; fl += g_recs[i].flops; by += g_recs[i].bytes; ++n;
+  }
+  *total_ms = ms; *launches = n; *flops = fl; *bytes = by;
+  return 0;
+}
 extern "C" const char* avf_last_error(void) { return g_err; }
 
 extern "C" int avf_device_ok(void) {

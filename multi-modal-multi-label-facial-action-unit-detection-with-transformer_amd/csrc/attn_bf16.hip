@@ -500,6 +500,7 @@ int attn_fwd_bf16(const bf16* qkv, bf16* o, float* lse2, int B, int N, int H, in
   AVF_REQUIRE(B > 0 && N > 0 && H > 0, "attn_fwd_bf16: bad shape");
   AVF_REQUIRE((int64_t)B * H < 65536, "attn_fwd_bf16: batch*heads too large for grid");
   AVF_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)o & 7) == 0, "attn_fwd_bf16: misaligned pointers");
+  TimingScope ts(KC_ATTN_FWD, 4.0 * B * H * (double)N * N * dh, 2.0 * 4.0 * B * N * H * dh, s);
   dim3 grid((unsigned)ceil_div(N, 128), (unsigned)(B * H));
   if (dh == 64) attn_fwd_bf16_kernel<64><<<grid, 256, 0, s>>>(qkv, o, lse2, B, N, H);
   else if (dh == 32) attn_fwd_bf16_kernel<32><<<grid, 256, 0, s>>>(qkv, o, lse2, B, N, H);
@@ -513,6 +514,7 @@ int attn_bwd_bf16(const bf16* qkv, const bf16* o, const bf16* d_o, const float* 
   AVF_REQUIRE((int64_t)B * H < 65536, "attn_bwd_bf16: batch*heads too large for grid");
   AVF_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)d_o & 15) == 0 && ((uintptr_t)dqkv & 7) == 0,
               "attn_bwd_bf16: misaligned pointers");
+  TimingScope ts(KC_ATTN_BWD, 10.0 * B * H * (double)N * N * dh, 2.0 * 8.0 * B * N * H * dh, s);
   AVF_TRY(attn_delta(AVF_BF16, o, d_o, delta, B, N, H, dh, s));
   dim3 grid((unsigned)ceil_div(N, 128), (unsigned)(B * H));
   if (dh == 64) {

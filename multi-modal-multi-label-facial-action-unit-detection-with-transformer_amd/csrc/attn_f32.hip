@@ -260,6 +260,7 @@ int attn_delta(int dtype, const void* o, const void* d_o, float* delta, int B, i
 int attn_fwd_f32(const float* qkv, float* o, float* lse2, int B, int N, int H, int dh, hipStream_t s) {
   AVF_REQUIRE(B > 0 && N > 0 && H > 0, "attn_fwd_f32: bad shape");
   AVF_REQUIRE((int64_t)B * H < 65536, "attn_fwd_f32: batch*heads too large for grid");
+  TimingScope ts(KC_ATTN_FWD, 4.0 * B * H * (double)N * N * dh, 4.0 * 4.0 * B * N * H * dh, s);
   dim3 grid((unsigned)ceil_div(N, 64), (unsigned)(B * H));
 #define L(D) attn_fwd_f32_kernel<D><<<grid, 64, 0, s>>>(qkv, o, lse2, B, N, H)
   AVF_DH_DISPATCH(dh, L)
@@ -271,6 +272,7 @@ int attn_bwd_f32(const float* qkv, const float* o, const float* d_o, const float
                  int B, int N, int H, int dh, hipStream_t s) {
   AVF_REQUIRE(B > 0 && N > 0 && H > 0, "attn_bwd_f32: bad shape");
   AVF_REQUIRE((int64_t)B * H < 65536, "attn_bwd_f32: batch*heads too large for grid");
+  TimingScope ts(KC_ATTN_BWD, 10.0 * B * H * (double)N * N * dh, 4.0 * 8.0 * B * N * H * dh, s);
   AVF_TRY(attn_delta(AVF_F32, o, d_o, delta, B, N, H, dh, s));
   dim3 grid((unsigned)ceil_div(N, 64), (unsigned)(B * H));
 #define L(D)                                                                                 \

@@ -30,6 +30,19 @@ int check_launch(const char* what);
   } while (0)
 
 // ---------------------------------------------------------------------------------------------
+// optional per-kernel-class HIP-event timing (bench.py's roofline line); off by default
+// ---------------------------------------------------------------------------------------------
+enum KernelClass {
+  KC_GEMM_BF16_NT = 0, KC_GEMM_BF16_TN, KC_GEMM_F32, KC_ATTN_FWD, KC_ATTN_BWD, KC_LAYERNORM, KC_OTHER, KC_COUNT
+};
+struct TimingScope {  // records a start/stop event pair around the launches issued during its lifetime
+  int slot;
+  hipStream_t stream;
+  TimingScope(int cls, double flops, double bytes, hipStream_t s);
+  ~TimingScope();
+};
+
+// ---------------------------------------------------------------------------------------------
 // element types
 // ---------------------------------------------------------------------------------------------
 struct bf16 {

@@ -300,6 +300,8 @@ int gemm_bf16_nt(const GemmArgs& a, hipStream_t s) {
               "gemm_bf16_nt: operands must be 16-byte aligned");
   AVF_REQUIRE(a.M < (1LL << 31) && a.N < (1LL << 31) && a.K < (1LL << 31), "gemm_bf16_nt: shape too large");
   NtParams p;
+  TimingScope ts(KC_GEMM_BF16_NT, 2.0 * a.M * a.N * a.K,
+                 2.0 * (a.M * a.K + a.N * a.K) + (a.c_dtype == AVF_F32 ? 4.0 : 2.0) * a.M * a.N, s);
   p.A = (const bf16*)a.A; p.lda = a.lda; p.B = (const bf16*)a.B; p.ldb = a.ldb;
   p.C = a.C; p.ldc = a.ldc; p.bias = a.bias; p.residual = a.residual; p.ldres = a.ldres;
   p.aux = (bf16*)a.aux; p.ldaux = a.ldaux;
@@ -351,6 +353,7 @@ int gemm_bf16_tn(const GemmArgs& a, hipStream_t s) {
   const int S = tn_splits(a.M, a.N, a.K);
   AVF_REQUIRE(S == 1 || a.workspace, "gemm_bf16_tn: split-K workspace missing");
   TnParams p;
+  TimingScope ts(KC_GEMM_BF16_TN, 2.0 * a.M * a.N * a.K, 2.0 * (a.M * a.K + a.N * a.K) + 4.0 * a.M * a.N, s);
   p.A = (const bf16*)a.A; p.lda = a.lda; p.B = (const bf16*)a.B; p.ldb = a.ldb;
   p.M = (int)a.M; p.N = (int)a.N; p.K = (int)a.K;
   p.kchunk = (int)(ceil_div(ceil_div(a.K, S), TR) * TR);

@@ -119,6 +119,7 @@ int gemm_f32(const GemmArgs& a, hipStream_t s) {
   AVF_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm_f32: bad shape");
   AVF_REQUIRE(a.M < (1LL << 31) && a.N < (1LL << 31) && a.K < (1LL << 31), "gemm_f32: shape too large");
   F32GemmParams p;
+  TimingScope ts(KC_GEMM_F32, 2.0 * a.M * a.N * a.K, 4.0 * (a.M * a.K + a.N * a.K + a.M * a.N), s);
   p.A = (const float*)a.A;
   p.B = (const float*)a.B;
   if (a.transA) { p.a_sm = 1; p.a_sk = a.lda; } else { p.a_sm = a.lda; p.a_sk = 1; }

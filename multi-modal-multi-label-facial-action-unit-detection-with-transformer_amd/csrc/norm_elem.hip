@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 int layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype, float* mean,
                   float* rstd, int64_t rows, int dim, float eps, hipStream_t s) {
   AVF_REQUIRE(rows > 0 && dim > 0, "layernorm_fwd: bad shape rows=%lld dim=%d", (long long)rows, dim);
+  TimingScope ts(KC_LAYERNORM, 0.0, (double)rows * dim * (4.0 + (y_dtype == AVF_BF16 ? 2.0 : 4.0)), s);
   dim3 grid((unsigned)ceil_div(rows, 4)), block(256);
   if (y_dtype == AVF_F32)
     ln_fwd_kernel<float><<<grid, block, 0, s>>>(x, gamma, beta, (float*)y, mean, rstd, rows, dim, eps);
@@ -201,6 +202,8 @@ int layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gam
                   float* dcolsum, void* ws, int64_t rows, int dim, hipStream_t s) {
   AVF_REQUIRE(rows > 0 && dim > 0 && ws, "layernorm_bwd: bad arguments");
   AVF_REQUIRE((size_t)3 * dim * sizeof(float) <= 64 * 1024, "layernorm_bwd: dim %d too large", dim);
+  TimingScope ts(KC_LAYERNORM, 0.0,
+                 (double)rows * dim * ((dy_dtype == AVF_BF16 ? 2.0 : 4.0) + 4.0 + (dres ? 4.0 : 0.0) + 4.0 + (dx_lo ? 2.0 : 0.0)), s);
   const int nb = (int)ceil_div(rows, LNB_ROWS_PER_BLOCK);
   const size_t lds = (size_t)3 * dim * sizeof(float);
   float* partial = (float*)ws;

@@ -1,0 +1,81 @@
+"""Per-clip data parallelism: one process per GPU, replicated weights, batch sharded across ranks,
+one SUM all-reduce of the parameter gradients per step (RCCL over xGMI on the GPUs; gloo in CPU tests).
+
+The reference has no distributed code at all (single process); the hot path shards
+naturally because every op is per-clip (LayerNorm, attention within a clip, per-token MLP).
+
+Overlap: each ``Transformer`` calls a hook right after a layer's backward has been enqueued (reverse layer
+order) with that layer's flat fp32 gradient bucket (11 tensors, 2.1 M floats at d=512).  The hook chains an
+event from the compute stream to a dedicated communication stream and launches the bucket's all-reduce
+there, so it runs under the backward of the earlier layers.  ``finish()`` reduces the few parameters
+outside the transformer stacks in one extra bucket and makes the compute stream wait for everything.
+Gradients are averaged (sum / world) so that the update equals a single-process step on the global batch.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class DataParallel:
+    def __init__(self, model: torch.nn.Module, process_group=None, broadcast_parameters: bool = True):
+        if not dist.is_initialized():
+            raise RuntimeError("DataParallel needs torch.distributed to be initialised (one process per GPU)")
+        self.model = model
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        self._stacks = [m for m in model.modules() if hasattr(m, "set_grad_hook") and hasattr(m, "flat_parameters")]
+        self._owned = set()
+        for st in self._stacks:
+            st.set_grad_hook(self._on_layer_grads)
+            self._owned.update(id(p) for p in st.flat_parameters())
+        self._cuda = any(p.is_cuda for p in model.parameters())
+        self._comm = torch.cuda.Stream() if self._cuda else None
+        self._pending: List = []
+        if broadcast_parameters:
+            for t in list(model.parameters()) + list(model.buffers()):
+                dist.broadcast(t.data, src=0, group=process_group)
+
+    # -- called from Transformer backward, once per layer ------------------------------------------
+    def _on_layer_grads(self, layer: int, flat: torch.Tensor):
+        work = self._launch(flat)
+        return work.wait  # accumulation path: make the current stream wait for this bucket
+
+    def _launch(self, flat: torch.Tensor):
+        if self._cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self._comm):
+                self._comm.wait_event(ev)
+                flat.div_(self.world)
+                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            flat.record_stream(self._comm)
+        else:
+            flat.div_(self.world)
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending.append((work, flat))
+        return work
+
+    # -- called once per step, after loss.backward() and before optimizer.step() -------------------
+    def finish(self):
+        rest = [p for p in self.model.parameters() if p.grad is not None and id(p) not in self._owned]
+        bucket: Optional[torch.Tensor] = None
+        if rest:
+            bucket = torch.cat([p.grad.reshape(-1) for p in rest])
+            self._launch(bucket)
+        for work, _ in self._pending:
+            work.wait()  # CUDA: the current stream waits (no host block); gloo: blocks until done
+        if self._cuda:
+            torch.cuda.current_stream().wait_stream(self._comm)
+        if bucket is not None:
+            off = 0
+            for p in rest:
+                n = p.numel()
+                p.grad.copy_(bucket[off:off + n].view_as(p.grad))
+                off += n
+        self._pending.clear()
+
+    def __call__(self, *a, **k):
+        return self.model(*a, **k)

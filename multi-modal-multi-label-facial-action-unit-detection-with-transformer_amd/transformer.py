@@ -119,7 +119,7 @@ class _StackFn(torch.autograd.Function):
         lo_a = torch.empty((B * N, D), dtype=torch.bfloat16, device=dev) if bf16 else None
         lo_b = torch.empty((B * N, D), dtype=torch.bfloat16, device=dev) if bf16 else None
         have_lo = False
-        grads: List[Optional[torch.Tensor]] = [None] * (L * PARAMS_PER_LAYER)
+        live = mod.flat_parameters()
         sizes = [p.numel() for p in ctx.params[:PARAMS_PER_LAYER]]
         hook = mod._grad_hook
         for l in reversed(range(L)):
@@ -135,13 +135,21 @@ class _StackFn(torch.autograd.Function):
                                          _ptr(lo_b), C.byref(gp), _ptr(ws), stream), f"layer_bwd[{l}]")
             lo_a, lo_b = lo_b, lo_a
             have_lo = bf16
-            for i, v in enumerate(views):
-                grads[l * PARAMS_PER_LAYER + i] = v
-            if hook is not None:
-                hook(l, flat)  # e.g. launch this layer's gradient all-reduce while earlier layers still run
+            waiter = hook(l, flat) if hook is not None else None  # e.g. launch this layer's all-reduce now
+            # Parameter gradients are handed over directly (views of the layer's flat buffer, no copy):
+            # ``.grad = view`` when empty, ``.grad += view`` when accumulating.
+            for p, v in zip(live[l * PARAMS_PER_LAYER:(l + 1) * PARAMS_PER_LAYER], views):
+                if not p.requires_grad:
+                    continue
+                if p.grad is None:
+                    p.grad = v
+                else:
+                    if waiter is not None:
+                        waiter()  # accumulation needs the reduced values
+                    p.grad.add_(v)
         ctx.saved_bufs = None
         ctx.xs = None
-        return (dx.view(B, N, D), None, *grads)
+        return (dx.view(B, N, D), None, *([None] * (L * PARAMS_PER_LAYER)))
 
 
 class Transformer(nn.Module):
@@ -157,7 +165,7 @@ class Transformer(nn.Module):
         self._ws = None
         self._lowp_bufs = None
         self._lowp_versions = None
-        self._grad_hook: Optional[Callable[[int, torch.Tensor], None]] = None
+        self._grad_hook: Optional[Callable] = None
 
     # ---- parameter plumbing --------------------------------------------------------------------
     def layer_parameters(self, l: int) -> List[torch.Tensor]:
@@ -175,9 +183,10 @@ class Transformer(nn.Module):
             out += self.layer_parameters(l)
         return out
 
-    def set_grad_hook(self, hook: Optional[Callable[[int, torch.Tensor], None]]):
+    def set_grad_hook(self, hook: Optional[Callable]):
         """``hook(layer_index, flat_fp32_grad_of_that_layer)`` is called right after the layer's backward has
-        been enqueued (reverse layer order) - the data-parallel wrapper launches its all-reduce there."""
+        been enqueued (reverse layer order) - the data-parallel wrapper launches its all-reduce there.  It may
+        return a callable that makes the current stream wait for that reduction."""
         self._grad_hook = hook
 
     def _cfg(self, B: int, N: int) -> _lib.LayerCfg:
