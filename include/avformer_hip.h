@@ -130,10 +130,13 @@ int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p, const voi
 
 /* dx_in (fp32) and all parameter gradients from dx_out (fp32).  dx_out_lo: optional bf16 copy of dx_out
  * (null => made internally); dx_in_lo: optional bf16 copy of dx_in to hand to the previous layer.
- * dx_in may alias dx_out. */
+ * dx_out_colsum: optional [D] column sums of dx_out (= this layer's b2 gradient) already computed by the
+ * caller's previous call; dx_in_colsum: optional [D] output, column sums of dx_in for the next call.
+ * dx_in may alias dx_out (dx_out_lo / dx_in_lo must then be distinct buffers). */
 int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p, const void* lowp, const float* x_in,
-                  const void* saved, const float* dx_out, const void* dx_out_lo, float* dx_in, void* dx_in_lo,
-                  const avf_layer_grads* g, void* workspace, void* stream);
+                  const void* saved, const float* dx_out, const void* dx_out_lo, const float* dx_out_colsum,
+                  float* dx_in, void* dx_in_lo, float* dx_in_colsum, const avf_layer_grads* g, void* workspace,
+                  void* stream);
 
 /* ---- optional HIP-event timing per kernel class (bench.py's roofline line) --------------------------
  * classes: 0 gemm_bf16_nt, 1 gemm_bf16_tn(+fold), 2 gemm_f32, 3 attn_fwd, 4 attn_bwd, 5 layernorm.

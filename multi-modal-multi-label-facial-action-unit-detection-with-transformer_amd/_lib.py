@@ -60,7 +60,7 @@ SIGNATURES = {
     "avf_layer_workspace_bytes": (_sz, [C.POINTER(LayerCfg)]),
     "avf_layer_prepare_weights": (_int, [C.POINTER(LayerCfg), C.POINTER(LayerPtrs), _vp, _vp]),
     "avf_layer_fwd": (_int, [C.POINTER(LayerCfg), C.POINTER(LayerPtrs), _vp, _vp, _vp, _vp, _vp, _vp]),
-    "avf_layer_bwd": (_int, [C.POINTER(LayerCfg), C.POINTER(LayerPtrs), _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+    "avf_layer_bwd": (_int, [C.POINTER(LayerCfg), C.POINTER(LayerPtrs), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                              C.POINTER(LayerPtrs), _vp, _vp]),
     "avf_timing_enable": (_int, [_int]),
     "avf_timing_read": (_int, [_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),

@@ -214,37 +214,47 @@ __global__ __launch_bounds__(64) void attn_dkv_f32_kernel(const float* __restric
   }
 }
 
-// delta[b,h,n] = sum_d dO[b,n,h,d] * O[b,n,h,d]   (= rowsum(dP o P))
-template <typename T>
+// delta[b,h,n] = sum_d dO[b,n,h,d] * O[b,n,h,d]   (= rowsum(dP o P)).  Each lane takes one 16-byte granule of a
+// token row (fully coalesced over [B*N, I]); the DH/VEC lanes of a head reduce with xor-shuffles.
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ d_o,
                                                          float* __restrict__ delta, int B, int N, int H, int DH) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over (b, n, h)
-  const int64_t total = (int64_t)B * N * H;
-  if (idx >= total) return;
-  const int h = (int)(idx % H);
-  const int64_t bn = idx / H;
-  const int n = (int)(bn % N);
-  const int b = (int)(bn / N);
-  const T* po = o + bn * (int64_t)H * DH + (int64_t)h * DH;
-  const T* pg = d_o + bn * (int64_t)H * DH + (int64_t)h * DH;
+  const int64_t gidx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // granule index over [B*N*I / VEC]
+  const int lph = DH / VEC;                                       // lanes per head (power of two, <= 64)
+  const int64_t total = (int64_t)B * N * H * lph;
   float a = 0.f;
-  for (int d = 0; d < DH; d += 4) {
-    float4 x = load4<T>(po + d), y = load4<T>(pg + d);
-    a += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+  if (gidx < total) {
+    const T* po = o + gidx * VEC;
+    const T* pg = d_o + gidx * VEC;
+#pragma unroll
+    for (int j = 0; j < VEC; j += 4) {
+      const float4 x = load4<T>(po + j), y = load4<T>(pg + j);
+      a += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+    }
   }
-  delta[((int64_t)b * H + h) * N + n] = a;
+  for (int off = lph >> 1; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+  if (gidx < total && (gidx & (lph - 1)) == 0) {
+    const int64_t head_idx = gidx / lph;  // over (b, n, h)
+    const int h = (int)(head_idx % H);
+    const int64_t bn = head_idx / H;
+    const int n = (int)(bn % N);
+    const int b = (int)(bn / N);
+    delta[((int64_t)b * H + h) * N + n] = a;
+  }
 }
 
 }  // namespace
 
 int attn_delta(int dtype, const void* o, const void* d_o, float* delta, int B, int N, int H, int dh, hipStream_t s) {
-  AVF_REQUIRE(dh % 4 == 0, "attn_delta: dim_head %d must be a multiple of 4", dh);
-  const int64_t total = (int64_t)B * N * H;
+  const int vec = dtype == AVF_F32 ? 4 : 8;
+  AVF_REQUIRE(dh % vec == 0 && ((dh / vec) & (dh / vec - 1)) == 0 && dh / vec <= 64,
+              "attn_delta: dim_head %d must be %d * a power of two", dh, vec);
+  const int64_t total = (int64_t)B * N * H * (dh / vec);
   const unsigned grid = (unsigned)ceil_div(total, 256);
   if (dtype == AVF_F32)
-    attn_delta_kernel<float><<<grid, 256, 0, s>>>((const float*)o, (const float*)d_o, delta, B, N, H, dh);
+    attn_delta_kernel<float, 4><<<grid, 256, 0, s>>>((const float*)o, (const float*)d_o, delta, B, N, H, dh);
   else
-    attn_delta_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)o, (const bf16*)d_o, delta, B, N, H, dh);
+    attn_delta_kernel<bf16, 8><<<grid, 256, 0, s>>>((const bf16*)o, (const bf16*)d_o, delta, B, N, H, dh);
   return check_launch("attn_delta_kernel");
 }
 

@@ -129,6 +129,23 @@ __device__ __forceinline__ float dgelu_tanh_f(float u) {
 }
 
 __host__ __device__ static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+// fast forms for the bf16 throughput path: tanh(z) = 1 - 2/(1 + 2^(2 z log2 e)) on v_exp_f32 / v_rcp_f32
+// (|error| ~1e-6, far below one bf16 ulp)
+__device__ __forceinline__ float fast_tanh(float z) {
+  const float e = __builtin_amdgcn_exp2f(z * 2.885390081777927f);  // 2*log2(e)
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
+}
+__device__ __forceinline__ float gelu_tanh_fast(float u) {
+  const float c = 0.7978845608028654f;
+  return 0.5f * u * (1.0f + fast_tanh(c * (u + 0.044715f * u * u * u)));
+}
+__device__ __forceinline__ float dgelu_tanh_fast(float u) {
+  const float c = 0.7978845608028654f;
+  const float u2 = u * u;
+  const float t = fast_tanh(c * (u + 0.044715f * u * u2));
+  return 0.5f * (1.0f + t) + 0.5f * u * (1.0f - t * t) * c * (1.0f + 3.0f * 0.044715f * u2);
+}
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ---------------------------------------------------------------------------------------------
@@ -143,7 +160,14 @@ int layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gam
 size_t colsum_ws(int64_t rows, int cols);
 int colsum(const void* in, int in_dtype, int64_t rows, int cols, int64_t ld, float* out, void* ws, hipStream_t s);
 int cast_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t s);
+// out[c] = sum_b partial[b][c]
+int fold_partials(const float* partial, int nb, int width, float* out, hipStream_t s);
+// workspace bytes for the fused column-sum partials of an NT GEMM with M rows and N columns
+size_t gemm_nt_colsum_ws(int64_t M, int64_t N);
 int prep_weight_bf16(const float* w, void* w_lo, void* w_t_lo, int rows, int cols, hipStream_t s);
+struct PrepDesc { const float* w; bf16* lo; bf16* t; int R, C; };
+struct PrepBatch { PrepDesc d[4]; };
+int prep_weights_multi(const PrepBatch& b, int count, hipStream_t s);
 
 struct GemmArgs {
   int dtype, transA, transB;
@@ -162,6 +186,7 @@ struct GemmArgs {
   void* aux;
   int64_t ldaux;
   void* workspace;
+  float* colsum;  // optional: column sums of the stored C (bf16 NT only; partials go to workspace)
 };
 size_t gemm_ws(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K);
 int gemm(const GemmArgs& a, hipStream_t s);
@@ -169,6 +194,19 @@ int gemm_f32(const GemmArgs& a, hipStream_t s);
 int gemm_bf16_nt(const GemmArgs& a, hipStream_t s);
 int gemm_bf16_tn(const GemmArgs& a, hipStream_t s);
 size_t gemm_bf16_tn_ws(int64_t M, int64_t N, int64_t K);
+// up to four C_i[M_i,N_i] = A_i[K,M_i]^T B_i[K,N_i] sharing K, one launch (weight gradients of one layer)
+struct TnGroupArgs {
+  int count;
+  int64_t K;
+  const void* A[4];
+  const void* B[4];
+  float* C[4];
+  int64_t M[4], N[4], lda[4], ldb[4];
+  void* workspace;
+};
+bool gemm_bf16_tn_group_ok(const TnGroupArgs& a);
+size_t gemm_bf16_tn_group_ws(const TnGroupArgs& a);
+int gemm_bf16_tn_group(const TnGroupArgs& a, hipStream_t s);
 
 int attn_fwd_f32(const float* qkv, float* o, float* lse2, int B, int N, int H, int dh, hipStream_t s);
 int attn_bwd_f32(const float* qkv, const float* o, const float* d_o, const float* lse2, float* dqkv, float* delta,

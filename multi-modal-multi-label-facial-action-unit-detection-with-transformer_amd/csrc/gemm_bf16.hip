@@ -13,6 +13,8 @@
 //   A_op[i=l&15][k=8(l>>4)+j], B_op[k=8(l>>4)+j][n=l&15], D col=l&15,row=4(l>>4)+r.
 // The NT kernel issues mfma(Bfrag, Afrag) so that a lane ends up with 4 CONSECUTIVE n for one m
 // (16-byte fp32 / 8-byte bf16 stores, float4 bias/residual loads).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace avf {
@@ -40,11 +42,76 @@ struct NtParams {
   int64_t ldres;
   bf16* aux;
   int64_t ldaux;
+  float* cs_partial;  // optional [tiles_m * WM][N] column-sum partials of the stored C values (bias gradients)
   int M, N, K;
 };
 
 // 16-byte chunk c (0..7) of tile row r lives at chunk slot c ^ (r & 7): conflict-free ds_read_b128
 __device__ __forceinline__ int nt_off(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
+
+// Shared epilogue.  A lane holds C[m = m_base + 16 i + li][n = n_base + 16 j + 4 lg + 0..3] in acc[i][j].
+// part_row >= 0: also emit the column sums of this wave's 64 rows into cs_partial[part_row][n] (plain stores;
+// a fold kernel adds the tiles_m*WM partial rows) - fuses the bias gradient "db = sum_rows dY" into the GEMM.
+template <int EPI, typename CT>
+__device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[4][4], int m_base, int n_base, int li,
+                                            int lg, int part_row) {
+  float cs[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cs[j][r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m_base + i * 16 + li;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n_base + j * 16 + 4 * lg;
+      if (n >= p.N) continue;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (p.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+      }
+      if (EPI == AVF_EPI_BIAS_RES) {
+        const float4 r = *reinterpret_cast<const float4*>(p.residual + (int64_t)m * p.ldres + n);
+        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+      } else if (EPI == AVF_EPI_BIAS_GELU) {
+        store4<bf16>(p.aux + (int64_t)m * p.ldaux + n, make_float4(v[0], v[1], v[2], v[3]));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_fast(v[r]);
+      } else if (EPI == AVF_EPI_DGELU) {
+        const float4 u = load4<bf16>(p.aux + (int64_t)m * p.ldaux + n);
+        v[0] *= dgelu_tanh_fast(u.x); v[1] *= dgelu_tanh_fast(u.y); v[2] *= dgelu_tanh_fast(u.z); v[3] *= dgelu_tanh_fast(u.w);
+      }
+      store4<CT>((CT*)p.C + (int64_t)m * p.ldc + n, make_float4(v[0], v[1], v[2], v[3]));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cs[j][r] += v[r];
+    }
+  }
+  if (part_row >= 0) {  // wave-uniform
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t = cs[j][r];
+        t += __shfl_xor(t, 1, 64);
+        t += __shfl_xor(t, 2, 64);
+        t += __shfl_xor(t, 4, 64);
+        t += __shfl_xor(t, 8, 64);
+        cs[j][r] = t;
+      }
+    if (li == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n_base + j * 16 + 4 * lg;
+        if (n < p.N)
+          *reinterpret_cast<float4*>(p.cs_partial + (int64_t)part_row * p.N + n) =
+              make_float4(cs[j][0], cs[j][1], cs[j][2], cs[j][3]);
+      }
+    }
+  }
+}
 
 template <int EPI, typename CT>
 __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(NtParams p) {
@@ -114,33 +181,141 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(NtParams p) {
     __syncthreads();
   }
 
-  // epilogue: lane holds C[m = ..+li][n = ..+4*lg + 0..3]
+  nt_epilogue<EPI, CT>(p, acc, m0 + wm * 64, n0 + wn * 64, li, lg,
+                       p.cs_partial ? (int)blockIdx.y * 2 + wm : -1);
+}
+
+// ------------------------------------------------------------------------------------------
+// NT kernel, LDS-DMA staged (K % 64 == 0): global_load_lds_dwordx4 writes each tile straight into LDS
+// (no staging VGPRs, no ds_write).  The LDS image must be lane-linear per wave-instruction (64 lanes x 16 B =
+// 8 tile rows), so the XOR swizzle of nt_off() is applied to the per-lane SOURCE chunk instead:
+// lane l fills row 8*j + (l>>3), slot l&7, from source chunk (l&7) ^ (l>>3).
+// (64*WM) x (64*WN) block tile, WM*WN wavefronts of 64x64 each; two LDS stages; the next tile's DMA is in
+// flight while the current one feeds the MFMAs; one barrier per K-step.  Block ids are remapped so that the
+// workgroups dealt to one XCD (ids congruent mod 8) cover a contiguous range of tiles and share A panels in its L2.
+// ------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+__device__ __forceinline__ void glds16(const void* g, char* l) {
+  __builtin_amdgcn_global_load_lds((gptr_t*)g, (lptr_t*)l, 16, 0, 0);
+}
+
+__device__ __forceinline__ int xcd_remap(int id, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = id & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+}
+
+template <int EPI, typename CT, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(NtParams p, int tiles_n, int nwg) {
+  constexpr int BMT = 64 * WM, BNT = 64 * WN, NW = WM * WN;
+  constexpr int A_BYTES = BMT * 128, B_BYTES = BNT * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_INS = (BMT / 8) / NW, B_INS = (BNT / 8) / NW;  // wave-instructions (8 rows each) per wave
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 15, lg = lane >> 4;
+  const int wg = xcd_remap(blockIdx.x, nwg);
+  const int m0 = (wg / tiles_n) * BMT, n0 = (wg % tiles_n) * BNT;
+
+  // per-lane source pointers (row clamped: rows past the edge re-read the last row and are never stored)
+  const int lrow = lane >> 3, lchunk = (lane & 7) ^ (lane >> 3);
+  const bf16* ga[A_INS];
+  const bf16* gb[B_INS];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + li;
-    if (m >= p.M) continue;
+  for (int j = 0; j < A_INS; ++j) {
+    int r = m0 + (wave * A_INS + j) * 8 + lrow;
+    r = r < p.M ? r : p.M - 1;
+    ga[j] = p.A + (int64_t)r * p.lda + lchunk * 8;
+  }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + 4 * lg;
-      if (n >= p.N) continue;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (p.bias) {
-        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+  for (int j = 0; j < B_INS; ++j) {
+    int r = n0 + (wave * B_INS + j) * 8 + lrow;
+    r = r < p.N ? r : p.N - 1;
+    gb[j] = p.B + (int64_t)r * p.ldb + lchunk * 8;
+  }
+  auto stage = [&](int st, int k0) {
+    char* sa = dsm + st * STAGE;
+    char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int j = 0; j < A_INS; ++j) glds16(ga[j] + k0, sa + (wave * A_INS + j) * 1024);
+#pragma unroll
+    for (int j = 0; j < B_INS; ++j) glds16(gb[j] + k0, sb + (wave * B_INS + j) * 1024);
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nt = p.K / TK;
+  stage(0, 0);
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    __syncthreads();  // (waits for this wave's DMA, then the barrier) tile t landed; everyone is done with tile t-1
+    if (t + 1 < nt) stage(cur ^ 1, (t + 1) * TK);
+    const char* sa = dsm + cur * STAGE;
+    const char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = *reinterpret_cast<const bf16x8_t*>(sa + nt_off(wm * 64 + i * 16 + li, ks * 4 + lg));
+        fb[i] = *reinterpret_cast<const bf16x8_t*>(sb + nt_off(wn * 64 + i * 16 + li, ks * 4 + lg));
       }
-      if (EPI == AVF_EPI_BIAS_RES) {
-        const float4 r = *reinterpret_cast<const float4*>(p.residual + (int64_t)m * p.ldres + n);
-        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-      } else if (EPI == AVF_EPI_BIAS_GELU) {
-        store4<bf16>(p.aux + (int64_t)m * p.ldaux + n, make_float4(v[0], v[1], v[2], v[3]));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
-      } else if (EPI == AVF_EPI_DGELU) {
-        const float4 u = load4<bf16>(p.aux + (int64_t)m * p.ldaux + n);
-        v[0] *= dgelu_tanh_f(u.x); v[1] *= dgelu_tanh_f(u.y); v[2] *= dgelu_tanh_f(u.z); v[3] *= dgelu_tanh_f(u.w);
-      }
-      store4<CT>((CT*)p.C + (int64_t)m * p.ldc + n, make_float4(v[0], v[1], v[2], v[3]));
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     }
+  }
+
+  nt_epilogue<EPI, CT>(p, acc, m0 + wm * 64, n0 + wn * 64, li, lg,
+                       p.cs_partial ? (wg / tiles_n) * WM + wm : -1);
+}
+
+template <int EPI, typename CT, int WM, int WN>
+int launch_nt_glds(const NtParams& p, hipStream_t s, int* part_rows) {
+  constexpr int BMT = 64 * WM, BNT = 64 * WN;
+  constexpr int SMEM = 2 * (BMT + BNT) * 128;
+  static bool raised = false;
+  if (!raised && SMEM > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_glds_kernel<EPI, CT, WM, WN>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    AVF_REQUIRE(e == hipSuccess, "gemm_bf16_nt: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
+    raised = true;
+  }
+  const int tiles_m = (p.M + BMT - 1) / BMT, tiles_n = (p.N + BNT - 1) / BNT;
+  const int nwg = tiles_m * tiles_n;
+  *part_rows = tiles_m * WM;
+  gemm_bf16_nt_glds_kernel<EPI, CT, WM, WN><<<nwg, WM * WN * 64, SMEM, s>>>(p, tiles_n, nwg);
+  return 0;
+}
+
+// tile choice: 0 = 128x128 (4 waves), 1 = 256x128 (8 waves), 2 = 128x256 (8 waves), 3 = 256x256 (16 waves)
+int pick_nt_tile(int64_t M, int64_t N) {
+  static const int override_tile = [] {
+    const char* e = getenv("AVF_NT_TILE");  // tuning aid: force one tile shape
+    return e ? atoi(e) : -1;
+  }();
+  if (override_tile >= 0) return override_tile;
+  const int64_t wg128 = ceil_div(M, 128) * ceil_div(N, 128);
+  if (wg128 >= 4 * 256 && N % 256 == 0 && M >= 256) return 3;
+  if (wg128 >= 2 * 256 && M >= 256) return 1;
+  return 0;
+}
+
+template <int EPI, typename CT>
+int launch_nt_glds_any(const NtParams& p, hipStream_t s, int* part_rows) {
+  switch (pick_nt_tile(p.M, p.N)) {
+    case 1: return launch_nt_glds<EPI, CT, 4, 2>(p, s, part_rows);
+    case 2: return launch_nt_glds<EPI, CT, 2, 4>(p, s, part_rows);
+    case 3: return launch_nt_glds<EPI, CT, 4, 4>(p, s, part_rows);
+    default: return launch_nt_glds<EPI, CT, 2, 2>(p, s, part_rows);
   }
 }
 
@@ -274,6 +449,149 @@ __global__ __launch_bounds__(256) void fold_slabs_kernel(const float* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// grouped TN kernel, LDS-DMA staged: up to 4 weight-gradient GEMMs that share the reduction axis
+// (the B*N token rows of one layer) in ONE launch, so the chip is filled even though each dW has only
+// 16..48 output tiles.  K % 64 == 0.  Staged rows are 256 B (128 bf16) with no padding (LDS-DMA images are
+// lane-linear); transposed-read bank conflicts are removed by XOR-ing the 16-byte chunk index with
+// (row & 7) << 1 on the SOURCE address and on the read address (8 consecutive rows -> 8 distinct 32-byte
+// windows of the 256-byte bank row).
+// ------------------------------------------------------------------------------------------
+struct TnProblem {
+  const bf16* A;  // [K, M]
+  const bf16* B;  // [K, N]
+  float* C;       // [M, N] dense
+  float* slabs;   // [S][M][N] (S > 1)
+  int lda, ldb, M, N, tiles_n, tile_start;
+};
+struct TnGroup {
+  TnProblem p[4];
+  int nprob, K, kchunk, S, total_tiles;
+};
+
+__device__ __forceinline__ bf16x8_t tr_frag_swz(const lds_char* tile, int row_base, int col_base, int li, int lg) {
+  const int row = row_base + 4 * lg + (li >> 2);  // row & 7 is the same for the +16 read
+  const int chunk = (col_base >> 3) + ((li & 3) >> 1);
+  const int off = ((chunk ^ ((row & 7) << 1)) << 4) + ((li & 1) << 3);
+  const lds_char* p0 = tile + row * 256 + off;
+  s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
+  s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0 + 16 * 256));
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  s16x8_t r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+
+__global__ __launch_bounds__(256) void gemm_bf16_tn_group_kernel(TnGroup g) {
+  constexpr int OPB = TR * 256;  // bytes per operand per stage (64 rows x 256 B) = 16 KiB
+  __shared__ __attribute__((aligned(16))) char smem[4 * OPB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 15, lg = lane >> 4;
+  // block -> (tile, split); splits of one tile are adjacent ids
+  const int tile = blockIdx.x / g.S, split = blockIdx.x - tile * g.S;
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (i < g.nprob && tile >= g.p[i].tile_start) pi = i;
+  const TnProblem& P = g.p[pi];
+  const int lt = tile - P.tile_start;
+  const int m0 = (lt / P.tiles_n) * TB, n0 = (lt % P.tiles_n) * TB;
+  const int kbeg = split * g.kchunk;
+  const int kend = (kbeg + g.kchunk) < g.K ? (kbeg + g.kchunk) : g.K;
+
+  // LDS-DMA source pointers: wave-instruction j of this wave fills rows 4*(4*wave + j) .. +3 (1 KiB)
+  const int lrow = lane >> 4, lslot = lane & 15;
+  const bf16* ga[4];
+  const bf16* gb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (wave * 4 + j) * 4 + lrow;
+    const int chunk = lslot ^ ((row & 7) << 1);
+    const int ca = (m0 + chunk * 8 < P.M) ? m0 + chunk * 8 : 0;  // columns past the edge: any valid address
+    const int cb = (n0 + chunk * 8 < P.N) ? n0 + chunk * 8 : 0;
+    ga[j] = P.A + (int64_t)(kbeg + row) * P.lda + ca;
+    gb[j] = P.B + (int64_t)(kbeg + row) * P.ldb + cb;
+  }
+  const int64_t astep = (int64_t)TR * P.lda, bstep = (int64_t)TR * P.ldb;
+  auto stage = [&](int st, int t) {
+    char* sa = smem + st * 2 * OPB;
+    char* sb = sa + OPB;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) glds16(ga[j] + t * astep, sa + (wave * 4 + j) * 1024);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) glds16(gb[j] + t * bstep, sb + (wave * 4 + j) * 1024);
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nt = kend > kbeg ? (kend - kbeg) / TR : 0;
+  if (nt > 0) stage(0, 0);
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    __syncthreads();
+    if (t + 1 < nt) stage(cur ^ 1, t + 1);
+    const lds_char* sa = (const lds_char*)(smem + cur * 2 * OPB);
+    const lds_char* sb = sa + OPB;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = tr_frag_swz(sa, ks * 32, wm * 64 + i * 16, li, lg);
+        fb[i] = tr_frag_swz(sb, ks * 32, wn * 64 + i * 16, li, lg);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+  }
+  float* out = g.S > 1 ? P.slabs + (int64_t)split * P.M * P.N : P.C;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + li;
+    if (m >= P.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + 4 * lg;
+      if (n >= P.N) continue;
+      *reinterpret_cast<float4*>(out + (int64_t)m * P.N + n) =
+          make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
+  }
+}
+
+// C_i = sum_s slabs_i[s]  for every problem of the group (one launch)
+__global__ __launch_bounds__(256) void fold_group_kernel(TnGroup g) {
+  const TnProblem& P = g.p[blockIdx.y];
+  const int64_t n4 = (int64_t)P.M * P.N / 4, slab = (int64_t)P.M * P.N;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (; i < n4; i += stride) {
+    float4 a = reinterpret_cast<const float4*>(P.slabs)[i];
+    for (int s = 1; s < g.S; ++s) {
+      const float4 b = reinterpret_cast<const float4*>(P.slabs + (int64_t)s * slab)[i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    reinterpret_cast<float4*>(P.C)[i] = a;
+  }
+}
+
+int tn_group_splits(int total_tiles, int64_t K) {
+  int64_t s = ceil_div(512, total_tiles);
+  const int64_t maxs = K / 1024 > 0 ? K / 1024 : 1;  // at least 16 K-steps per workgroup
+  if (s > maxs) s = maxs;
+  if (s > 16) s = 16;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
 int tn_splits(int64_t M, int64_t N, int64_t K) {
   const int64_t tiles = ceil_div(M, TB) * ceil_div(N, TB);
   int64_t s = ceil_div(512, tiles);
@@ -285,6 +603,8 @@ int tn_splits(int64_t M, int64_t N, int64_t K) {
 }
 
 }  // namespace
+
+size_t gemm_nt_colsum_ws(int64_t M, int64_t N) { return (size_t)(ceil_div(M, 64) + 4) * N * sizeof(float); }
 
 size_t gemm_bf16_tn_ws(int64_t M, int64_t N, int64_t K) {
   const int s = tn_splits(M, N, K);
@@ -310,9 +630,19 @@ int gemm_bf16_nt(const GemmArgs& a, hipStream_t s) {
   AVF_REQUIRE(grid.y < 65536, "gemm_bf16_nt: M too large for grid");
   const bool cf32 = a.c_dtype == AVF_F32;
   AVF_REQUIRE(cf32 || a.c_dtype == AVF_BF16, "gemm_bf16_nt: bad c_dtype");
+  const bool dma = (a.K % TK == 0);
+  int part_rows = (int)grid.y * 2;  // register-staged kernel: 2 wave rows per 128-row tile
+  p.cs_partial = nullptr;
+  if (a.colsum) {
+    AVF_REQUIRE(a.workspace, "gemm_bf16_nt: column-sum workspace missing");
+    p.cs_partial = (float*)a.workspace;
+  }
 #define LAUNCH(E)                                                         \
   do {                                                                    \
-    if (cf32) gemm_bf16_nt_kernel<E, float><<<grid, 256, 0, s>>>(p);      \
+    if (dma) {                                                            \
+      if (cf32) AVF_TRY((launch_nt_glds_any<E, float>(p, s, &part_rows))); \
+      else AVF_TRY((launch_nt_glds_any<E, bf16>(p, s, &part_rows)));      \
+    } else if (cf32) gemm_bf16_nt_kernel<E, float><<<grid, 256, 0, s>>>(p); \
     else gemm_bf16_nt_kernel<E, bf16><<<grid, 256, 0, s>>>(p);            \
   } while (0)
   switch (a.epilogue) {
@@ -332,7 +662,9 @@ int gemm_bf16_nt(const GemmArgs& a, hipStream_t s) {
     default: AVF_REQUIRE(false, "gemm_bf16_nt: bad epilogue %d", a.epilogue);
   }
 #undef LAUNCH
-  return check_launch("gemm_bf16_nt_kernel");
+  AVF_TRY(check_launch("gemm_bf16_nt_kernel"));
+  if (a.colsum) AVF_TRY(fold_partials(p.cs_partial, part_rows, (int)a.N, a.colsum, s));
+  return 0;
 }
 
 int gemm_bf16_tn(const GemmArgs& a, hipStream_t s) {
@@ -369,6 +701,66 @@ int gemm_bf16_tn(const GemmArgs& a, hipStream_t s) {
     if (blocks > 2048) blocks = 2048;
     fold_slabs_kernel<<<(unsigned)blocks, 256, 0, s>>>((const float*)a.workspace, S, a.M * a.N, (float*)a.C, n4);
     AVF_TRY(check_launch("fold_slabs_kernel"));
+  }
+  return 0;
+}
+
+bool gemm_bf16_tn_group_ok(const TnGroupArgs& a) {
+  if (a.count < 1 || a.count > 4 || a.K <= 0 || a.K % TR != 0) return false;
+  for (int i = 0; i < a.count; ++i) {
+    if (a.M[i] % 8 || a.N[i] % 8 || a.lda[i] % 8 || a.ldb[i] % 8) return false;
+    if (((uintptr_t)a.A[i] & 15) || ((uintptr_t)a.B[i] & 15) || ((uintptr_t)a.C[i] & 15)) return false;
+  }
+  return true;
+}
+
+size_t gemm_bf16_tn_group_ws(const TnGroupArgs& a) {
+  int tiles = 0;
+  size_t elems = 0;
+  for (int i = 0; i < a.count; ++i) {
+    tiles += (int)(ceil_div(a.M[i], TB) * ceil_div(a.N[i], TB));
+    elems += (size_t)a.M[i] * a.N[i];
+  }
+  const int S = tn_group_splits(tiles, a.K);
+  return S > 1 ? (size_t)S * elems * sizeof(float) : 0;
+}
+
+int gemm_bf16_tn_group(const TnGroupArgs& a, hipStream_t s) {
+  AVF_REQUIRE(gemm_bf16_tn_group_ok(a), "gemm_bf16_tn_group: unsupported shapes/alignment (K%%64, M%%8, N%%8, 16-byte alignment)");
+  TnGroup g;
+  memset(&g, 0, sizeof(g));
+  g.nprob = a.count;
+  g.K = (int)a.K;
+  int tiles = 0;
+  double flops = 0, bytes = 0;
+  for (int i = 0; i < a.count; ++i) {
+    TnProblem& P = g.p[i];
+    P.A = (const bf16*)a.A[i]; P.B = (const bf16*)a.B[i]; P.C = a.C[i];
+    P.lda = (int)a.lda[i]; P.ldb = (int)a.ldb[i]; P.M = (int)a.M[i]; P.N = (int)a.N[i];
+    P.tiles_n = (int)ceil_div(a.N[i], TB);
+    P.tile_start = tiles;
+    tiles += (int)ceil_div(a.M[i], TB) * P.tiles_n;
+    flops += 2.0 * a.M[i] * a.N[i] * a.K;
+    bytes += 2.0 * (a.M[i] + a.N[i]) * a.K + 4.0 * a.M[i] * a.N[i];
+  }
+  g.total_tiles = tiles;
+  g.S = tn_group_splits(tiles, a.K);
+  g.kchunk = (int)(ceil_div(ceil_div(a.K, g.S), TR) * TR);
+  if (g.S > 1) {
+    AVF_REQUIRE(a.workspace, "gemm_bf16_tn_group: split-K workspace missing");
+    float* w = (float*)a.workspace;
+    for (int i = 0; i < a.count; ++i) {
+      g.p[i].slabs = w;
+      w += (size_t)g.S * a.M[i] * a.N[i];
+    }
+  }
+  TimingScope ts(KC_GEMM_BF16_TN, flops, bytes, s);
+  gemm_bf16_tn_group_kernel<<<tiles * g.S, 256, 0, s>>>(g);
+  AVF_TRY(check_launch("gemm_bf16_tn_group_kernel"));
+  if (g.S > 1) {
+    dim3 grid(256, a.count);
+    fold_group_kernel<<<grid, 256, 0, s>>>(g);
+    AVF_TRY(check_launch("fold_group_kernel"));
   }
   return 0;
 }

@@ -102,6 +102,22 @@ size_t carve_lowp(const Dims& d, void* base, LowP* l) {
   return c.off;
 }
 
+// the four weight-gradient GEMMs of a layer as one grouped launch: dW2 = gy^T g, dW1 = du^T h2, dWo = gm^T o,
+// dWqkv = dqkv^T h1 (all reduce over the R token rows)
+TnGroupArgs dw_group(const Dims& d, const void* gy, const void* g_act, const void* du, const void* h2, const void* gm,
+                     const void* o, const void* dqkv, const void* h1, const avf_layer_grads* g) {
+  TnGroupArgs a;
+  memset(&a, 0, sizeof(a));
+  a.count = 4;
+  a.K = d.R;
+  a.A[0] = dqkv; a.B[0] = h1; a.C[0] = g ? g->w_qkv : nullptr; a.M[0] = 3 * d.I; a.N[0] = d.D;
+  a.A[1] = du;   a.B[1] = h2; a.C[1] = g ? g->w1 : nullptr;    a.M[1] = d.M;     a.N[1] = d.D;
+  a.A[2] = gy;   a.B[2] = g_act; a.C[2] = g ? g->w2 : nullptr; a.M[2] = d.D;     a.N[2] = d.M;
+  a.A[3] = gm;   a.B[3] = o;  a.C[3] = g ? g->w_out : nullptr; a.M[3] = d.D;     a.N[3] = d.I;
+  for (int i = 0; i < 4; ++i) { a.lda[i] = a.M[i]; a.ldb[i] = a.N[i]; }
+  return a;
+}
+
 struct Work {
   void *du, *dh, *d_o, *dqkv, *dx_mid_lo, *dx_out_lo, *ln_ws, *cs_ws, *gemm_ws;
   float *dx_mid, *delta;
@@ -119,7 +135,9 @@ size_t carve_work(const Dims& d, void* base, Work* w) {
   t.delta = (float*)c.take((size_t)d.B * d.H * d.N * 4);
   t.ln_ws = c.take(layernorm_bwd_ws(d.R, d.D));
   const int maxc = d.M > d.D ? d.M : d.D;
-  t.cs_ws = c.take(colsum_ws(d.R, maxc));
+  size_t csb = colsum_ws(d.R, maxc);
+  if (d.dt == AVF_BF16 && gemm_nt_colsum_ws(d.R, d.M) > csb) csb = gemm_nt_colsum_ws(d.R, d.M);
+  t.cs_ws = c.take(csb);
   size_t g = 0;
   if (d.dt == AVF_BF16) {
     size_t a = gemm_bf16_tn_ws(3 * d.I, d.D, d.R), b = gemm_bf16_tn_ws(d.D, d.I, d.R);
@@ -127,6 +145,9 @@ size_t carve_work(const Dims& d, void* base, Work* w) {
     g = a > b ? a : b;
     g = g > e ? g : e;
     g = g > f ? g : f;
+    TnGroupArgs ga = dw_group(d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    const size_t gg = gemm_bf16_tn_group_ws(ga);
+    g = g > gg ? g : gg;
   }
   t.gemm_ws = c.take(g);
   if (w) *w = t;
@@ -141,13 +162,14 @@ int linear_fwd(const Dims& d, const void* A, int in, const void* W, int out, voi
   a.M = d.R; a.N = out; a.K = in;
   a.A = A; a.lda = in; a.B = W; a.ldb = in;
   a.C = C; a.ldc = out; a.c_dtype = c_dtype; a.epilogue = epi;
-  a.bias = bias; a.residual = res; a.ldres = out; a.aux = aux; a.ldaux = out; a.workspace = nullptr;
+  a.bias = bias; a.residual = res; a.ldres = out; a.aux = aux; a.ldaux = out; a.workspace = nullptr; a.colsum = nullptr;
   return gemm(a, s);
 }
 
 // dX[R, in] = dY[R, out] * W[out, in].  bf16 mode consumes the transposed copy Wt[in, out] as an NT GEMM.
+// colsum (bf16 mode only, optional): column sums of the produced dX, fused in the GEMM epilogue (ws = partials)
 int linear_dx(const Dims& d, const void* dY, int out, const void* W_f32, const void* Wt_lo, int in, void* dX, int epi,
-              void* aux, hipStream_t s) {
+              void* aux, hipStream_t s, float* colsum_out = nullptr, void* ws = nullptr) {
   GemmArgs a;
   a.dtype = d.dt; a.transA = 0;
   a.M = d.R; a.N = in; a.K = out;
@@ -155,7 +177,7 @@ int linear_dx(const Dims& d, const void* dY, int out, const void* W_f32, const v
   if (d.dt == AVF_BF16) { a.transB = 1; a.B = Wt_lo; a.ldb = out; }
   else { a.transB = 0; a.B = W_f32; a.ldb = in; }
   a.C = dX; a.ldc = in; a.c_dtype = d.dt; a.epilogue = epi;
-  a.bias = nullptr; a.residual = nullptr; a.ldres = 0; a.aux = aux; a.ldaux = in; a.workspace = nullptr;
+  a.bias = nullptr; a.residual = nullptr; a.ldres = 0; a.aux = aux; a.ldaux = in; a.workspace = ws; a.colsum = colsum_out;
   return gemm(a, s);
 }
 
@@ -166,7 +188,7 @@ int linear_dw(const Dims& d, const void* dY, int out, const void* X, int in, flo
   a.M = out; a.N = in; a.K = d.R;
   a.A = dY; a.lda = out; a.B = X; a.ldb = in;
   a.C = dW; a.ldc = in; a.c_dtype = AVF_F32; a.epilogue = AVF_EPI_NONE;
-  a.bias = nullptr; a.residual = nullptr; a.ldres = 0; a.aux = nullptr; a.ldaux = 0; a.workspace = ws;
+  a.bias = nullptr; a.residual = nullptr; a.ldres = 0; a.aux = nullptr; a.ldaux = 0; a.workspace = ws; a.colsum = nullptr;
   return gemm(a, s);
 }
 
@@ -216,11 +238,12 @@ extern "C" int avf_layer_prepare_weights(const avf_layer_cfg* cfg, const avf_lay
   hipStream_t s = (hipStream_t)stream;
   LowP l;
   carve_lowp(d, lowp, &l);
-  AVF_TRY(prep_weight_bf16(p->w_qkv, l.wqkv, l.wqkv_t, 3 * d.I, d.D, s));
-  AVF_TRY(prep_weight_bf16(p->w_out, l.wo, l.wo_t, d.D, d.I, s));
-  AVF_TRY(prep_weight_bf16(p->w1, l.w1, l.w1_t, d.M, d.D, s));
-  AVF_TRY(prep_weight_bf16(p->w2, l.w2, l.w2_t, d.D, d.M, s));
-  return 0;
+  PrepBatch b;
+  b.d[0] = PrepDesc{p->w_qkv, (bf16*)l.wqkv, (bf16*)l.wqkv_t, 3 * d.I, d.D};
+  b.d[1] = PrepDesc{p->w_out, (bf16*)l.wo, (bf16*)l.wo_t, d.D, d.I};
+  b.d[2] = PrepDesc{p->w1, (bf16*)l.w1, (bf16*)l.w1_t, d.M, d.D};
+  b.d[3] = PrepDesc{p->w2, (bf16*)l.w2, (bf16*)l.w2_t, d.D, d.M};
+  return prep_weights_multi(b, 4, s);
 }
 
 extern "C" int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p, const void* lowp, const float* x_in,
@@ -253,8 +276,9 @@ extern "C" int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p
 }
 
 extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p, const void* lowp, const float* x_in,
-                             const void* saved, const float* dx_out, const void* dx_out_lo, float* dx_in,
-                             void* dx_in_lo, const avf_layer_grads* g, void* workspace, void* stream) {
+                             const void* saved, const float* dx_out, const void* dx_out_lo,
+                             const float* dx_out_colsum, float* dx_in, void* dx_in_lo, float* dx_in_colsum,
+                             const avf_layer_grads* g, void* workspace, void* stream) {
   Dims d;
   AVF_TRY(make_dims(cfg, &d));
   AVF_REQUIRE(p && x_in && saved && dx_out && dx_in && g && workspace, "layer_bwd: null pointer");
@@ -277,18 +301,31 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
       gy = w.dx_out_lo;
     }
   }
+  const void* gm = lo ? (const void*)w.dx_mid_lo : (const void*)w.dx_mid;
+  // bf16 mode: the four dW GEMMs run as ONE grouped launch at the end of the layer (their operands all stay
+  // alive in the workspace), when the shapes allow the LDS-DMA kernel
+  TnGroupArgs grp = dw_group(d, gy, sv.g, w.du, sv.h2, gm, sv.o, w.dqkv, sv.h1, g);
+  grp.workspace = w.gemm_ws;
+  const bool grouped = lo && gemm_bf16_tn_group_ok(grp);
+
   // ---- feed-forward half -------------------------------------------------------------------
-  AVF_TRY(colsum(dx_out, AVF_F32, d.R, d.D, d.D, g->b2, w.cs_ws, s));
-  AVF_TRY(linear_dw(d, gy, d.D, sv.g, d.M, g->w2, w.gemm_ws, s));
-  AVF_TRY(linear_dx(d, gy, d.D, p->w2, l.w2_t, d.M, w.du, AVF_EPI_DGELU, sv.u, s));
-  AVF_TRY(colsum(w.du, d.dt, d.R, d.M, d.M, g->b1, w.cs_ws, s));
-  AVF_TRY(linear_dw(d, w.du, d.M, sv.h2, d.D, g->w1, w.gemm_ws, s));
+  // db2 = column sums of dx_out: handed over by the caller (the next layer's LN1 backward produced them) or summed here
+  if (dx_out_colsum) AVF_REQUIRE(hipMemcpyAsync(g->b2, dx_out_colsum, (size_t)d.D * 4, hipMemcpyDeviceToDevice, s) == hipSuccess,
+                                 "layer_bwd: memcpy failed");
+  else AVF_TRY(colsum(dx_out, AVF_F32, d.R, d.D, d.D, g->b2, w.cs_ws, s));
+  if (!grouped) AVF_TRY(linear_dw(d, gy, d.D, sv.g, d.M, g->w2, w.gemm_ws, s));
+  if (lo) {  // db1 = colsum(du) fused into the dGELU GEMM epilogue
+    AVF_TRY(linear_dx(d, gy, d.D, p->w2, l.w2_t, d.M, w.du, AVF_EPI_DGELU, sv.u, s, g->b1, w.cs_ws));
+  } else {
+    AVF_TRY(linear_dx(d, gy, d.D, p->w2, l.w2_t, d.M, w.du, AVF_EPI_DGELU, sv.u, s));
+    AVF_TRY(colsum(w.du, d.dt, d.R, d.M, d.M, g->b1, w.cs_ws, s));
+  }
+  if (!grouped) AVF_TRY(linear_dw(d, w.du, d.M, sv.h2, d.D, g->w1, w.gemm_ws, s));
   AVF_TRY(linear_dx(d, w.du, d.M, p->w1, l.w1_t, d.D, w.dh, AVF_EPI_NONE, nullptr, s));
   AVF_TRY(layernorm_bwd(w.dh, d.dt, sv.x_mid, p->ln2_w, sv.mean2, sv.rstd2, dx_out, w.dx_mid,
                         lo ? w.dx_mid_lo : nullptr, g->ln2_w, g->ln2_b, g->b_out, w.ln_ws, d.R, d.D, s));
   // ---- attention half ----------------------------------------------------------------------
-  const void* gm = lo ? (const void*)w.dx_mid_lo : (const void*)w.dx_mid;
-  AVF_TRY(linear_dw(d, gm, d.D, sv.o, d.I, g->w_out, w.gemm_ws, s));
+  if (!grouped) AVF_TRY(linear_dw(d, gm, d.D, sv.o, d.I, g->w_out, w.gemm_ws, s));
   AVF_TRY(linear_dx(d, gm, d.D, p->w_out, l.wo_t, d.I, w.d_o, AVF_EPI_NONE, nullptr, s));
   if (lo)
     AVF_TRY(attn_bwd_bf16((const bf16*)sv.qkv, (const bf16*)sv.o, (const bf16*)w.d_o, sv.lse2, (bf16*)w.dqkv, w.delta,
@@ -296,9 +333,11 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   else
     AVF_TRY(attn_bwd_f32((const float*)sv.qkv, (const float*)sv.o, (const float*)w.d_o, sv.lse2, (float*)w.dqkv,
                          w.delta, d.B, d.N, d.H, d.dh, s));
-  AVF_TRY(linear_dw(d, w.dqkv, 3 * d.I, sv.h1, d.D, g->w_qkv, w.gemm_ws, s));
+  if (!grouped) AVF_TRY(linear_dw(d, w.dqkv, 3 * d.I, sv.h1, d.D, g->w_qkv, w.gemm_ws, s));
   AVF_TRY(linear_dx(d, w.dqkv, 3 * d.I, p->w_qkv, l.wqkv_t, d.D, w.dh, AVF_EPI_NONE, nullptr, s));
+  // dx_in may alias dx_out, which the grouped dW2 GEMM does not read (it uses the bf16 copy gy)
   AVF_TRY(layernorm_bwd(w.dh, d.dt, x_in, p->ln1_w, sv.mean1, sv.rstd1, w.dx_mid, dx_in, lo ? dx_in_lo : nullptr,
-                        g->ln1_w, g->ln1_b, nullptr, w.ln_ws, d.R, d.D, s));
+                        g->ln1_w, g->ln1_b, dx_in_colsum, w.ln_ws, d.R, d.D, s));
+  if (grouped) AVF_TRY(gemm_bf16_tn_group(grp, s));
   return 0;
 }

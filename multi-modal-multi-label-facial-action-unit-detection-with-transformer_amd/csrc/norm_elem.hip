@@ -173,28 +173,120 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DyT* __restrict__ dy,
   for (int i = threadIdx.x; i < 3 * D; i += 256) out[i] = lds[i];
 }
 
-// out[j] = sum_b partial[b][j], j in [0, width): 64 columns x 4 partial-groups per block
+// Fast path (D % 4 == 0, D <= 256*NV): every lane owns the same NV float4 column chunks for all the rows
+// its wave processes, so the per-column sums (dgamma, dbeta, colsum(dx)) accumulate in registers; the
+// four waves of a block are combined through LDS with plain adds (deterministic), one partial per block.
+constexpr int LNR_ROWS_PER_BLOCK = 16;
+
+template <typename DyT, int NV>
+__global__ __launch_bounds__(256) void ln_bwd_reg_kernel(const DyT* __restrict__ dy, const float* __restrict__ x,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ dres, float* __restrict__ dx,
+                                                         bf16* __restrict__ dx_lo, float* __restrict__ partial,
+                                                         int64_t rows, int D, int want_colsum) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [4 waves][3][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row0 = (int64_t)blockIdx.x * LNR_ROWS_PER_BLOCK;
+  const float invD = 1.0f / (float)D;
+  float4 g[NV], adg[NV], adb[NV], acs[NV];
+  bool act[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane * 4 + 256 * i;
+    act[i] = c < D;
+    g[i] = act[i] ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    adg[i] = adb[i] = acs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int rr = wave; rr < LNR_ROWS_PER_BLOCK; rr += 4) {
+    const int64_t row = row0 + rr;
+    if (row >= rows) break;
+    const float mu = mean[row], rs = rstd[row];
+    float4 d[NV], xh[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane * 4 + 256 * i;
+      d[i] = xh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (act[i]) {
+        d[i] = load4<DyT>(dy + row * D + c);
+        const float4 v = *reinterpret_cast<const float4*>(x + row * D + c);
+        xh[i] = make_float4((v.x - mu) * rs, (v.y - mu) * rs, (v.z - mu) * rs, (v.w - mu) * rs);
+      }
+      const float g0 = d[i].x * g[i].x, g1 = d[i].y * g[i].y, g2 = d[i].z * g[i].z, g3 = d[i].w * g[i].w;
+      s1 += (g0 + g1) + (g2 + g3);
+      s2 += (g0 * xh[i].x + g1 * xh[i].y) + (g2 * xh[i].z + g3 * xh[i].w);
+    }
+    s1 = wave_sum(s1) * invD;
+    s2 = wave_sum(s2) * invD;  // mean(g * xhat)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (!act[i]) continue;
+      const int c = lane * 4 + 256 * i;
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (dres) r = *reinterpret_cast<const float4*>(dres + row * D + c);
+      float4 o;
+      o.x = rs * (d[i].x * g[i].x - s1 - xh[i].x * s2) + r.x;
+      o.y = rs * (d[i].y * g[i].y - s1 - xh[i].y * s2) + r.y;
+      o.z = rs * (d[i].z * g[i].z - s1 - xh[i].z * s2) + r.z;
+      o.w = rs * (d[i].w * g[i].w - s1 - xh[i].w * s2) + r.w;
+      *reinterpret_cast<float4*>(dx + row * D + c) = o;
+      if (dx_lo) store4<bf16>(dx_lo + row * D + c, o);
+      adg[i].x += d[i].x * xh[i].x; adg[i].y += d[i].y * xh[i].y; adg[i].z += d[i].z * xh[i].z; adg[i].w += d[i].w * xh[i].w;
+      adb[i].x += d[i].x; adb[i].y += d[i].y; adb[i].z += d[i].z; adb[i].w += d[i].w;
+      acs[i].x += o.x; acs[i].y += o.y; acs[i].z += o.z; acs[i].w += o.w;
+    }
+  }
+  float* mine = lds + wave * 3 * D;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if (!act[i]) continue;
+    const int c = lane * 4 + 256 * i;
+    *reinterpret_cast<float4*>(mine + c) = adg[i];
+    *reinterpret_cast<float4*>(mine + D + c) = adb[i];
+    *reinterpret_cast<float4*>(mine + 2 * D + c) = acs[i];
+  }
+  __syncthreads();
+  float* out = partial + (int64_t)blockIdx.x * 3 * D;
+  const int n = want_colsum ? 3 * D : 2 * D;
+  for (int i = threadIdx.x; i < n; i += 256)
+    out[i] = (lds[i] + lds[3 * D + i]) + (lds[6 * D + i] + lds[9 * D + i]);
+}
+
+// out[j] = sum_b partial[b][j], j in [0, width): 32 columns x 8 partial-groups per block
+
 __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ partial, int nb, int width,
                                                             float* __restrict__ o0, float* __restrict__ o1,
                                                             float* __restrict__ o2, int seg) {
-  __shared__ float red[4][64];
-  const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + cl;
-  float acc = 0.f;
-  if (col < width)
-    for (int b = grp; b < nb; b += 4) acc += partial[(int64_t)b * width + col];
-  red[grp][cl] = acc;
+  __shared__ float red[8][32];
+  const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + cl;
+  float a0 = 0.f, a1 = 0.f;
+  if (col < width) {
+    int b = grp;
+    for (; b + 8 < nb; b += 16) {
+      a0 += partial[(int64_t)b * width + col];
+      a1 += partial[(int64_t)(b + 8) * width + col];
+    }
+    if (b < nb) a0 += partial[(int64_t)b * width + col];
+  }
+  red[grp][cl] = a0 + a1;
   __syncthreads();
   if (grp == 0 && col < width) {
-    float v = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    float v = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) + ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]));
     const int which = col / seg, c = col - which * seg;
     float* dst = which == 0 ? o0 : (which == 1 ? o1 : o2);
     if (dst) dst[c] = v;
   }
 }
 
+int fold_partials(const float* partial, int nb, int width, float* out, hipStream_t s) {
+  fold_partials_kernel<<<(unsigned)ceil_div(width, 32), 256, 0, s>>>(partial, nb, width, out, nullptr, nullptr, width);
+  return check_launch("fold_partials_kernel");
+}
+
 size_t layernorm_bwd_ws(int64_t rows, int dim) {
-  return (size_t)ceil_div(rows, LNB_ROWS_PER_BLOCK) * 3 * dim * sizeof(float);
+  return (size_t)ceil_div(rows, LNR_ROWS_PER_BLOCK) * 3 * dim * sizeof(float);  // LNR < LNB: covers both paths
 }
 
 int layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean,
@@ -204,25 +296,59 @@ int layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gam
   AVF_REQUIRE((size_t)3 * dim * sizeof(float) <= 64 * 1024, "layernorm_bwd: dim %d too large", dim);
   TimingScope ts(KC_LAYERNORM, 0.0,
                  (double)rows * dim * ((dy_dtype == AVF_BF16 ? 2.0 : 4.0) + 4.0 + (dres ? 4.0 : 0.0) + 4.0 + (dx_lo ? 2.0 : 0.0)), s);
-  const int nb = (int)ceil_div(rows, LNB_ROWS_PER_BLOCK);
-  const size_t lds = (size_t)3 * dim * sizeof(float);
   float* partial = (float*)ws;
-  const bool vec = (dim & 3) == 0;
   const int wc = dcolsum ? 1 : 0;
+  int nb;
+  const bool fast = (dim % 4 == 0) && dim <= 1536 && (dy_dtype == AVF_F32 || dy_dtype == AVF_BF16);
+  if (fast) {
+    nb = (int)ceil_div(rows, LNR_ROWS_PER_BLOCK);
+    const size_t lds = (size_t)4 * 3 * dim * sizeof(float);
+    const int nv = (dim + 255) / 256;
+    if (lds > 64 * 1024) {  // only the NV=6 instantiations (D up to 1536) can exceed the default dynamic-LDS limit
+      static bool raised = false;
+      if (!raised) {
+        hipError_t e1 = hipFuncSetAttribute((const void*)ln_bwd_reg_kernel<float, 6>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 3 * 1536 * 4);
+        hipError_t e2 = hipFuncSetAttribute((const void*)ln_bwd_reg_kernel<bf16, 6>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 3 * 1536 * 4);
+        AVF_REQUIRE(e1 == hipSuccess && e2 == hipSuccess, "layernorm_bwd: cannot raise dynamic LDS limit");
+        raised = true;
+      }
+    }
+#define LAUNCH_NV(T, NVV)                                                                                          \
+  ln_bwd_reg_kernel<T, NVV><<<nb, 256, lds, s>>>((const T*)dy, x, gamma, mean, rstd, dres, dx, (bf16*)dx_lo, partial, \
+                                                 rows, dim, wc)
+#define LAUNCH_T(T)                                   \
+  switch (nv) {                                       \
+    case 1: LAUNCH_NV(T, 1); break;                   \
+    case 2: LAUNCH_NV(T, 2); break;                   \
+    case 3: LAUNCH_NV(T, 3); break;                   \
+    case 4: LAUNCH_NV(T, 4); break;                   \
+    default: LAUNCH_NV(T, 6); break;                  \
+  }
+    if (dy_dtype == AVF_F32) { LAUNCH_T(float) } else { LAUNCH_T(bf16) }
+#undef LAUNCH_T
+#undef LAUNCH_NV
+    AVF_TRY(check_launch("ln_bwd_reg_kernel"));
+  } else {
+    nb = (int)ceil_div(rows, LNB_ROWS_PER_BLOCK);
+    const size_t lds = (size_t)3 * dim * sizeof(float);
+    const bool vec = (dim & 3) == 0;
 #define LAUNCH(T, V)                                                                                            \
   ln_bwd_kernel<T, V><<<nb, 256, lds, s>>>((const T*)dy, x, gamma, mean, rstd, dres, dx, (bf16*)dx_lo, partial, \
                                            rows, dim, wc)
-  if (dy_dtype == AVF_F32) {
-    if (vec) LAUNCH(float, true); else LAUNCH(float, false);
-  } else if (dy_dtype == AVF_BF16) {
-    if (vec) LAUNCH(bf16, true); else LAUNCH(bf16, false);
-  } else {
-    AVF_REQUIRE(false, "layernorm_bwd: bad dtype %d", dy_dtype);
-  }
+    if (dy_dtype == AVF_F32) {
+      if (vec) LAUNCH(float, true); else LAUNCH(float, false);
+    } else if (dy_dtype == AVF_BF16) {
+      if (vec) LAUNCH(bf16, true); else LAUNCH(bf16, false);
+    } else {
+      AVF_REQUIRE(false, "layernorm_bwd: bad dtype %d", dy_dtype);
+    }
 #undef LAUNCH
-  AVF_TRY(check_launch("ln_bwd_kernel"));
+    AVF_TRY(check_launch("ln_bwd_kernel"));
+  }
   const int width = 3 * dim;
-  fold_partials_kernel<<<(unsigned)ceil_div(width, 64), 256, 0, s>>>(partial, nb, width, dgamma, dbeta, dcolsum, dim);
+  fold_partials_kernel<<<(unsigned)ceil_div(width, 32), 256, 0, s>>>(partial, nb, width, dgamma, dbeta, dcolsum, dim);
   return check_launch("fold_partials_kernel");
 }
 
@@ -270,7 +396,7 @@ int colsum(const void* in, int in_dtype, int64_t rows, int cols, int64_t ld, flo
   else
     AVF_REQUIRE(false, "colsum: bad dtype %d", in_dtype);
   AVF_TRY(check_launch("colsum_kernel"));
-  fold_partials_kernel<<<(unsigned)ceil_div(cols, 64), 256, 0, s>>>((const float*)ws, ch, cols, out, nullptr, nullptr,
+  fold_partials_kernel<<<(unsigned)ceil_div(cols, 32), 256, 0, s>>>((const float*)ws, ch, cols, out, nullptr, nullptr,
                                                                      cols);
   return check_launch("fold_partials_kernel");
 }
@@ -318,6 +444,41 @@ __global__ __launch_bounds__(256) void prep_weight_kernel(const float* __restric
       if (c < C && r < R) w_t[(int64_t)c * R + r] = from_f32<bf16>(tile[tx][ty + 8 * i]);
     }
   }
+}
+
+// up to 4 weights in one launch (blockIdx.z selects the matrix)
+__global__ __launch_bounds__(256) void prep_weights_multi_kernel(PrepBatch b) {
+  __shared__ float tile[32][33];
+  const PrepDesc d = b.d[blockIdx.z];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  if (c0 >= d.C || r0 >= d.R) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int r = r0 + ty + 8 * i, c = c0 + tx;
+    float v = (r < d.R && c < d.C) ? d.w[(int64_t)r * d.C + c] : 0.f;
+    tile[ty + 8 * i][tx] = v;
+    if (r < d.R && c < d.C) d.lo[(int64_t)r * d.C + c] = from_f32<bf16>(v);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (c < d.C && r < d.R) d.t[(int64_t)c * d.R + r] = from_f32<bf16>(tile[tx][ty + 8 * i]);
+  }
+}
+
+int prep_weights_multi(const PrepBatch& b, int count, hipStream_t s) {
+  AVF_REQUIRE(count >= 1 && count <= 4, "prep_weights_multi: count must be 1..4");
+  int mr = 0, mc = 0;
+  for (int i = 0; i < count; ++i) {
+    AVF_REQUIRE(b.d[i].w && b.d[i].lo && b.d[i].t && b.d[i].R > 0 && b.d[i].C > 0, "prep_weights_multi: bad descriptor");
+    mr = b.d[i].R > mr ? b.d[i].R : mr;
+    mc = b.d[i].C > mc ? b.d[i].C : mc;
+  }
+  dim3 grid((unsigned)ceil_div(mc, 32), (unsigned)ceil_div(mr, 32), (unsigned)count);
+  prep_weights_multi_kernel<<<grid, 256, 0, s>>>(b);
+  return check_launch("prep_weights_multi_kernel");
 }
 
 int prep_weight_bf16(const float* w, void* w_lo, void* w_t_lo, int rows, int cols, hipStream_t s) {

@@ -119,6 +119,9 @@ class _StackFn(torch.autograd.Function):
         lo_a = torch.empty((B * N, D), dtype=torch.bfloat16, device=dev) if bf16 else None
         lo_b = torch.empty((B * N, D), dtype=torch.bfloat16, device=dev) if bf16 else None
         have_lo = False
+        cs_a = torch.empty(D, dtype=torch.float32, device=dev)  # column sums of dx, handed layer to layer
+        cs_b = torch.empty(D, dtype=torch.float32, device=dev)
+        have_cs = False
         live = mod.flat_parameters()
         sizes = [p.numel() for p in ctx.params[:PARAMS_PER_LAYER]]
         hook = mod._grad_hook
@@ -131,10 +134,14 @@ class _StackFn(torch.autograd.Function):
             gp = _lib.LayerPtrs(*[v.data_ptr() for v in views])
             pp = mod._param_struct(ctx.params, l)
             _lib.check(lib.avf_layer_bwd(C.byref(cfg), C.byref(pp), _ptr(ctx.lowps[l]), _ptr(ctx.xs[l]),
-                                         _ptr(ctx.saved_bufs[l]), _ptr(dx), _ptr(lo_a) if have_lo else None, _ptr(dx),
-                                         _ptr(lo_b), C.byref(gp), _ptr(ws), stream), f"layer_bwd[{l}]")
+                                         _ptr(ctx.saved_bufs[l]), _ptr(dx), _ptr(lo_a) if have_lo else None,
+                                         _ptr(cs_a) if have_cs else None, _ptr(dx), _ptr(lo_b),
+                                         _ptr(cs_b) if l > 0 else None, C.byref(gp), _ptr(ws), stream),
+                       f"layer_bwd[{l}]")
             lo_a, lo_b = lo_b, lo_a
+            cs_a, cs_b = cs_b, cs_a
             have_lo = bf16
+            have_cs = True
             waiter = hook(l, flat) if hook is not None else None  # e.g. launch this layer's all-reduce now
             # Parameter gradients are handed over directly (views of the layer's flat buffer, no copy):
             # ``.grad = view`` when empty, ``.grad += view`` when accumulating.
@@ -164,7 +171,8 @@ class Transformer(nn.Module):
         self.layers = nn.ModuleList([_make_layer(dim, heads, dim_head, mlp_dim, dropout) for _ in range(depth)])
         self._ws = None
         self._lowp_bufs = None
-        self._lowp_versions = None
+        self._lowp_ptrs = None
+        self.cache_weights = False
         self._grad_hook: Optional[Callable] = None
 
     # ---- parameter plumbing --------------------------------------------------------------------
@@ -209,21 +217,28 @@ class Transformer(nn.Module):
         return self._ws
 
     def _lowp(self, lib, cfg, params, dev, stream):
-        """bf16 weight copies (+ transposes), refreshed only when a master weight changed."""
+        """bf16 weight copies (+ transposes) of the fp32 masters.  Refreshed on EVERY forward (an optimizer
+        step changes the masters; in-place fused optimizers are not reliably visible through tensor version
+        counters).  Inference loops may set ``self.cache_weights = True`` after the weights are final; call
+        ``refresh_weights()`` if they change afterwards."""
         if cfg.dtype != _lib.BF16:
             return [None] * self.depth
         need = lib.avf_layer_lowp_bytes(C.byref(cfg))
-        versions = [(p.data_ptr(), p._version) for p in params]
+        fresh = False
         if (self._lowp_bufs is None or self._lowp_bufs[0].numel() < need or self._lowp_bufs[0].device != dev):
             self._lowp_bufs = [torch.empty(need, dtype=torch.uint8, device=dev) for _ in range(self.depth)]
-            self._lowp_versions = None
-        if self._lowp_versions != versions:
+            fresh = True
+        ptrs = [p.data_ptr() for p in params]
+        if fresh or not self.cache_weights or self._lowp_ptrs != ptrs:
             for l in range(self.depth):
                 pp = self._param_struct(params, l)
                 _lib.check(lib.avf_layer_prepare_weights(C.byref(cfg), C.byref(pp), _ptr(self._lowp_bufs[l]), stream),
                            f"prepare_weights[{l}]")
-            self._lowp_versions = versions
+            self._lowp_ptrs = ptrs
         return self._lowp_bufs
+
+    def refresh_weights(self):
+        self._lowp_ptrs = None
 
     # ---- forward -------------------------------------------------------------------------------
     def forward(self, x, mask=None):
