@@ -13,6 +13,8 @@
 //   dK / dV      : S = Q K^T      -> lane owns a key column;  dV^T = dO^T P,  dK^T = Q^T dS.
 // k-slot map of a packed accumulator pair / transposed fragment (32 reduction rows per k-step):
 //   slot j of lane group g  <->  row 16*(j>>2) + 4*g + (j&3).
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace avf {
@@ -98,6 +100,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
   const bf16* kbase = qbase + I;
   const bf16* vbase = qbase + 2 * I;
   const int q0 = blockIdx.x * 128 + wave * 32;
+  const bool active = __builtin_amdgcn_readfirstlane(q0) < N;
   const float c = LOG2E / sqrtf((float)DH);
 
   bf16x8_t fq[2][KS];
@@ -137,63 +140,76 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
     const char* kt = smem + cur * STAGE;
     const lds_char* vt = (const lds_char*)(smem + cur * STAGE + 64 * KLD);
 
-    // S^T[key][q] = K Q^T
-    f32x4_t st[4][2];
+    // One K/V tile.  TAIL = the tile holds keys past N: only its valid 16-key blocks are computed and the
+    // rest is masked; full tiles take the branch-free instantiation.  Waves whose 32 query rows all lie past N
+    // only help with staging and barriers.
+    auto tile_body = [&](auto tail_tag) {
+      constexpr bool TAIL = decltype(tail_tag)::value;
+      const int nkb = TAIL ? (N - t * 64 + 15) / 16 : 4;
+      // S^T[key][q] = K Q^T
+      f32x4_t st[4][2];
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      st[kb][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      st[kb][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int kb = 0; kb < 4; ++kb) {
+        st[kb][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        st[kb][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (!TAIL || kb < nkb) {
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8_t fk = row_frag<KLD>(kt, kb * 16 + li, ks * 32 + 8 * lg);
-        st[kb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq[0][ks], st[kb][0], 0, 0, 0);
-        st[kb][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq[1][ks], st[kb][1], 0, 0, 0);
-      }
-    }
-    const bool partial = (t * 64 + 64 > N);
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      float tmax = -INFINITY;
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float s = st[kb][qb][r] * c;
-          if (partial && (t * 64 + kb * 16 + 4 * lg + r >= N)) s = -INFINITY;
-          st[kb][qb][r] = s;
-          tmax = fmaxf(tmax, s);
+          for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8_t fk = row_frag<KLD>(kt, kb * 16 + li, ks * 32 + 8 * lg);
+            st[kb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq[0][ks], st[kb][0], 0, 0, 0);
+            st[kb][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq[1][ks], st[kb][1], 0, 0, 0);
+          }
         }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-      const float mn = fmaxf(m[qb], tmax);
-      const float alpha = __builtin_amdgcn_exp2f(m[qb] - mn);
-      m[qb] = mn;
-      float ps = 0.f;
+      }
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb)
+      for (int qb = 0; qb < 2; ++qb) {
+        float tmax = -INFINITY;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(st[kb][qb][r] - mn);
-          st[kb][qb][r] = pv;
-          ps += pv;
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float sv_ = st[kb][qb][r] * c;
+            if (TAIL && (t * 64 + kb * 16 + 4 * lg + r >= N)) sv_ = -INFINITY;
+            st[kb][qb][r] = sv_;
+            tmax = fmaxf(tmax, sv_);
+          }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mn = fmaxf(m[qb], tmax);
+        const float alpha = __builtin_amdgcn_exp2f(m[qb] - mn);
+        m[qb] = mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(st[kb][qb][r] - mn);
+            st[kb][qb][r] = pv;
+            ps += pv;
+          }
+        lsum[qb] = lsum[qb] * alpha + ps;
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+          ot[d][qb][0] *= alpha; ot[d][qb][1] *= alpha; ot[d][qb][2] *= alpha; ot[d][qb][3] *= alpha;
         }
-      lsum[qb] = lsum[qb] * alpha + ps;
-#pragma unroll
-      for (int d = 0; d < DB; ++d) {
-        ot[d][qb][0] *= alpha; ot[d][qb][1] *= alpha; ot[d][qb][2] *= alpha; ot[d][qb][3] *= alpha;
       }
-    }
-    // O^T[d][q] += V^T P^T
+      // O^T[d][q] += V^T P^T
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const bf16x8_t p0 = pack_pair(st[2 * s][0], st[2 * s + 1][0]);
-      const bf16x8_t p1 = pack_pair(st[2 * s][1], st[2 * s + 1][1]);
+      for (int s = 0; s < 2; ++s) {
+        if (TAIL && 2 * s >= nkb) continue;
+        const bf16x8_t p0 = pack_pair(st[2 * s][0], st[2 * s + 1][0]);
+        const bf16x8_t p1 = pack_pair(st[2 * s][1], st[2 * s + 1][1]);
 #pragma unroll
-      for (int d = 0; d < DB; ++d) {
-        const bf16x8_t fv = tr_frag<VLD>(vt, 32 * s, d * 16, li, lg);
-        ot[d][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, p0, ot[d][0], 0, 0, 0);
-        ot[d][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, p1, ot[d][1], 0, 0, 0);
+        for (int d = 0; d < DB; ++d) {
+          const bf16x8_t fv = tr_frag<VLD>(vt, 32 * s, d * 16, li, lg);
+          ot[d][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, p0, ot[d][0], 0, 0, 0);
+          ot[d][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, p1, ot[d][1], 0, 0, 0);
+        }
       }
+    };
+    if (active) {
+      if (t * 64 + 64 > N) tile_body(std::true_type{});
+      else tile_body(std::false_type{});
     }
     if (t + 1 < nt) {
       sk.template commit<KLD>(smem + (cur ^ 1) * STAGE, tid);
@@ -244,6 +260,7 @@ __global__ __launch_bounds__(256) void attn_dq_bf16_kernel(const bf16* __restric
   const bf16* vbase = qbase + 2 * I;
   const bf16* gbase = d_o + (int64_t)b * N * I + h * DH;
   const int q0 = blockIdx.x * 128 + wave * 32;
+  const bool active = __builtin_amdgcn_readfirstlane(q0) < N;
   const float scale = 1.0f / sqrtf((float)DH);
   const float c = LOG2E * scale;
 
@@ -287,41 +304,51 @@ __global__ __launch_bounds__(256) void attn_dq_bf16_kernel(const bf16* __restric
     }
     const char* kt = smem + cur * STAGE;
     const char* vt = smem + cur * STAGE + 64 * KLD;
-    const bool partial = (t * 64 + 64 > N);
-
-    f32x4_t ds[4][2];
+    auto tile_body = [&](auto tail_tag) {
+      constexpr bool TAIL = decltype(tail_tag)::value;
+      const int nkb = TAIL ? (N - t * 64 + 15) / 16 : 4;
+      f32x4_t ds[4][2];
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+      for (int kb = 0; kb < 4; ++kb) {
+        ds[kb][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        ds[kb][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (TAIL && kb >= nkb) continue;
+        f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8_t fk = row_frag<KLD>(kt, kb * 16 + li, ks * 32 + 8 * lg);
-        const bf16x8_t fv = row_frag<VLD>(vt, kb * 16 + li, ks * 32 + 8 * lg);
-        s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq[0][ks], s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq[1][ks], s1, 0, 0, 0);
-        p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, fg[0][ks], p0, 0, 0, 0);
-        p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, fg[1][ks], p1, 0, 0, 0);
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8_t fk = row_frag<KLD>(kt, kb * 16 + li, ks * 32 + 8 * lg);
+          const bf16x8_t fv = row_frag<VLD>(vt, kb * 16 + li, ks * 32 + 8 * lg);
+          s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq[0][ks], s0, 0, 0, 0);
+          s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq[1][ks], s1, 0, 0, 0);
+          p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, fg[0][ks], p0, 0, 0, 0);
+          p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, fg[1][ks], p1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool dead = TAIL && (t * 64 + kb * 16 + 4 * lg + r >= N);
+          const float e0 = dead ? 0.f : __builtin_amdgcn_exp2f(s0[r] * c - L[0]);
+          const float e1 = dead ? 0.f : __builtin_amdgcn_exp2f(s1[r] * c - L[1]);
+          ds[kb][0][r] = e0 * (p0[r] - dl[0]);
+          ds[kb][1][r] = e1 * (p1[r] - dl[1]);
+        }
       }
+      // dQ^T[d][q] += K^T dS^T
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const bool dead = partial && (t * 64 + kb * 16 + 4 * lg + r >= N);
-        const float e0 = dead ? 0.f : __builtin_amdgcn_exp2f(s0[r] * c - L[0]);
-        const float e1 = dead ? 0.f : __builtin_amdgcn_exp2f(s1[r] * c - L[1]);
-        ds[kb][0][r] = e0 * (p0[r] - dl[0]);
-        ds[kb][1][r] = e1 * (p1[r] - dl[1]);
+      for (int s = 0; s < 2; ++s) {
+        if (TAIL && 2 * s >= nkb) continue;
+        const bf16x8_t a0 = pack_pair(ds[2 * s][0], ds[2 * s + 1][0]);
+        const bf16x8_t a1 = pack_pair(ds[2 * s][1], ds[2 * s + 1][1]);
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+          const bf16x8_t fkt = tr_frag<KLD>((const lds_char*)kt, 32 * s, d * 16, li, lg);
+          dqt[d][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fkt, a0, dqt[d][0], 0, 0, 0);
+          dqt[d][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fkt, a1, dqt[d][1], 0, 0, 0);
+        }
       }
-    }
-    // dQ^T[d][q] += K^T dS^T
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const bf16x8_t a0 = pack_pair(ds[2 * s][0], ds[2 * s + 1][0]);
-      const bf16x8_t a1 = pack_pair(ds[2 * s][1], ds[2 * s + 1][1]);
-#pragma unroll
-      for (int d = 0; d < DB; ++d) {
-        const bf16x8_t fkt = tr_frag<KLD>((const lds_char*)kt, 32 * s, d * 16, li, lg);
-        dqt[d][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fkt, a0, dqt[d][0], 0, 0, 0);
-        dqt[d][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fkt, a1, dqt[d][1], 0, 0, 0);
-      }
+    };
+    if (active) {
+      if (t * 64 + 64 > N) tile_body(std::true_type{});
+      else tile_body(std::false_type{});
     }
     if (t + 1 < nt) {
       sk.template commit<KLD>(smem + (cur ^ 1) * STAGE, tid);
@@ -365,6 +392,7 @@ __global__ __launch_bounds__(256) void attn_dkv_bf16_kernel(const bf16* __restri
   const bf16* vbase = qbase + 2 * I;
   const bf16* gbase = d_o + (int64_t)b * N * I + h * DH;
   const int k0 = blockIdx.x * 128 + wave * 32;
+  const bool active = __builtin_amdgcn_readfirstlane(k0) < N;
   const float scale = 1.0f / sqrtf((float)DH);
   const float c = LOG2E * scale;
 
@@ -426,48 +454,59 @@ __global__ __launch_bounds__(256) void attn_dkv_bf16_kernel(const bf16* __restri
     const float* Ls = reinterpret_cast<const float*>(qt + 2 * 64 * TLD);
     const float* Ds = Ls + 64;
 
-    f32x4_t pm[4][2], dsm[4][2];  // P and dS, [q-block][key-block]
+    auto tile_body = [&](auto tail_tag) {
+      constexpr bool TAIL = decltype(tail_tag)::value;
+      const int nqb = TAIL ? (N - t * 64 + 15) / 16 : 4;  // 16-query blocks with valid rows
+      f32x4_t pm[4][2], dsm[4][2];                       // P and dS, [q-block][key-block]
 #pragma unroll
-    for (int qb = 0; qb < 4; ++qb) {
-      f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+      for (int qb = 0; qb < 4; ++qb) {
+        pm[qb][0] = pm[qb][1] = dsm[qb][0] = dsm[qb][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (TAIL && qb >= nqb) continue;
+        f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8_t fqr = row_frag<TLD>(qt, qb * 16 + li, ks * 32 + 8 * lg);
-        const bf16x8_t fgr = row_frag<TLD>(gt, qb * 16 + li, ks * 32 + 8 * lg);
-        s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqr, fk[0][ks], s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqr, fk[1][ks], s1, 0, 0, 0);
-        p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fgr, fv[0][ks], p0, 0, 0, 0);
-        p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fgr, fv[1][ks], p1, 0, 0, 0);
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8_t fqr = row_frag<TLD>(qt, qb * 16 + li, ks * 32 + 8 * lg);
+          const bf16x8_t fgr = row_frag<TLD>(gt, qb * 16 + li, ks * 32 + 8 * lg);
+          s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqr, fk[0][ks], s0, 0, 0, 0);
+          s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqr, fk[1][ks], s1, 0, 0, 0);
+          p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fgr, fv[0][ks], p0, 0, 0, 0);
+          p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fgr, fv[1][ks], p1, 0, 0, 0);
+        }
+        const float4 l4 = *reinterpret_cast<const float4*>(Ls + qb * 16 + 4 * lg);
+        const float4 d4 = *reinterpret_cast<const float4*>(Ds + qb * 16 + 4 * lg);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e0 = __builtin_amdgcn_exp2f(s0[r] * c - lv[r]);
+          const float e1 = __builtin_amdgcn_exp2f(s1[r] * c - lv[r]);
+          pm[qb][0][r] = e0;
+          pm[qb][1][r] = e1;
+          dsm[qb][0][r] = e0 * (p0[r] - dv[r]);
+          dsm[qb][1][r] = e1 * (p1[r] - dv[r]);
+        }
       }
-      const float4 l4 = *reinterpret_cast<const float4*>(Ls + qb * 16 + 4 * lg);
-      const float4 d4 = *reinterpret_cast<const float4*>(Ds + qb * 16 + 4 * lg);
-      const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+      // dV^T[d][key] += dO^T P ; dK^T[d][key] += Q^T dS
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e0 = __builtin_amdgcn_exp2f(s0[r] * c - lv[r]);
-        const float e1 = __builtin_amdgcn_exp2f(s1[r] * c - lv[r]);
-        pm[qb][0][r] = e0;
-        pm[qb][1][r] = e1;
-        dsm[qb][0][r] = e0 * (p0[r] - dv[r]);
-        dsm[qb][1][r] = e1 * (p1[r] - dv[r]);
+      for (int s = 0; s < 2; ++s) {
+        if (TAIL && 2 * s >= nqb) continue;
+        const bf16x8_t pa0 = pack_pair(pm[2 * s][0], pm[2 * s + 1][0]);
+        const bf16x8_t pa1 = pack_pair(pm[2 * s][1], pm[2 * s + 1][1]);
+        const bf16x8_t da0 = pack_pair(dsm[2 * s][0], dsm[2 * s + 1][0]);
+        const bf16x8_t da1 = pack_pair(dsm[2 * s][1], dsm[2 * s + 1][1]);
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+          const bf16x8_t fgt = tr_frag<TLD>((const lds_char*)gt, 32 * s, d * 16, li, lg);
+          const bf16x8_t fqt = tr_frag<TLD>((const lds_char*)qt, 32 * s, d * 16, li, lg);
+          dvt[d][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fgt, pa0, dvt[d][0], 0, 0, 0);
+          dvt[d][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fgt, pa1, dvt[d][1], 0, 0, 0);
+          dkt[d][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqt, da0, dkt[d][0], 0, 0, 0);
+          dkt[d][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqt, da1, dkt[d][1], 0, 0, 0);
+        }
       }
-    }
-    // dV^T[d][key] += dO^T P ; dK^T[d][key] += Q^T dS
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const bf16x8_t pa0 = pack_pair(pm[2 * s][0], pm[2 * s + 1][0]);
-      const bf16x8_t pa1 = pack_pair(pm[2 * s][1], pm[2 * s + 1][1]);
-      const bf16x8_t da0 = pack_pair(dsm[2 * s][0], dsm[2 * s + 1][0]);
-      const bf16x8_t da1 = pack_pair(dsm[2 * s][1], dsm[2 * s + 1][1]);
-#pragma unroll
-      for (int d = 0; d < DB; ++d) {
-        const bf16x8_t fgt = tr_frag<TLD>((const lds_char*)gt, 32 * s, d * 16, li, lg);
-        const bf16x8_t fqt = tr_frag<TLD>((const lds_char*)qt, 32 * s, d * 16, li, lg);
-        dvt[d][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fgt, pa0, dvt[d][0], 0, 0, 0);
-        dvt[d][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fgt, pa1, dvt[d][1], 0, 0, 0);
-        dkt[d][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqt, da0, dkt[d][0], 0, 0, 0);
-        dkt[d][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqt, da1, dkt[d][1], 0, 0, 0);
-      }
+    };
+    if (active) {
+      if (t * 64 + 64 > N) tile_body(std::true_type{});
+      else tile_body(std::false_type{});
     }
     if (t + 1 < nt) {
       char* nx = smem + (cur ^ 1) * STAGE;

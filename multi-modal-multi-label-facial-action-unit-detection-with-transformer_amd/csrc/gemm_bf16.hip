@@ -50,43 +50,65 @@ struct NtParams {
 __device__ __forceinline__ int nt_off(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
 
 // Shared epilogue.  A lane holds C[m = m_base + 16 i + li][n = n_base + 16 j + 4 lg + 0..3] in acc[i][j].
+// All global reads of the epilogue (bias, fp32 residual, saved pre-activation) are issued up front from CLAMPED
+// addresses - no branch sits between them, so their latencies overlap instead of serialising - and only the
+// stores are predicated on the tile edge.
 // part_row >= 0: also emit the column sums of this wave's 64 rows into cs_partial[part_row][n] (plain stores;
 // a fold kernel adds the tiles_m*WM partial rows) - fuses the bias gradient "db = sum_rows dY" into the GEMM.
 template <int EPI, typename CT>
 __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[4][4], int m_base, int n_base, int li,
                                             int lg, int part_row) {
+  int nn[4], nc[4];
+  float4 bj[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    nn[j] = n_base + j * 16 + 4 * lg;
+    nc[j] = nn[j] < p.N ? nn[j] : 0;
+    bj[j] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nc[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   float cs[4][4];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int r = 0; r < 4; ++r) cs[j][r] = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m_base + i * 16 + li;
-    if (m >= p.M) continue;
+  for (int half = 0; half < 2; ++half) {
+    float4 ex[2][4];  // residual (fp32) or saved pre-activation (bf16 -> fp32) for this half
+    int mm[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n_base + j * 16 + 4 * lg;
-      if (n >= p.N) continue;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (p.bias) {
-        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    for (int ii = 0; ii < 2; ++ii) {
+      mm[ii] = m_base + (half * 2 + ii) * 16 + li;
+      const int mc = mm[ii] < p.M ? mm[ii] : p.M - 1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (EPI == AVF_EPI_BIAS_RES) ex[ii][j] = *reinterpret_cast<const float4*>(p.residual + (int64_t)mc * p.ldres + nc[j]);
+        else if (EPI == AVF_EPI_DGELU) ex[ii][j] = load4<bf16>(p.aux + (int64_t)mc * p.ldaux + nc[j]);
       }
-      if (EPI == AVF_EPI_BIAS_RES) {
-        const float4 r = *reinterpret_cast<const float4*>(p.residual + (int64_t)m * p.ldres + n);
-        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-      } else if (EPI == AVF_EPI_BIAS_GELU) {
-        store4<bf16>(p.aux + (int64_t)m * p.ldaux + n, make_float4(v[0], v[1], v[2], v[3]));
+    }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_fast(v[r]);
-      } else if (EPI == AVF_EPI_DGELU) {
-        const float4 u = load4<bf16>(p.aux + (int64_t)m * p.ldaux + n);
-        v[0] *= dgelu_tanh_fast(u.x); v[1] *= dgelu_tanh_fast(u.y); v[2] *= dgelu_tanh_fast(u.z); v[3] *= dgelu_tanh_fast(u.w);
+    for (int ii = 0; ii < 2; ++ii) {
+      const int i = half * 2 + ii;
+      const bool mok = mm[ii] < p.M;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v[4] = {acc[i][j][0] + bj[j].x, acc[i][j][1] + bj[j].y, acc[i][j][2] + bj[j].z, acc[i][j][3] + bj[j].w};
+        const bool ok = mok && nn[j] < p.N;
+        if (EPI == AVF_EPI_BIAS_RES) {
+          v[0] += ex[ii][j].x; v[1] += ex[ii][j].y; v[2] += ex[ii][j].z; v[3] += ex[ii][j].w;
+        } else if (EPI == AVF_EPI_BIAS_GELU) {
+          if (ok) store4<bf16>(p.aux + (int64_t)mm[ii] * p.ldaux + nn[j], make_float4(v[0], v[1], v[2], v[3]));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_fast(v[r]);
+        } else if (EPI == AVF_EPI_DGELU) {
+          v[0] *= dgelu_tanh_fast(ex[ii][j].x); v[1] *= dgelu_tanh_fast(ex[ii][j].y);
+          v[2] *= dgelu_tanh_fast(ex[ii][j].z); v[3] *= dgelu_tanh_fast(ex[ii][j].w);
+        }
+        if (ok) {
+          store4<CT>((CT*)p.C + (int64_t)mm[ii] * p.ldc + nn[j], make_float4(v[0], v[1], v[2], v[3]));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cs[j][r] += v[r];
+        }
       }
-      store4<CT>((CT*)p.C + (int64_t)m * p.ldc + n, make_float4(v[0], v[1], v[2], v[3]));
-#pragma unroll
-      for (int r = 0; r < 4; ++r) cs[j][r] += v[r];
     }
   }
   if (part_row >= 0) {  // wave-uniform
@@ -103,12 +125,10 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[4]
       }
     if (li == 0) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n_base + j * 16 + 4 * lg;
-        if (n < p.N)
-          *reinterpret_cast<float4*>(p.cs_partial + (int64_t)part_row * p.N + n) =
+      for (int j = 0; j < 4; ++j)
+        if (nn[j] < p.N)
+          *reinterpret_cast<float4*>(p.cs_partial + (int64_t)part_row * p.N + nn[j]) =
               make_float4(cs[j][0], cs[j][1], cs[j][2], cs[j][3]);
-      }
     }
   }
 }
@@ -206,7 +226,12 @@ __device__ __forceinline__ int xcd_remap(int id, int nwg) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
 }
 
-template <int EPI, typename CT, int WM, int WN>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int EPI, typename CT, int WM, int WN, int NS>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(NtParams p, int tiles_n, int nwg) {
   constexpr int BMT = 64 * WM, BNT = 64 * WN, NW = WM * WN;
   constexpr int A_BYTES = BMT * 128, B_BYTES = BNT * 128, STAGE = A_BYTES + B_BYTES;
@@ -250,12 +275,26 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(NtParam
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+  // NS-stage ring: tiles t .. t+NS-2 are in flight while tile t is consumed.  Each wave counts its own DMA
+  // instructions (INS per tile) with s_waitcnt vmcnt(N) - never draining to 0 inside the loop - and one raw
+  // s_barrier per K-step makes every wave's landed tile visible and frees the slot of tile t-1 for tile t+NS-1.
+  constexpr int INS = A_INS + B_INS;
   const int nt = p.K / TK;
-  stage(0, 0);
+#pragma unroll
+  for (int i = 0; i < NS - 1; ++i)
+    if (i < nt) stage(i, i * TK);
+  int cur = 0;
   for (int t = 0; t < nt; ++t) {
-    const int cur = t & 1;
-    __syncthreads();  // (waits for this wave's DMA, then the barrier) tile t landed; everyone is done with tile t-1
-    if (t + 1 < nt) stage(cur ^ 1, (t + 1) * TK);
+    const int ahead = (nt - 1 - t) < (NS - 2) ? (nt - 1 - t) : (NS - 2);  // tiles issued after tile t
+    if (ahead >= 2) wait_vmcnt<2 * INS>();
+    else if (ahead == 1) wait_vmcnt<INS>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (t + NS - 1 < nt) {
+      int slot = cur + NS - 1;
+      slot = slot >= NS ? slot - NS : slot;
+      stage(slot, (t + NS - 1) * TK);
+    }
     const char* sa = dsm + cur * STAGE;
     const char* sb = sa + A_BYTES;
 #pragma unroll
@@ -272,19 +311,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(NtParam
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     }
+    cur = (cur + 1 == NS) ? 0 : cur + 1;
   }
 
   nt_epilogue<EPI, CT>(p, acc, m0 + wm * 64, n0 + wn * 64, li, lg,
                        p.cs_partial ? (wg / tiles_n) * WM + wm : -1);
 }
 
-template <int EPI, typename CT, int WM, int WN>
+template <int EPI, typename CT, int WM, int WN, int NS>
 int launch_nt_glds(const NtParams& p, hipStream_t s, int* part_rows) {
   constexpr int BMT = 64 * WM, BNT = 64 * WN;
-  constexpr int SMEM = 2 * (BMT + BNT) * 128;
+  constexpr int SMEM = NS * (BMT + BNT) * 128;
+  static_assert(NS >= 2 && NS <= 4 && SMEM <= 160 * 1024, "stage count / LDS budget");
   static bool raised = false;
   if (!raised && SMEM > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_glds_kernel<EPI, CT, WM, WN>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_glds_kernel<EPI, CT, WM, WN, NS>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     AVF_REQUIRE(e == hipSuccess, "gemm_bf16_nt: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
     raised = true;
@@ -292,30 +333,30 @@ int launch_nt_glds(const NtParams& p, hipStream_t s, int* part_rows) {
   const int tiles_m = (p.M + BMT - 1) / BMT, tiles_n = (p.N + BNT - 1) / BNT;
   const int nwg = tiles_m * tiles_n;
   *part_rows = tiles_m * WM;
-  gemm_bf16_nt_glds_kernel<EPI, CT, WM, WN><<<nwg, WM * WN * 64, SMEM, s>>>(p, tiles_n, nwg);
+  gemm_bf16_nt_glds_kernel<EPI, CT, WM, WN, NS><<<nwg, WM * WN * 64, SMEM, s>>>(p, tiles_n, nwg);
   return 0;
 }
 
-// tile choice: 0 = 128x128 (4 waves), 1 = 256x128 (8 waves), 2 = 128x256 (8 waves), 3 = 256x256 (16 waves)
+// tile configurations (block tile, wavefronts, LDS stages):
+//   0: 128x128, 4 waves, 2 stages ( 64 KiB, 2 blocks/CU)     1: 128x128, 4 waves, 4 stages (128 KiB, 1 block/CU)
+//   2: 256x128, 8 waves, 3 stages (144 KiB, 1 block/CU)      3: 128x128, 4 waves, 3 stages ( 96 KiB, 1 block/CU)
 int pick_nt_tile(int64_t M, int64_t N) {
   static const int override_tile = [] {
-    const char* e = getenv("AVF_NT_TILE");  // tuning aid: force one tile shape
+    const char* e = getenv("AVF_NT_TILE");  // tuning aid: force one configuration
     return e ? atoi(e) : -1;
   }();
   if (override_tile >= 0) return override_tile;
-  const int64_t wg128 = ceil_div(M, 128) * ceil_div(N, 128);
-  if (wg128 >= 4 * 256 && N % 256 == 0 && M >= 256) return 3;
-  if (wg128 >= 2 * 256 && M >= 256) return 1;
+  (void)M; (void)N;
   return 0;
 }
 
 template <int EPI, typename CT>
 int launch_nt_glds_any(const NtParams& p, hipStream_t s, int* part_rows) {
   switch (pick_nt_tile(p.M, p.N)) {
-    case 1: return launch_nt_glds<EPI, CT, 4, 2>(p, s, part_rows);
-    case 2: return launch_nt_glds<EPI, CT, 2, 4>(p, s, part_rows);
-    case 3: return launch_nt_glds<EPI, CT, 4, 4>(p, s, part_rows);
-    default: return launch_nt_glds<EPI, CT, 2, 2>(p, s, part_rows);
+    case 1: return launch_nt_glds<EPI, CT, 2, 2, 4>(p, s, part_rows);
+    case 2: return launch_nt_glds<EPI, CT, 4, 2, 3>(p, s, part_rows);
+    case 3: return launch_nt_glds<EPI, CT, 2, 2, 3>(p, s, part_rows);
+    default: return launch_nt_glds<EPI, CT, 2, 2, 2>(p, s, part_rows);
   }
 }
 
