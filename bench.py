@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+bwd(+all-reduce) only")
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--graph", action="store_true", help="capture the step into a HIP graph and replay it")
     args = ap.parse_args()
 
     import torch
@@ -146,15 +147,42 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    events = not args.no_kernel_events
-    if events:
-        A._lib.timing_enable(True)
+    run = step
+    if args.graph:
+        if opt is not None:
+            for gdict in opt.param_groups:
+                gdict["capturable"] = True
+            step()
+        gr = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.cuda.graph(gr):
+            static_loss = step()
+        run = lambda: (gr.replay(), static_loss)[1]
+        for _ in range(3):
+            run()
+        fence()
+    # ---- timed region: exactly K steps between two fences, no instrumentation ------------------------------
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        loss = run()
     fence()
     dt = time.perf_counter() - t0
+    # ---- the same K steps again with a HIP-event pair around every kernel launch of the hot path (on the launch
+    # stream): per-kernel-class durations for the roofline line.  Kept out of the region above because the ~220
+    # event records per step serialise kernel boundaries (+15-20 % step time).
+    events = not args.no_kernel_events
+    dt_events = None
     if events:
+        A._lib.timing_enable(True)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt_events = time.perf_counter() - t1
         A._lib.timing_enable(False)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -178,6 +206,8 @@ def main():
     if rank == 0:
         flops_step = 3.0 * stack_flops_fwd(c, B)
         result["stack_tflops_per_gpu"] = round(flops_step / (ms_per_step * 1e-3) / 1e12, 2)
+        if dt_events is not None:
+            result["ms_per_step_with_kernel_events"] = round(dt_events / args.steps * 1e3, 4)
         if events:
             tm = A._lib.timing_read()
             mfma = {k: v for k, v in tm.items() if k.startswith("gemm") or k.startswith("attn")}
@@ -193,7 +223,8 @@ def main():
                     "flops_per_launch": d["flops"] / d["launches"],
                     "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                     "algorithmic_GBps": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1),
-                    "measured": "HIP events around every launch of this kernel class on the launch stream, timed steps",
+                    "measured": "HIP events around every launch of this kernel class on the launch stream, over K "
+                                "instrumented steps run right after the timed region (same process, same inputs)",
                 }
             result["kernel_classes"] = {
                 k: {"ms_per_step": round(v["ms"] / args.steps, 4), "launches_per_step": v["launches"] / args.steps,

@@ -55,32 +55,33 @@ __device__ __forceinline__ int nt_off(int r, int c) { return r * 128 + ((c ^ (r 
 // stores are predicated on the tile edge.
 // part_row >= 0: also emit the column sums of this wave's 64 rows into cs_partial[part_row][n] (plain stores;
 // a fold kernel adds the tiles_m*WM partial rows) - fuses the bias gradient "db = sum_rows dY" into the GEMM.
-template <int EPI, typename CT>
-__device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[4][4], int m_base, int n_base, int li,
+template <int EPI, typename CT, int MI, int NI>
+__device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI][NI], int m_base, int n_base, int li,
                                             int lg, int part_row) {
-  int nn[4], nc[4];
-  float4 bj[4];
+  static_assert(MI % 2 == 0, "MI must be even");
+  int nn[NI], nc[NI];
+  float4 bj[NI];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < NI; ++j) {
     nn[j] = n_base + j * 16 + 4 * lg;
     nc[j] = nn[j] < p.N ? nn[j] : 0;
     bj[j] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nc[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  float cs[4][4];
+  float cs[NI][4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < NI; ++j)
 #pragma unroll
     for (int r = 0; r < 4; ++r) cs[j][r] = 0.f;
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    float4 ex[2][4];  // residual (fp32) or saved pre-activation (bf16 -> fp32) for this half
+  for (int half = 0; half < MI / 2; ++half) {
+    float4 ex[2][NI];  // residual (fp32) or saved pre-activation (bf16 -> fp32) for this pair of row blocks
     int mm[2];
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii) {
       mm[ii] = m_base + (half * 2 + ii) * 16 + li;
       const int mc = mm[ii] < p.M ? mm[ii] : p.M - 1;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NI; ++j) {
         if (EPI == AVF_EPI_BIAS_RES) ex[ii][j] = *reinterpret_cast<const float4*>(p.residual + (int64_t)mc * p.ldres + nc[j]);
         else if (EPI == AVF_EPI_DGELU) ex[ii][j] = load4<bf16>(p.aux + (int64_t)mc * p.ldaux + nc[j]);
       }
@@ -90,7 +91,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[4]
       const int i = half * 2 + ii;
       const bool mok = mm[ii] < p.M;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NI; ++j) {
         float v[4] = {acc[i][j][0] + bj[j].x, acc[i][j][1] + bj[j].y, acc[i][j][2] + bj[j].z, acc[i][j][3] + bj[j].w};
         const bool ok = mok && nn[j] < p.N;
         if (EPI == AVF_EPI_BIAS_RES) {
@@ -113,7 +114,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[4]
   }
   if (part_row >= 0) {  // wave-uniform
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NI; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float t = cs[j][r];
@@ -125,7 +126,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[4]
       }
     if (li == 0) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NI; ++j)
         if (nn[j] < p.N)
           *reinterpret_cast<float4*>(p.cs_partial + (int64_t)part_row * p.N + nn[j]) =
               make_float4(cs[j][0], cs[j][1], cs[j][2], cs[j][3]);
@@ -201,8 +202,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(NtParams p) {
     __syncthreads();
   }
 
-  nt_epilogue<EPI, CT>(p, acc, m0 + wm * 64, n0 + wn * 64, li, lg,
-                       p.cs_partial ? (int)blockIdx.y * 2 + wm : -1);
+  nt_epilogue<EPI, CT, 4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, li, lg,
+                             p.cs_partial ? (int)blockIdx.y * 2 + wm : -1);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -231,9 +232,11 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int EPI, typename CT, int WM, int WN, int NS>
+template <int EPI, typename CT, int WM, int WN, int MI, int NI, int NS>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(NtParams p, int tiles_n, int nwg) {
-  constexpr int BMT = 64 * WM, BNT = 64 * WN, NW = WM * WN;
+  constexpr int WTM = 16 * MI, WTN = 16 * NI;  // per-wave output tile
+  constexpr int BMT = WTM * WM, BNT = WTN * WN, NW = WM * WN;
+  static_assert((BMT / 8) % NW == 0 && (BNT / 8) % NW == 0, "tile rows must split evenly over the waves");
   constexpr int A_BYTES = BMT * 128, B_BYTES = BNT * 128, STAGE = A_BYTES + B_BYTES;
   constexpr int A_INS = (BMT / 8) / NW, B_INS = (BNT / 8) / NW;  // wave-instructions (8 rows each) per wave
   extern __shared__ __attribute__((aligned(16))) char dsm[];
@@ -269,11 +272,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(NtParam
     for (int j = 0; j < B_INS; ++j) glds16(gb[j] + k0, sb + (wave * B_INS + j) * 1024);
   };
 
-  f32x4_t acc[4][4];
+  f32x4_t acc[MI][NI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   // NS-stage ring: tiles t .. t+NS-2 are in flight while tile t is consumed.  Each wave counts its own DMA
   // instructions (INS per tile) with s_waitcnt vmcnt(N) - never draining to 0 inside the loop - and one raw
@@ -299,33 +302,34 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(NtParam
     const char* sb = sa + A_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t fa[4], fb[4];
+      bf16x8_t fa[MI], fb[NI];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fa[i] = *reinterpret_cast<const bf16x8_t*>(sa + nt_off(wm * 64 + i * 16 + li, ks * 4 + lg));
-        fb[i] = *reinterpret_cast<const bf16x8_t*>(sb + nt_off(wn * 64 + i * 16 + li, ks * 4 + lg));
-      }
+      for (int i = 0; i < MI; ++i)
+        fa[i] = *reinterpret_cast<const bf16x8_t*>(sa + nt_off(wm * WTM + i * 16 + li, ks * 4 + lg));
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < NI; ++j)
+        fb[j] = *reinterpret_cast<const bf16x8_t*>(sb + nt_off(wn * WTN + j * 16 + li, ks * 4 + lg));
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     }
     cur = (cur + 1 == NS) ? 0 : cur + 1;
   }
 
-  nt_epilogue<EPI, CT>(p, acc, m0 + wm * 64, n0 + wn * 64, li, lg,
-                       p.cs_partial ? (wg / tiles_n) * WM + wm : -1);
+  nt_epilogue<EPI, CT, MI, NI>(p, acc, m0 + wm * WTM, n0 + wn * WTN, li, lg,
+                               p.cs_partial ? (wg / tiles_n) * WM + wm : -1);
 }
 
-template <int EPI, typename CT, int WM, int WN, int NS>
+template <int EPI, typename CT, int WM, int WN, int MI, int NI, int NS>
 int launch_nt_glds(const NtParams& p, hipStream_t s, int* part_rows) {
-  constexpr int BMT = 64 * WM, BNT = 64 * WN;
+  constexpr int BMT = 16 * MI * WM, BNT = 16 * NI * WN;
   constexpr int SMEM = NS * (BMT + BNT) * 128;
   static_assert(NS >= 2 && NS <= 4 && SMEM <= 160 * 1024, "stage count / LDS budget");
   static bool raised = false;
   if (!raised && SMEM > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_glds_kernel<EPI, CT, WM, WN, NS>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_glds_kernel<EPI, CT, WM, WN, MI, NI, NS>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     AVF_REQUIRE(e == hipSuccess, "gemm_bf16_nt: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
     raised = true;
@@ -333,30 +337,34 @@ int launch_nt_glds(const NtParams& p, hipStream_t s, int* part_rows) {
   const int tiles_m = (p.M + BMT - 1) / BMT, tiles_n = (p.N + BNT - 1) / BNT;
   const int nwg = tiles_m * tiles_n;
   *part_rows = tiles_m * WM;
-  gemm_bf16_nt_glds_kernel<EPI, CT, WM, WN, NS><<<nwg, WM * WN * 64, SMEM, s>>>(p, tiles_n, nwg);
+  gemm_bf16_nt_glds_kernel<EPI, CT, WM, WN, MI, NI, NS><<<nwg, WM * WN * 64, SMEM, s>>>(p, tiles_n, nwg);
   return 0;
 }
 
-// tile configurations (block tile, wavefronts, LDS stages):
-//   0: 128x128, 4 waves, 2 stages ( 64 KiB, 2 blocks/CU)     1: 128x128, 4 waves, 4 stages (128 KiB, 1 block/CU)
-//   2: 256x128, 8 waves, 3 stages (144 KiB, 1 block/CU)      3: 128x128, 4 waves, 3 stages ( 96 KiB, 1 block/CU)
+// tile configurations (block tile, wavefronts, LDS stages, resident blocks per CU):
+//   0: 128x128, 4 waves, 2 stages (64 KiB, 2/CU)      1: 64x128, 4 waves (32x64 each), 2 stages (48 KiB, 3/CU)
+//   2: 256x128, 8 waves, 3 stages (144 KiB, 1/CU)     3: 128x64, 4 waves (64x32 each), 2 stages (48 KiB, 3/CU)
+//   4: 64x64,   4 waves (32x32 each), 2 stages (32 KiB, 5/CU)
 int pick_nt_tile(int64_t M, int64_t N) {
   static const int override_tile = [] {
     const char* e = getenv("AVF_NT_TILE");  // tuning aid: force one configuration
     return e ? atoi(e) : -1;
   }();
   if (override_tile >= 0) return override_tile;
-  (void)M; (void)N;
-  return 0;
+  // 128x128 tiles keep two blocks per CU busy once there are >= 512 of them; below that the finer 64x128 tile
+  // (three blocks per CU) balances the 256 CUs better (measured on M = 10368 / 16384, N = 512 .. 1536)
+  const int64_t wg128 = ceil_div(M, 128) * ceil_div(N, 128);
+  return wg128 < 512 ? 1 : 0;
 }
 
 template <int EPI, typename CT>
 int launch_nt_glds_any(const NtParams& p, hipStream_t s, int* part_rows) {
   switch (pick_nt_tile(p.M, p.N)) {
-    case 1: return launch_nt_glds<EPI, CT, 2, 2, 4>(p, s, part_rows);
-    case 2: return launch_nt_glds<EPI, CT, 4, 2, 3>(p, s, part_rows);
-    case 3: return launch_nt_glds<EPI, CT, 2, 2, 3>(p, s, part_rows);
-    default: return launch_nt_glds<EPI, CT, 2, 2, 2>(p, s, part_rows);
+    case 1: return launch_nt_glds<EPI, CT, 2, 2, 2, 4, 2>(p, s, part_rows);
+    case 2: return launch_nt_glds<EPI, CT, 4, 2, 4, 4, 3>(p, s, part_rows);
+    case 3: return launch_nt_glds<EPI, CT, 2, 2, 4, 2, 2>(p, s, part_rows);
+    case 4: return launch_nt_glds<EPI, CT, 2, 2, 2, 2, 2>(p, s, part_rows);
+    default: return launch_nt_glds<EPI, CT, 2, 2, 4, 4, 2>(p, s, part_rows);
   }
 }
 

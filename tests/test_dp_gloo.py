@@ -1,0 +1,107 @@
+"""CPU, world_size=2 over gloo: the data-parallel wrapper (dp.DataParallel) - per-layer gradient buckets handed
+over by the transformer's backward hook, the extra bucket for parameters outside the stacks, averaging, and the
+parameter broadcast.  The layer math on CPU is the ORACLE (checker role only); the property tested is the one the
+8-GPU path relies on: N-rank averaged gradients == single-process gradients on the concatenated batch (the hot path
+has no cross-clip coupling)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import avformer_amd as A
+import oracle
+
+D, L, H, DH, M = 32, 2, 4, 8, 64
+
+
+class OracleStack(A.Transformer):
+    """Same parameter holders / hook protocol as the HIP Transformer, CPU math from the oracle (tests only)."""
+
+    def forward(self, x, mask=None):
+        sd = dict(self.state_dict(keep_vars=True))
+        return oracle.transformer_forward(x, sd, self.depth, self.heads)
+
+    def emulate_backward_hooks(self):
+        # what _StackFn.backward does on the GPU: per layer (reverse order) one flat fp32 bucket whose views are .grad
+        for l in reversed(range(self.depth)):
+            ps = self.layer_parameters(l)
+            flat = torch.cat([p.grad.reshape(-1) for p in ps])
+            off = 0
+            for p in ps:
+                n = p.numel()
+                p.grad = flat[off:off + n].view_as(p)
+                off += n
+            if self._grad_hook is not None:
+                self._grad_hook(l, flat)
+
+
+class TinyModel(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.pos = torch.nn.Parameter(torch.randn(1, 6, D) * 0.1)
+        self.stack = OracleStack(D, L, H, DH, M)
+        self.fc = torch.nn.Linear(D, 12)
+
+    def forward(self, x):
+        return self.fc(self.stack(x + self.pos).mean(1))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100 + rank)  # deliberately different init per rank: the wrapper must broadcast rank 0's
+        model = TinyModel()
+        dp = A.dp.DataParallel(model)
+        g = torch.Generator().manual_seed(7)
+        x = torch.randn(8, 6, D, generator=g)
+        y = (torch.rand(8, 12, generator=g) > 0.5).float()
+        # reference: full batch, single process, rank 0's (broadcast) weights
+        ref = TinyModel()
+        ref.load_state_dict(model.state_dict())
+        oracle.au_loss(ref(x), y).backward()
+        # data parallel: each rank takes its half
+        sl = slice(rank * 4, rank * 4 + 4)
+        model.zero_grad(set_to_none=True)
+        oracle.au_loss(model(x[sl]), y[sl]).backward()
+        model.stack.emulate_backward_hooks()
+        dp.finish()
+        worst = 0.0
+        for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+            worst = max(worst, (p.grad - q.grad).abs().max().item() / (q.grad.abs().max().item() + 1e-12))
+        same_w = all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), ref.state_dict().values()))
+        out.put((rank, worst, same_w, len(dp._pending)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_two_ranks_match_single_process():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, worst, same_w, pending in res:
+        assert worst < 1e-5, (rank, worst)
+        assert same_w and pending == 0
+
+
+def test_dp_requires_process_group():
+    with pytest.raises(RuntimeError, match="torch.distributed"):
+        A.dp.DataParallel(torch.nn.Linear(2, 2))
