@@ -83,7 +83,7 @@ struct TileStager {
 // forward
 // =============================================================================================
 template <int DH>
-__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
+__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
                                                             float* __restrict__ lse2, int B, int N, int H) {
   constexpr int KS = DH / 32, DB = DH / 16;
   constexpr int KLD = DH * 2 + 16;  // K tile: row reads (ds_read_b128)
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
 // backward: dQ  (query on the lane; sweeps key tiles)
 // =============================================================================================
 template <int DH>
-__global__ __launch_bounds__(256) void attn_dq_bf16_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
+__global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
                                                            const float* __restrict__ lse2,
                                                            const float* __restrict__ delta, bf16* __restrict__ dqkv,
                                                            int B, int N, int H) {
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void attn_dq_bf16_kernel(const bf16* __restric
 // backward: dK, dV  (key on the lane; sweeps query tiles)
 // =============================================================================================
 template <int DH>
-__global__ __launch_bounds__(256) void attn_dkv_bf16_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
+__global__ __launch_bounds__(256, 2) void attn_dkv_bf16_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
                                                             const float* __restrict__ lse2,
                                                             const float* __restrict__ delta, bf16* __restrict__ dqkv,
                                                             int B, int N, int H) {
@@ -454,45 +454,48 @@ __global__ __launch_bounds__(256) void attn_dkv_bf16_kernel(const bf16* __restri
     const float* Ls = reinterpret_cast<const float*>(qt + 2 * 64 * TLD);
     const float* Ds = Ls + 64;
 
+    // One Q/dO tile, processed as two 32-query k-steps so that only one pair of P / dS blocks is live at a time
+    // (keeps the kernel under 256 registers -> two waves per SIMD).
     auto tile_body = [&](auto tail_tag) {
       constexpr bool TAIL = decltype(tail_tag)::value;
       const int nqb = TAIL ? (N - t * 64 + 15) / 16 : 4;  // 16-query blocks with valid rows
-      f32x4_t pm[4][2], dsm[4][2];                       // P and dS, [q-block][key-block]
-#pragma unroll
-      for (int qb = 0; qb < 4; ++qb) {
-        pm[qb][0] = pm[qb][1] = dsm[qb][0] = dsm[qb][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        if (TAIL && qb >= nqb) continue;
-        f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const bf16x8_t fqr = row_frag<TLD>(qt, qb * 16 + li, ks * 32 + 8 * lg);
-          const bf16x8_t fgr = row_frag<TLD>(gt, qb * 16 + li, ks * 32 + 8 * lg);
-          s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqr, fk[0][ks], s0, 0, 0, 0);
-          s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqr, fk[1][ks], s1, 0, 0, 0);
-          p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fgr, fv[0][ks], p0, 0, 0, 0);
-          p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fgr, fv[1][ks], p1, 0, 0, 0);
-        }
-        const float4 l4 = *reinterpret_cast<const float4*>(Ls + qb * 16 + 4 * lg);
-        const float4 d4 = *reinterpret_cast<const float4*>(Ds + qb * 16 + 4 * lg);
-        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e0 = __builtin_amdgcn_exp2f(s0[r] * c - lv[r]);
-          const float e1 = __builtin_amdgcn_exp2f(s1[r] * c - lv[r]);
-          pm[qb][0][r] = e0;
-          pm[qb][1][r] = e1;
-          dsm[qb][0][r] = e0 * (p0[r] - dv[r]);
-          dsm[qb][1][r] = e1 * (p1[r] - dv[r]);
-        }
-      }
-      // dV^T[d][key] += dO^T P ; dK^T[d][key] += Q^T dS
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         if (TAIL && 2 * s >= nqb) continue;
-        const bf16x8_t pa0 = pack_pair(pm[2 * s][0], pm[2 * s + 1][0]);
-        const bf16x8_t pa1 = pack_pair(pm[2 * s][1], pm[2 * s + 1][1]);
-        const bf16x8_t da0 = pack_pair(dsm[2 * s][0], dsm[2 * s + 1][0]);
-        const bf16x8_t da1 = pack_pair(dsm[2 * s][1], dsm[2 * s + 1][1]);
+        f32x4_t pm[2][2], dsm[2][2];  // P and dS, [q-block of the pair][key-block]
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const int qb = 2 * s + h2;
+          pm[h2][0] = pm[h2][1] = dsm[h2][0] = dsm[h2][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+          if (TAIL && qb >= nqb) continue;
+          f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8_t fqr = row_frag<TLD>(qt, qb * 16 + li, ks * 32 + 8 * lg);
+            const bf16x8_t fgr = row_frag<TLD>(gt, qb * 16 + li, ks * 32 + 8 * lg);
+            s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqr, fk[0][ks], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqr, fk[1][ks], s1, 0, 0, 0);
+            p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fgr, fv[0][ks], p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fgr, fv[1][ks], p1, 0, 0, 0);
+          }
+          const float4 l4 = *reinterpret_cast<const float4*>(Ls + qb * 16 + 4 * lg);
+          const float4 d4 = *reinterpret_cast<const float4*>(Ds + qb * 16 + 4 * lg);
+          const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e0 = __builtin_amdgcn_exp2f(s0[r] * c - lv[r]);
+            const float e1 = __builtin_amdgcn_exp2f(s1[r] * c - lv[r]);
+            pm[h2][0][r] = e0;
+            pm[h2][1][r] = e1;
+            dsm[h2][0][r] = e0 * (p0[r] - dv[r]);
+            dsm[h2][1][r] = e1 * (p1[r] - dv[r]);
+          }
+        }
+        // dV^T[d][key] += dO^T P ; dK^T[d][key] += Q^T dS
+        const bf16x8_t pa0 = pack_pair(pm[0][0], pm[1][0]);
+        const bf16x8_t pa1 = pack_pair(pm[0][1], pm[1][1]);
+        const bf16x8_t da0 = pack_pair(dsm[0][0], dsm[1][0]);
+        const bf16x8_t da1 = pack_pair(dsm[0][1], dsm[1][1]);
 #pragma unroll
         for (int d = 0; d < DB; ++d) {
           const bf16x8_t fgt = tr_frag<TLD>((const lds_char*)gt, 32 * s, d * 16, li, lg);

@@ -1,5 +1,5 @@
 import os, sys, torch
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import avformer_amd as A
 ops = A.ops
 def timeit(fn, iters=20, warm=3):
@@ -11,8 +11,11 @@ def timeit(fn, iters=20, warm=3):
     A._lib.timing_enable(False)
     tm = A._lib.timing_read()
     return sum(v["ms"] for v in tm.values()) / iters * 1e-3
-for (m, n, k) in [(10368, 1536, 512), (10368, 1536, 2048), (10368, 1536, 8192), (10368, 512, 8192), (16384, 1024, 8192), (16384, 2048, 4096), (4096, 4096, 4096)]:
+shapes = [(10368, 1536, k) for k in (64, 128, 256, 512, 1024)] + [(10368, 512, k) for k in (64, 256, 512, 1024, 1536)]
+for (m, n, k) in shapes:
     a = torch.randn(m, k, device="cuda").bfloat16()
     b = (torch.randn(n, k, device="cuda") / k ** 0.5).bfloat16()
     t = timeit(lambda: ops.gemm(a, b, out_dtype=torch.bfloat16))
-    print(f"M={m} N={n} K={k}: {t*1e6:8.1f} us {2.0*m*n*k/t/1e12:7.1f} TF/s")
+    res = torch.randn(m, n, device="cuda"); bias = torch.randn(n, device="cuda")
+    t2 = timeit(lambda: ops.gemm(a, b, out_dtype=torch.float32, epilogue=ops.EPI_BIAS_RES, bias=bias, residual=res))
+    print(f"M={m} N={n} K={k}: plain bf16 out {t*1e6:7.1f} us ({2.0*m*n*k/t/1e12:6.1f} TF/s) | bias+res f32 out {t2*1e6:7.1f} us")
