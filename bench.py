@@ -40,6 +40,18 @@ def stack_flops_fwd(c, B):
     return L * (2.0 * B * N * (3 * D * I + I * D + 2 * D * M) + 4.0 * B * N * N * I)
 
 
+def pmc_traffic(kernel_class):
+    """HBM bytes per launch of a kernel class from the committed PMC profile of this same command
+    (profiles/r01_traffic.json, produced by tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE /
+    --pmc WRITE_SIZE passes with the gfx950 correction); None if absent - bench.py cannot read PMCs itself."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        v = json.load(open(path))["per_class"].get(kernel_class)
+        return None if v is None else round(float(v))
+    except Exception:
+        return None
+
+
 def cpu_baseline(c, steps, threads):
     """The oracle (a port of the reference's op sequence) fwd+bwd on the host CPU, same shapes."""
     import torch
@@ -218,7 +230,7 @@ def main():
                 peak = MFMA_PEAK_TFLOPS[args.dtype]
                 result["roofline"] = {
                     "kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": None,
+                    "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom),
                     "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2), "launches": d["launches"],
                     "flops_per_launch": d["flops"] / d["launches"],
                     "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],

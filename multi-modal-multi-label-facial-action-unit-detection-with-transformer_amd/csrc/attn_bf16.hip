@@ -26,6 +26,17 @@ typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 
 constexpr float LOG2E = 1.4426950408889634f;
 
+// 1-D grid of nblk * B*H blocks.  Hardware deals consecutive block ids round-robin over the 8 XCDs; this
+// bijection hands each XCD a CONTIGUOUS range of logical ids, so the row blocks of one (batch, head) - which
+// share that head's K/V (or Q/dO) - run on one XCD and hit in its L2 instead of re-fetching from HBM.
+__device__ __forceinline__ void block_coords(int nblk, int& blk, int& bh) {
+  const int nwg = gridDim.x, id = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, x = id & 7;
+  const int lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+  bh = lid / nblk;
+  blk = lid - bh * nblk;
+}
+
 template <int LD>
 __device__ __forceinline__ bf16x8_t tr_frag(const lds_char* tile, int row_base, int col_base, int li, int lg) {
   const lds_char* p0 = tile + (row_base + 4 * lg + (li >> 2)) * LD + (col_base + 4 * (li & 3)) * 2;
@@ -93,13 +104,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16* __res
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
-  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  int blk, bh;
+  block_coords((N + 127) / 128, blk, bh);
+  const int b = bh / H, h = bh - b * H;
   const int I = H * DH;
   const int64_t ld = 3 * (int64_t)I;
   const bf16* qbase = qkv + (int64_t)b * N * ld + h * DH;
   const bf16* kbase = qbase + I;
   const bf16* vbase = qbase + 2 * I;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = blk * 128 + wave * 32;
   const bool active = __builtin_amdgcn_readfirstlane(q0) < N;
   const float c = LOG2E / sqrtf((float)DH);
 
@@ -252,14 +265,16 @@ __global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(const bf16* __rest
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
-  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  int blk, bh;
+  block_coords((N + 127) / 128, blk, bh);
+  const int b = bh / H, h = bh - b * H;
   const int I = H * DH;
   const int64_t ld = 3 * (int64_t)I;
   const bf16* qbase = qkv + (int64_t)b * N * ld + h * DH;
   const bf16* kbase = qbase + I;
   const bf16* vbase = qbase + 2 * I;
   const bf16* gbase = d_o + (int64_t)b * N * I + h * DH;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = blk * 128 + wave * 32;
   const bool active = __builtin_amdgcn_readfirstlane(q0) < N;
   const float scale = 1.0f / sqrtf((float)DH);
   const float c = LOG2E * scale;
@@ -384,14 +399,16 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_bf16_kernel(const bf16* __res
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
-  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  int blk, bh;
+  block_coords((N + 127) / 128, blk, bh);
+  const int b = bh / H, h = bh - b * H;
   const int I = H * DH;
   const int64_t ld = 3 * (int64_t)I;
   const bf16* qbase = qkv + (int64_t)b * N * ld + h * DH;
   const bf16* kbase = qbase + I;
   const bf16* vbase = qbase + 2 * I;
   const bf16* gbase = d_o + (int64_t)b * N * I + h * DH;
-  const int k0 = blockIdx.x * 128 + wave * 32;
+  const int k0 = blk * 128 + wave * 32;
   const bool active = __builtin_amdgcn_readfirstlane(k0) < N;
   const float scale = 1.0f / sqrtf((float)DH);
   const float c = LOG2E * scale;
@@ -540,10 +557,10 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_bf16_kernel(const bf16* __res
 
 int attn_fwd_bf16(const bf16* qkv, bf16* o, float* lse2, int B, int N, int H, int dh, hipStream_t s) {
   AVF_REQUIRE(B > 0 && N > 0 && H > 0, "attn_fwd_bf16: bad shape");
-  AVF_REQUIRE((int64_t)B * H < 65536, "attn_fwd_bf16: batch*heads too large for grid");
+  AVF_REQUIRE(ceil_div(N, 128) * B * H < (1LL << 31), "attn_fwd_bf16: grid too large");
   AVF_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)o & 7) == 0, "attn_fwd_bf16: misaligned pointers");
   TimingScope ts(KC_ATTN_FWD, 4.0 * B * H * (double)N * N * dh, 2.0 * 4.0 * B * N * H * dh, s);
-  dim3 grid((unsigned)ceil_div(N, 128), (unsigned)(B * H));
+  const unsigned grid = (unsigned)(ceil_div(N, 128) * B * H);
   if (dh == 64) attn_fwd_bf16_kernel<64><<<grid, 256, 0, s>>>(qkv, o, lse2, B, N, H);
   else if (dh == 32) attn_fwd_bf16_kernel<32><<<grid, 256, 0, s>>>(qkv, o, lse2, B, N, H);
   else AVF_REQUIRE(false, "attention (bf16): unsupported dim_head %d (32 or 64)", dh);
@@ -553,12 +570,12 @@ int attn_fwd_bf16(const bf16* qkv, bf16* o, float* lse2, int B, int N, int H, in
 int attn_bwd_bf16(const bf16* qkv, const bf16* o, const bf16* d_o, const float* lse2, bf16* dqkv, float* delta, int B,
                   int N, int H, int dh, hipStream_t s) {
   AVF_REQUIRE(B > 0 && N > 0 && H > 0, "attn_bwd_bf16: bad shape");
-  AVF_REQUIRE((int64_t)B * H < 65536, "attn_bwd_bf16: batch*heads too large for grid");
+  AVF_REQUIRE(ceil_div(N, 128) * B * H < (1LL << 31), "attn_bwd_bf16: grid too large");
   AVF_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)d_o & 15) == 0 && ((uintptr_t)dqkv & 7) == 0,
               "attn_bwd_bf16: misaligned pointers");
   TimingScope ts(KC_ATTN_BWD, 10.0 * B * H * (double)N * N * dh, 2.0 * 8.0 * B * N * H * dh, s);
   AVF_TRY(attn_delta(AVF_BF16, o, d_o, delta, B, N, H, dh, s));
-  dim3 grid((unsigned)ceil_div(N, 128), (unsigned)(B * H));
+  const unsigned grid = (unsigned)(ceil_div(N, 128) * B * H);
   if (dh == 64) {
     attn_dq_bf16_kernel<64><<<grid, 256, 0, s>>>(qkv, d_o, lse2, delta, dqkv, B, N, H);
     attn_dkv_bf16_kernel<64><<<grid, 256, 0, s>>>(qkv, d_o, lse2, delta, dqkv, B, N, H);
