@@ -342,29 +342,28 @@ int launch_nt_glds(const NtParams& p, hipStream_t s, int* part_rows) {
 }
 
 // tile configurations (block tile, wavefronts, LDS stages, resident blocks per CU):
-//   0: 128x128, 4 waves, 2 stages (64 KiB, 2/CU)      1: 64x128, 4 waves (32x64 each), 2 stages (48 KiB, 3/CU)
-//   2: 256x128, 8 waves, 3 stages (144 KiB, 1/CU)     3: 128x64, 4 waves (64x32 each), 2 stages (48 KiB, 3/CU)
-//   4: 64x64,   4 waves (32x32 each), 2 stages (32 KiB, 5/CU)
+//   0: 128x128, 4 waves of 64x64, 2 stages (64 KiB, 2/CU)
+//   1:  64x128, 4 waves of 32x64, 2 stages (48 KiB, 3/CU)   - finer grain for grids that cannot fill the chip
+//   2: 128x128, 8 waves of 64x32, 2 stages (64 KiB, 2/CU)   - twice the waves per CU hide the DMA / epilogue
+//                                                             latency better (+5..8 % measured at K = 512..1536)
+// (a 4-stage ring at one block per CU, 256x128 / 256x256 tiles, 64x64 tiles and a persistent tile loop were
+//  measured slower on this path's shapes - M = 10k..16k, N = 512..1536, K = 512..1536 - and removed)
 int pick_nt_tile(int64_t M, int64_t N) {
   static const int override_tile = [] {
     const char* e = getenv("AVF_NT_TILE");  // tuning aid: force one configuration
     return e ? atoi(e) : -1;
   }();
   if (override_tile >= 0) return override_tile;
-  // 128x128 tiles keep two blocks per CU busy once there are >= 512 of them; below that the finer 64x128 tile
-  // (three blocks per CU) balances the 256 CUs better (measured on M = 10368 / 16384, N = 512 .. 1536)
   const int64_t wg128 = ceil_div(M, 128) * ceil_div(N, 128);
-  return wg128 < 512 ? 1 : 0;
+  return wg128 < 512 ? 1 : 2;
 }
 
 template <int EPI, typename CT>
 int launch_nt_glds_any(const NtParams& p, hipStream_t s, int* part_rows) {
   switch (pick_nt_tile(p.M, p.N)) {
+    case 0: return launch_nt_glds<EPI, CT, 2, 2, 4, 4, 2>(p, s, part_rows);
     case 1: return launch_nt_glds<EPI, CT, 2, 2, 2, 4, 2>(p, s, part_rows);
-    case 2: return launch_nt_glds<EPI, CT, 4, 2, 4, 4, 3>(p, s, part_rows);
-    case 3: return launch_nt_glds<EPI, CT, 2, 2, 4, 2, 2>(p, s, part_rows);
-    case 4: return launch_nt_glds<EPI, CT, 2, 2, 2, 2, 2>(p, s, part_rows);
-    default: return launch_nt_glds<EPI, CT, 2, 2, 4, 4, 2>(p, s, part_rows);
+    default: return launch_nt_glds<EPI, CT, 2, 4, 4, 2, 2>(p, s, part_rows);
   }
 }
 

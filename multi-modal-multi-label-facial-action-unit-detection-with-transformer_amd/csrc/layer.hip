@@ -310,9 +310,11 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
 
   // ---- feed-forward half -------------------------------------------------------------------
   // db2 = column sums of dx_out: handed over by the caller (the next layer's LN1 backward produced them) or summed here
-  if (dx_out_colsum) AVF_REQUIRE(hipMemcpyAsync(g->b2, dx_out_colsum, (size_t)d.D * 4, hipMemcpyDeviceToDevice, s) == hipSuccess,
-                                 "layer_bwd: memcpy failed");
-  else AVF_TRY(colsum(dx_out, AVF_F32, d.R, d.D, d.D, g->b2, w.cs_ws, s));
+  // (the caller normally points the previous call's dx_in_colsum straight at this layer's b2 slot: nothing to do)
+  if (dx_out_colsum && dx_out_colsum != g->b2)
+    AVF_REQUIRE(hipMemcpyAsync(g->b2, dx_out_colsum, (size_t)d.D * 4, hipMemcpyDeviceToDevice, s) == hipSuccess,
+                "layer_bwd: memcpy failed");
+  else if (!dx_out_colsum) AVF_TRY(colsum(dx_out, AVF_F32, d.R, d.D, d.D, g->b2, w.cs_ws, s));
   if (!grouped) AVF_TRY(linear_dw(d, gy, d.D, sv.g, d.M, g->w2, w.gemm_ws, s));
   if (lo) {  // db1 = colsum(du) fused into the dGELU GEMM epilogue
     AVF_TRY(linear_dx(d, gy, d.D, p->w2, l.w2_t, d.M, w.du, AVF_EPI_DGELU, sv.u, s, g->b1, w.cs_ws));

@@ -66,17 +66,75 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   }
 }
 
+// D % 4 == 0 and D <= 256*NV: the row lives in registers (one HBM read, no re-reads from cache)
+template <typename OutT, int NV>
+__global__ __launch_bounds__(256) void ln_fwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, OutT* __restrict__ y,
+                                                         float* __restrict__ mean, float* __restrict__ rstd,
+                                                         int64_t rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane * 4 + 256 * i;
+    v[i] = c < D ? *reinterpret_cast<const float4*>(x + row * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mu = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane * 4 + 256 * i;
+    if (c < D) {
+      const float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, d = v[i].w - mu;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float rs = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  if (lane == 0) {
+    mean[row] = mu;
+    rstd[row] = rs;
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane * 4 + 256 * i;
+    if (c < D) {
+      const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+      const float4 b = *reinterpret_cast<const float4*>(beta + c);
+      store4<OutT>(y + row * D + c, make_float4((v[i].x - mu) * rs * g.x + b.x, (v[i].y - mu) * rs * g.y + b.y,
+                                                (v[i].z - mu) * rs * g.z + b.z, (v[i].w - mu) * rs * g.w + b.w));
+    }
+  }
+}
+
 int layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype, float* mean,
                   float* rstd, int64_t rows, int dim, float eps, hipStream_t s) {
   AVF_REQUIRE(rows > 0 && dim > 0, "layernorm_fwd: bad shape rows=%lld dim=%d", (long long)rows, dim);
+  AVF_REQUIRE(y_dtype == AVF_F32 || y_dtype == AVF_BF16, "layernorm_fwd: bad dtype %d", y_dtype);
   TimingScope ts(KC_LAYERNORM, 0.0, (double)rows * dim * (4.0 + (y_dtype == AVF_BF16 ? 2.0 : 4.0)), s);
   dim3 grid((unsigned)ceil_div(rows, 4)), block(256);
-  if (y_dtype == AVF_F32)
+  if (dim % 4 == 0 && dim <= 1536) {
+    const int nv = (dim + 255) / 256;
+#define LAUNCH_NV(T, NVV) ln_fwd_reg_kernel<T, NVV><<<grid, block, 0, s>>>(x, gamma, beta, (T*)y, mean, rstd, rows, dim, eps)
+#define LAUNCH_T(T)                 \
+  switch (nv) {                     \
+    case 1: LAUNCH_NV(T, 1); break; \
+    case 2: LAUNCH_NV(T, 2); break; \
+    case 3: LAUNCH_NV(T, 3); break; \
+    case 4: LAUNCH_NV(T, 4); break; \
+    default: LAUNCH_NV(T, 6); break;\
+  }
+    if (y_dtype == AVF_F32) { LAUNCH_T(float) } else { LAUNCH_T(bf16) }
+#undef LAUNCH_T
+#undef LAUNCH_NV
+  } else if (y_dtype == AVF_F32) {
     ln_fwd_kernel<float><<<grid, block, 0, s>>>(x, gamma, beta, (float*)y, mean, rstd, rows, dim, eps);
-  else if (y_dtype == AVF_BF16)
+  } else {
     ln_fwd_kernel<bf16><<<grid, block, 0, s>>>(x, gamma, beta, (bf16*)y, mean, rstd, rows, dim, eps);
-  else
-    AVF_REQUIRE(false, "layernorm_fwd: bad dtype %d", y_dtype);
+  }
   return check_launch("ln_fwd_kernel");
 }
 

@@ -119,33 +119,35 @@ class _StackFn(torch.autograd.Function):
         lo_a = torch.empty((B * N, D), dtype=torch.bfloat16, device=dev) if bf16 else None
         lo_b = torch.empty((B * N, D), dtype=torch.bfloat16, device=dev) if bf16 else None
         have_lo = False
-        cs_a = torch.empty(D, dtype=torch.float32, device=dev)  # column sums of dx, handed layer to layer
-        cs_b = torch.empty(D, dtype=torch.float32, device=dev)
-        have_cs = False
         live = mod.flat_parameters()
         sizes = [p.numel() for p in ctx.params[:PARAMS_PER_LAYER]]
         hook = mod._grad_hook
-        for l in reversed(range(L)):
+        # one flat fp32 gradient bucket per layer; the tensors' .grad become views of it
+        flats, views = [], []
+        for l in range(L):
             flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
-            views, off = [], 0
+            vs, off = [], 0
             for i, n in enumerate(sizes):
-                views.append(flat[off:off + n].view_as(ctx.params[l * PARAMS_PER_LAYER + i]))
+                vs.append(flat[off:off + n].view_as(ctx.params[l * PARAMS_PER_LAYER + i]))
                 off += n
-            gp = _lib.LayerPtrs(*[v.data_ptr() for v in views])
+            flats.append(flat)
+            views.append(vs)
+        B2 = PARAMS_PER_LAYER - 1  # index of net.3.bias: its gradient = column sums of the layer's dx_out
+        for l in reversed(range(L)):
+            gp = _lib.LayerPtrs(*[v.data_ptr() for v in views[l]])
             pp = mod._param_struct(ctx.params, l)
+            # LN1' of this layer writes the column sums of dx_in directly into the previous layer's b2 gradient
             _lib.check(lib.avf_layer_bwd(C.byref(cfg), C.byref(pp), _ptr(ctx.lowps[l]), _ptr(ctx.xs[l]),
                                          _ptr(ctx.saved_bufs[l]), _ptr(dx), _ptr(lo_a) if have_lo else None,
-                                         _ptr(cs_a) if have_cs else None, _ptr(dx), _ptr(lo_b),
-                                         _ptr(cs_b) if l > 0 else None, C.byref(gp), _ptr(ws), stream),
+                                         _ptr(views[l][B2]) if l < L - 1 else None, _ptr(dx), _ptr(lo_b),
+                                         _ptr(views[l - 1][B2]) if l > 0 else None, C.byref(gp), _ptr(ws), stream),
                        f"layer_bwd[{l}]")
             lo_a, lo_b = lo_b, lo_a
-            cs_a, cs_b = cs_b, cs_a
             have_lo = bf16
-            have_cs = True
-            waiter = hook(l, flat) if hook is not None else None  # e.g. launch this layer's all-reduce now
+            waiter = hook(l, flats[l]) if hook is not None else None  # e.g. launch this layer's all-reduce now
             # Parameter gradients are handed over directly (views of the layer's flat buffer, no copy):
             # ``.grad = view`` when empty, ``.grad += view`` when accumulating.
-            for p, v in zip(live[l * PARAMS_PER_LAYER:(l + 1) * PARAMS_PER_LAYER], views):
+            for p, v in zip(live[l * PARAMS_PER_LAYER:(l + 1) * PARAMS_PER_LAYER], views[l]):
                 if not p.requires_grad:
                     continue
                 if p.grad is None:
