@@ -46,7 +46,11 @@ typedef struct avf_layer_cfg {
   int32_t dtype;       /* AVF_F32 | AVF_BF16                                                    */
   int32_t project_out; /* 0 iff heads==1 && dim_head==dim (nn.Identity)   heads.py:207          */
   float ln_eps;        /* nn.LayerNorm default 1e-5                       heads.py:181          */
-  float dropout_p;     /* must be 0 in this version (eval()/p=0 semantics) heads.py:194-196,216 */
+  float dropout_p;     /* nn.Dropout p of the three sites (after to_out, after GELU, after net.3)
+                          heads.py:194-196,216; 0 = eval()/no dropout.  p > 0 needs AVF_BF16.  Masks are a pure
+                          function of (seed, layer_index, site, element), regenerated in backward.               */
+  uint32_t seed_lo, seed_hi; /* dropout seed: use a fresh value per forward, the same one in its backward        */
+  int32_t layer_index; /* position of this layer in its stack (keys the dropout masks)                          */
 } avf_layer_cfg;
 
 /* fp32 master parameters of one layer, in state_dict order:
@@ -129,7 +133,8 @@ int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p, const voi
                   float* x_out, void* saved, void* workspace, void* stream);
 
 /* dx_in (fp32) and all parameter gradients from dx_out (fp32).  dx_out_lo: optional bf16 copy of dx_out
- * (null => made internally); dx_in_lo: optional bf16 copy of dx_in to hand to the previous layer.
+ * (null => made internally); dx_in_lo: optional bf16 copy of dx_in to hand to the previous layer (with dropout
+ * active it already carries layer_index-1's site-2 mask, which is what that layer's MLP gradients consume).
  * dx_out_colsum: optional [D] column sums of dx_out (= this layer's b2 gradient) already computed by the
  * caller's previous call; dx_in_colsum: optional [D] output, column sums of dx_in for the next call.
  * dx_in may alias dx_out (dx_out_lo / dx_in_lo must then be distinct buffers). */
@@ -137,6 +142,11 @@ int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p, const voi
                   const void* saved, const float* dx_out, const void* dx_out_lo, const float* dx_out_colsum,
                   float* dx_in, void* dx_in_lo, float* dx_in_colsum, const avf_layer_grads* g, void* workspace,
                   void* stream);
+
+/* test aid: the keep/(1-p) factors (0 or 1/(1-p_eff)) dropout site `site` (0 after to_out, 1 after GELU, 2 after
+ * net.3) of layer `layer_index` applies to a [rows, cols] activation, as fp32 [rows, cols] (cols % 4 == 0). */
+int avf_dropout_factors(uint32_t seed_lo, uint32_t seed_hi, int layer_index, int site, float p, int64_t rows, int cols,
+                        float* out, void* stream);
 
 /* ---- optional HIP-event timing per kernel class (bench.py's roofline line) --------------------------
  * classes: 0 gemm_bf16_nt, 1 gemm_bf16_tn(+fold), 2 gemm_f32, 3 attn_fwd, 4 attn_bwd, 5 layernorm.

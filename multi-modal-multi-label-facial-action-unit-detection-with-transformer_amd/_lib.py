@@ -25,7 +25,8 @@ _sz = C.c_size_t
 class LayerCfg(C.Structure):
     _fields_ = [("batch", C.c_int32), ("tokens", C.c_int32), ("dim", C.c_int32), ("heads", C.c_int32),
                 ("dim_head", C.c_int32), ("mlp_dim", C.c_int32), ("dtype", C.c_int32), ("project_out", C.c_int32),
-                ("ln_eps", C.c_float), ("dropout_p", C.c_float)]
+                ("ln_eps", C.c_float), ("dropout_p", C.c_float), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32),
+                ("layer_index", C.c_int32)]
 
 
 PARAM_FIELDS = ("ln1_w", "ln1_b", "w_qkv", "w_out", "b_out", "ln2_w", "ln2_b", "w1", "b1", "w2", "b2")
@@ -62,6 +63,7 @@ SIGNATURES = {
     "avf_layer_fwd": (_int, [C.POINTER(LayerCfg), C.POINTER(LayerPtrs), _vp, _vp, _vp, _vp, _vp, _vp]),
     "avf_layer_bwd": (_int, [C.POINTER(LayerCfg), C.POINTER(LayerPtrs), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                              C.POINTER(LayerPtrs), _vp, _vp]),
+    "avf_dropout_factors": (_int, [C.c_uint32, C.c_uint32, _int, _int, _f, _i64, _int, _vp, _vp]),
     "avf_timing_enable": (_int, [_int]),
     "avf_timing_read": (_int, [_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                C.POINTER(C.c_double)]),

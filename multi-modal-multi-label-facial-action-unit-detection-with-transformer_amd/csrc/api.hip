@@ -164,6 +164,13 @@ extern "C" int avf_cast_f32_to_bf16(const float* in, void* out, int64_t n, void*
   AVF_REQUIRE(in && out, "cast: null pointer");
   return cast_f32_to_bf16(in, out, n, (hipStream_t)stream);
 }
+extern "C" int avf_dropout_factors(uint32_t seed_lo, uint32_t seed_hi, int layer_index, int site, float p, int64_t rows,
+                                   int cols, float* out, void* stream) {
+  AVF_REQUIRE(out && rows > 0 && cols > 0 && cols % 4 == 0 && p > 0.f && p < 1.f && site >= 0 && site < 3,
+              "dropout_factors: bad arguments");
+  const DropCfg d = make_drop(p, ((uint64_t)seed_hi << 32) | seed_lo, layer_index, site);
+  return dropout_factors(d, out, rows * cols, (hipStream_t)stream);
+}
 extern "C" int avf_prep_weight_bf16(const float* w, void* w_lo, void* w_t_lo, int rows, int cols, void* stream) {
   AVF_REQUIRE(w, "prep_weight: null pointer");
   return prep_weight_bf16(w, w_lo, w_t_lo, rows, cols, (hipStream_t)stream);
@@ -181,7 +188,7 @@ extern "C" int avf_gemm(int dtype, int transA, int transB, int64_t M, int64_t N,
   a.M = M; a.N = N; a.K = K;
   a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
   a.c_dtype = c_dtype; a.epilogue = epilogue; a.bias = bias; a.residual = residual; a.ldres = ldres;
-  a.aux = aux; a.ldaux = ldaux; a.workspace = workspace; a.colsum = nullptr;
+  a.aux = aux; a.ldaux = ldaux; a.workspace = workspace; a.colsum = nullptr; a.drop = kNoDrop;
   return gemm(a, (hipStream_t)stream);
 }
 

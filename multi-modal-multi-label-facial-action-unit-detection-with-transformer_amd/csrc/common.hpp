@@ -146,6 +146,44 @@ __device__ __forceinline__ float dgelu_tanh_fast(float u) {
   return 0.5f * (1.0f + t) + 0.5f * u * (1.0f - t * t) * c * (1.0f + 3.0f * 0.044715f * u2);
 }
 
+// ---------------------------------------------------------------------------------------------
+// dropout (nn.Dropout at heads.py:194,196,216): counter-based, stateless.  One splitmix64 hash per group of 4
+// consecutive elements gives four 16-bit uniforms; an element is dropped when its uniform < thresh16 = round(p*65536)
+// and kept elements are scaled by 1/(1-p_eff).  The mask of element (row, col) of a site depends only on
+// (seed, layer, site, row*ld + col), so forward and backward regenerate identical masks without storing them.
+// ---------------------------------------------------------------------------------------------
+struct DropCfg {
+  uint64_t key;     // mix of (seed, layer, site); meaningless when thresh16 == 0
+  uint32_t thresh16;  // 0 = dropout disabled
+  float scale;
+};
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+  return z ^ (z >> 31);
+}
+// sites of one layer: 0 = after to_out (heads.py:216), 1 = after GELU (heads.py:194), 2 = after net.3 (heads.py:196)
+inline DropCfg make_drop(float p, uint64_t seed, int layer, int site) {
+  DropCfg d;
+  uint32_t t = (uint32_t)(p * 65536.0f + 0.5f);
+  if (t > 65535u) t = 65535u;
+  d.thresh16 = p > 0.f ? t : 0u;
+  d.scale = 1.0f / (1.0f - (float)d.thresh16 / 65536.0f);
+  d.key = mix64(seed + 0xD1B54A32D192ED03ULL * (uint64_t)(layer * 4 + site + 1));
+  return d;
+}
+static const DropCfg kNoDrop = {0, 0, 1.0f};
+// keep*scale factors of the 4 elements starting at linear index idx (idx % 4 == 0)
+__device__ __forceinline__ float4 drop_factor4(const DropCfg& d, uint64_t idx) {
+  const uint64_t h = mix64(d.key + idx * 0x9E3779B97F4A7C15ULL);
+  float4 f;
+  f.x = ((uint32_t)(h) & 0xffffu) >= d.thresh16 ? d.scale : 0.f;
+  f.y = ((uint32_t)(h >> 16) & 0xffffu) >= d.thresh16 ? d.scale : 0.f;
+  f.z = ((uint32_t)(h >> 32) & 0xffffu) >= d.thresh16 ? d.scale : 0.f;
+  f.w = ((uint32_t)(h >> 48) & 0xffffu) >= d.thresh16 ? d.scale : 0.f;
+  return f;
+}
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ---------------------------------------------------------------------------------------------
@@ -154,12 +192,15 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 int layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype, float* mean,
                   float* rstd, int64_t rows, int dim, float eps, hipStream_t s);
 size_t layernorm_bwd_ws(int64_t rows, int dim);
+// drop: mask applied to the bf16 copy dx_lo AND to the column sums (they feed the Linear behind a dropout site);
+// dx itself (the residual stream gradient) is never masked.
 int layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean,
                   const float* rstd, const float* dres, float* dx, void* dx_lo, float* dgamma, float* dbeta,
-                  float* dcolsum, void* ws, int64_t rows, int dim, hipStream_t s);
+                  float* dcolsum, void* ws, int64_t rows, int dim, hipStream_t s, const DropCfg& drop = kNoDrop);
 size_t colsum_ws(int64_t rows, int cols);
 int colsum(const void* in, int in_dtype, int64_t rows, int cols, int64_t ld, float* out, void* ws, hipStream_t s);
-int cast_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t s);
+int cast_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t s, const DropCfg& drop = kNoDrop);
+int dropout_factors(const DropCfg& drop, float* out, int64_t n, hipStream_t s);  // test aid: keep*scale per element
 // out[c] = sum_b partial[b][c]
 int fold_partials(const float* partial, int nb, int width, float* out, hipStream_t s);
 // workspace bytes for the fused column-sum partials of an NT GEMM with M rows and N columns
@@ -187,6 +228,7 @@ struct GemmArgs {
   int64_t ldaux;
   void* workspace;
   float* colsum;  // optional: column sums of the stored C (bf16 NT only; partials go to workspace)
+  DropCfg drop;   // bf16 NT only: BIAS_RES masks (acc+bias) before the residual, BIAS_GELU masks gelu(u), DGELU masks acc
 };
 size_t gemm_ws(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K);
 int gemm(const GemmArgs& a, hipStream_t s);

@@ -43,6 +43,7 @@ struct NtParams {
   bf16* aux;
   int64_t ldaux;
   float* cs_partial;  // optional [tiles_m * WM][N] column-sum partials of the stored C values (bias gradients)
+  DropCfg drop;       // dropout site fused in the epilogue (thresh16 == 0: none); element index = m * N + n
   int M, N, K;
 };
 
@@ -94,15 +95,18 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
       for (int j = 0; j < NI; ++j) {
         float v[4] = {acc[i][j][0] + bj[j].x, acc[i][j][1] + bj[j].y, acc[i][j][2] + bj[j].z, acc[i][j][3] + bj[j].w};
         const bool ok = mok && nn[j] < p.N;
-        if (EPI == AVF_EPI_BIAS_RES) {
-          v[0] += ex[ii][j].x; v[1] += ex[ii][j].y; v[2] += ex[ii][j].z; v[3] += ex[ii][j].w;
-        } else if (EPI == AVF_EPI_BIAS_GELU) {
+        float4 df = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (p.drop.thresh16) df = drop_factor4(p.drop, (uint64_t)mm[ii] * p.N + nn[j]);  // wave-uniform branch
+        if (EPI == AVF_EPI_BIAS_RES) {  // x + Dropout(Linear(.))
+          v[0] = v[0] * df.x + ex[ii][j].x; v[1] = v[1] * df.y + ex[ii][j].y;
+          v[2] = v[2] * df.z + ex[ii][j].z; v[3] = v[3] * df.w + ex[ii][j].w;
+        } else if (EPI == AVF_EPI_BIAS_GELU) {  // Dropout(GELU(u)); u is saved unmasked
           if (ok) store4<bf16>(p.aux + (int64_t)mm[ii] * p.ldaux + nn[j], make_float4(v[0], v[1], v[2], v[3]));
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_fast(v[r]);
-        } else if (EPI == AVF_EPI_DGELU) {
-          v[0] *= dgelu_tanh_fast(ex[ii][j].x); v[1] *= dgelu_tanh_fast(ex[ii][j].y);
-          v[2] *= dgelu_tanh_fast(ex[ii][j].z); v[3] *= dgelu_tanh_fast(ex[ii][j].w);
+          v[0] = gelu_tanh_fast(v[0]) * df.x; v[1] = gelu_tanh_fast(v[1]) * df.y;
+          v[2] = gelu_tanh_fast(v[2]) * df.z; v[3] = gelu_tanh_fast(v[3]) * df.w;
+        } else if (EPI == AVF_EPI_DGELU) {  // backward through Dropout then GELU
+          v[0] *= df.x * dgelu_tanh_fast(ex[ii][j].x); v[1] *= df.y * dgelu_tanh_fast(ex[ii][j].y);
+          v[2] *= df.z * dgelu_tanh_fast(ex[ii][j].z); v[3] *= df.w * dgelu_tanh_fast(ex[ii][j].w);
         }
         if (ok) {
           store4<CT>((CT*)p.C + (int64_t)mm[ii] * p.ldc + nn[j], make_float4(v[0], v[1], v[2], v[3]));
@@ -673,6 +677,8 @@ int gemm_bf16_nt(const GemmArgs& a, hipStream_t s) {
   p.A = (const bf16*)a.A; p.lda = a.lda; p.B = (const bf16*)a.B; p.ldb = a.ldb;
   p.C = a.C; p.ldc = a.ldc; p.bias = a.bias; p.residual = a.residual; p.ldres = a.ldres;
   p.aux = (bf16*)a.aux; p.ldaux = a.ldaux;
+  p.drop = a.drop;
+  AVF_REQUIRE(!a.drop.thresh16 || a.epilogue != AVF_EPI_NONE, "gemm_bf16_nt: dropout needs a fused epilogue");
   p.M = (int)a.M; p.N = (int)a.N; p.K = (int)a.K;
   dim3 grid((unsigned)ceil_div(a.N, TB), (unsigned)ceil_div(a.M, TB));
   AVF_REQUIRE(grid.y < 65536, "gemm_bf16_nt: M too large for grid");

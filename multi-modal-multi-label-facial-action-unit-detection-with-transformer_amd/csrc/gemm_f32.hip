@@ -116,6 +116,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(F32GemmParams p) {
 
 int gemm_f32(const GemmArgs& a, hipStream_t s) {
   AVF_REQUIRE(a.c_dtype == AVF_F32, "gemm_f32: C must be fp32");
+  AVF_REQUIRE(!a.drop.thresh16, "gemm_f32: dropout is only implemented on the bf16 path");
   AVF_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm_f32: bad shape");
   AVF_REQUIRE(a.M < (1LL << 31) && a.N < (1LL << 31) && a.K < (1LL << 31), "gemm_f32: shape too large");
   F32GemmParams p;

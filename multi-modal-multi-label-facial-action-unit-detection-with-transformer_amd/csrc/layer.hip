@@ -23,6 +23,9 @@ struct Dims {
   int D, H, dh, I, M, B, N;
   int dt;     // compute dtype
   size_t es;  // element size of compute dtype
+  float p;    // dropout probability (0 = off)
+  uint64_t seed;
+  int layer;
 };
 
 int make_dims(const avf_layer_cfg* c, Dims* d) {
@@ -30,13 +33,18 @@ int make_dims(const avf_layer_cfg* c, Dims* d) {
   AVF_REQUIRE(c->batch > 0 && c->tokens > 0 && c->dim > 0 && c->heads > 0 && c->dim_head > 0 && c->mlp_dim > 0,
               "layer: non-positive shape in cfg");
   AVF_REQUIRE(c->dtype == AVF_F32 || c->dtype == AVF_BF16, "layer: bad dtype %d", c->dtype);
-  AVF_REQUIRE(c->dropout_p == 0.0f, "layer: dropout_p=%g is not supported by this version (use eval()/p=0)",
+  AVF_REQUIRE(c->dropout_p >= 0.0f && c->dropout_p < 1.0f, "layer: dropout_p=%g out of range", (double)c->dropout_p);
+  AVF_REQUIRE(c->dropout_p == 0.0f || c->dtype == AVF_BF16,
+              "layer: dropout_p=%g needs the bf16 path (the fp32 parity mode is defined at p=0 / eval())",
               (double)c->dropout_p);
+  AVF_REQUIRE(c->dropout_p == 0.0f || (c->dim % 4 == 0 && c->dim <= 1536 && c->mlp_dim % 4 == 0),
+              "layer: dropout needs dim %% 4 == 0, dim <= 1536");
   AVF_REQUIRE(c->project_out == 1,
               "layer: the nn.Identity to_out case (heads==1 && dim_head==dim, heads.py:207) is not supported");
   d->B = c->batch; d->N = c->tokens; d->D = c->dim; d->H = c->heads; d->dh = c->dim_head;
   d->I = c->heads * c->dim_head; d->M = c->mlp_dim; d->R = (int64_t)c->batch * c->tokens;
   d->dt = c->dtype; d->es = c->dtype == AVF_BF16 ? 2 : 4;
+  d->p = c->dropout_p; d->seed = ((uint64_t)c->seed_hi << 32) | c->seed_lo; d->layer = c->layer_index;
   if (c->dtype == AVF_BF16) {
     AVF_REQUIRE(d->D % 8 == 0 && d->I % 8 == 0 && d->M % 8 == 0, "layer(bf16): dim, inner and mlp_dim must be multiples of 8");
     AVF_REQUIRE(d->dh == 32 || d->dh == 64, "layer(bf16): dim_head must be 32 or 64 (got %d)", d->dh);
@@ -156,20 +164,22 @@ size_t carve_work(const Dims& d, void* base, Work* w) {
 
 // C[R, out] = A[R, in] * W[out, in]^T  (nn.Linear forward)
 int linear_fwd(const Dims& d, const void* A, int in, const void* W, int out, void* C, int c_dtype, int epi,
-               const float* bias, const float* res, void* aux, hipStream_t s) {
+               const float* bias, const float* res, void* aux, hipStream_t s, const DropCfg& drop = kNoDrop) {
   GemmArgs a;
   a.dtype = d.dt; a.transA = 0; a.transB = 1;
   a.M = d.R; a.N = out; a.K = in;
   a.A = A; a.lda = in; a.B = W; a.ldb = in;
   a.C = C; a.ldc = out; a.c_dtype = c_dtype; a.epilogue = epi;
   a.bias = bias; a.residual = res; a.ldres = out; a.aux = aux; a.ldaux = out; a.workspace = nullptr; a.colsum = nullptr;
+  a.drop = drop;
   return gemm(a, s);
 }
 
 // dX[R, in] = dY[R, out] * W[out, in].  bf16 mode consumes the transposed copy Wt[in, out] as an NT GEMM.
 // colsum (bf16 mode only, optional): column sums of the produced dX, fused in the GEMM epilogue (ws = partials)
 int linear_dx(const Dims& d, const void* dY, int out, const void* W_f32, const void* Wt_lo, int in, void* dX, int epi,
-              void* aux, hipStream_t s, float* colsum_out = nullptr, void* ws = nullptr) {
+              void* aux, hipStream_t s, float* colsum_out = nullptr, void* ws = nullptr,
+              const DropCfg& drop = kNoDrop) {
   GemmArgs a;
   a.dtype = d.dt; a.transA = 0;
   a.M = d.R; a.N = in; a.K = out;
@@ -178,6 +188,7 @@ int linear_dx(const Dims& d, const void* dY, int out, const void* W_f32, const v
   else { a.transB = 0; a.B = W_f32; a.ldb = in; }
   a.C = dX; a.ldc = in; a.c_dtype = d.dt; a.epilogue = epi;
   a.bias = nullptr; a.residual = nullptr; a.ldres = 0; a.aux = aux; a.ldaux = in; a.workspace = ws; a.colsum = colsum_out;
+  a.drop = drop;
   return gemm(a, s);
 }
 
@@ -189,6 +200,7 @@ int linear_dw(const Dims& d, const void* dY, int out, const void* X, int in, flo
   a.A = dY; a.lda = out; a.B = X; a.ldb = in;
   a.C = dW; a.ldc = in; a.c_dtype = AVF_F32; a.epilogue = AVF_EPI_NONE;
   a.bias = nullptr; a.residual = nullptr; a.ldres = 0; a.aux = nullptr; a.ldaux = 0; a.workspace = ws; a.colsum = nullptr;
+  a.drop = kNoDrop;
   return gemm(a, s);
 }
 
@@ -268,10 +280,12 @@ extern "C" int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   AVF_TRY(linear_fwd(d, sv.h1, d.D, wqkv, 3 * d.I, sv.qkv, d.dt, AVF_EPI_NONE, nullptr, nullptr, nullptr, s));
   if (lo) AVF_TRY(attn_fwd_bf16((const bf16*)sv.qkv, (bf16*)sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s));
   else AVF_TRY(attn_fwd_f32((const float*)sv.qkv, (float*)sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s));
-  AVF_TRY(linear_fwd(d, sv.o, d.I, wo, d.D, sv.x_mid, AVF_F32, AVF_EPI_BIAS_RES, p->b_out, x_in, nullptr, s));
+  const DropCfg dr0 = make_drop(d.p, d.seed, d.layer, 0), dr1 = make_drop(d.p, d.seed, d.layer, 1),
+                dr2 = make_drop(d.p, d.seed, d.layer, 2);
+  AVF_TRY(linear_fwd(d, sv.o, d.I, wo, d.D, sv.x_mid, AVF_F32, AVF_EPI_BIAS_RES, p->b_out, x_in, nullptr, s, dr0));
   AVF_TRY(layernorm_fwd(sv.x_mid, p->ln2_w, p->ln2_b, sv.h2, d.dt, sv.mean2, sv.rstd2, d.R, d.D, cfg->ln_eps, s));
-  AVF_TRY(linear_fwd(d, sv.h2, d.D, w1, d.M, sv.g, d.dt, AVF_EPI_BIAS_GELU, p->b1, nullptr, sv.u, s));
-  AVF_TRY(linear_fwd(d, sv.g, d.M, w2, d.D, x_out, AVF_F32, AVF_EPI_BIAS_RES, p->b2, sv.x_mid, nullptr, s));
+  AVF_TRY(linear_fwd(d, sv.h2, d.D, w1, d.M, sv.g, d.dt, AVF_EPI_BIAS_GELU, p->b1, nullptr, sv.u, s, dr1));
+  AVF_TRY(linear_fwd(d, sv.g, d.M, w2, d.D, x_out, AVF_F32, AVF_EPI_BIAS_RES, p->b2, sv.x_mid, nullptr, s, dr2));
   return 0;
 }
 
@@ -293,12 +307,18 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   const bool lo = d.dt == AVF_BF16;
 
   // gradient of the layer output in the compute dtype (GEMM operand)
+  // dropout: the Linears behind a dropout site see the masked, rescaled gradient (the residual stream does not)
+  const DropCfg dr0 = make_drop(d.p, d.seed, d.layer, 0), dr1 = make_drop(d.p, d.seed, d.layer, 1),
+                dr2 = make_drop(d.p, d.seed, d.layer, 2);
+  const DropCfg dr_prev2 = d.layer > 0 ? make_drop(d.p, d.seed, d.layer - 1, 2) : kNoDrop;
   const void* gy = dx_out;
+  bool own_copy = false;
   if (lo) {
-    if (dx_out_lo) gy = dx_out_lo;
+    if (dx_out_lo) gy = dx_out_lo;  // the caller's previous call already applied this layer's site-2 mask
     else {
-      AVF_TRY(cast_f32_to_bf16(dx_out, w.dx_out_lo, d.R * d.D, s));
+      AVF_TRY(cast_f32_to_bf16(dx_out, w.dx_out_lo, d.R * d.D, s, dr2));
       gy = w.dx_out_lo;
+      own_copy = true;
     }
   }
   const void* gm = lo ? (const void*)w.dx_mid_lo : (const void*)w.dx_mid;
@@ -314,10 +334,17 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   if (dx_out_colsum && dx_out_colsum != g->b2)
     AVF_REQUIRE(hipMemcpyAsync(g->b2, dx_out_colsum, (size_t)d.D * 4, hipMemcpyDeviceToDevice, s) == hipSuccess,
                 "layer_bwd: memcpy failed");
-  else if (!dx_out_colsum) AVF_TRY(colsum(dx_out, AVF_F32, d.R, d.D, d.D, g->b2, w.cs_ws, s));
+  else if (!dx_out_colsum) {
+    if (d.p > 0.f) {  // db2 sums the MASKED gradient
+      AVF_REQUIRE(own_copy, "layer_bwd: with dropout pass dx_out_colsum together with dx_out_lo");
+      AVF_TRY(colsum(gy, AVF_BF16, d.R, d.D, d.D, g->b2, w.cs_ws, s));
+    } else {
+      AVF_TRY(colsum(dx_out, AVF_F32, d.R, d.D, d.D, g->b2, w.cs_ws, s));
+    }
+  }
   if (!grouped) AVF_TRY(linear_dw(d, gy, d.D, sv.g, d.M, g->w2, w.gemm_ws, s));
   if (lo) {  // db1 = colsum(du) fused into the dGELU GEMM epilogue
-    AVF_TRY(linear_dx(d, gy, d.D, p->w2, l.w2_t, d.M, w.du, AVF_EPI_DGELU, sv.u, s, g->b1, w.cs_ws));
+    AVF_TRY(linear_dx(d, gy, d.D, p->w2, l.w2_t, d.M, w.du, AVF_EPI_DGELU, sv.u, s, g->b1, w.cs_ws, dr1));
   } else {
     AVF_TRY(linear_dx(d, gy, d.D, p->w2, l.w2_t, d.M, w.du, AVF_EPI_DGELU, sv.u, s));
     AVF_TRY(colsum(w.du, d.dt, d.R, d.M, d.M, g->b1, w.cs_ws, s));
@@ -325,7 +352,7 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   if (!grouped) AVF_TRY(linear_dw(d, w.du, d.M, sv.h2, d.D, g->w1, w.gemm_ws, s));
   AVF_TRY(linear_dx(d, w.du, d.M, p->w1, l.w1_t, d.D, w.dh, AVF_EPI_NONE, nullptr, s));
   AVF_TRY(layernorm_bwd(w.dh, d.dt, sv.x_mid, p->ln2_w, sv.mean2, sv.rstd2, dx_out, w.dx_mid,
-                        lo ? w.dx_mid_lo : nullptr, g->ln2_w, g->ln2_b, g->b_out, w.ln_ws, d.R, d.D, s));
+                        lo ? w.dx_mid_lo : nullptr, g->ln2_w, g->ln2_b, g->b_out, w.ln_ws, d.R, d.D, s, dr0));
   // ---- attention half ----------------------------------------------------------------------
   if (!grouped) AVF_TRY(linear_dw(d, gm, d.D, sv.o, d.I, g->w_out, w.gemm_ws, s));
   AVF_TRY(linear_dx(d, gm, d.D, p->w_out, l.wo_t, d.I, w.d_o, AVF_EPI_NONE, nullptr, s));
@@ -339,7 +366,7 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   AVF_TRY(linear_dx(d, w.dqkv, 3 * d.I, p->w_qkv, l.wqkv_t, d.D, w.dh, AVF_EPI_NONE, nullptr, s));
   // dx_in may alias dx_out, which the grouped dW2 GEMM does not read (it uses the bf16 copy gy)
   AVF_TRY(layernorm_bwd(w.dh, d.dt, x_in, p->ln1_w, sv.mean1, sv.rstd1, w.dx_mid, dx_in, lo ? dx_in_lo : nullptr,
-                        g->ln1_w, g->ln1_b, dx_in_colsum, w.ln_ws, d.R, d.D, s));
+                        g->ln1_w, g->ln1_b, dx_in_colsum, w.ln_ws, d.R, d.D, s, dr_prev2));
   if (grouped) AVF_TRY(gemm_bf16_tn_group(grp, s));
   return 0;
 }

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void ln_bwd_reg_kernel(const DyT* __restrict__
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ dres, float* __restrict__ dx,
                                                          bf16* __restrict__ dx_lo, float* __restrict__ partial,
-                                                         int64_t rows, int D, int want_colsum) {
+                                                         int64_t rows, int D, int want_colsum, DropCfg drop) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [4 waves][3][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t row0 = (int64_t)blockIdx.x * LNR_ROWS_PER_BLOCK;
@@ -289,6 +289,10 @@ __global__ __launch_bounds__(256) void ln_bwd_reg_kernel(const DyT* __restrict__
       o.z = rs * (d[i].z * g[i].z - s1 - xh[i].z * s2) + r.z;
       o.w = rs * (d[i].w * g[i].w - s1 - xh[i].w * s2) + r.w;
       *reinterpret_cast<float4*>(dx + row * D + c) = o;
+      if (drop.thresh16) {  // what the Linear behind the dropout site sees: masked, rescaled
+        const float4 f = drop_factor4(drop, (uint64_t)row * D + c);
+        o.x *= f.x; o.y *= f.y; o.z *= f.z; o.w *= f.w;
+      }
       if (dx_lo) store4<bf16>(dx_lo + row * D + c, o);
       adg[i].x += d[i].x * xh[i].x; adg[i].y += d[i].y * xh[i].y; adg[i].z += d[i].z * xh[i].z; adg[i].w += d[i].w * xh[i].w;
       adb[i].x += d[i].x; adb[i].y += d[i].y; adb[i].z += d[i].z; adb[i].w += d[i].w;
@@ -398,8 +402,9 @@ size_t layernorm_bwd_ws(int64_t rows, int dim) {
 
 int layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean,
                   const float* rstd, const float* dres, float* dx, void* dx_lo, float* dgamma, float* dbeta,
-                  float* dcolsum, void* ws, int64_t rows, int dim, hipStream_t s) {
+                  float* dcolsum, void* ws, int64_t rows, int dim, hipStream_t s, const DropCfg& drop) {
   AVF_REQUIRE(rows > 0 && dim > 0 && ws, "layernorm_bwd: bad arguments");
+  AVF_REQUIRE(!drop.thresh16 || (dim % 4 == 0 && dim <= 1536), "layernorm_bwd: dropout needs dim %% 4 == 0 and dim <= 1536");
   AVF_REQUIRE((size_t)3 * dim * sizeof(float) <= 64 * 1024, "layernorm_bwd: dim %d too large", dim);
   TimingScope ts(KC_LAYERNORM, 0.0,
                  (double)rows * dim * ((dy_dtype == AVF_BF16 ? 2.0 : 4.0) + 4.0 + (dres ? 4.0 : 0.0) + 4.0 + (dx_lo ? 2.0 : 0.0)), s);
@@ -424,7 +429,7 @@ int layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gam
     }
 #define LAUNCH_NV(T, NVV)                                                                                          \
   ln_bwd_reg_kernel<T, NVV><<<nb, 256, lds, s>>>((const T*)dy, x, gamma, mean, rstd, dres, dx, (bf16*)dx_lo, partial, \
-                                                 rows, dim, wc)
+                                                 rows, dim, wc, drop)
 #define LAUNCH_T(T)                                   \
   switch (nv) {                                       \
     case 1: LAUNCH_NV(T, 1); break;                   \
@@ -509,21 +514,42 @@ int colsum(const void* in, int in_dtype, int64_t rows, int cols, int64_t ld, flo
 // casts / weight preparation
 // =============================================================================================
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ in, bf16* __restrict__ out,
-                                                        int64_t n) {
+                                                        int64_t n, DropCfg drop) {
   int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   const int64_t stride = (int64_t)gridDim.x * 256 * 4;
-  for (; i + 3 < n; i += stride) store4<bf16>(out + i, *reinterpret_cast<const float4*>(in + i));
+  for (; i + 3 < n; i += stride) {
+    float4 v = *reinterpret_cast<const float4*>(in + i);
+    if (drop.thresh16) {
+      const float4 f = drop_factor4(drop, (uint64_t)i);
+      v.x *= f.x; v.y *= f.y; v.z *= f.z; v.w *= f.w;
+    }
+    store4<bf16>(out + i, v);
+  }
   // tail (n not a multiple of 4): handled by the thread whose i lands on it
   if (i < n && i + 3 >= n)
     for (int64_t j = i; j < n; ++j) out[j] = from_f32<bf16>(in[j]);
 }
 
-int cast_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t s) {
+__global__ __launch_bounds__(256) void dropout_factors_kernel(DropCfg drop, float* __restrict__ out, int64_t n) {
+  int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+  for (; i + 3 < n; i += stride) *reinterpret_cast<float4*>(out + i) = drop_factor4(drop, (uint64_t)i);
+}
+int dropout_factors(const DropCfg& drop, float* out, int64_t n, hipStream_t s) {
+  AVF_REQUIRE(n > 0 && n % 4 == 0 && drop.thresh16, "dropout_factors: n %% 4 == 0 and p > 0 required");
+  int64_t blocks = ceil_div(n, 1024);
+  if (blocks > 2048) blocks = 2048;
+  dropout_factors_kernel<<<(unsigned)blocks, 256, 0, s>>>(drop, out, n);
+  return check_launch("dropout_factors_kernel");
+}
+
+int cast_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t s, const DropCfg& drop) {
   AVF_REQUIRE(n > 0, "cast: n must be positive");
+  AVF_REQUIRE(!drop.thresh16 || n % 4 == 0, "cast: dropout needs n %% 4 == 0");
   AVF_REQUIRE((((uintptr_t)in) & 15) == 0 && (((uintptr_t)out) & 7) == 0, "cast: pointers must be 16B/8B aligned");
   int64_t blocks = ceil_div(n, 1024);
   if (blocks > 2048) blocks = 2048;
-  cast_bf16_kernel<<<(unsigned)blocks, 256, 0, s>>>(in, (bf16*)out, n);
+  cast_bf16_kernel<<<(unsigned)blocks, 256, 0, s>>>(in, (bf16*)out, n, drop);
   return check_launch("cast_bf16_kernel");
 }
 

@@ -185,6 +185,14 @@ def au_loss(logits: torch.Tensor, labels: torch.Tensor, pos_weight: torch.Tensor
     return loss, grad
 
 
+def dropout_factors(seed: int, layer: int, site: int, p: float, rows: int, cols: int, device="cuda") -> torch.Tensor:
+    """keep/(1-p) factors of dropout site `site` of layer `layer` for a [rows, cols] activation (test aid)."""
+    out = torch.empty((rows, cols), dtype=torch.float32, device=device)
+    _lib.check(_lib.load().avf_dropout_factors(seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, layer, site, float(p), rows,
+                                               cols, _ptr(out), _stream()), "dropout_factors")
+    return out
+
+
 # hardware self-tests -------------------------------------------------------------------------------
 def selftest_mfma_bf16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     c = torch.empty((16, 16), dtype=torch.float32, device=a.device)

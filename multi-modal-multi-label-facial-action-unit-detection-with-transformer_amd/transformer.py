@@ -69,8 +69,11 @@ class _StackFn(torch.autograd.Function):
         B, N, D = x.shape
         dev = x.device
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        cfg = mod._cfg(B, N)
         L = mod.depth
+        seed = mod._next_seed()
+        mod.last_seed = seed
+        cfgs = [mod._cfg(B, N, l, seed) for l in range(L)]
+        cfg = cfgs[0]
         params = [p.detach() for p in params]
         need_grad = any(ctx.needs_input_grad)  # (grad mode is off inside Function.forward)
         saved_bytes = lib.avf_layer_saved_bytes(C.byref(cfg))
@@ -89,12 +92,12 @@ class _StackFn(torch.autograd.Function):
                 shared = shared if shared is not None else torch.empty(saved_bytes, dtype=torch.uint8, device=dev)
                 sv = shared
             x_out = torch.empty((B * N, D), dtype=torch.float32, device=dev)
-            _lib.check(lib.avf_layer_fwd(C.byref(cfg), C.byref(pp), _ptr(lowps[l]), _ptr(xs[-1]), _ptr(x_out), _ptr(sv),
+            _lib.check(lib.avf_layer_fwd(C.byref(cfgs[l]), C.byref(pp), _ptr(lowps[l]), _ptr(xs[-1]), _ptr(x_out), _ptr(sv),
                                          _ptr(ws), stream), f"layer_fwd[{l}]")
             saved.append(sv)
             xs.append(x_out)
         ctx.mod = mod
-        ctx.cfg = cfg
+        ctx.cfgs = cfgs
         ctx.shape = (B, N, D)
         ctx.xs = xs[:-1] if need_grad else None
         ctx.saved_bufs = saved if need_grad else None
@@ -106,7 +109,8 @@ class _StackFn(torch.autograd.Function):
     def backward(ctx, dy):
         lib = _lib.load()
         mod = ctx.mod
-        cfg = ctx.cfg
+        cfgs = ctx.cfgs
+        cfg = cfgs[0]
         B, N, D = ctx.shape
         dev = dy.device
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -137,7 +141,7 @@ class _StackFn(torch.autograd.Function):
             gp = _lib.LayerPtrs(*[v.data_ptr() for v in views[l]])
             pp = mod._param_struct(ctx.params, l)
             # LN1' of this layer writes the column sums of dx_in directly into the previous layer's b2 gradient
-            _lib.check(lib.avf_layer_bwd(C.byref(cfg), C.byref(pp), _ptr(ctx.lowps[l]), _ptr(ctx.xs[l]),
+            _lib.check(lib.avf_layer_bwd(C.byref(cfgs[l]), C.byref(pp), _ptr(ctx.lowps[l]), _ptr(ctx.xs[l]),
                                          _ptr(ctx.saved_bufs[l]), _ptr(dx), _ptr(lo_a) if have_lo else None,
                                          _ptr(views[l][B2]) if l < L - 1 else None, _ptr(dx), _ptr(lo_b),
                                          _ptr(views[l - 1][B2]) if l > 0 else None, C.byref(gp), _ptr(ws), stream),
@@ -176,6 +180,8 @@ class Transformer(nn.Module):
         self._lowp_ptrs = None
         self.cache_weights = False
         self._grad_hook: Optional[Callable] = None
+        self._drop_calls = 0
+        self.last_seed = 0
 
     # ---- parameter plumbing --------------------------------------------------------------------
     def layer_parameters(self, l: int) -> List[torch.Tensor]:
@@ -199,14 +205,23 @@ class Transformer(nn.Module):
         return a callable that makes the current stream wait for that reduction."""
         self._grad_hook = hook
 
-    def _cfg(self, B: int, N: int) -> _lib.LayerCfg:
-        p = self.dropout if self.training else 0.0
-        if p != 0.0:
+    def _cfg(self, B: int, N: int, layer: int = 0, seed: int = 0) -> _lib.LayerCfg:
+        p = self.dropout if self.training else 0.0  # nn.Dropout semantics: identity in eval()
+        if p != 0.0 and self.compute_dtype != _lib.BF16:
             raise NotImplementedError(
-                f"dropout={p} in training mode is not implemented by the HIP path yet; call .eval() or construct "
-                f"with dropout=0 (parity with the reference is defined at p=0 / eval, SURVEY.md section 7)")
+                f"dropout={p} in training mode needs compute_dtype='bf16'; the fp32 parity mode is defined at "
+                f"p=0 / eval() (SURVEY.md section 7)")
         return _lib.LayerCfg(B, N, self.dim, self.heads, self.dim_head, self.mlp_dim, self.compute_dtype,
-                             int(self.project_out), 1e-5, 0.0)
+                             int(self.project_out), 1e-5, float(p), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, layer)
+
+    def _next_seed(self) -> int:
+        """Fresh 64-bit dropout seed per forward, reproducible under torch.manual_seed (the masks themselves come
+        from a counter-based hash in the kernels, not from torch's generator)."""
+        if not (self.training and self.dropout > 0.0):
+            return 0
+        self._drop_calls += 1
+        return (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._drop_calls * 0xD1B54A32D192ED03 + id(self) % 65521) \
+            & 0xFFFFFFFFFFFFFFFF
 
     @staticmethod
     def _param_struct(params, l) -> _lib.LayerPtrs:

@@ -89,24 +89,34 @@ def transformer_param_names(layer: int, project_out: bool = True) -> List[str]:
 
 
 def layer_forward(x: Tensor, sd: Dict[str, Tensor], layer: int, heads: int, prefix: str = "",
-                  mask: Optional[Tensor] = None) -> Tensor:
-    """One (Residual(PreNorm(Attention)), Residual(PreNorm(FeedForward))) pair - heads.py:246-255."""
+                  mask: Optional[Tensor] = None, drop=None) -> Tensor:
+    """One (Residual(PreNorm(Attention)), Residual(PreNorm(FeedForward))) pair - heads.py:246-255.
+
+    ``drop`` (optional): three tensors of keep/(1-p) factors for the nn.Dropout sites of the layer - after to_out
+    (heads.py:216), after GELU (heads.py:194), after net.3 (heads.py:196) - i.e. explicit masks instead of torch's
+    generator, so that a kernel's counter-based masks can be replayed exactly."""
     p = f"{prefix}layers.{layer}"
+    f0, f1, f2 = drop if drop is not None else (None, None, None)
     h = layernorm(x, sd[f"{p}.0.fn.norm.weight"], sd[f"{p}.0.fn.norm.bias"])
-    x = attention_forward(h, sd[f"{p}.0.fn.fn.to_qkv.weight"],
+    a = attention_forward(h, sd[f"{p}.0.fn.fn.to_qkv.weight"],
                           sd.get(f"{p}.0.fn.fn.to_out.0.weight"), sd.get(f"{p}.0.fn.fn.to_out.0.bias"),
-                          heads, mask) + x
+                          heads, mask)
+    x = (a if f0 is None else a * f0.view_as(a)) + x
     h = layernorm(x, sd[f"{p}.1.fn.norm.weight"], sd[f"{p}.1.fn.norm.bias"])
-    x = feedforward_forward(h, sd[f"{p}.1.fn.fn.net.0.weight"], sd[f"{p}.1.fn.fn.net.0.bias"],
-                            sd[f"{p}.1.fn.fn.net.3.weight"], sd[f"{p}.1.fn.fn.net.3.bias"]) + x
+    u = h @ sd[f"{p}.1.fn.fn.net.0.weight"].t() + sd[f"{p}.1.fn.fn.net.0.bias"]
+    g = gelu_tanh(u)
+    if f1 is not None:
+        g = g * f1.view_as(g)
+    f = g @ sd[f"{p}.1.fn.fn.net.3.weight"].t() + sd[f"{p}.1.fn.fn.net.3.bias"]
+    x = (f if f2 is None else f * f2.view_as(f)) + x
     return x
 
 
 def transformer_forward(x: Tensor, sd: Dict[str, Tensor], depth: int, heads: int, prefix: str = "",
-                        mask: Optional[Tensor] = None) -> Tensor:
-    """models/heads.py:252-256."""
+                        mask: Optional[Tensor] = None, drop=None) -> Tensor:
+    """models/heads.py:252-256.  ``drop``: optional list (one entry per layer) of the three factor tensors."""
     for i in range(depth):
-        x = layer_forward(x, sd, i, heads, prefix, mask)
+        x = layer_forward(x, sd, i, heads, prefix, mask, None if drop is None else drop[i])
     return x
 
 

@@ -88,13 +88,21 @@ def test_no_cpu_fallback():
         A.ops.layernorm_fwd(torch.zeros(2, 8), torch.ones(8), torch.zeros(8))
 
 
-def test_dropout_training_is_rejected_loudly():
-    t = A.Transformer(32, 1, 8, 32, 64, dropout=0.2)
+def test_dropout_configuration():
+    t = A.Transformer(32, 1, 8, 32, 64, dropout=0.2, compute_dtype="f32")
     t.train()
-    with pytest.raises(NotImplementedError, match="dropout"):
+    with pytest.raises(NotImplementedError, match="bf16"):  # parity mode is defined at p=0 / eval()
         t._cfg(1, 4)
     t.eval()
-    t._cfg(1, 4)
+    assert t._cfg(1, 4).dropout_p == 0.0
+    t = A.Transformer(32, 1, 8, 32, 64, dropout=0.2)  # bf16: dropout is live in train(), identity in eval()
+    t.train()
+    c = t._cfg(1, 4, layer=3, seed=(7 << 32) | 9)
+    assert abs(c.dropout_p - 0.2) < 1e-7 and (c.seed_lo, c.seed_hi, c.layer_index) == (9, 7, 3)
+    s1, s2 = t._next_seed(), t._next_seed()
+    assert s1 != s2 and s1 != 0
+    t.eval()
+    assert t._cfg(1, 4).dropout_p == 0.0 and t._next_seed() == 0
 
 
 def test_registry():
