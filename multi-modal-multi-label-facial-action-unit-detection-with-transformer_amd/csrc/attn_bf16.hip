@@ -181,14 +181,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16* __res
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float sv_ = st[kb][qb][r] * c;
-            if (TAIL && (t * 64 + kb * 16 + 4 * lg + r >= N)) sv_ = -INFINITY;
-            st[kb][qb][r] = sv_;
-            tmax = fmaxf(tmax, sv_);
+            if (TAIL && (t * 64 + kb * 16 + 4 * lg + r >= N)) st[kb][qb][r] = -INFINITY;
+            tmax = fmaxf(tmax, st[kb][qb][r]);  // raw scores: the scale c > 0 commutes with max
           }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float mn = fmaxf(m[qb], tmax);
+        const float mn = fmaxf(m[qb], tmax * c);
         const float alpha = __builtin_amdgcn_exp2f(m[qb] - mn);
         m[qb] = mn;
         float ps = 0.f;
@@ -196,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16* __res
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float pv = __builtin_amdgcn_exp2f(st[kb][qb][r] - mn);
+            const float pv = __builtin_amdgcn_exp2f(fmaf(st[kb][qb][r], c, -mn));  // 2^(c*s - m): one FMA + exp
             st[kb][qb][r] = pv;
             ps += pv;
           }

@@ -61,7 +61,11 @@ __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
   return __builtin_bit_cast(uint16_t, b);
 }
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+  // one v_cvt_pk_bf16_f32 for the pair (a scalar cast per element costs two converts plus shift/or)
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 template <typename T>

@@ -533,12 +533,16 @@ __device__ __forceinline__ bf16x8_t tr_frag_swz(const lds_char* tile, int row_ba
   return __builtin_bit_cast(bf16x8_t, r);
 }
 
-__global__ __launch_bounds__(256) void gemm_bf16_tn_group_kernel(TnGroup g) {
+// WNW = wavefronts along N (2 -> 4 waves of 64x64, 4 -> 8 waves of 64x32)
+template <int WNW>
+__global__ __launch_bounds__(128 * WNW) void gemm_bf16_tn_group_kernel(TnGroup g) {
   constexpr int OPB = TR * 256;  // bytes per operand per stage (64 rows x 256 B) = 16 KiB
+  constexpr int NI = 8 / WNW;    // 16-column blocks per wave
+  constexpr int INS = 8 / WNW;   // LDS-DMA instructions per wave per operand per stage (16 in total)
   __shared__ __attribute__((aligned(16))) char smem[4 * OPB];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WNW, wn = wave % WNW;
   const int li = lane & 15, lg = lane >> 4;
   // block -> (tile, split); splits of one tile are adjacent ids
   const int tile = blockIdx.x / g.S, split = blockIdx.x - tile * g.S;
@@ -554,11 +558,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_group_kernel(TnGroup g) {
 
   // LDS-DMA source pointers: wave-instruction j of this wave fills rows 4*(4*wave + j) .. +3 (1 KiB)
   const int lrow = lane >> 4, lslot = lane & 15;
-  const bf16* ga[4];
-  const bf16* gb[4];
+  const bf16* ga[INS];
+  const bf16* gb[INS];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = (wave * 4 + j) * 4 + lrow;
+  for (int j = 0; j < INS; ++j) {
+    const int row = (wave * INS + j) * 4 + lrow;
     const int chunk = lslot ^ ((row & 7) << 1);
     const int ca = (m0 + chunk * 8 < P.M) ? m0 + chunk * 8 : 0;  // columns past the edge: any valid address
     const int cb = (n0 + chunk * 8 < P.N) ? n0 + chunk * 8 : 0;
@@ -570,16 +574,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_group_kernel(TnGroup g) {
     char* sa = smem + st * 2 * OPB;
     char* sb = sa + OPB;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) glds16(ga[j] + t * astep, sa + (wave * 4 + j) * 1024);
+    for (int j = 0; j < INS; ++j) glds16(ga[j] + t * astep, sa + (wave * INS + j) * 1024);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) glds16(gb[j] + t * bstep, sb + (wave * 4 + j) * 1024);
+    for (int j = 0; j < INS; ++j) glds16(gb[j] + t * bstep, sb + (wave * INS + j) * 1024);
   };
 
-  f32x4_t acc[4][4];
+  f32x4_t acc[4][NI];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int nt = kend > kbeg ? (kend - kbeg) / TR : 0;
   if (nt > 0) stage(0, 0);
@@ -591,16 +595,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_group_kernel(TnGroup g) {
     const lds_char* sb = sa + OPB;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t fa[4], fb[4];
+      bf16x8_t fa[4], fb[NI];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fa[i] = tr_frag_swz(sa, ks * 32, wm * 64 + i * 16, li, lg);
-        fb[i] = tr_frag_swz(sb, ks * 32, wn * 64 + i * 16, li, lg);
-      }
+      for (int i = 0; i < 4; ++i) fa[i] = tr_frag_swz(sa, ks * 32, wm * 64 + i * 16, li, lg);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) fb[j] = tr_frag_swz(sb, ks * 32, wn * (16 * NI) + j * 16, li, lg);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     }
   }
@@ -610,8 +613,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_group_kernel(TnGroup g) {
     const int m = m0 + wm * 64 + i * 16 + li;
     if (m >= P.M) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + 4 * lg;
+    for (int j = 0; j < NI; ++j) {
+      const int n = n0 + wn * (16 * NI) + j * 16 + 4 * lg;
       if (n >= P.N) continue;
       *reinterpret_cast<float4*>(out + (int64_t)m * P.N + n) =
           make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
@@ -809,7 +812,12 @@ int gemm_bf16_tn_group(const TnGroupArgs& a, hipStream_t s) {
     }
   }
   TimingScope ts(KC_GEMM_BF16_TN, flops, bytes, s);
-  gemm_bf16_tn_group_kernel<<<tiles * g.S, 256, 0, s>>>(g);
+  static const int tn_waves = [] {
+    const char* e = getenv("AVF_TN_WAVES");  // tuning aid
+    return e ? atoi(e) : 4;  // 8 waves measured 5 % slower here (unlike the NT kernel)
+  }();
+  if (tn_waves == 4) gemm_bf16_tn_group_kernel<2><<<tiles * g.S, 256, 0, s>>>(g);
+  else gemm_bf16_tn_group_kernel<4><<<tiles * g.S, 512, 0, s>>>(g);
   AVF_TRY(check_launch("gemm_bf16_tn_group_kernel"));
   if (g.S > 1) {
     dim3 grid(256, a.count);
