@@ -97,7 +97,7 @@ template <int DH>
 __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
                                                             float* __restrict__ lse2, int B, int N, int H) {
   constexpr int KS = DH / 32, DB = DH / 16;
-  constexpr int KLD = DH * 2 + 16;  // K tile: row reads (ds_read_b128)
+  constexpr int KLD = DH * 2 + 32;  // K tile: row reads (ds_read_b128); +32 B keeps them conflict-free (PMC-checked)
   constexpr int VLD = DH * 2 + 32;  // V tile: transposed reads, 8 consecutive rows -> 8 distinct bank windows
   constexpr int STAGE = 64 * KLD + 64 * VLD;
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(const bf16* __rest
                                                            int B, int N, int H) {
   constexpr int KS = DH / 32, DB = DH / 16;
   constexpr int KLD = DH * 2 + 32;  // K tile: row reads AND transposed reads
-  constexpr int VLD = DH * 2 + 16;  // V tile: row reads only
+  constexpr int VLD = DH * 2 + 32;  // V tile: row reads only (+32 B: conflict-free, PMC-checked)
   constexpr int STAGE = 64 * KLD + 64 * VLD;
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 

@@ -304,21 +304,26 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(NtParam
     }
     const char* sa = dsm + cur * STAGE;
     const char* sb = sa + A_BYTES;
+    // all fragment reads of the K-step are issued before its first MFMA (the compiler then waits with counted
+    // lgkmcnt, so the second half's reads overlap the first half's MFMAs instead of serialising behind them)
+    bf16x8_t fa[2][MI], fb[2][NI];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t fa[MI], fb[NI];
 #pragma unroll
       for (int i = 0; i < MI; ++i)
-        fa[i] = *reinterpret_cast<const bf16x8_t*>(sa + nt_off(wm * WTM + i * 16 + li, ks * 4 + lg));
+        fa[ks][i] = *reinterpret_cast<const bf16x8_t*>(sa + nt_off(wm * WTM + i * 16 + li, ks * 4 + lg));
 #pragma unroll
       for (int j = 0; j < NI; ++j)
-        fb[j] = *reinterpret_cast<const bf16x8_t*>(sb + nt_off(wn * WTN + j * 16 + li, ks * 4 + lg));
+        fb[ks][j] = *reinterpret_cast<const bf16x8_t*>(sb + nt_off(wn * WTN + j * 16 + li, ks * 4 + lg));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-    }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
     cur = (cur + 1 == NS) ? 0 : cur + 1;
   }
 
@@ -350,8 +355,9 @@ int launch_nt_glds(const NtParams& p, hipStream_t s, int* part_rows) {
 //   1:  64x128, 4 waves of 32x64, 2 stages (48 KiB, 3/CU)   - finer grain for grids that cannot fill the chip
 //   2: 128x128, 8 waves of 64x32, 2 stages (64 KiB, 2/CU)   - twice the waves per CU hide the DMA / epilogue
 //                                                             latency better (+5..8 % measured at K = 512..1536)
-// (a 4-stage ring at one block per CU, 256x128 / 256x256 tiles, 64x64 tiles and a persistent tile loop were
-//  measured slower on this path's shapes - M = 10k..16k, N = 512..1536, K = 512..1536 - and removed)
+// (3- and 4-stage rings, 256x128 / 256x256 tiles, 64x64 tiles and a persistent tile loop were all measured slower
+//  on this path's shapes - M = 10k..16k, N = 512..1536, K = 512..1536 - and removed: the waves wait ~55 % of their
+//  cycles (SQ_WAIT_ANY) on LDS/barrier latency, which more resident waves hide better than deeper DMA rings)
 int pick_nt_tile(int64_t M, int64_t N) {
   static const int override_tile = [] {
     const char* e = getenv("AVF_NT_TILE");  // tuning aid: force one configuration
