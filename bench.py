@@ -113,8 +113,14 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     A._lib.load()  # no fallback: fails here if the HIP library is missing
-    if world > 1:
+    # AVF_BENCH_FORCE_DP=1: take the multi-GPU code path (process group, data-parallel wrapper, barriers) even with one
+    # rank - the only way to rehearse it on a one-GPU box
+    use_dist = world > 1 or os.environ.get("AVF_BENCH_FORCE_DP") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         dist.init_process_group("nccl", device_id=dev)
 
     c = dict(CONFIGS[args.config])
@@ -137,7 +143,7 @@ def main():
             opt = torch.optim.Adam(model.parameters(), lr=5e-4, weight_decay=5e-5, fused=True)
         except Exception:
             opt = torch.optim.Adam(model.parameters(), lr=5e-4, weight_decay=5e-5)
-    dp = A.dp.DataParallel(model) if world > 1 else None
+    dp = A.dp.DataParallel(model) if use_dist else None
 
     def step():
         model.zero_grad(set_to_none=True)
@@ -152,7 +158,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -197,7 +203,7 @@ def main():
         dt_events = time.perf_counter() - t1
         A._lib.timing_enable(False)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = t.item()
     ms_per_step = dt / args.steps * 1e3
@@ -212,7 +218,7 @@ def main():
                                f"transformer stack d={c['dim']} L={c['depth']} H={c['heads']}x{c['dim_head']} "
                                f"mlp={c['mlp_dim']}, T_v={Tv}+T_a={Ta} tokens, B={B}/GPU",
                    "global_batch": B * world, "seq_len": Tv + Ta, "parallelism": f"dp{world}",
-                   "step": "zero_grad+fwd+AULoss+bwd" + ("+allreduce" if world > 1 else "") + ("+adam" if opt else ""),
+                   "step": "zero_grad+fwd+AULoss+bwd" + ("+allreduce" if use_dist else "") + ("+adam" if opt else ""),
                    "loss": float(loss.item())},
     }
     if rank == 0:
@@ -255,7 +261,7 @@ def main():
                 "sample": f"{args.cpu_steps} fwd+bwd steps (after 1 warm-up) of the same workload (B={B}) through "
                           f"oracle/ (fp32 eager PyTorch ops, un-fused, as the reference), {sec:.2f} s/step"}
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -49,8 +49,8 @@ class DataParallel:
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(self._comm):
                 self._comm.wait_event(ev)
-                flat.div_(self.world)
-                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                # RCCL averages inside the collective (ncclAvg): no separate scaling pass over the bucket
+                work = dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
             flat.record_stream(self._comm)
         else:
             flat.div_(self.world)
