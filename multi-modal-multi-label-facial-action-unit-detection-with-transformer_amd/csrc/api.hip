@@ -188,7 +188,7 @@ extern "C" int avf_gemm(int dtype, int transA, int transB, int64_t M, int64_t N,
   a.M = M; a.N = N; a.K = K;
   a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
   a.c_dtype = c_dtype; a.epilogue = epilogue; a.bias = bias; a.residual = residual; a.ldres = ldres;
-  a.aux = aux; a.ldaux = ldaux; a.workspace = workspace; a.colsum = nullptr; a.drop = kNoDrop;
+  a.aux = aux; a.ldaux = ldaux; a.workspace = workspace; a.colsum = nullptr; a.drop = kNoDrop; a.defer_fold = nullptr;
   return gemm(a, (hipStream_t)stream);
 }
 

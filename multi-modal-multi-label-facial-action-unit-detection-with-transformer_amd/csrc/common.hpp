@@ -193,6 +193,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // ---------------------------------------------------------------------------------------------
 // internal launchers shared between translation units (all return 0 / non-zero)
 // ---------------------------------------------------------------------------------------------
+struct FoldJob;
 int layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype, float* mean,
                   float* rstd, int64_t rows, int dim, float eps, hipStream_t s);
 size_t layernorm_bwd_ws(int64_t rows, int dim);
@@ -200,13 +201,65 @@ size_t layernorm_bwd_ws(int64_t rows, int dim);
 // dx itself (the residual stream gradient) is never masked.
 int layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean,
                   const float* rstd, const float* dres, float* dx, void* dx_lo, float* dgamma, float* dbeta,
-                  float* dcolsum, void* ws, int64_t rows, int dim, hipStream_t s, const DropCfg& drop = kNoDrop);
+                  float* dcolsum, void* ws, int64_t rows, int dim, hipStream_t s, const DropCfg& drop = kNoDrop,
+                  FoldJob* defer_fold = nullptr);
 size_t colsum_ws(int64_t rows, int cols);
 int colsum(const void* in, int in_dtype, int64_t rows, int cols, int64_t ld, float* out, void* ws, hipStream_t s);
 int cast_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t s, const DropCfg& drop = kNoDrop);
 int dropout_factors(const DropCfg& drop, float* out, int64_t n, hipStream_t s);  // test aid: keep*scale per element
 // out[c] = sum_b partial[b][c]
 int fold_partials(const float* partial, int nb, int width, float* out, hipStream_t s);
+
+// A deferred column fold: out_k[c] = sum_b partial[b][k*seg + c] for the (up to 3) segments of width/seg.
+// Kernels that produce per-block partial sums can hand the fold back to the caller, which runs all folds of a layer
+// in ONE launch together with the split-K slab fold of the weight gradients (fewer launches: each costs ~6 us here).
+struct FoldJob {
+  const float* partial;
+  int nb, width, seg;
+  float *o0, *o1, *o2;
+};
+struct FoldList {
+  FoldJob job[3];
+  int count;
+};
+// 32 columns (8 quads) x 32 row groups per 256-thread block; width % 4 == 0, 16-byte aligned partials
+__device__ __forceinline__ void fold_columns_vec(const FoldJob& j, int colgroup, float4 (*red)[8]) {
+  const int cq = threadIdx.x & 7, grp = threadIdx.x >> 3;
+  const int col = colgroup * 32 + cq * 4;
+  float4 a[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col < j.width) {
+    int b = grp;
+    for (; b + 96 < j.nb; b += 128) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float4 t = *reinterpret_cast<const float4*>(j.partial + (int64_t)(b + 32 * u) * j.width + col);
+        a[u].x += t.x; a[u].y += t.y; a[u].z += t.z; a[u].w += t.w;
+      }
+    }
+    for (; b < j.nb; b += 32) {
+      const float4 t = *reinterpret_cast<const float4*>(j.partial + (int64_t)b * j.width + col);
+      a[0].x += t.x; a[0].y += t.y; a[0].z += t.z; a[0].w += t.w;
+    }
+  }
+  red[grp][cq] = make_float4((a[0].x + a[1].x) + (a[2].x + a[3].x), (a[0].y + a[1].y) + (a[2].y + a[3].y),
+                             (a[0].z + a[1].z) + (a[2].z + a[3].z), (a[0].w + a[1].w) + (a[2].w + a[3].w));
+  __syncthreads();
+  if (threadIdx.x < 32) {  // thread -> (quad, component)
+    const int q = threadIdx.x >> 2, comp = threadIdx.x & 3;
+    const int c = colgroup * 32 + threadIdx.x;
+    if (c < j.width) {
+      float v = 0.f;
+#pragma unroll
+      for (int g2 = 0; g2 < 32; ++g2) v += reinterpret_cast<const float*>(&red[g2][q])[comp];
+      const int which = c / j.seg, cc = c - which * j.seg;
+      float* dst = which == 0 ? j.o0 : (which == 1 ? j.o1 : j.o2);
+      if (dst) dst[cc] = v;
+    }
+  }
+  __syncthreads();
+}
 // workspace bytes for the fused column-sum partials of an NT GEMM with M rows and N columns
 size_t gemm_nt_colsum_ws(int64_t M, int64_t N);
 int prep_weight_bf16(const float* w, void* w_lo, void* w_t_lo, int rows, int cols, hipStream_t s);
@@ -233,6 +286,7 @@ struct GemmArgs {
   void* workspace;
   float* colsum;  // optional: column sums of the stored C (bf16 NT only; partials go to workspace)
   DropCfg drop;   // bf16 NT only: BIAS_RES masks (acc+bias) before the residual, BIAS_GELU masks gelu(u), DGELU masks acc
+  FoldJob* defer_fold;  // with colsum: do not launch the fold, describe it here instead
 };
 size_t gemm_ws(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K);
 int gemm(const GemmArgs& a, hipStream_t s);
@@ -252,7 +306,7 @@ struct TnGroupArgs {
 };
 bool gemm_bf16_tn_group_ok(const TnGroupArgs& a);
 size_t gemm_bf16_tn_group_ws(const TnGroupArgs& a);
-int gemm_bf16_tn_group(const TnGroupArgs& a, hipStream_t s);
+int gemm_bf16_tn_group(const TnGroupArgs& a, hipStream_t s, const FoldList* extra_folds = nullptr);
 
 int attn_fwd_f32(const float* qkv, float* o, float* lse2, int B, int N, int H, int dh, hipStream_t s);
 int attn_bwd_f32(const float* qkv, const float* o, const float* d_o, const float* lse2, float* dqkv, float* delta,

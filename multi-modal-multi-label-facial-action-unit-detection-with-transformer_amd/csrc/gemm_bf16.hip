@@ -628,8 +628,16 @@ __global__ __launch_bounds__(128 * WNW) void gemm_bf16_tn_group_kernel(TnGroup g
   }
 }
 
-// C_i = sum_s slabs_i[s]  for every problem of the group (one launch)
-__global__ __launch_bounds__(256) void fold_group_kernel(TnGroup g) {
+// C_i = sum_s slabs_i[s]  for every problem of the group, plus the layer's deferred column folds (one launch):
+// blockIdx.y < nslab selects a weight-gradient problem, the remaining rows select a FoldJob.
+__global__ __launch_bounds__(256) void fold_group_kernel(TnGroup g, int nslab, FoldList fl) {
+  if ((int)blockIdx.y >= nslab) {
+    __shared__ float4 red[32][8];
+    const FoldJob& job = fl.job[blockIdx.y - nslab];
+    const int groups = (job.width + 31) / 32;
+    for (int cg = blockIdx.x; cg < groups; cg += gridDim.x) fold_columns_vec(job, cg, red);
+    return;
+  }
   const TnProblem& P = g.p[blockIdx.y];
   const int64_t n4 = (int64_t)P.M * P.N / 4, slab = (int64_t)P.M * P.N;
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -726,7 +734,10 @@ int gemm_bf16_nt(const GemmArgs& a, hipStream_t s) {
   }
 #undef LAUNCH
   AVF_TRY(check_launch("gemm_bf16_nt_kernel"));
-  if (a.colsum) AVF_TRY(fold_partials(p.cs_partial, part_rows, (int)a.N, a.colsum, s));
+  if (a.colsum) {
+    if (a.defer_fold) *a.defer_fold = FoldJob{p.cs_partial, part_rows, (int)a.N, (int)a.N, a.colsum, nullptr, nullptr};
+    else AVF_TRY(fold_partials(p.cs_partial, part_rows, (int)a.N, a.colsum, s));
+  }
   return 0;
 }
 
@@ -788,7 +799,7 @@ size_t gemm_bf16_tn_group_ws(const TnGroupArgs& a) {
   return S > 1 ? (size_t)S * elems * sizeof(float) : 0;
 }
 
-int gemm_bf16_tn_group(const TnGroupArgs& a, hipStream_t s) {
+int gemm_bf16_tn_group(const TnGroupArgs& a, hipStream_t s, const FoldList* extra_folds) {
   AVF_REQUIRE(gemm_bf16_tn_group_ok(a), "gemm_bf16_tn_group: unsupported shapes/alignment (K%%64, M%%8, N%%8, 16-byte alignment)");
   TnGroup g;
   memset(&g, 0, sizeof(g));
@@ -825,9 +836,13 @@ int gemm_bf16_tn_group(const TnGroupArgs& a, hipStream_t s) {
   if (tn_waves == 4) gemm_bf16_tn_group_kernel<2><<<tiles * g.S, 256, 0, s>>>(g);
   else gemm_bf16_tn_group_kernel<4><<<tiles * g.S, 512, 0, s>>>(g);
   AVF_TRY(check_launch("gemm_bf16_tn_group_kernel"));
-  if (g.S > 1) {
-    dim3 grid(256, a.count);
-    fold_group_kernel<<<grid, 256, 0, s>>>(g);
+  FoldList fl;
+  memset(&fl, 0, sizeof(fl));
+  if (extra_folds) fl = *extra_folds;
+  const int nslab = g.S > 1 ? a.count : 0;
+  if (nslab + fl.count > 0) {
+    dim3 grid(256, nslab + fl.count);
+    fold_group_kernel<<<grid, 256, 0, s>>>(g, nslab, fl);
     AVF_TRY(check_launch("fold_group_kernel"));
   }
   return 0;

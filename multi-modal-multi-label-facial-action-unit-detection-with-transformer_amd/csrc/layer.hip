@@ -127,7 +127,7 @@ TnGroupArgs dw_group(const Dims& d, const void* gy, const void* g_act, const voi
 }
 
 struct Work {
-  void *du, *dh, *d_o, *dqkv, *dx_mid_lo, *dx_out_lo, *ln_ws, *cs_ws, *gemm_ws;
+  void *du, *dh, *d_o, *dqkv, *dx_mid_lo, *dx_out_lo, *ln_ws, *ln_ws1, *cs_ws, *gemm_ws;
   float *dx_mid, *delta;
 };
 size_t carve_work(const Dims& d, void* base, Work* w) {
@@ -142,6 +142,7 @@ size_t carve_work(const Dims& d, void* base, Work* w) {
   t.dx_out_lo = c.take(d.dt == AVF_BF16 ? d.R * d.D * 2 : 0);
   t.delta = (float*)c.take((size_t)d.B * d.H * d.N * 4);
   t.ln_ws = c.take(layernorm_bwd_ws(d.R, d.D));
+  t.ln_ws1 = c.take(layernorm_bwd_ws(d.R, d.D));  // LN1 partials (its fold may be deferred past LN2's)
   const int maxc = d.M > d.D ? d.M : d.D;
   size_t csb = colsum_ws(d.R, maxc);
   if (d.dt == AVF_BF16 && gemm_nt_colsum_ws(d.R, d.M) > csb) csb = gemm_nt_colsum_ws(d.R, d.M);
@@ -171,7 +172,7 @@ int linear_fwd(const Dims& d, const void* A, int in, const void* W, int out, voi
   a.A = A; a.lda = in; a.B = W; a.ldb = in;
   a.C = C; a.ldc = out; a.c_dtype = c_dtype; a.epilogue = epi;
   a.bias = bias; a.residual = res; a.ldres = out; a.aux = aux; a.ldaux = out; a.workspace = nullptr; a.colsum = nullptr;
-  a.drop = drop;
+  a.drop = drop; a.defer_fold = nullptr;
   return gemm(a, s);
 }
 
@@ -179,7 +180,7 @@ int linear_fwd(const Dims& d, const void* A, int in, const void* W, int out, voi
 // colsum (bf16 mode only, optional): column sums of the produced dX, fused in the GEMM epilogue (ws = partials)
 int linear_dx(const Dims& d, const void* dY, int out, const void* W_f32, const void* Wt_lo, int in, void* dX, int epi,
               void* aux, hipStream_t s, float* colsum_out = nullptr, void* ws = nullptr,
-              const DropCfg& drop = kNoDrop) {
+              const DropCfg& drop = kNoDrop, FoldJob* defer = nullptr) {
   GemmArgs a;
   a.dtype = d.dt; a.transA = 0;
   a.M = d.R; a.N = in; a.K = out;
@@ -188,7 +189,7 @@ int linear_dx(const Dims& d, const void* dY, int out, const void* W_f32, const v
   else { a.transB = 0; a.B = W_f32; a.ldb = in; }
   a.C = dX; a.ldc = in; a.c_dtype = d.dt; a.epilogue = epi;
   a.bias = nullptr; a.residual = nullptr; a.ldres = 0; a.aux = aux; a.ldaux = in; a.workspace = ws; a.colsum = colsum_out;
-  a.drop = drop;
+  a.drop = drop; a.defer_fold = defer;
   return gemm(a, s);
 }
 
@@ -200,7 +201,7 @@ int linear_dw(const Dims& d, const void* dY, int out, const void* X, int in, flo
   a.A = dY; a.lda = out; a.B = X; a.ldb = in;
   a.C = dW; a.ldc = in; a.c_dtype = AVF_F32; a.epilogue = AVF_EPI_NONE;
   a.bias = nullptr; a.residual = nullptr; a.ldres = 0; a.aux = nullptr; a.ldaux = 0; a.workspace = ws; a.colsum = nullptr;
-  a.drop = kNoDrop;
+  a.drop = kNoDrop; a.defer_fold = nullptr;
   return gemm(a, s);
 }
 
@@ -327,6 +328,9 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   TnGroupArgs grp = dw_group(d, gy, sv.g, w.du, sv.h2, gm, sv.o, w.dqkv, sv.h1, g);
   grp.workspace = w.gemm_ws;
   const bool grouped = lo && gemm_bf16_tn_group_ok(grp);
+  FoldList folds;
+  memset(&folds, 0, sizeof(folds));
+  folds.count = 3;
 
   // ---- feed-forward half -------------------------------------------------------------------
   // db2 = column sums of dx_out: handed over by the caller (the next layer's LN1 backward produced them) or summed here
@@ -344,7 +348,8 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   }
   if (!grouped) AVF_TRY(linear_dw(d, gy, d.D, sv.g, d.M, g->w2, w.gemm_ws, s));
   if (lo) {  // db1 = colsum(du) fused into the dGELU GEMM epilogue
-    AVF_TRY(linear_dx(d, gy, d.D, p->w2, l.w2_t, d.M, w.du, AVF_EPI_DGELU, sv.u, s, g->b1, w.cs_ws, dr1));
+    AVF_TRY(linear_dx(d, gy, d.D, p->w2, l.w2_t, d.M, w.du, AVF_EPI_DGELU, sv.u, s, g->b1, w.cs_ws, dr1,
+                      grouped ? &folds.job[0] : nullptr));
   } else {
     AVF_TRY(linear_dx(d, gy, d.D, p->w2, l.w2_t, d.M, w.du, AVF_EPI_DGELU, sv.u, s));
     AVF_TRY(colsum(w.du, d.dt, d.R, d.M, d.M, g->b1, w.cs_ws, s));
@@ -352,7 +357,8 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   if (!grouped) AVF_TRY(linear_dw(d, w.du, d.M, sv.h2, d.D, g->w1, w.gemm_ws, s));
   AVF_TRY(linear_dx(d, w.du, d.M, p->w1, l.w1_t, d.D, w.dh, AVF_EPI_NONE, nullptr, s));
   AVF_TRY(layernorm_bwd(w.dh, d.dt, sv.x_mid, p->ln2_w, sv.mean2, sv.rstd2, dx_out, w.dx_mid,
-                        lo ? w.dx_mid_lo : nullptr, g->ln2_w, g->ln2_b, g->b_out, w.ln_ws, d.R, d.D, s, dr0));
+                        lo ? w.dx_mid_lo : nullptr, g->ln2_w, g->ln2_b, g->b_out, w.ln_ws, d.R, d.D, s, dr0,
+                        grouped ? &folds.job[1] : nullptr));
   // ---- attention half ----------------------------------------------------------------------
   if (!grouped) AVF_TRY(linear_dw(d, gm, d.D, sv.o, d.I, g->w_out, w.gemm_ws, s));
   AVF_TRY(linear_dx(d, gm, d.D, p->w_out, l.wo_t, d.I, w.d_o, AVF_EPI_NONE, nullptr, s));
@@ -366,7 +372,10 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   AVF_TRY(linear_dx(d, w.dqkv, 3 * d.I, p->w_qkv, l.wqkv_t, d.D, w.dh, AVF_EPI_NONE, nullptr, s));
   // dx_in may alias dx_out, which the grouped dW2 GEMM does not read (it uses the bf16 copy gy)
   AVF_TRY(layernorm_bwd(w.dh, d.dt, x_in, p->ln1_w, sv.mean1, sv.rstd1, w.dx_mid, dx_in, lo ? dx_in_lo : nullptr,
-                        g->ln1_w, g->ln1_b, dx_in_colsum, w.ln_ws, d.R, d.D, s, dr_prev2));
-  if (grouped) AVF_TRY(gemm_bf16_tn_group(grp, s));
+                        g->ln1_w, g->ln1_b, dx_in_colsum, w.ln_ws1, d.R, d.D, s, dr_prev2,
+                        grouped ? &folds.job[2] : nullptr));
+  // one launch folds the split-K slabs of the four weight gradients and the three deferred column folds
+  // (db1; dgamma2/dbeta2/dbo; dgamma1/dbeta1/previous layer's db2)
+  if (grouped) AVF_TRY(gemm_bf16_tn_group(grp, s, &folds));
   return 0;
 }

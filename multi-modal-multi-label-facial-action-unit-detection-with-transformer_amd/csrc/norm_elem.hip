@@ -343,50 +343,15 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restr
 }
 
 // width % 4 == 0: 8 column quads (32 columns) x 32 row groups per block, 16-byte loads, 4 loads in flight
-__global__ __launch_bounds__(256) void fold_partials_vec_kernel(const float* __restrict__ partial, int nb, int width,
-                                                                float* __restrict__ o0, float* __restrict__ o1,
-                                                                float* __restrict__ o2, int seg) {
+__global__ __launch_bounds__(256) void fold_partials_vec_kernel(FoldJob job) {
   __shared__ float4 red[32][8];
-  const int cq = threadIdx.x & 7, grp = threadIdx.x >> 3;
-  const int col = blockIdx.x * 32 + cq * 4;
-  float4 a[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (col < width) {
-    int b = grp;
-    for (; b + 96 < nb; b += 128) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float4 t = *reinterpret_cast<const float4*>(partial + (int64_t)(b + 32 * u) * width + col);
-        a[u].x += t.x; a[u].y += t.y; a[u].z += t.z; a[u].w += t.w;
-      }
-    }
-    for (; b < nb; b += 32) {
-      const float4 t = *reinterpret_cast<const float4*>(partial + (int64_t)b * width + col);
-      a[0].x += t.x; a[0].y += t.y; a[0].z += t.z; a[0].w += t.w;
-    }
-  }
-  red[grp][cq] = make_float4((a[0].x + a[1].x) + (a[2].x + a[3].x), (a[0].y + a[1].y) + (a[2].y + a[3].y),
-                             (a[0].z + a[1].z) + (a[2].z + a[3].z), (a[0].w + a[1].w) + (a[2].w + a[3].w));
-  __syncthreads();
-  if (threadIdx.x < 32) {  // thread -> (quad, component)
-    const int q = threadIdx.x >> 2, comp = threadIdx.x & 3;
-    const int c = blockIdx.x * 32 + threadIdx.x;
-    if (c < width) {
-      float v = 0.f;
-#pragma unroll
-      for (int g2 = 0; g2 < 32; ++g2) v += reinterpret_cast<const float*>(&red[g2][q])[comp];
-      const int which = c / seg, cc = c - which * seg;
-      float* dst = which == 0 ? o0 : (which == 1 ? o1 : o2);
-      if (dst) dst[cc] = v;
-    }
-  }
+  fold_columns_vec(job, blockIdx.x, red);
 }
 
 static int launch_fold(const float* partial, int nb, int width, float* o0, float* o1, float* o2, int seg, hipStream_t s) {
   const unsigned grid = (unsigned)ceil_div(width, 32);
   if (width % 4 == 0 && (((uintptr_t)partial) & 15) == 0)
-    fold_partials_vec_kernel<<<grid, 256, 0, s>>>(partial, nb, width, o0, o1, o2, seg);
+    fold_partials_vec_kernel<<<grid, 256, 0, s>>>(FoldJob{partial, nb, width, seg, o0, o1, o2});
   else
     fold_partials_kernel<<<grid, 256, 0, s>>>(partial, nb, width, o0, o1, o2, seg);
   return check_launch("fold_partials_kernel");
@@ -402,7 +367,8 @@ size_t layernorm_bwd_ws(int64_t rows, int dim) {
 
 int layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean,
                   const float* rstd, const float* dres, float* dx, void* dx_lo, float* dgamma, float* dbeta,
-                  float* dcolsum, void* ws, int64_t rows, int dim, hipStream_t s, const DropCfg& drop) {
+                  float* dcolsum, void* ws, int64_t rows, int dim, hipStream_t s, const DropCfg& drop,
+                  FoldJob* defer_fold) {
   AVF_REQUIRE(rows > 0 && dim > 0 && ws, "layernorm_bwd: bad arguments");
   AVF_REQUIRE(!drop.thresh16 || (dim % 4 == 0 && dim <= 1536), "layernorm_bwd: dropout needs dim %% 4 == 0 and dim <= 1536");
   AVF_REQUIRE((size_t)3 * dim * sizeof(float) <= 64 * 1024, "layernorm_bwd: dim %d too large", dim);
@@ -460,6 +426,11 @@ int layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gam
     AVF_TRY(check_launch("ln_bwd_kernel"));
   }
   const int width = 3 * dim;
+  if (defer_fold) {
+    AVF_REQUIRE(width % 4 == 0 && (((uintptr_t)partial) & 15) == 0, "layernorm_bwd: deferred fold needs dim %% 4 == 0");
+    *defer_fold = FoldJob{partial, nb, width, dim, dgamma, dbeta, dcolsum};
+    return 0;
+  }
   return launch_fold(partial, nb, width, dgamma, dbeta, dcolsum, dim, s);
 }
 
