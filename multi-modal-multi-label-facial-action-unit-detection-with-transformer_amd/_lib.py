@@ -80,8 +80,10 @@ class HipLibraryError(RuntimeError):
     pass
 
 
-def load(build_if_missing: bool = False):
-    """Load (once) and return the ctypes handle.  Raises HipLibraryError if unavailable."""
+def load(build_if_missing: bool = True):
+    """Load (once) and return the ctypes handle.  If the shared library has not been built yet and hipcc is present,
+    it is compiled in-tree first (``python __graft_entry__.py`` does the same explicitly).  Raises HipLibraryError
+    when neither a built library nor a toolchain is available - there is no CPU fallback."""
     global _lib
     if _lib is not None:
         return _lib
@@ -90,12 +92,16 @@ def load(build_if_missing: bool = False):
             return _lib
         path = _build.lib_path()
         if not os.path.exists(path):
+            err = None
             if build_if_missing:
-                _build.build()
-            else:
+                try:
+                    _build.build()
+                except Exception as e:  # toolchain missing or compile error: report both facts
+                    err = e
+            if not os.path.exists(path):
                 raise HipLibraryError(
-                    f"{path} not found - build it first (python __graft_entry__.py or "
-                    f"python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+                    f"{path} not found and could not be built ({err}); run python __graft_entry__.py on a machine "
+                    f"with hipcc - there is no CPU fallback")
         try:
             lib = C.CDLL(path)
         except OSError as e:  # pragma: no cover - environment dependent

@@ -673,7 +673,9 @@ int tn_splits(int64_t M, int64_t N, int64_t K) {
 
 }  // namespace
 
-size_t gemm_nt_colsum_ws(int64_t M, int64_t N) { return (size_t)(ceil_div(M, 64) + 4) * N * sizeof(float); }
+// one partial row per (tile row, wave row); the finest configuration has 32-row wave tiles, and the last tile may be
+// ragged in both its block and its wave rows - size for ceil(M/32) plus a block's worth of slack
+size_t gemm_nt_colsum_ws(int64_t M, int64_t N) { return (size_t)(ceil_div(M, 32) + 8) * N * sizeof(float); }
 
 size_t gemm_bf16_tn_ws(int64_t M, int64_t N, int64_t K) {
   const int s = tn_splits(M, N, K);
@@ -734,6 +736,8 @@ int gemm_bf16_nt(const GemmArgs& a, hipStream_t s) {
   }
 #undef LAUNCH
   AVF_TRY(check_launch("gemm_bf16_nt_kernel"));
+  AVF_REQUIRE(!a.colsum || (size_t)part_rows * a.N * sizeof(float) <= gemm_nt_colsum_ws(a.M, a.N),
+              "gemm_bf16_nt: column-sum partials exceed their workspace (internal error)");
   if (a.colsum) {
     if (a.defer_fold) *a.defer_fold = FoldJob{p.cs_partial, part_rows, (int)a.N, (int)a.N, a.colsum, nullptr, nullptr};
     else AVF_TRY(fold_partials(p.cs_partial, part_rows, (int)a.N, a.colsum, s));

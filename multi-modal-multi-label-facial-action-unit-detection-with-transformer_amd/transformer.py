@@ -107,6 +107,11 @@ class _StackFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        with torch.cuda.device(dy.device):
+            return _StackFn._backward(ctx, dy)
+
+    @staticmethod
+    def _backward(ctx, dy):
         lib = _lib.load()
         mod = ctx.mod
         cfgs = ctx.cfgs
@@ -271,4 +276,5 @@ class Transformer(nn.Module):
         for p in params:
             if p.dtype != torch.float32 or not p.is_cuda:
                 raise RuntimeError("Transformer (HIP): parameters must be fp32 tensors on the GPU (model.to('cuda'))")
-        return _StackFn.apply(x.to(torch.float32), self, *params)
+        with torch.cuda.device(x.device):  # launches go to the input's device and its current stream
+            return _StackFn.apply(x.to(torch.float32), self, *params)

@@ -60,6 +60,8 @@ CONFIGS = {
     "tformer_real": (5, 17, 512, 3, 8, 64, 1024),
     "au_head_real": (6, 12, 256, 3, 8, 32, 256),
     "c2_small_batch": (4, 324, 512, 6, 8, 64, 1024),
+    "c4_model_short": (2, 200, 768, 2, 12, 64, 1536),   # BASELINE.json configs[3] model (d=768, 12 heads), short clip
+    "wide_tformer": (3, 17, 1536, 1, 8, 64, 1024),       # tformer.py:301 TFormer(dim=128*12): D=1536, I=512
 }
 
 

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Step time of the REAL avformer head shapes (reference avformer.py: two AU_former stacks d=128 L=2 over 12 tokens +
+former_AU_head d=256 L=3 over 12 tokens; B=64 = opts.py default batch).  These shapes are launch-bound."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import avformer_amd as A
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+torch.manual_seed(0)
+model = A.build_model("avformer", task="AU").cuda().train()
+opt = torch.optim.Adam(model.parameters(), lr=5e-4, weight_decay=5e-5, fused=True)
+x = {"clip": torch.randn(B, 512, device="cuda"), "audio_features": torch.randn(B, 512, device="cuda")}
+y = (torch.rand(B, 12, device="cuda") > 0.5).float()
+def step():
+    model.zero_grad(set_to_none=True)
+    loss = model.get_au_loss(model(x), y)
+    loss.backward()
+    opt.step()
+    return loss
+for _ in range(10): step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(50): step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 50
+print(f"real avformer heads, B={B}: {dt*1e3:.3f} ms/step, {B/dt:.0f} clips/s")
