@@ -25,6 +25,38 @@ from .ops import avf_dtype
 
 PARAMS_PER_LAYER = 11
 
+# AVF_DEBUG_CANARY=1: every byte buffer handed to the library (saved activations, workspace, bf16 weights) gets a
+# 4 KiB guard band filled with 0xA5 behind it, verified after each forward/backward - catches writes past the end of a
+# carved region (tests/test_gpu_transformer.py::test_no_out_of_bounds_writes).
+import os as _os
+
+_CANARY = 4096 if _os.environ.get("AVF_DEBUG_CANARY") == "1" else 0
+_guarded: list = []  # weak references to the guarded buffers that are still alive
+
+
+def _alloc_bytes(nbytes: int, dev) -> torch.Tensor:
+    t = torch.empty(max(int(nbytes), 16) + _CANARY, dtype=torch.uint8, device=dev)
+    if _CANARY:
+        import weakref
+        t[-_CANARY:].fill_(0xA5)
+        _guarded.append(weakref.ref(t))
+    return t
+
+
+def _check_canaries():
+    if not _CANARY:
+        return
+    torch.cuda.synchronize()
+    alive = []
+    for r in _guarded:
+        t = r()
+        if t is None:
+            continue
+        alive.append(r)
+        if not bool((t[-_CANARY:] == 0xA5).all()):
+            raise RuntimeError(f"libavformer_hip wrote past the end of a {t.numel() - _CANARY}-byte buffer")
+    _guarded[:] = alive
+
 
 class _Holder(nn.Module):
     """Parameter container; mirrors the reference's wrapper nesting so state_dict keys match."""
@@ -87,9 +119,9 @@ class _StackFn(torch.autograd.Function):
         for l in range(L):
             pp = mod._param_struct(params, l)
             if need_grad:
-                sv = torch.empty(saved_bytes, dtype=torch.uint8, device=dev)
+                sv = _alloc_bytes(saved_bytes, dev)
             else:
-                shared = shared if shared is not None else torch.empty(saved_bytes, dtype=torch.uint8, device=dev)
+                shared = shared if shared is not None else _alloc_bytes(saved_bytes, dev)
                 sv = shared
             x_out = torch.empty((B * N, D), dtype=torch.float32, device=dev)
             _lib.check(lib.avf_layer_fwd(C.byref(cfgs[l]), C.byref(pp), _ptr(lowps[l]), _ptr(xs[-1]), _ptr(x_out), _ptr(sv),
@@ -103,6 +135,7 @@ class _StackFn(torch.autograd.Function):
         ctx.saved_bufs = saved if need_grad else None
         ctx.params = params
         ctx.lowps = lowps
+        _check_canaries()
         return xs[-1].view(B, N, D)
 
     @staticmethod
@@ -165,6 +198,7 @@ class _StackFn(torch.autograd.Function):
                     if waiter is not None:
                         waiter()  # accumulation needs the reduced values
                     p.grad.add_(v)
+        _check_canaries()
         ctx.saved_bufs = None
         ctx.xs = None
         return (dx.view(B, N, D), None, *([None] * (L * PARAMS_PER_LAYER)))
@@ -234,8 +268,8 @@ class Transformer(nn.Module):
 
     def _workspace(self, lib, cfg, dev):
         need = lib.avf_layer_workspace_bytes(C.byref(cfg))
-        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
-            self._ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+        if self._ws is None or self._ws.numel() - _CANARY < need or self._ws.device != dev:
+            self._ws = _alloc_bytes(need, dev)
         return self._ws
 
     def _lowp(self, lib, cfg, params, dev, stream):
@@ -247,8 +281,8 @@ class Transformer(nn.Module):
             return [None] * self.depth
         need = lib.avf_layer_lowp_bytes(C.byref(cfg))
         fresh = False
-        if (self._lowp_bufs is None or self._lowp_bufs[0].numel() < need or self._lowp_bufs[0].device != dev):
-            self._lowp_bufs = [torch.empty(need, dtype=torch.uint8, device=dev) for _ in range(self.depth)]
+        if (self._lowp_bufs is None or self._lowp_bufs[0].numel() - _CANARY < need or self._lowp_bufs[0].device != dev):
+            self._lowp_bufs = [_alloc_bytes(need, dev) for _ in range(self.depth)]
             fresh = True
         ptrs = [p.data_ptr() for p in params]
         if fresh or not self.cache_weights or self._lowp_ptrs != ptrs:

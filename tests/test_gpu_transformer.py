@@ -266,3 +266,62 @@ def test_cpu_input_fails_loudly():
     t = A.Transformer(32, 1, 8, 32, 64)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         t(torch.randn(1, 4, 32))
+
+
+SWEEP = [
+    # B, N, D, L, H, dh, M   - ragged rows, every tile configuration, grouped and per-GEMM weight-gradient paths
+    (1, 1, 64, 1, 8, 32, 64), (1, 5, 64, 2, 2, 32, 128), (7, 9, 128, 1, 4, 32, 64), (2, 63, 192, 1, 8, 32, 384),
+    (3, 64, 256, 2, 8, 32, 512), (2, 65, 256, 1, 4, 64, 256), (5, 127, 128, 1, 8, 64, 1024), (1, 128, 384, 1, 6, 64, 768),
+    (2, 129, 512, 1, 8, 64, 1024), (9, 49, 256, 1, 8, 32, 512), (16, 17, 512, 2, 8, 64, 1024), (3, 333, 64, 1, 1, 32, 64),
+    (1, 1024, 128, 1, 2, 64, 256), (4, 96, 1024, 1, 16, 64, 512), (8, 256, 320, 1, 5, 64, 640),
+]
+
+
+@pytest.mark.parametrize("cfg", SWEEP, ids=lambda c: "x".join(map(str, c)))
+def test_shape_sweep_bf16_vs_parity_mode(cfg):
+    """throughput path vs the parity path on the same device, forward and every gradient, across tile/edge cases"""
+    B, N, D, L, H, dh, M = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    sd = oracle.init_transformer_state(D, L, H, dh, M, generator=g)
+    x = torch.randn(B, N, D, generator=g)
+    t16 = make_hip_transformer(sd, D, L, H, dh, M, "bf16")
+    t32 = make_hip_transformer(sd, D, L, H, dh, M, "f32")
+    y16, dx16, g16 = hip_transformer_run(t16, x, SQ)
+    y32, dx32, g32 = hip_transformer_run(t32, x, SQ)
+    assert torch.isfinite(y16).all() and torch.isfinite(dx16).all()
+    assert rel_fro(y16, y32) < 1.5e-2, rel_fro(y16, y32)
+    assert rel_fro(dx16, dx32) < 4e-2, rel_fro(dx16, dx32)
+    for k in g32:
+        tol = 6e-2 if g32[k].numel() <= 2048 else 4e-2  # bias / LayerNorm vectors: few elements, noisier norm
+        assert rel_fro(g16[k], g32[k]) < tol, (k, rel_fro(g16[k], g32[k]))
+
+
+def test_no_out_of_bounds_writes():
+    """re-run a spread of shapes in a child process with AVF_DEBUG_CANARY=1: every byte buffer handed to the library
+    carries a guard band that must survive forward and backward (a past-the-end write in a carved workspace region was
+    the one memory bug of round 1; this keeps it from coming back)"""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+import avformer_amd as A
+import oracle
+for cfg in [(2, 200, 768, 2, 12, 64, 1536), (3, 77, 256, 1, 8, 32, 512), (1, 5, 64, 2, 2, 32, 128), (4, 324, 512, 2, 8, 64, 1024),
+            (16, 17, 512, 1, 8, 64, 1024), (2, 49, 48, 1, 8, 32, 96)]:
+    B, N, D, L, H, dh, M = cfg
+    for mode in ("bf16", "f32"):
+        for p in (0.0, 0.3):
+            if p and mode == "f32":
+                continue
+            t = A.Transformer(D, L, H, dh, M, dropout=p, compute_dtype=mode).cuda().train()
+            x = torch.randn(B, N, D, device="cuda", requires_grad=True)
+            t(x).pow(2).mean().backward()
+            with torch.no_grad():
+                t.eval()(x)
+print("CANARIES_OK")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AVF_DEBUG_CANARY="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "CANARIES_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
