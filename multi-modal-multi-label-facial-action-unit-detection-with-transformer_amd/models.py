@@ -27,12 +27,9 @@ from .transformer import Transformer
 
 def load_pretrain(model, weight_path):
     """reference avformer.py:28-35 - strips 'module.' prefixes, strict=False; a missing file is skipped
-    (the reference hard-codes K:\\ paths and would crash)."""
-    if not weight_path or not os.path.exists(weight_path):
-        return False
-    sd = torch.load(weight_path, map_location="cpu")
-    model.load_state_dict(OrderedDict((k.replace("module.", ""), v) for k, v in sd.items()), strict=False)
-    return True
+    (the reference hard-codes K:\\ paths and would crash).  See checkpoint.py for the other loaders."""
+    from .checkpoint import load_pretrain as _load
+    return _load(model, weight_path) is not None
 
 
 class AudioFormer(nn.Module):
