@@ -51,6 +51,9 @@ typedef struct avf_layer_cfg {
                           function of (seed, layer_index, site, element), regenerated in backward.               */
   uint32_t seed_lo, seed_hi; /* dropout seed: use a fresh value per forward, the same one in its backward        */
   int32_t layer_index; /* position of this layer in its stack (keys the dropout masks)                          */
+  const void* seed_dev; /* optional device pointer to a uint64 seed; when non-null it replaces seed_lo/hi and is read
+                          by the kernels at run time, so a captured hipGraph draws fresh masks on every replay
+                          (the caller advances the value between forwards, e.g. with a captured add)            */
 } avf_layer_cfg;
 
 /* fp32 master parameters of one layer, in state_dict order:

@@ -157,8 +157,10 @@ __device__ __forceinline__ float dgelu_tanh_fast(float u) {
 // (seed, layer, site, row*ld + col), so forward and backward regenerate identical masks without storing them.
 // ---------------------------------------------------------------------------------------------
 struct DropCfg {
-  uint64_t key;     // mix of (seed, layer, site); meaningless when thresh16 == 0
-  uint32_t thresh16;  // 0 = dropout disabled
+  uint64_t key;              // mix64(seed + site_const) for a host-side seed; meaningless when thresh16 == 0
+  const uint64_t* seed_dev;  // optional: the seed lives in device memory (graph-replayable); key is then derived
+  uint64_t site_const;       // in the kernel as mix64(*seed_dev + site_const)
+  uint32_t thresh16;         // 0 = dropout disabled
   float scale;
 };
 __host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
@@ -167,19 +169,25 @@ __host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
   return z ^ (z >> 31);
 }
 // sites of one layer: 0 = after to_out (heads.py:216), 1 = after GELU (heads.py:194), 2 = after net.3 (heads.py:196)
-inline DropCfg make_drop(float p, uint64_t seed, int layer, int site) {
+inline DropCfg make_drop(float p, uint64_t seed, int layer, int site, const uint64_t* seed_dev = nullptr) {
   DropCfg d;
   uint32_t t = (uint32_t)(p * 65536.0f + 0.5f);
   if (t > 65535u) t = 65535u;
   d.thresh16 = p > 0.f ? t : 0u;
   d.scale = 1.0f / (1.0f - (float)d.thresh16 / 65536.0f);
-  d.key = mix64(seed + 0xD1B54A32D192ED03ULL * (uint64_t)(layer * 4 + site + 1));
+  d.site_const = 0xD1B54A32D192ED03ULL * (uint64_t)(layer * 4 + site + 1);
+  d.key = mix64(seed + d.site_const);
+  d.seed_dev = seed_dev;
   return d;
 }
-static const DropCfg kNoDrop = {0, 0, 1.0f};
+static const DropCfg kNoDrop = {0, nullptr, 0, 0, 1.0f};
+// the mask key of a site: from the device-resident seed when there is one (wave-uniform scalar load), else the host's
+__device__ __forceinline__ uint64_t drop_key(const DropCfg& d) {
+  return d.seed_dev ? mix64(*d.seed_dev + d.site_const) : d.key;
+}
 // keep*scale factors of the 4 elements starting at linear index idx (idx % 4 == 0)
-__device__ __forceinline__ float4 drop_factor4(const DropCfg& d, uint64_t idx) {
-  const uint64_t h = mix64(d.key + idx * 0x9E3779B97F4A7C15ULL);
+__device__ __forceinline__ float4 drop_factor4(const DropCfg& d, uint64_t key, uint64_t idx) {
+  const uint64_t h = mix64(key + idx * 0x9E3779B97F4A7C15ULL);
   float4 f;
   f.x = ((uint32_t)(h) & 0xffffu) >= d.thresh16 ? d.scale : 0.f;
   f.y = ((uint32_t)(h >> 16) & 0xffffu) >= d.thresh16 ? d.scale : 0.f;

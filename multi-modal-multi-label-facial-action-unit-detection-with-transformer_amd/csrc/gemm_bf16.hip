@@ -68,6 +68,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
     nc[j] = nn[j] < p.N ? nn[j] : 0;
     bj[j] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nc[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  const uint64_t dkey = p.drop.thresh16 ? drop_key(p.drop) : 0;
   float cs[NI][4];
 #pragma unroll
   for (int j = 0; j < NI; ++j)
@@ -96,7 +97,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
         float v[4] = {acc[i][j][0] + bj[j].x, acc[i][j][1] + bj[j].y, acc[i][j][2] + bj[j].z, acc[i][j][3] + bj[j].w};
         const bool ok = mok && nn[j] < p.N;
         float4 df = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (p.drop.thresh16) df = drop_factor4(p.drop, (uint64_t)mm[ii] * p.N + nn[j]);  // wave-uniform branch
+        if (p.drop.thresh16) df = drop_factor4(p.drop, dkey, (uint64_t)mm[ii] * p.N + nn[j]);  // wave-uniform branch
         if (EPI == AVF_EPI_BIAS_RES) {  // x + Dropout(Linear(.))
           v[0] = v[0] * df.x + ex[ii][j].x; v[1] = v[1] * df.y + ex[ii][j].y;
           v[2] = v[2] * df.z + ex[ii][j].z; v[3] = v[3] * df.w + ex[ii][j].w;

@@ -25,6 +25,7 @@ struct Dims {
   size_t es;  // element size of compute dtype
   float p;    // dropout probability (0 = off)
   uint64_t seed;
+  const uint64_t* seed_dev;
   int layer;
 };
 
@@ -45,6 +46,7 @@ int make_dims(const avf_layer_cfg* c, Dims* d) {
   d->I = c->heads * c->dim_head; d->M = c->mlp_dim; d->R = (int64_t)c->batch * c->tokens;
   d->dt = c->dtype; d->es = c->dtype == AVF_BF16 ? 2 : 4;
   d->p = c->dropout_p; d->seed = ((uint64_t)c->seed_hi << 32) | c->seed_lo; d->layer = c->layer_index;
+  d->seed_dev = (const uint64_t*)c->seed_dev;
   if (c->dtype == AVF_BF16) {
     AVF_REQUIRE(d->D % 8 == 0 && d->I % 8 == 0 && d->M % 8 == 0, "layer(bf16): dim, inner and mlp_dim must be multiples of 8");
     AVF_REQUIRE(d->dh == 32 || d->dh == 64, "layer(bf16): dim_head must be 32 or 64 (got %d)", d->dh);
@@ -281,8 +283,8 @@ extern "C" int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   AVF_TRY(linear_fwd(d, sv.h1, d.D, wqkv, 3 * d.I, sv.qkv, d.dt, AVF_EPI_NONE, nullptr, nullptr, nullptr, s));
   if (lo) AVF_TRY(attn_fwd_bf16((const bf16*)sv.qkv, (bf16*)sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s));
   else AVF_TRY(attn_fwd_f32((const float*)sv.qkv, (float*)sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s));
-  const DropCfg dr0 = make_drop(d.p, d.seed, d.layer, 0), dr1 = make_drop(d.p, d.seed, d.layer, 1),
-                dr2 = make_drop(d.p, d.seed, d.layer, 2);
+  const DropCfg dr0 = make_drop(d.p, d.seed, d.layer, 0, d.seed_dev), dr1 = make_drop(d.p, d.seed, d.layer, 1, d.seed_dev),
+                dr2 = make_drop(d.p, d.seed, d.layer, 2, d.seed_dev);
   AVF_TRY(linear_fwd(d, sv.o, d.I, wo, d.D, sv.x_mid, AVF_F32, AVF_EPI_BIAS_RES, p->b_out, x_in, nullptr, s, dr0));
   AVF_TRY(layernorm_fwd(sv.x_mid, p->ln2_w, p->ln2_b, sv.h2, d.dt, sv.mean2, sv.rstd2, d.R, d.D, cfg->ln_eps, s));
   AVF_TRY(linear_fwd(d, sv.h2, d.D, w1, d.M, sv.g, d.dt, AVF_EPI_BIAS_GELU, p->b1, nullptr, sv.u, s, dr1));
@@ -309,9 +311,9 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
 
   // gradient of the layer output in the compute dtype (GEMM operand)
   // dropout: the Linears behind a dropout site see the masked, rescaled gradient (the residual stream does not)
-  const DropCfg dr0 = make_drop(d.p, d.seed, d.layer, 0), dr1 = make_drop(d.p, d.seed, d.layer, 1),
-                dr2 = make_drop(d.p, d.seed, d.layer, 2);
-  const DropCfg dr_prev2 = d.layer > 0 ? make_drop(d.p, d.seed, d.layer - 1, 2) : kNoDrop;
+  const DropCfg dr0 = make_drop(d.p, d.seed, d.layer, 0, d.seed_dev), dr1 = make_drop(d.p, d.seed, d.layer, 1, d.seed_dev),
+                dr2 = make_drop(d.p, d.seed, d.layer, 2, d.seed_dev);
+  const DropCfg dr_prev2 = d.layer > 0 ? make_drop(d.p, d.seed, d.layer - 1, 2, d.seed_dev) : kNoDrop;
   const void* gy = dx_out;
   bool own_copy = false;
   if (lo) {

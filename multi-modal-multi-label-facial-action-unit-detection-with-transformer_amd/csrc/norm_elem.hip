@@ -247,6 +247,7 @@ __global__ __launch_bounds__(256) void ln_bwd_reg_kernel(const DyT* __restrict__
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t row0 = (int64_t)blockIdx.x * LNR_ROWS_PER_BLOCK;
   const float invD = 1.0f / (float)D;
+  const uint64_t dkey = drop.thresh16 ? drop_key(drop) : 0;
   float4 g[NV], adg[NV], adb[NV], acs[NV];
   bool act[NV];
 #pragma unroll
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(256) void ln_bwd_reg_kernel(const DyT* __restrict__
       o.w = rs * (d[i].w * g[i].w - s1 - xh[i].w * s2) + r.w;
       *reinterpret_cast<float4*>(dx + row * D + c) = o;
       if (drop.thresh16) {  // what the Linear behind the dropout site sees: masked, rescaled
-        const float4 f = drop_factor4(drop, (uint64_t)row * D + c);
+        const float4 f = drop_factor4(drop, dkey, (uint64_t)row * D + c);
         o.x *= f.x; o.y *= f.y; o.z *= f.z; o.w *= f.w;
       }
       if (dx_lo) store4<bf16>(dx_lo + row * D + c, o);
@@ -486,12 +487,13 @@ int colsum(const void* in, int in_dtype, int64_t rows, int cols, int64_t ld, flo
 // =============================================================================================
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ in, bf16* __restrict__ out,
                                                         int64_t n, DropCfg drop) {
+  const uint64_t dkey = drop.thresh16 ? drop_key(drop) : 0;
   int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   const int64_t stride = (int64_t)gridDim.x * 256 * 4;
   for (; i + 3 < n; i += stride) {
     float4 v = *reinterpret_cast<const float4*>(in + i);
     if (drop.thresh16) {
-      const float4 f = drop_factor4(drop, (uint64_t)i);
+      const float4 f = drop_factor4(drop, dkey, (uint64_t)i);
       v.x *= f.x; v.y *= f.y; v.z *= f.z; v.w *= f.w;
     }
     store4<bf16>(out + i, v);
@@ -502,9 +504,10 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
 }
 
 __global__ __launch_bounds__(256) void dropout_factors_kernel(DropCfg drop, float* __restrict__ out, int64_t n) {
+  const uint64_t dkey = drop_key(drop);
   int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   const int64_t stride = (int64_t)gridDim.x * 256 * 4;
-  for (; i + 3 < n; i += stride) *reinterpret_cast<float4*>(out + i) = drop_factor4(drop, (uint64_t)i);
+  for (; i + 3 < n; i += stride) *reinterpret_cast<float4*>(out + i) = drop_factor4(drop, dkey, (uint64_t)i);
 }
 int dropout_factors(const DropCfg& drop, float* out, int64_t n, hipStream_t s) {
   AVF_REQUIRE(n > 0 && n % 4 == 0 && drop.thresh16, "dropout_factors: n %% 4 == 0 and p > 0 required");

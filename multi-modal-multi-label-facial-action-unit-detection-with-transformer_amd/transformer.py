@@ -102,9 +102,8 @@ class _StackFn(torch.autograd.Function):
         dev = x.device
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         L = mod.depth
-        seed = mod._next_seed()
-        mod.last_seed = seed
-        cfgs = [mod._cfg(B, N, l, seed) for l in range(L)]
+        seed_t = mod._advance_seed(dev)  # None unless dropout is live; a device tensor otherwise (graph-replayable)
+        cfgs = [mod._cfg(B, N, l, seed_t) for l in range(L)]
         cfg = cfgs[0]
         params = [p.detach() for p in params]
         need_grad = any(ctx.needs_input_grad)  # (grad mode is off inside Function.forward)
@@ -130,6 +129,7 @@ class _StackFn(torch.autograd.Function):
             xs.append(x_out)
         ctx.mod = mod
         ctx.cfgs = cfgs
+        ctx.seed_t = seed_t  # the kernels of backward read the same device word
         ctx.shape = (B, N, D)
         ctx.xs = xs[:-1] if need_grad else None
         ctx.saved_bufs = saved if need_grad else None
@@ -219,8 +219,8 @@ class Transformer(nn.Module):
         self._lowp_ptrs = None
         self.cache_weights = False
         self._grad_hook: Optional[Callable] = None
-        self._drop_calls = 0
-        self.last_seed = 0
+        self._seed_dev = None
+        self._last_seed_t = None
 
     # ---- parameter plumbing --------------------------------------------------------------------
     def layer_parameters(self, l: int) -> List[torch.Tensor]:
@@ -244,23 +244,34 @@ class Transformer(nn.Module):
         return a callable that makes the current stream wait for that reduction."""
         self._grad_hook = hook
 
-    def _cfg(self, B: int, N: int, layer: int = 0, seed: int = 0) -> _lib.LayerCfg:
+    def _cfg(self, B: int, N: int, layer: int = 0, seed_t: Optional[torch.Tensor] = None) -> _lib.LayerCfg:
         p = self.dropout if self.training else 0.0  # nn.Dropout semantics: identity in eval()
         if p != 0.0 and self.compute_dtype != _lib.BF16:
             raise NotImplementedError(
                 f"dropout={p} in training mode needs compute_dtype='bf16'; the fp32 parity mode is defined at "
                 f"p=0 / eval() (SURVEY.md section 7)")
         return _lib.LayerCfg(B, N, self.dim, self.heads, self.dim_head, self.mlp_dim, self.compute_dtype,
-                             int(self.project_out), 1e-5, float(p), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, layer)
+                             int(self.project_out), 1e-5, float(p), 0, 0, layer,
+                             seed_t.data_ptr() if (seed_t is not None and p != 0.0) else None)
 
-    def _next_seed(self) -> int:
-        """Fresh 64-bit dropout seed per forward, reproducible under torch.manual_seed (the masks themselves come
-        from a counter-based hash in the kernels, not from torch's generator)."""
+    def _advance_seed(self, dev) -> Optional[torch.Tensor]:
+        """Dropout seed of this forward, as a DEVICE tensor: the module's counter (initialised from torch.initial_seed(),
+        so runs are reproducible under torch.manual_seed) is advanced by an in-place add and snapshotted; the kernels read
+        the snapshot at run time.  Both ops are capturable, so a hipGraph of a training step draws fresh masks on every
+        replay.  (The masks come from a counter-based hash in the kernels, not from torch's generator.)"""
         if not (self.training and self.dropout > 0.0):
-            return 0
-        self._drop_calls += 1
-        return (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._drop_calls * 0xD1B54A32D192ED03 + id(self) % 65521) \
-            & 0xFFFFFFFFFFFFFFFF
+            return None
+        if self._seed_dev is None or self._seed_dev.device != dev:
+            host = (torch.initial_seed() * 0x9E3779B97F4A7C15 + (id(self) % 65521) * 0xD1B54A32D192ED03) & 0x7FFFFFFFFFFFFFFF
+            self._seed_dev = torch.tensor([host], dtype=torch.int64, device=dev)
+        self._seed_dev.add_(1)
+        self._last_seed_t = self._seed_dev.clone()
+        return self._last_seed_t
+
+    @property
+    def last_seed(self) -> int:
+        """the 64-bit seed the latest training forward used (host sync; for tests / mask replay)"""
+        return 0 if self._last_seed_t is None else int(self._last_seed_t.item()) & 0xFFFFFFFFFFFFFFFF
 
     @staticmethod
     def _param_struct(params, l) -> _lib.LayerPtrs:

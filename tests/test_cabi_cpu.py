@@ -97,12 +97,14 @@ def test_dropout_configuration():
     assert t._cfg(1, 4).dropout_p == 0.0
     t = A.Transformer(32, 1, 8, 32, 64, dropout=0.2)  # bf16: dropout is live in train(), identity in eval()
     t.train()
-    c = t._cfg(1, 4, layer=3, seed=(7 << 32) | 9)
-    assert abs(c.dropout_p - 0.2) < 1e-7 and (c.seed_lo, c.seed_hi, c.layer_index) == (9, 7, 3)
-    s1, s2 = t._next_seed(), t._next_seed()
-    assert s1 != s2 and s1 != 0
+    seed_t = torch.zeros(1, dtype=torch.int64)
+    c = t._cfg(1, 4, layer=3, seed_t=seed_t)
+    assert abs(c.dropout_p - 0.2) < 1e-7 and c.layer_index == 3 and c.seed_dev == seed_t.data_ptr()
+    s1 = t._advance_seed(torch.device("cpu"))
+    s2 = t._advance_seed(torch.device("cpu"))
+    assert int(s2) == int(s1) + 1 and t.last_seed == int(s2) & 0xFFFFFFFFFFFFFFFF
     t.eval()
-    assert t._cfg(1, 4).dropout_p == 0.0 and t._next_seed() == 0
+    assert t._cfg(1, 4, seed_t=seed_t).dropout_p == 0.0 and t._advance_seed(torch.device("cpu")) is None
 
 
 def test_registry():

@@ -22,4 +22,14 @@ t0 = time.perf_counter()
 for _ in range(50): step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 50
-print(f"real avformer heads, B={B}: {dt*1e3:.3f} ms/step, {B/dt:.0f} clips/s")
+print(f"real avformer heads (train mode, dropout 0.2), B={B}: eager {dt*1e3:.3f} ms/step, {B/dt:.0f} clips/s")
+opt2 = torch.optim.Adam(model.parameters(), lr=5e-4, weight_decay=5e-5, fused=True, capturable=True)
+batch = dict(x, labels=y)
+gs = A.graphs.GraphedTrainStep(model, opt2, lambda m, b: m.get_au_loss(m({"clip": b["clip"], "audio_features": b["audio_features"]}), b["labels"]), batch)
+for _ in range(10): gs(batch)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(50): gs(batch)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 50
+print(f"real avformer heads (train mode, dropout 0.2), B={B}: hipGraph replay {dt*1e3:.3f} ms/step, {B/dt:.0f} clips/s")
