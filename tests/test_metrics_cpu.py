@@ -1,0 +1,44 @@
+"""CPU: the AU metric against the reference's sklearn recipe (metrics/accf1.py:47-77, restated here with sklearn)."""
+import warnings
+
+import numpy as np
+import torch
+from sklearn.metrics import accuracy_score, f1_score
+
+import avformer_amd as A
+
+
+def reference_recipe(y_pred, y_true, ignore=-1):
+    labeled = y_true != ignore
+    acc, f1 = 0, []
+    for i in range(y_pred.shape[1]):
+        leave = y_true[:, i] != ignore
+        t, p = y_true[leave, i], y_pred[leave, i]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            f1.append(f1_score(y_true=t, y_pred=p, average="binary"))
+        acc += accuracy_score(y_true=t, y_pred=p, normalize=False)
+    return acc / labeled.sum(), float(np.mean(f1))
+
+
+def test_matches_sklearn_recipe_over_batches():
+    rng = np.random.default_rng(0)
+    m = A.metrics.MultiLabelAccF1(ignore_index=-1)
+    preds, trues = [], []
+    for b in range(7):
+        logits = torch.from_numpy(rng.normal(size=(37, 21)).astype(np.float32))
+        y = (rng.random((37, 12)) > 0.6).astype(np.float32)
+        y[rng.random((37, 12)) < 0.1] = -1
+        if b == 0:
+            y[:, 5] = 0          # an AU with no positive label at all
+        m.update_from_logits(logits, torch.from_numpy(y))
+        preds.append(np.round(torch.sigmoid(logits[:, :12]).numpy()))
+        trues.append(y)
+    y_pred, y_true = np.vstack(preds), np.vstack(trues)
+    acc_ref, f1_ref = reference_recipe(y_pred, y_true)
+    acc, f1 = m.get()
+    assert abs(acc - acc_ref) < 1e-12 and abs(f1 - f1_ref) < 1e-12
+    assert abs(m.score() - (0.5 * f1_ref + 0.5 * acc_ref)) < 1e-12
+    m.clear()
+    m.update(torch.zeros(4, 12), torch.zeros(4, 12))
+    assert m.get() == (1.0, 0.0)   # all negatives, none predicted: accuracy 1, F1 defined as 0 (sklearn zero_division)
