@@ -34,7 +34,19 @@ def _stale(target: str, deps) -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every .hip source to an object and link the shared library.  Returns its path."""
+    """Compile every .hip source to an object and link the shared library.  Returns its path.
+    Serialised across processes with a file lock (eight ranks of a node may import at once)."""
+    import fcntl
+    os.makedirs(LIBDIR, exist_ok=True)
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool, verbose: bool) -> str:
     hipcc = _hipcc()
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
