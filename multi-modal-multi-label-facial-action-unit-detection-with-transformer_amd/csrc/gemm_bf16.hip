@@ -654,6 +654,11 @@ __global__ __launch_bounds__(256) void fold_group_kernel(TnGroup g, int nslab, F
 }
 
 int tn_group_splits(int total_tiles, int64_t K) {
+  static const int forced = [] {
+    const char* e = getenv("AVF_TN_SPLITS");  // tuning aid
+    return e ? atoi(e) : 0;
+  }();
+  if (forced > 0) return forced;
   int64_t s = ceil_div(512, total_tiles);
   const int64_t maxs = K / 1024 > 0 ? K / 1024 : 1;  // at least 16 K-steps per workgroup
   if (s > maxs) s = maxs;
