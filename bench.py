@@ -146,7 +146,8 @@ def main():
     dp = A.dp.DataParallel(model) if use_dist else None
 
     def step():
-        model.zero_grad(set_to_none=True)
+        # optimizer.zero_grad() as the reference (train.py:206); Module.zero_grad walks the whole module tree (0.7 ms)
+        (opt if opt is not None else model).zero_grad(set_to_none=True)
         out = model(batch)
         loss = model.get_au_loss(out, labels)
         loss.backward()

@@ -11,7 +11,7 @@ opt = torch.optim.Adam(model.parameters(), lr=5e-4, weight_decay=5e-5, fused=Tru
 x = {"clip": torch.randn(B, 512, device="cuda"), "audio_features": torch.randn(B, 512, device="cuda")}
 y = (torch.rand(B, 12, device="cuda") > 0.5).float()
 def step():
-    model.zero_grad(set_to_none=True)
+    opt.zero_grad(set_to_none=True)
     loss = model.get_au_loss(model(x), y)
     loss.backward()
     opt.step()
