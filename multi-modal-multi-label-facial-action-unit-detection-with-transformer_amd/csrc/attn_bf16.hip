@@ -26,6 +26,13 @@ typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 
 constexpr float LOG2E = 1.4426950408889634f;
 
+// Phase stamps for tools/diag/attn_phases.hip (that file defines these and includes this one); nothing in the product.
+#ifndef AVF_PHASE_MARK
+#define AVF_PHASE_INIT()
+#define AVF_PHASE_MARK(slot)
+#define AVF_PHASE_FLUSH()
+#endif
+
 // 1-D grid of nblk * B*H blocks.  Hardware deals consecutive block ids round-robin over the 8 XCDs; this
 // bijection hands each XCD a CONTIGUOUS range of logical ids, so the row blocks of one (batch, head) - which
 // share that head's K/V (or Q/dO) - run on one XCD and hit in its L2 instead of re-fetching from HBM.
@@ -115,6 +122,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16* __res
   const int q0 = blk * 128 + wave * 32;
   const bool active = __builtin_amdgcn_readfirstlane(q0) < N;
   const float c = LOG2E / sqrtf((float)DH);
+  AVF_PHASE_INIT();
 
   bf16x8_t fq[2][KS];
 #pragma unroll
@@ -142,6 +150,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16* __res
     sv.template commit<VLD>(smem + 64 * KLD, tid);
   }
   __syncthreads();
+  AVF_PHASE_MARK(0);
   for (int t = 0; t < nt; ++t) {
     const int cur = t & 1;
     if (t + 1 < nt) {
@@ -150,6 +159,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16* __res
       sk.issue(kbase, ld, r0, nv, tid);
       sv.issue(vbase, ld, r0, nv, tid);
     }
+    AVF_PHASE_MARK(1);
     const char* kt = smem + cur * STAGE;
     const lds_char* vt = (const lds_char*)(smem + cur * STAGE + 64 * KLD);
 
@@ -174,6 +184,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16* __res
           }
         }
       }
+      AVF_PHASE_MARK(2);
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
         float tmax = -INFINITY;
@@ -204,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16* __res
           ot[d][qb][0] *= alpha; ot[d][qb][1] *= alpha; ot[d][qb][2] *= alpha; ot[d][qb][3] *= alpha;
         }
       }
+      AVF_PHASE_MARK(3);
       // O^T[d][q] += V^T P^T
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -222,11 +234,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16* __res
       if (t * 64 + 64 > N) tile_body(std::true_type{});
       else tile_body(std::false_type{});
     }
+    AVF_PHASE_MARK(4);
     if (t + 1 < nt) {
       sk.template commit<KLD>(smem + (cur ^ 1) * STAGE, tid);
       sv.template commit<VLD>(smem + (cur ^ 1) * STAGE + 64 * KLD, tid);
     }
+    AVF_PHASE_MARK(5);
     __syncthreads();
+    AVF_PHASE_MARK(6);
   }
 
 #pragma unroll
@@ -245,6 +260,281 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16* __res
       if (lg == 0) lse2[(int64_t)bh * N + q] = m[qb] + log2f(l);
     }
   }
+  AVF_PHASE_MARK(7);
+  AVF_PHASE_FLUSH();
+}
+
+// =============================================================================================
+// head-resident variants (dim_head 64, N <= 512): ONE workgroup per (batch, head) keeps the head's whole K and V
+// (or Q and dO) in LDS - 128 B per row, N rounded up to 32 rows - so nothing is staged twice, there is no ring and no
+// per-tile barrier: ceil(N/32) wavefronts of 32 query (key) rows each free-run over the key (query) tiles, which lets
+// the MFMA phase of one wave overlap the softmax VALU phase of another on the same SIMD.
+//
+// LDS image: written by LDS-DMA (global_load_lds_dwordx4, 64 lanes x 16 B = 8 rows per instruction, no staging
+// VGPRs), so it is lane-linear per instruction; bank conflicts are avoided by permuting the SOURCE chunk instead:
+// row r holds logical 16-B chunk c at slot c ^ res_swz(r), res_swz(r) = ((r>>1)&3)<<1.  That is conflict-free for the
+// ds_read_b128 row fragments (lane groups of 16: rows x two adjacent chunks) and for ds_read_b64_tr_b16 (lane groups of
+// 32: 8 consecutive rows x two adjacent chunks).  Rows past N are loaded from row N-1 (finite values; their
+// probabilities are exactly 0).
+// Arrival: two barriers only - after the first RES_A key tiles have landed, and after everything has (see ResLoader).
+// Softmax: running maximum with LAZY rescaling - the accumulators are rescaled only when some row's maximum grew by
+// more than 2^RES_TAU since the last rescale (a wave-uniform branch, rare after the first tile), so probabilities
+// stay <= 2^RES_TAU; the row sums come from the MFMA (a ones fragment as a 65th value row), the cross-lane maximum
+// from v_permlane{16,32}_swap instead of LDS permutes.  lse2 = m + log2(l) is exact whatever m is.
+// =============================================================================================
+constexpr int RES_MAX_N = 512;
+constexpr int RES_A = 2;          // key tiles whose DMA is issued before any compute
+constexpr float RES_TAU = 6.0f;   // log2 of the largest probability kept before a rescale
+
+__device__ __forceinline__ void glds16(const void* g, char* l) {
+  typedef __attribute__((address_space(1))) const void gptr_t;
+  typedef __attribute__((address_space(3))) void lptr_t;
+  __builtin_amdgcn_global_load_lds((gptr_t*)g, (lptr_t*)l, 16, 0, 0);
+}
+
+// s_waitcnt vmcnt(n) for a run-time n (at most ~12 pieces per wave); a stricter wait is always safe
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
+  switch (n) {
+#define AVF_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    AVF_W(1) AVF_W(2) AVF_W(3) AVF_W(4) AVF_W(5) AVF_W(6) AVF_W(7) AVF_W(8) AVF_W(9) AVF_W(10) AVF_W(11) AVF_W(12)
+    AVF_W(13) AVF_W(14) AVF_W(15) AVF_W(16)
+#undef AVF_W
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+__device__ __forceinline__ float vmax(float a, float b) {  // v_max_f32 without the NaN-canonicalising pre-ops
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// max over the four lanes {li, li+16, li+32, li+48} (the four key groups of one query column), VALU only
+__device__ __forceinline__ float colmax4(float v) {
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = vmax(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return vmax(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
+__device__ __forceinline__ bf16x8_t ones_frag() {
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+  u32x4_t r = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+
+__device__ __forceinline__ bf16x8_t lds_row_frag(const char* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
+
+__device__ __forceinline__ bf16x8_t lds_tr_frag(const char* p) {  // rows +0 and +16 of a 32-row k-step
+  const lds_char* q = (const lds_char*)p;
+  s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)q);
+  s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(q + 16 * 128));
+  s16x8_t r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+
+// DMA schedule of a head-resident kernel.  Two [rows, 64] bf16 operands a, b (row strides lda, ldb elements) go to
+// their LDS images in 8-row pieces, ordered a0 b0 a1 b1 ... (16 pieces per 64-row tile, so arrival is in tile order);
+// piece p belongs to wave p mod W and each wave walks its pieces with a cursor.  Phase 1 (the first RES_A tiles) is
+// issued up front; the rest is issued one piece at a time from hooks inside the first tile's compute, so no wave sits
+// in a full memory queue while the SIMD idles, and tile 1 covers the latency of the last pieces.
+struct ResLoader {
+  const bf16 *a, *b;
+  int64_t lda, ldb;
+  char *la, *lb;
+  int npieces, N, W, lrow, chunk, cur;
+  __device__ __forceinline__ void init(const bf16* a_, int64_t lda_, char* la_, const bf16* b_, int64_t ldb_, char* lb_,
+                                       int rows_padded, int N_, int wave, int W_, int lane) {
+    a = a_; b = b_; lda = lda_; ldb = ldb_; la = la_; lb = lb_;
+    npieces = rows_padded / 4;  // 2 operands x rows/8
+    N = N_; W = W_; cur = wave;
+    lrow = lane >> 3;
+    chunk = (lane & 7) ^ (((lrow >> 1) & 3) << 1);
+  }
+  __device__ __forceinline__ void issue_one() {  // wave-uniform; no-op once the wave's pieces are out
+    if (cur < npieces) {
+      const int i = cur >> 1;
+      int row = i * 8 + lrow;
+      row = row < N ? row : N - 1;
+      if (cur & 1) glds16(b + (int64_t)row * ldb + chunk * 8, lb + i * 1024);
+      else glds16(a + (int64_t)row * lda + chunk * 8, la + i * 1024);
+      cur += W;
+    }
+  }
+  __device__ __forceinline__ void issue_until(int limit) {
+    const int lim = limit < npieces ? limit : npieces;
+    while (cur < lim) issue_one();
+  }
+};
+
+template <int MAXW>
+__global__ __launch_bounds__(MAXW * 64) void attn_fwd_res_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
+                                                                float* __restrict__ lse2, int N, int H) {
+  constexpr int DH = 64, KS = 2, DB = 4;
+  extern __shared__ __attribute__((aligned(16))) char res_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), W = blockDim.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+  const int I = H * DH;
+  const int64_t ld = 3 * (int64_t)I;
+  const bf16* qbase = qkv + (int64_t)b * N * ld + h * DH;
+  const bf16* kbase = qbase + I;
+  const bf16* vbase = qbase + 2 * I;
+  const int NP = (N + 31) & ~31;
+  char* ksm = res_smem;
+  char* vsm = res_smem + NP * 128;
+  const int q0 = wave * 32;
+  const float c = LOG2E / sqrtf((float)DH);
+  AVF_PHASE_INIT();
+
+  bf16x8_t fq[2][KS];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int q = q0 + qb * 16 + li;
+      fq[qb][ks] = load_frag_global(qbase + (int64_t)q * ld + ks * 32 + 8 * lg, q < N);
+    }
+  ResLoader loader;
+  loader.init(kbase, ld, ksm, vbase, ld, vsm, NP, N, wave, W, lane);
+  const int nt = (N + 63) / 64;
+  loader.issue_until(16 * RES_A);
+
+  // per-lane read offsets inside a 64-row tile (see the layout note above)
+  int krd[KS], vrd[DB];
+  {
+    const int swz_r = ((li >> 1) & 3) << 1;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) krd[ks] = li * 128 + (((ks * 4 + lg) ^ swz_r) << 4);
+    const int swz_t = ((2 * lg + (li >> 3)) & 3) << 1;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+      vrd[d] = (4 * lg + (li >> 2)) * 128 + (((2 * d + ((li & 3) >> 1)) ^ swz_t) << 4) + (li & 1) * 8;
+  }
+
+  f32x4_t ot[DB][2], ls[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    ls[qb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < DB; ++d) ot[d][qb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  float m[2] = {-INFINITY, -INFINITY};
+  const bf16x8_t ones = ones_frag();
+
+  auto tile = [&](int t, auto tail_tag, auto feed_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
+    constexpr bool FEED = decltype(feed_tag)::value;  // this tile also issues the remaining DMA pieces
+    const int nkb = TAIL ? (N - t * 64 + 15) / 16 : 4;
+    const char* kt = ksm + t * 8192;
+    const char* vt = vsm + t * 8192;
+    f32x4_t st[4][2];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      st[kb][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      st[kb][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      if (!TAIL || kb < nkb) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8_t fk = lds_row_frag(kt + kb * 2048 + krd[ks]);
+          st[kb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq[0][ks], st[kb][0], 0, 0, 0);
+          st[kb][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq[1][ks], st[kb][1], 0, 0, 0);
+        }
+      }
+      if (FEED) loader.issue_one();
+    }
+    AVF_PHASE_MARK(2);
+    float cand[2];
+    bool grow = false;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (TAIL && (t * 64 + kb * 16 + 4 * lg + r >= N)) st[kb][qb][r] = -INFINITY;
+          tmax = fmaxf(tmax, st[kb][qb][r]);
+        }
+      cand[qb] = colmax4(tmax) * c;
+      grow = grow || (cand[qb] > m[qb] + RES_TAU);
+    }
+    if (__builtin_amdgcn_ballot_w64(grow) != 0) {  // wave-uniform
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        const float mn = fmaxf(m[qb], cand[qb]);
+        const float alpha = __builtin_amdgcn_exp2f(m[qb] - mn);
+        m[qb] = mn;
+        ls[qb][0] *= alpha; ls[qb][1] *= alpha; ls[qb][2] *= alpha; ls[qb][3] *= alpha;
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+          ot[d][qb][0] *= alpha; ot[d][qb][1] *= alpha; ot[d][qb][2] *= alpha; ot[d][qb][3] *= alpha;
+        }
+      }
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[kb][qb][r] = __builtin_amdgcn_exp2f(fmaf(st[kb][qb][r], c, -m[qb]));
+    AVF_PHASE_MARK(3);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      if (TAIL && 2 * s2 >= nkb) continue;
+      __builtin_amdgcn_sched_barrier(0);  // keep the V fragments of this k-step from being hoisted over the softmax
+      const bf16x8_t p0 = pack_pair(st[2 * s2][0], st[2 * s2 + 1][0]);
+      const bf16x8_t p1 = pack_pair(st[2 * s2][1], st[2 * s2 + 1][1]);
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+        const bf16x8_t fv = lds_tr_frag(vt + s2 * 4096 + vrd[d]);
+        ot[d][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, p0, ot[d][0], 0, 0, 0);
+        ot[d][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, p1, ot[d][1], 0, 0, 0);
+      }
+      ls[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, p0, ls[0], 0, 0, 0);
+      ls[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, p1, ls[1], 0, 0, 0);
+      if (FEED) loader.issue_one();
+    }
+    if (FEED) loader.issue_until(1 << 30);
+    AVF_PHASE_MARK(4);
+  };
+
+  const int nfull = N / 64;
+  AVF_PHASE_MARK(1);
+  wait_vmcnt_dyn(0);
+  __builtin_amdgcn_s_barrier();  // the first RES_A tiles are visible
+  AVF_PHASE_MARK(0);
+  if (nfull > 0) tile(0, std::false_type{}, std::true_type{});
+  else tile(0, std::true_type{}, std::true_type{});
+  for (int t = 1; t < nt && t < RES_A; ++t) {
+    if (t < nfull) tile(t, std::false_type{}, std::false_type{});
+    else tile(t, std::true_type{}, std::false_type{});
+  }
+  if (nt > RES_A) {
+    wait_vmcnt_dyn(0);
+    __builtin_amdgcn_s_barrier();  // everything is visible; no further synchronisation
+    AVF_PHASE_MARK(5);
+    for (int t = RES_A; t < nfull; ++t) tile(t, std::false_type{}, std::false_type{});
+    if (nfull < nt) tile(nfull, std::true_type{}, std::false_type{});
+  }
+
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int q = q0 + qb * 16 + li;
+    if (q < N) {
+      const float l = ls[qb][0];
+      const float inv = 1.0f / l;
+      bf16* orow = o + ((int64_t)b * N + q) * I + h * DH;
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+        store4<bf16>(orow + d * 16 + 4 * lg,
+                     make_float4(ot[d][qb][0] * inv, ot[d][qb][1] * inv, ot[d][qb][2] * inv, ot[d][qb][3] * inv));
+      if (lg == 0) lse2[(int64_t)bh * N + q] = m[qb] + log2f(l);
+    }
+  }
+  AVF_PHASE_MARK(7);
+  AVF_PHASE_FLUSH();
 }
 
 // =============================================================================================
@@ -553,11 +843,40 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_bf16_kernel(const bf16* __res
 
 }  // namespace
 
+namespace {
+// head-resident kernels: dim_head 64, the head's two operands fit in LDS; AVF_ATTN_RESIDENT=0 forces the streaming ones
+bool use_resident(int N, int dh) {
+  static const int allow = [] {
+    const char* e = getenv("AVF_ATTN_RESIDENT");
+    return e ? atoi(e) : 1;
+  }();
+  return allow && dh == 64 && N <= RES_MAX_N;
+}
+
+int raise_lds(const void* fn, const char* name) {
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, RES_MAX_N * 128 * 2 + 4096);
+  AVF_REQUIRE(e == hipSuccess, "%s: cannot raise dynamic LDS limit: %s", name, hipGetErrorString(e));
+  return 0;
+}
+}  // namespace
+
 int attn_fwd_bf16(const bf16* qkv, bf16* o, float* lse2, int B, int N, int H, int dh, hipStream_t s) {
   AVF_REQUIRE(B > 0 && N > 0 && H > 0, "attn_fwd_bf16: bad shape");
   AVF_REQUIRE(ceil_div(N, 128) * B * H < (1LL << 31), "attn_fwd_bf16: grid too large");
   AVF_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)o & 7) == 0, "attn_fwd_bf16: misaligned pointers");
   TimingScope ts(KC_ATTN_FWD, 4.0 * B * H * (double)N * N * dh, 2.0 * 4.0 * B * N * H * dh, s);
+  if (use_resident(N, dh)) {
+    const int W = (int)ceil_div(N, 32);
+    const size_t smem = (size_t)((N + 31) & ~31) * 128 * 2;
+    if (W <= 12) {
+      AVF_TRY(raise_lds((const void*)attn_fwd_res_kernel<12>, "attn_fwd_res<12>"));
+      attn_fwd_res_kernel<12><<<B * H, W * 64, smem, s>>>(qkv, o, lse2, N, H);
+    } else {
+      AVF_TRY(raise_lds((const void*)attn_fwd_res_kernel<16>, "attn_fwd_res<16>"));
+      attn_fwd_res_kernel<16><<<B * H, W * 64, smem, s>>>(qkv, o, lse2, N, H);
+    }
+    return check_launch("attn_fwd_res_kernel");
+  }
   const unsigned grid = (unsigned)(ceil_div(N, 128) * B * H);
   if (dh == 64) attn_fwd_bf16_kernel<64><<<grid, 256, 0, s>>>(qkv, o, lse2, B, N, H);
   else if (dh == 32) attn_fwd_bf16_kernel<32><<<grid, 256, 0, s>>>(qkv, o, lse2, B, N, H);
