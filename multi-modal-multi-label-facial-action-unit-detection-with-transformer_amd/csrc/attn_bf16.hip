@@ -265,25 +265,27 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16* __res
 }
 
 // =============================================================================================
-// head-resident variants (dim_head 64, N <= 512): ONE workgroup per (batch, head) keeps the head's whole K and V
-// (or Q and dO) in LDS - 128 B per row, N rounded up to 32 rows - so nothing is staged twice, there is no ring and no
-// per-tile barrier: ceil(N/32) wavefronts of 32 query (key) rows each free-run over the key (query) tiles, which lets
-// the MFMA phase of one wave overlap the softmax VALU phase of another on the same SIMD.
+// head-resident variants (dim_head 64, N <= RES_MAX_N): ONE workgroup per (batch, head) keeps the head's whole K and
+// V (or Q and dO) in LDS - 128 B per row, N rounded up to 32 rows - so nothing is staged twice, there is no ring and
+// no per-tile barrier.  The N rows are cut into V = ceil(N/32) groups of 32 query (key) rows; the workgroup has
+// W = ceil(V / passes) wavefronts (passes = ceil(V/12): at most 12 waves, three per SIMD at <= 168 VGPRs) and wave w
+// takes groups w, w+W, ...  After the load phase the waves free-run over the key (query) tiles, which lets the MFMA
+// phase of one wave overlap the softmax VALU phase of another on the same SIMD.
 //
 // LDS image: written by LDS-DMA (global_load_lds_dwordx4, 64 lanes x 16 B = 8 rows per instruction, no staging
 // VGPRs), so it is lane-linear per instruction; bank conflicts are avoided by permuting the SOURCE chunk instead:
-// row r holds logical 16-B chunk c at slot c ^ res_swz(r), res_swz(r) = ((r>>1)&3)<<1.  That is conflict-free for the
-// ds_read_b128 row fragments (lane groups of 16: rows x two adjacent chunks) and for ds_read_b64_tr_b16 (lane groups of
-// 32: 8 consecutive rows x two adjacent chunks).  Rows past N are loaded from row N-1 (finite values; their
-// probabilities are exactly 0).
-// Arrival: two barriers only - after the first RES_A key tiles have landed, and after everything has (see ResLoader).
-// Softmax: running maximum with LAZY rescaling - the accumulators are rescaled only when some row's maximum grew by
-// more than 2^RES_TAU since the last rescale (a wave-uniform branch, rare after the first tile), so probabilities
-// stay <= 2^RES_TAU; the row sums come from the MFMA (a ones fragment as a 65th value row), the cross-lane maximum
-// from v_permlane{16,32}_swap instead of LDS permutes.  lse2 = m + log2(l) is exact whatever m is.
+// row r holds logical 16-B chunk c at slot c ^ res_swz(r), res_swz(r) = ((r>>1)&3)<<1.  That is conflict-free
+// (SQ_LDS_BANK_CONFLICT = 0) for the ds_read_b128 row fragments (lane groups of 16: rows x two adjacent chunks) and
+// for ds_read_b64_tr_b16 (lane groups of 32: 8 consecutive rows x two adjacent chunks).  Rows past N are loaded
+// from row N-1 (finite values; their probabilities are exactly 0).
+// Arrival: two barriers only - after the first RES_A tiles have landed, and after everything has (see ResLoader).
+// Forward softmax: running maximum with LAZY rescaling - the accumulators are rescaled only when some row's maximum
+// grew by more than 2^RES_TAU since the last rescale (a wave-uniform branch, rare after the first tile), so
+// probabilities stay <= 2^RES_TAU; the row sums come from the MFMA (a ones fragment as a 65th value row), the
+// cross-lane maximum from v_permlane{16,32}_swap instead of LDS permutes.  lse2 = m + log2(l) is exact whatever m is.
 // =============================================================================================
-constexpr int RES_MAX_N = 512;
-constexpr int RES_A = 2;          // key tiles whose DMA is issued before any compute
+constexpr int RES_MAX_N = 576;    // (N rounded to 32) * 256 B + the dK/dV kernel's statistics <= 160 KB
+constexpr int RES_A = 2;          // tiles whose DMA is issued before any compute
 constexpr float RES_TAU = 6.0f;   // log2 of the largest probability kept before a rescale
 
 __device__ __forceinline__ void glds16(const void* g, char* l) {
@@ -292,16 +294,13 @@ __device__ __forceinline__ void glds16(const void* g, char* l) {
   __builtin_amdgcn_global_load_lds((gptr_t*)g, (lptr_t*)l, 16, 0, 0);
 }
 
-// s_waitcnt vmcnt(n) for a run-time n (at most ~12 pieces per wave); a stricter wait is always safe
-__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
-  switch (n) {
-#define AVF_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-    AVF_W(1) AVF_W(2) AVF_W(3) AVF_W(4) AVF_W(5) AVF_W(6) AVF_W(7) AVF_W(8) AVF_W(9) AVF_W(10) AVF_W(11) AVF_W(12)
-    AVF_W(13) AVF_W(14) AVF_W(15) AVF_W(16)
-#undef AVF_W
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-  }
+__device__ __forceinline__ void glds4(const void* g, char* l) {
+  typedef __attribute__((address_space(1))) const void gptr_t;
+  typedef __attribute__((address_space(3))) void lptr_t;
+  __builtin_amdgcn_global_load_lds((gptr_t*)g, (lptr_t*)l, 4, 0, 0);
 }
+
+__device__ __forceinline__ void wait_all_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ float vmax(float a, float b) {  // v_max_f32 without the NaN-canonicalising pre-ops
   float r;
@@ -367,7 +366,45 @@ struct ResLoader {
   }
 };
 
-template <int MAXW>
+// per-lane byte offsets inside a 64-row tile of an LDS image: row[ks] for the ds_read_b128 row fragment of row
+// block kb (add kb*2048), tr[d] for the transposed fragment of 32-row k-step s2 (add s2*4096)
+struct ResOffsets {
+  int row[2], tr[4];
+  __device__ __forceinline__ void init(int li, int lg) {
+    const int swz_r = ((li >> 1) & 3) << 1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) row[ks] = li * 128 + (((ks * 4 + lg) ^ swz_r) << 4);
+    const int swz_t = ((2 * lg + (li >> 3)) & 3) << 1;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+      tr[d] = (4 * lg + (li >> 2)) * 128 + (((2 * d + ((li & 3) >> 1)) ^ swz_t) << 4) + (li & 1) * 8;
+  }
+};
+
+// Tile schedule shared by the three kernels: pass 0 of every wave gates on the two arrival barriers and feeds the
+// remaining DMA from its first tile; later passes (more 32-row groups than waves) run without any synchronisation.
+template <bool MULTI, typename TileFn, typename SyncFn>
+__device__ __forceinline__ void res_sweep(int N, bool first, TileFn&& tile, SyncFn&& sync) {
+  const int nt = (N + 63) / 64, nfull = N / 64;
+  const bool first_pass = !MULTI || first;  // single-pass kernels: known at compile time
+  int t0 = 0;
+  if (first_pass) {
+    sync();  // the first RES_A tiles are visible
+    if (nfull > 0) tile(0, std::false_type{}, std::true_type{});
+    else tile(0, std::true_type{}, std::true_type{});
+    t0 = nt < RES_A ? nt : RES_A;
+    for (int t = 1; t < t0; ++t) {
+      if (t < nfull) tile(t, std::false_type{}, std::false_type{});
+      else tile(t, std::true_type{}, std::false_type{});
+    }
+    if (nt > RES_A) sync();  // everything is visible
+  }
+  for (int t = t0; t < nfull; ++t) tile(t, std::false_type{}, std::false_type{});  // the hot loop: one variant only
+  if (nfull < nt && t0 <= nfull) tile(nfull, std::true_type{}, std::false_type{});
+}
+
+// MULTI: more 32-row groups than waves (each wave loops over its groups); otherwise exactly one group per wave
+template <int MAXW, bool MULTI>
 __global__ __launch_bounds__(MAXW * 64) void attn_fwd_res_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
                                                                 float* __restrict__ lse2, int N, int H) {
   constexpr int DH = 64, KS = 2, DB = 4;
@@ -381,159 +418,420 @@ __global__ __launch_bounds__(MAXW * 64) void attn_fwd_res_kernel(const bf16* __r
   const bf16* qbase = qkv + (int64_t)b * N * ld + h * DH;
   const bf16* kbase = qbase + I;
   const bf16* vbase = qbase + 2 * I;
-  const int NP = (N + 31) & ~31;
+  const int NP = (N + 31) & ~31, V = NP >> 5;
   char* ksm = res_smem;
   char* vsm = res_smem + NP * 128;
-  const int q0 = wave * 32;
   const float c = LOG2E / sqrtf((float)DH);
   AVF_PHASE_INIT();
-
-  bf16x8_t fq[2][KS];
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int q = q0 + qb * 16 + li;
-      fq[qb][ks] = load_frag_global(qbase + (int64_t)q * ld + ks * 32 + 8 * lg, q < N);
-    }
   ResLoader loader;
   loader.init(kbase, ld, ksm, vbase, ld, vsm, NP, N, wave, W, lane);
-  const int nt = (N + 63) / 64;
-  loader.issue_until(16 * RES_A);
-
-  // per-lane read offsets inside a 64-row tile (see the layout note above)
-  int krd[KS], vrd[DB];
-  {
-    const int swz_r = ((li >> 1) & 3) << 1;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) krd[ks] = li * 128 + (((ks * 4 + lg) ^ swz_r) << 4);
-    const int swz_t = ((2 * lg + (li >> 3)) & 3) << 1;
-#pragma unroll
-    for (int d = 0; d < DB; ++d)
-      vrd[d] = (4 * lg + (li >> 2)) * 128 + (((2 * d + ((li & 3) >> 1)) ^ swz_t) << 4) + (li & 1) * 8;
-  }
-
-  f32x4_t ot[DB][2], ls[2];
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    ls[qb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int d = 0; d < DB; ++d) ot[d][qb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  }
-  float m[2] = {-INFINITY, -INFINITY};
+  ResOffsets off;
+  off.init(li, lg);
   const bf16x8_t ones = ones_frag();
 
-  auto tile = [&](int t, auto tail_tag, auto feed_tag) {
-    constexpr bool TAIL = decltype(tail_tag)::value;
-    constexpr bool FEED = decltype(feed_tag)::value;  // this tile also issues the remaining DMA pieces
-    const int nkb = TAIL ? (N - t * 64 + 15) / 16 : 4;
-    const char* kt = ksm + t * 8192;
-    const char* vt = vsm + t * 8192;
-    f32x4_t st[4][2];
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      st[kb][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      st[kb][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      if (!TAIL || kb < nkb) {
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const bf16x8_t fk = lds_row_frag(kt + kb * 2048 + krd[ks]);
-          st[kb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq[0][ks], st[kb][0], 0, 0, 0);
-          st[kb][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq[1][ks], st[kb][1], 0, 0, 0);
-        }
-      }
-      if (FEED) loader.issue_one();
-    }
-    AVF_PHASE_MARK(2);
-    float cand[2];
-    bool grow = false;
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      float tmax = -INFINITY;
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (TAIL && (t * 64 + kb * 16 + 4 * lg + r >= N)) st[kb][qb][r] = -INFINITY;
-          tmax = fmaxf(tmax, st[kb][qb][r]);
-        }
-      cand[qb] = colmax4(tmax) * c;
-      grow = grow || (cand[qb] > m[qb] + RES_TAU);
-    }
-    if (__builtin_amdgcn_ballot_w64(grow) != 0) {  // wave-uniform
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
-        const float mn = fmaxf(m[qb], cand[qb]);
-        const float alpha = __builtin_amdgcn_exp2f(m[qb] - mn);
-        m[qb] = mn;
-        ls[qb][0] *= alpha; ls[qb][1] *= alpha; ls[qb][2] *= alpha; ls[qb][3] *= alpha;
-#pragma unroll
-        for (int d = 0; d < DB; ++d) {
-          ot[d][qb][0] *= alpha; ot[d][qb][1] *= alpha; ot[d][qb][2] *= alpha; ot[d][qb][3] *= alpha;
-        }
-      }
-    }
+  int grp = wave;
+  do {
+    const bool first_pass = !MULTI || grp == wave;
+    const int q0 = grp * 32;
+    bf16x8_t fq[2][KS];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) st[kb][qb][r] = __builtin_amdgcn_exp2f(fmaf(st[kb][qb][r], c, -m[qb]));
-    AVF_PHASE_MARK(3);
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      if (TAIL && 2 * s2 >= nkb) continue;
-      __builtin_amdgcn_sched_barrier(0);  // keep the V fragments of this k-step from being hoisted over the softmax
-      const bf16x8_t p0 = pack_pair(st[2 * s2][0], st[2 * s2 + 1][0]);
-      const bf16x8_t p1 = pack_pair(st[2 * s2][1], st[2 * s2 + 1][1]);
-#pragma unroll
-      for (int d = 0; d < DB; ++d) {
-        const bf16x8_t fv = lds_tr_frag(vt + s2 * 4096 + vrd[d]);
-        ot[d][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, p0, ot[d][0], 0, 0, 0);
-        ot[d][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, p1, ot[d][1], 0, 0, 0);
+      for (int ks = 0; ks < KS; ++ks) {
+        const int q = q0 + qb * 16 + li;
+        fq[qb][ks] = load_frag_global(qbase + (int64_t)q * ld + ks * 32 + 8 * lg, q < N);
       }
-      ls[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, p0, ls[0], 0, 0, 0);
-      ls[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, p1, ls[1], 0, 0, 0);
-      if (FEED) loader.issue_one();
-    }
-    if (FEED) loader.issue_until(1 << 30);
-    AVF_PHASE_MARK(4);
-  };
+    if (first_pass) loader.issue_until(16 * RES_A);
 
-  const int nfull = N / 64;
-  AVF_PHASE_MARK(1);
-  wait_vmcnt_dyn(0);
-  __builtin_amdgcn_s_barrier();  // the first RES_A tiles are visible
-  AVF_PHASE_MARK(0);
-  if (nfull > 0) tile(0, std::false_type{}, std::true_type{});
-  else tile(0, std::true_type{}, std::true_type{});
-  for (int t = 1; t < nt && t < RES_A; ++t) {
-    if (t < nfull) tile(t, std::false_type{}, std::false_type{});
-    else tile(t, std::true_type{}, std::false_type{});
-  }
-  if (nt > RES_A) {
-    wait_vmcnt_dyn(0);
-    __builtin_amdgcn_s_barrier();  // everything is visible; no further synchronisation
-    AVF_PHASE_MARK(5);
-    for (int t = RES_A; t < nfull; ++t) tile(t, std::false_type{}, std::false_type{});
-    if (nfull < nt) tile(nfull, std::true_type{}, std::false_type{});
-  }
+    f32x4_t ot[DB][2], ls[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      ls[qb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int d = 0; d < DB; ++d) ot[d][qb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    float m[2] = {-INFINITY, -INFINITY};
+
+    auto tile = [&](int t, auto tail_tag, auto feed_tag) {
+      constexpr bool TAIL = decltype(tail_tag)::value;
+      constexpr bool FEED = decltype(feed_tag)::value;  // this tile also issues the remaining DMA pieces
+      const int nkb = TAIL ? (N - t * 64 + 15) / 16 : 4;
+      const char* kt = ksm + t * 8192;
+      const char* vt = vsm + t * 8192;
+      f32x4_t st[4][2];
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        st[kb][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        st[kb][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (!TAIL || kb < nkb) {
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8_t fk = lds_row_frag(kt + kb * 2048 + off.row[ks]);
+            st[kb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq[0][ks], st[kb][0], 0, 0, 0);
+            st[kb][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq[1][ks], st[kb][1], 0, 0, 0);
+          }
+        }
+        if (FEED) loader.issue_one();
+      }
+      AVF_PHASE_MARK(2);
+      float cand[2];
+      bool grow = false;
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (TAIL && (t * 64 + kb * 16 + 4 * lg + r >= N)) st[kb][qb][r] = -INFINITY;
+            tmax = fmaxf(tmax, st[kb][qb][r]);
+          }
+        cand[qb] = colmax4(tmax) * c;
+        grow = grow || (cand[qb] > m[qb] + RES_TAU);
+      }
+      if (__builtin_amdgcn_ballot_w64(grow) != 0) {  // wave-uniform
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+          const float mn = fmaxf(m[qb], cand[qb]);
+          const float alpha = __builtin_amdgcn_exp2f(m[qb] - mn);
+          m[qb] = mn;
+          ls[qb][0] *= alpha; ls[qb][1] *= alpha; ls[qb][2] *= alpha; ls[qb][3] *= alpha;
+#pragma unroll
+          for (int d = 0; d < DB; ++d) {
+            ot[d][qb][0] *= alpha; ot[d][qb][1] *= alpha; ot[d][qb][2] *= alpha; ot[d][qb][3] *= alpha;
+          }
+        }
+      }
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) st[kb][qb][r] = __builtin_amdgcn_exp2f(fmaf(st[kb][qb][r], c, -m[qb]));
+      AVF_PHASE_MARK(3);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        if (TAIL && 2 * s2 >= nkb) continue;
+        __builtin_amdgcn_sched_barrier(0);  // keep the V fragments of this k-step from being hoisted over the softmax
+        const bf16x8_t p0 = pack_pair(st[2 * s2][0], st[2 * s2 + 1][0]);
+        const bf16x8_t p1 = pack_pair(st[2 * s2][1], st[2 * s2 + 1][1]);
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+          const bf16x8_t fv = lds_tr_frag(vt + s2 * 4096 + off.tr[d]);
+          ot[d][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, p0, ot[d][0], 0, 0, 0);
+          ot[d][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, p1, ot[d][1], 0, 0, 0);
+        }
+        ls[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, p0, ls[0], 0, 0, 0);
+        ls[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, p1, ls[1], 0, 0, 0);
+        if (FEED) loader.issue_one();
+      }
+      if (FEED) loader.issue_until(1 << 30);
+      AVF_PHASE_MARK(4);
+    };
+    AVF_PHASE_MARK(1);
+    res_sweep<MULTI>(N, first_pass, tile, [&] {
+      wait_all_loads();
+      __builtin_amdgcn_s_barrier();
+      AVF_PHASE_MARK(0);
+    });
 
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    const int q = q0 + qb * 16 + li;
-    if (q < N) {
-      const float l = ls[qb][0];
-      const float inv = 1.0f / l;
-      bf16* orow = o + ((int64_t)b * N + q) * I + h * DH;
+    for (int qb = 0; qb < 2; ++qb) {
+      const int q = q0 + qb * 16 + li;
+      if (q < N) {
+        const float l = ls[qb][0];
+        const float inv = 1.0f / l;
+        bf16* orow = o + ((int64_t)b * N + q) * I + h * DH;
 #pragma unroll
-      for (int d = 0; d < DB; ++d)
-        store4<bf16>(orow + d * 16 + 4 * lg,
-                     make_float4(ot[d][qb][0] * inv, ot[d][qb][1] * inv, ot[d][qb][2] * inv, ot[d][qb][3] * inv));
-      if (lg == 0) lse2[(int64_t)bh * N + q] = m[qb] + log2f(l);
+        for (int d = 0; d < DB; ++d)
+          store4<bf16>(orow + d * 16 + 4 * lg,
+                       make_float4(ot[d][qb][0] * inv, ot[d][qb][1] * inv, ot[d][qb][2] * inv, ot[d][qb][3] * inv));
+        if (lg == 0) lse2[(int64_t)bh * N + q] = m[qb] + log2f(l);
+      }
     }
+    AVF_PHASE_MARK(7);
+  } while (MULTI && (grp += W) < V);
+  AVF_PHASE_FLUSH();
+}
+
+// ---------------------------------------------------------------------------------------------
+// head-resident dQ: K and V images as in the forward; 32 query rows per group.
+// ---------------------------------------------------------------------------------------------
+// MULTI: more 32-row groups than waves (each wave loops over its groups); otherwise exactly one group per wave
+template <int MAXW, bool MULTI>
+__global__ __launch_bounds__(MAXW * 64) void attn_dq_res_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
+                                                               const float* __restrict__ lse2,
+                                                               const float* __restrict__ delta, bf16* __restrict__ dqkv,
+                                                               int N, int H) {
+  constexpr int DH = 64, KS = 2, DB = 4;
+  extern __shared__ __attribute__((aligned(16))) char res_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), W = blockDim.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+  const int I = H * DH;
+  const int64_t ld = 3 * (int64_t)I;
+  const bf16* qbase = qkv + (int64_t)b * N * ld + h * DH;
+  const bf16* kbase = qbase + I;
+  const bf16* vbase = qbase + 2 * I;
+  const bf16* gbase = d_o + (int64_t)b * N * I + h * DH;
+  const int NP = (N + 31) & ~31, V = NP >> 5;
+  char* ksm = res_smem;
+  char* vsm = res_smem + NP * 128;
+  const float scale = 1.0f / sqrtf((float)DH);
+  const float c = LOG2E * scale;
+  ResLoader loader;
+  loader.init(kbase, ld, ksm, vbase, ld, vsm, NP, N, wave, W, lane);
+  ResOffsets off;
+  off.init(li, lg);
+
+  int grp = wave;
+  do {
+    const bool first_pass = !MULTI || grp == wave;
+    const int q0 = grp * 32;
+    bf16x8_t fq[2][KS], fg[2][KS];
+    float L[2], dl[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int q = q0 + qb * 16 + li;
+      const bool ok = q < N;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        fq[qb][ks] = load_frag_global(qbase + (int64_t)q * ld + ks * 32 + 8 * lg, ok);
+        fg[qb][ks] = load_frag_global(gbase + (int64_t)q * I + ks * 32 + 8 * lg, ok);
+      }
+      L[qb] = ok ? lse2[(int64_t)bh * N + q] : 0.f;
+      dl[qb] = ok ? delta[(int64_t)bh * N + q] : 0.f;
+    }
+    if (first_pass) loader.issue_until(16 * RES_A);
+
+    f32x4_t dqt[DB][2];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) dqt[d][qb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    auto tile = [&](int t, auto tail_tag, auto feed_tag) {
+      constexpr bool TAIL = decltype(tail_tag)::value;
+      constexpr bool FEED = decltype(feed_tag)::value;
+      const int nkb = TAIL ? (N - t * 64 + 15) / 16 : 4;
+      const char* kt = ksm + t * 8192;
+      const char* vt = vsm + t * 8192;
+      f32x4_t ds[4][2];
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        ds[kb][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        ds[kb][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (!TAIL || kb < nkb) {
+          f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8_t fk = lds_row_frag(kt + kb * 2048 + off.row[ks]);
+            const bf16x8_t fv = lds_row_frag(vt + kb * 2048 + off.row[ks]);
+            s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq[0][ks], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq[1][ks], s1, 0, 0, 0);
+            p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, fg[0][ks], p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, fg[1][ks], p1, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool dead = TAIL && (t * 64 + kb * 16 + 4 * lg + r >= N);
+            const float e0 = dead ? 0.f : __builtin_amdgcn_exp2f(fmaf(s0[r], c, -L[0]));
+            const float e1 = dead ? 0.f : __builtin_amdgcn_exp2f(fmaf(s1[r], c, -L[1]));
+            ds[kb][0][r] = e0 * (p0[r] - dl[0]);
+            ds[kb][1][r] = e1 * (p1[r] - dl[1]);
+          }
+        }
+        if (FEED) loader.issue_one();
+      }
+      // dQ^T[d][q] += K^T dS^T
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        if (TAIL && 2 * s2 >= nkb) continue;
+        const bf16x8_t a0 = pack_pair(ds[2 * s2][0], ds[2 * s2 + 1][0]);
+        const bf16x8_t a1 = pack_pair(ds[2 * s2][1], ds[2 * s2 + 1][1]);
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+          const bf16x8_t fkt = lds_tr_frag(kt + s2 * 4096 + off.tr[d]);
+          dqt[d][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fkt, a0, dqt[d][0], 0, 0, 0);
+          dqt[d][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fkt, a1, dqt[d][1], 0, 0, 0);
+        }
+        if (FEED) loader.issue_one();
+      }
+      if (FEED) loader.issue_until(1 << 30);
+    };
+    res_sweep<MULTI>(N, first_pass, tile, [&] {
+      wait_all_loads();
+      __builtin_amdgcn_s_barrier();
+    });
+
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int q = q0 + qb * 16 + li;
+      if (q < N) {
+        bf16* out = dqkv + ((int64_t)b * N + q) * ld + h * DH;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+          store4<bf16>(out + d * 16 + 4 * lg, make_float4(dqt[d][qb][0] * scale, dqt[d][qb][1] * scale,
+                                                          dqt[d][qb][2] * scale, dqt[d][qb][3] * scale));
+      }
+    }
+   } while (MULTI && (grp += W) < V);
+}
+
+// ---------------------------------------------------------------------------------------------
+// head-resident dK, dV: Q and dO images (+ the head's lse2 / delta rows, by 4-byte LDS-DMA) in LDS; 32 key rows per
+// group.  Query rows past N are copies of row N-1: their probabilities are zeroed in the tail tile.
+// ---------------------------------------------------------------------------------------------
+// MULTI: more 32-row groups than waves (each wave loops over its groups); otherwise exactly one group per wave
+template <int MAXW, bool MULTI>
+__global__ __launch_bounds__(MAXW * 64) void attn_dkv_res_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
+                                                                const float* __restrict__ lse2,
+                                                                const float* __restrict__ delta, bf16* __restrict__ dqkv,
+                                                                int N, int H) {
+  constexpr int DH = 64, KS = 2, DB = 4;
+  extern __shared__ __attribute__((aligned(16))) char res_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), W = blockDim.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+  const int I = H * DH;
+  const int64_t ld = 3 * (int64_t)I;
+  const bf16* qbase = qkv + (int64_t)b * N * ld + h * DH;
+  const bf16* kbase = qbase + I;
+  const bf16* vbase = qbase + 2 * I;
+  const bf16* gbase = d_o + (int64_t)b * N * I + h * DH;
+  const int NP = (N + 31) & ~31, V = NP >> 5;
+  const int NP64 = (N + 63) & ~63;
+  char* qsm = res_smem;
+  char* gsm = res_smem + NP * 128;
+  float* Ls = reinterpret_cast<float*>(res_smem + 2 * NP * 128);
+  float* Ds = Ls + NP64;
+  const float scale = 1.0f / sqrtf((float)DH);
+  const float c = LOG2E * scale;
+  AVF_PHASE_INIT();
+  // the softmax statistics of the head's query rows: 64 floats per DMA piece, lse2 pieces then delta pieces
+  for (int j = wave; j < NP64 / 32; j += W) {
+    const int blk = j >> 1;
+    int row = blk * 64 + lane;
+    row = row < N ? row : N - 1;
+    const float* src = (j & 1) ? delta : lse2;
+    glds4(src + (int64_t)bh * N + row, reinterpret_cast<char*>(((j & 1) ? Ds : Ls) + blk * 64));
   }
-  AVF_PHASE_MARK(7);
+  ResLoader loader;
+  loader.init(qbase, ld, qsm, gbase, I, gsm, NP, N, wave, W, lane);
+  ResOffsets off;
+  off.init(li, lg);
+
+  int grp = wave;
+  do {
+    const bool first_pass = !MULTI || grp == wave;
+    const int k0 = grp * 32;
+    bf16x8_t fk[2][KS], fv[2][KS];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int key = k0 + kb * 16 + li;
+        fk[kb][ks] = load_frag_global(kbase + (int64_t)key * ld + ks * 32 + 8 * lg, key < N);
+        fv[kb][ks] = load_frag_global(vbase + (int64_t)key * ld + ks * 32 + 8 * lg, key < N);
+      }
+    if (first_pass) loader.issue_until(16 * RES_A);
+
+    f32x4_t dvt[DB][2], dkt[DB][2];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        dvt[d][kb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        dkt[d][kb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+
+    auto tile = [&](int t, auto tail_tag, auto feed_tag) {
+      constexpr bool TAIL = decltype(tail_tag)::value;
+      constexpr bool FEED = decltype(feed_tag)::value;
+      const int nqb = TAIL ? (N - t * 64 + 15) / 16 : 4;  // 16-query blocks with valid rows
+      const char* qt = qsm + t * 8192;
+      const char* gt = gsm + t * 8192;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        if (TAIL && 2 * s2 >= nqb) continue;
+        f32x4_t pm[2][2], dsm[2][2];  // P and dS, [q-block of the pair][key-block]
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const int qb = 2 * s2 + h2;
+          pm[h2][0] = pm[h2][1] = dsm[h2][0] = dsm[h2][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+          if (!TAIL || qb < nqb) {
+            f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+              const bf16x8_t fqr = lds_row_frag(qt + qb * 2048 + off.row[ks]);
+              const bf16x8_t fgr = lds_row_frag(gt + qb * 2048 + off.row[ks]);
+              s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqr, fk[0][ks], s0, 0, 0, 0);
+              s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqr, fk[1][ks], s1, 0, 0, 0);
+              p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fgr, fv[0][ks], p0, 0, 0, 0);
+              p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fgr, fv[1][ks], p1, 0, 0, 0);
+            }
+            const float4 l4 = *reinterpret_cast<const float4*>(Ls + t * 64 + qb * 16 + 4 * lg);
+            const float4 d4 = *reinterpret_cast<const float4*>(Ds + t * 64 + qb * 16 + 4 * lg);
+            const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const bool dead = TAIL && (t * 64 + qb * 16 + 4 * lg + r >= N);
+              const float e0 = dead ? 0.f : __builtin_amdgcn_exp2f(fmaf(s0[r], c, -lv[r]));
+              const float e1 = dead ? 0.f : __builtin_amdgcn_exp2f(fmaf(s1[r], c, -lv[r]));
+              pm[h2][0][r] = e0;
+              pm[h2][1][r] = e1;
+              dsm[h2][0][r] = e0 * (p0[r] - dv[r]);
+              dsm[h2][1][r] = e1 * (p1[r] - dv[r]);
+            }
+          }
+          if (FEED) loader.issue_one();
+        }
+        AVF_PHASE_MARK(2);
+        // dV^T[d][key] += dO^T P ; dK^T[d][key] += Q^T dS
+        const bf16x8_t pa0 = pack_pair(pm[0][0], pm[1][0]);
+        const bf16x8_t pa1 = pack_pair(pm[0][1], pm[1][1]);
+        const bf16x8_t da0 = pack_pair(dsm[0][0], dsm[1][0]);
+        const bf16x8_t da1 = pack_pair(dsm[0][1], dsm[1][1]);
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+          const bf16x8_t fgt = lds_tr_frag(gt + s2 * 4096 + off.tr[d]);
+          const bf16x8_t fqt = lds_tr_frag(qt + s2 * 4096 + off.tr[d]);
+          dvt[d][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fgt, pa0, dvt[d][0], 0, 0, 0);
+          dvt[d][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fgt, pa1, dvt[d][1], 0, 0, 0);
+          dkt[d][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqt, da0, dkt[d][0], 0, 0, 0);
+          dkt[d][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fqt, da1, dkt[d][1], 0, 0, 0);
+        }
+        if (FEED) loader.issue_one();
+        AVF_PHASE_MARK(4);
+      }
+      if (FEED) loader.issue_until(1 << 30);
+    };
+    AVF_PHASE_MARK(1);
+    res_sweep<MULTI>(N, first_pass, tile, [&] {
+      wait_all_loads();
+      __builtin_amdgcn_s_barrier();
+      AVF_PHASE_MARK(0);
+    });
+
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int key = k0 + kb * 16 + li;
+      if (key < N) {
+        bf16* outk = dqkv + ((int64_t)b * N + key) * ld + I + h * DH;
+        bf16* outv = outk + I;
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+          store4<bf16>(outk + d * 16 + 4 * lg, make_float4(dkt[d][kb][0] * scale, dkt[d][kb][1] * scale,
+                                                           dkt[d][kb][2] * scale, dkt[d][kb][3] * scale));
+          store4<bf16>(outv + d * 16 + 4 * lg,
+                       make_float4(dvt[d][kb][0], dvt[d][kb][1], dvt[d][kb][2], dvt[d][kb][3]));
+        }
+      }
+    }
+    AVF_PHASE_MARK(7);
+  } while (MULTI && (grp += W) < V);
   AVF_PHASE_FLUSH();
 }
 
@@ -853,10 +1151,22 @@ bool use_resident(int N, int dh) {
   return allow && dh == 64 && N <= RES_MAX_N;
 }
 
-int raise_lds(const void* fn, const char* name) {
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, RES_MAX_N * 128 * 2 + 4096);
+// waves per workgroup: V = ceil(N/32) row groups spread over ceil(V/12) passes (multi-pass kernels: at most 8 waves)
+bool res_multi(int N) { return ceil_div(N, 32) > 12; }
+int res_waves(int N) {
+  const int V = (int)ceil_div(N, 32);
+  if (V <= 12) return V;
+  const int passes = (int)ceil_div(V, 8);
+  return (int)ceil_div(V, passes);
+}
+
+template <typename K, typename... Args>
+int res_launch(K kernel, const char* name, int blocks, int waves, size_t smem, hipStream_t s, Args... args) {
+  hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   AVF_REQUIRE(e == hipSuccess, "%s: cannot raise dynamic LDS limit: %s", name, hipGetErrorString(e));
-  return 0;
+  AVF_REQUIRE(smem <= 160 * 1024, "%s: %zu bytes of LDS", name, smem);
+  kernel<<<blocks, waves * 64, smem, s>>>(args...);
+  return check_launch(name);
 }
 }  // namespace
 
@@ -866,16 +1176,11 @@ int attn_fwd_bf16(const bf16* qkv, bf16* o, float* lse2, int B, int N, int H, in
   AVF_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)o & 7) == 0, "attn_fwd_bf16: misaligned pointers");
   TimingScope ts(KC_ATTN_FWD, 4.0 * B * H * (double)N * N * dh, 2.0 * 4.0 * B * N * H * dh, s);
   if (use_resident(N, dh)) {
-    const int W = (int)ceil_div(N, 32);
+    const int W = res_waves(N);
     const size_t smem = (size_t)((N + 31) & ~31) * 128 * 2;
-    if (W <= 12) {
-      AVF_TRY(raise_lds((const void*)attn_fwd_res_kernel<12>, "attn_fwd_res<12>"));
-      attn_fwd_res_kernel<12><<<B * H, W * 64, smem, s>>>(qkv, o, lse2, N, H);
-    } else {
-      AVF_TRY(raise_lds((const void*)attn_fwd_res_kernel<16>, "attn_fwd_res<16>"));
-      attn_fwd_res_kernel<16><<<B * H, W * 64, smem, s>>>(qkv, o, lse2, N, H);
-    }
-    return check_launch("attn_fwd_res_kernel");
+    if (res_multi(N)) return res_launch(attn_fwd_res_kernel<8, true>, "attn_fwd_res<8,multi>", B * H, W, smem, s, qkv, o, lse2, N, H);
+    if (W <= 8) return res_launch(attn_fwd_res_kernel<8, false>, "attn_fwd_res<8>", B * H, W, smem, s, qkv, o, lse2, N, H);
+    return res_launch(attn_fwd_res_kernel<12, false>, "attn_fwd_res<12>", B * H, W, smem, s, qkv, o, lse2, N, H);
   }
   const unsigned grid = (unsigned)(ceil_div(N, 128) * B * H);
   if (dh == 64) attn_fwd_bf16_kernel<64><<<grid, 256, 0, s>>>(qkv, o, lse2, B, N, H);
@@ -892,6 +1197,20 @@ int attn_bwd_bf16(const bf16* qkv, const bf16* o, const bf16* d_o, const float* 
               "attn_bwd_bf16: misaligned pointers");
   TimingScope ts(KC_ATTN_BWD, 10.0 * B * H * (double)N * N * dh, 2.0 * 8.0 * B * N * H * dh, s);
   AVF_TRY(attn_delta(AVF_BF16, o, d_o, delta, B, N, H, dh, s));
+  if (use_resident(N, dh)) {
+    const int W = res_waves(N);
+    const size_t smem = (size_t)((N + 31) & ~31) * 128 * 2, smem_kv = smem + (size_t)((N + 63) & ~63) * 8;
+    if (res_multi(N)) {
+      AVF_TRY(res_launch(attn_dq_res_kernel<8, true>, "attn_dq_res<8,multi>", B * H, W, smem, s, qkv, d_o, lse2, delta, dqkv, N, H));
+      return res_launch(attn_dkv_res_kernel<8, true>, "attn_dkv_res<8,multi>", B * H, W, smem_kv, s, qkv, d_o, lse2, delta, dqkv, N, H);
+    }
+    if (W <= 8) {
+      AVF_TRY(res_launch(attn_dq_res_kernel<8, false>, "attn_dq_res<8>", B * H, W, smem, s, qkv, d_o, lse2, delta, dqkv, N, H));
+      return res_launch(attn_dkv_res_kernel<8, false>, "attn_dkv_res<8>", B * H, W, smem_kv, s, qkv, d_o, lse2, delta, dqkv, N, H);
+    }
+    AVF_TRY(res_launch(attn_dq_res_kernel<12, false>, "attn_dq_res<12>", B * H, W, smem, s, qkv, d_o, lse2, delta, dqkv, N, H));
+    return res_launch(attn_dkv_res_kernel<12, false>, "attn_dkv_res<12>", B * H, W, smem_kv, s, qkv, d_o, lse2, delta, dqkv, N, H);
+  }
   const unsigned grid = (unsigned)(ceil_div(N, 128) * B * H);
   if (dh == 64) {
     attn_dq_bf16_kernel<64><<<grid, 256, 0, s>>>(qkv, d_o, lse2, delta, dqkv, B, N, H);

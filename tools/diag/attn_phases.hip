@@ -57,6 +57,8 @@ int main(int argc, char** argv) {
   hipMalloc(&qkv, nq * 2); hipMalloc(&o, (size_t)B * N * I * 2); hipMalloc(&lse, (size_t)B * H * N * 4);
   hipMemcpy(qkv, h.data(), nq * 2, hipMemcpyHostToDevice);
   const bool res = argc > 4 ? atoi(argv[4]) != 0 : (N <= 512);
+  const int mode = argc > 5 ? atoi(argv[5]) : 0;  // 0 forward, 2 dK/dV (head-resident only; slots 2 = S, dP, softmax  4 = dV, dK MFMAs)
+  uint16_t* dqkv; hipMalloc(&dqkv, nq * 2);
   const int grid = res ? B * H : ((N + 127) / 128) * B * H;
   hipMalloc(&ph, (size_t)grid * 16 * 12 * 8);
   hipMemset(ph, 0, (size_t)grid * 16 * 12 * 8);
@@ -65,15 +67,19 @@ int main(int argc, char** argv) {
   for (int it = 0; it < 5; ++it) {
     hipEventRecord(e0);
     if (res) {
-      const int W = (N + 31) / 32;
-      const size_t smem = (size_t)((N + 31) & ~31) * 256;
-      if (W <= 12) {
-        hipFuncSetAttribute((const void*)avf::attn_fwd_res_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        avf::attn_fwd_res_kernel<12><<<grid, W * 64, smem>>>((const avf::bf16*)qkv, (avf::bf16*)o, lse, N, H);
-      } else {
-        hipFuncSetAttribute((const void*)avf::attn_fwd_res_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        avf::attn_fwd_res_kernel<16><<<grid, W * 64, smem>>>((const avf::bf16*)qkv, (avf::bf16*)o, lse, N, H);
-      }
+      const int V = (N + 31) / 32, passes = V <= 12 ? 1 : (V + 7) / 8, W = (V + passes - 1) / passes;
+      const size_t smem = (size_t)((N + 31) & ~31) * 256 + (mode == 2 ? (size_t)((N + 63) & ~63) * 8 : 0);
+      const avf::bf16 *q = (const avf::bf16*)qkv, *g = (const avf::bf16*)o;
+#define AVF_DIAG_LAUNCH(K, ...) \
+  hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+  K<<<grid, W * 64, smem>>>(__VA_ARGS__)
+      typedef avf::bf16 T;
+      if (mode == 2 && passes > 1) { AVF_DIAG_LAUNCH((avf::attn_dkv_res_kernel<8, true>), q, g, lse, lse, (T*)dqkv, N, H); }
+      else if (mode == 2 && W <= 8) { AVF_DIAG_LAUNCH((avf::attn_dkv_res_kernel<8, false>), q, g, lse, lse, (T*)dqkv, N, H); }
+      else if (mode == 2) { AVF_DIAG_LAUNCH((avf::attn_dkv_res_kernel<12, false>), q, g, lse, lse, (T*)dqkv, N, H); }
+      else if (passes > 1) { AVF_DIAG_LAUNCH((avf::attn_fwd_res_kernel<8, true>), q, (T*)o, lse, N, H); }
+      else if (W <= 8) { AVF_DIAG_LAUNCH((avf::attn_fwd_res_kernel<8, false>), q, (T*)o, lse, N, H); }
+      else { AVF_DIAG_LAUNCH((avf::attn_fwd_res_kernel<12, false>), q, (T*)o, lse, N, H); }
     } else {
       avf::attn_fwd_bf16_kernel<64><<<grid, 256>>>((const avf::bf16*)qkv, (avf::bf16*)o, lse, B, N, H);
     }
