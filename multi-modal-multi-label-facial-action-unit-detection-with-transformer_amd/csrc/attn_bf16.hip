@@ -316,6 +316,27 @@ __device__ __forceinline__ float colmax4(float v) {
   return vmax(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
+// sum over the four lanes {li, li+16, li+32, li+48}
+__device__ __forceinline__ float colsum4(float v) {
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// dot product of two 8-element bf16 fragments, fp32
+__device__ __forceinline__ float dot8(const bf16x8_t& x, const bf16x8_t& y) {
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+  const u32x4_t a = __builtin_bit_cast(u32x4_t, x), b = __builtin_bit_cast(u32x4_t, y);
+  float acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    acc = fmaf(__uint_as_float(a[i] << 16), __uint_as_float(b[i] << 16), acc);
+    acc = fmaf(__uint_as_float(a[i] & 0xffff0000u), __uint_as_float(b[i] & 0xffff0000u), acc);
+  }
+  return acc;
+}
+
 __device__ __forceinline__ bf16x8_t ones_frag() {
   typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
   u32x4_t r = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
@@ -555,14 +576,16 @@ __global__ __launch_bounds__(MAXW * 64) void attn_fwd_res_kernel(const bf16* __r
 }
 
 // ---------------------------------------------------------------------------------------------
-// head-resident dQ: K and V images as in the forward; 32 query rows per group.
+// head-resident dQ: K and V images as in the forward; 32 query rows per group.  Also produces
+// delta[q] = sum_d O[q,d] dO[q,d] for its rows (from the dO fragments it holds anyway) and writes it for the
+// dK/dV kernel that follows on the stream - no separate delta launch on this path.
 // ---------------------------------------------------------------------------------------------
 // MULTI: more 32-row groups than waves (each wave loops over its groups); otherwise exactly one group per wave
 template <int MAXW, bool MULTI>
-__global__ __launch_bounds__(MAXW * 64) void attn_dq_res_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
-                                                               const float* __restrict__ lse2,
-                                                               const float* __restrict__ delta, bf16* __restrict__ dqkv,
-                                                               int N, int H) {
+__global__ __launch_bounds__(MAXW * 64) void attn_dq_res_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
+                                                               const bf16* __restrict__ d_o,
+                                                               const float* __restrict__ lse2, float* __restrict__ delta,
+                                                               bf16* __restrict__ dqkv, int N, int H) {
   constexpr int DH = 64, KS = 2, DB = 4;
   extern __shared__ __attribute__((aligned(16))) char res_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -575,6 +598,7 @@ __global__ __launch_bounds__(MAXW * 64) void attn_dq_res_kernel(const bf16* __re
   const bf16* kbase = qbase + I;
   const bf16* vbase = qbase + 2 * I;
   const bf16* gbase = d_o + (int64_t)b * N * I + h * DH;
+  const bf16* obase = o + (int64_t)b * N * I + h * DH;
   const int NP = (N + 31) & ~31, V = NP >> 5;
   char* ksm = res_smem;
   char* vsm = res_smem + NP * 128;
@@ -601,7 +625,12 @@ __global__ __launch_bounds__(MAXW * 64) void attn_dq_res_kernel(const bf16* __re
         fg[qb][ks] = load_frag_global(gbase + (int64_t)q * I + ks * 32 + 8 * lg, ok);
       }
       L[qb] = ok ? lse2[(int64_t)bh * N + q] : 0.f;
-      dl[qb] = ok ? delta[(int64_t)bh * N + q] : 0.f;
+      float part = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        part += dot8(load_frag_global(obase + (int64_t)q * I + ks * 32 + 8 * lg, ok), fg[qb][ks]);
+      dl[qb] = colsum4(part);
+      if (ok && lg == 0) delta[(int64_t)bh * N + q] = dl[qb];
     }
     if (first_pass) loader.issue_until(16 * RES_A);
 
@@ -1196,21 +1225,21 @@ int attn_bwd_bf16(const bf16* qkv, const bf16* o, const bf16* d_o, const float* 
   AVF_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)d_o & 15) == 0 && ((uintptr_t)dqkv & 7) == 0,
               "attn_bwd_bf16: misaligned pointers");
   TimingScope ts(KC_ATTN_BWD, 10.0 * B * H * (double)N * N * dh, 2.0 * 8.0 * B * N * H * dh, s);
-  AVF_TRY(attn_delta(AVF_BF16, o, d_o, delta, B, N, H, dh, s));
-  if (use_resident(N, dh)) {
+  if (use_resident(N, dh)) {  // delta comes out of the dQ kernel
     const int W = res_waves(N);
     const size_t smem = (size_t)((N + 31) & ~31) * 128 * 2, smem_kv = smem + (size_t)((N + 63) & ~63) * 8;
     if (res_multi(N)) {
-      AVF_TRY(res_launch(attn_dq_res_kernel<8, true>, "attn_dq_res<8,multi>", B * H, W, smem, s, qkv, d_o, lse2, delta, dqkv, N, H));
+      AVF_TRY(res_launch(attn_dq_res_kernel<8, true>, "attn_dq_res<8,multi>", B * H, W, smem, s, qkv, o, d_o, lse2, delta, dqkv, N, H));
       return res_launch(attn_dkv_res_kernel<8, true>, "attn_dkv_res<8,multi>", B * H, W, smem_kv, s, qkv, d_o, lse2, delta, dqkv, N, H);
     }
     if (W <= 8) {
-      AVF_TRY(res_launch(attn_dq_res_kernel<8, false>, "attn_dq_res<8>", B * H, W, smem, s, qkv, d_o, lse2, delta, dqkv, N, H));
+      AVF_TRY(res_launch(attn_dq_res_kernel<8, false>, "attn_dq_res<8>", B * H, W, smem, s, qkv, o, d_o, lse2, delta, dqkv, N, H));
       return res_launch(attn_dkv_res_kernel<8, false>, "attn_dkv_res<8>", B * H, W, smem_kv, s, qkv, d_o, lse2, delta, dqkv, N, H);
     }
-    AVF_TRY(res_launch(attn_dq_res_kernel<12, false>, "attn_dq_res<12>", B * H, W, smem, s, qkv, d_o, lse2, delta, dqkv, N, H));
+    AVF_TRY(res_launch(attn_dq_res_kernel<12, false>, "attn_dq_res<12>", B * H, W, smem, s, qkv, o, d_o, lse2, delta, dqkv, N, H));
     return res_launch(attn_dkv_res_kernel<12, false>, "attn_dkv_res<12>", B * H, W, smem_kv, s, qkv, d_o, lse2, delta, dqkv, N, H);
   }
+  AVF_TRY(attn_delta(AVF_BF16, o, d_o, delta, B, N, H, dh, s));
   const unsigned grid = (unsigned)(ceil_div(N, 128) * B * H);
   if (dh == 64) {
     attn_dq_bf16_kernel<64><<<grid, 256, 0, s>>>(qkv, d_o, lse2, delta, dqkv, B, N, H);
