@@ -200,6 +200,64 @@ def test_attention_bf16(ops, B, N, H, dh):
         assert e < 2e-2, (name, e)
 
 
+@pytest.mark.parametrize("N", [1, 15, 16, 31, 33, 63, 64, 65, 96, 127, 128, 200, 256, 320, 383, 384, 385, 448, 500, 512,
+                               575, 576, 577, 640])
+def test_attention_bf16_dh64_lengths(ops, N):
+    """dim_head 64 over the sequence lengths where the kernel family changes: one group per wave (N <= 384, 8- and
+    12-wave builds), several groups per wave (385..576), the streaming kernels (> 576); tails of 1..63 rows."""
+    B, H, dh = 2, 2, 64
+    g = torch.Generator().manual_seed(1000 + N)
+    qkv = torch.randn(B * N, 3 * H * dh, generator=g).to(torch.bfloat16)
+    d_o = torch.randn(B * N, H * dh, generator=g).to(torch.bfloat16)
+    o_ref, lse_ref, dqkv_ref = _attn_ref(qkv.float(), B, N, H, dh, d_o.float())
+    o, lse2 = ops.attn_fwd(qkv.cuda(), B, N, H, dh)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse2).all()
+    assert rel_fro(o, o_ref) < 1e-2, rel_fro(o, o_ref)
+    _close(lse2, lse_ref.float(), atol=2e-2, rtol=1e-3)
+    dqkv = ops.attn_bwd(qkv.cuda(), o, d_o.cuda(), lse2, B, N, H, dh)
+    assert torch.isfinite(dqkv.float()).all()
+    I = H * dh
+    for name, sl in (("dq", slice(0, I)), ("dk", slice(I, 2 * I)), ("dv", slice(2 * I, 3 * I))):
+        if N == 1 and name != "dv":  # a single key: p = 1, dS = 0 exactly -> dq = dk = 0 (no relative error to take)
+            assert max_abs(dqkv[:, sl], dqkv_ref[:, sl]) < 1e-2
+            continue
+        e = rel_fro(dqkv[:, sl], dqkv_ref[:, sl])
+        assert e < 2e-2, (name, e)
+
+
+@pytest.mark.parametrize("mode", ["ramp", "small_steps", "huge"])
+def test_attention_bf16_rescale_paths(ops, mode):
+    """lazy rescaling of the head-resident forward: 'ramp' = the row maximum grows by much more than the threshold in
+    every key tile (rescale each tile); 'small_steps' = it grows by less than the threshold per tile (stale maximum,
+    probabilities above 1 in the accumulators); 'huge' = scores of magnitude ~1e3 (log2 domain ~1.4e3)."""
+    B, N, H, dh = 1, 324, 1, 64
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(N, dh, generator=g)
+    k = torch.randn(N, dh, generator=g)
+    v = torch.randn(N, dh, generator=g)
+    u = torch.randn(dh, generator=g)
+    u = u / u.norm()
+    if mode == "ramp":      # score(q_i, k_j) ~ 8 * 6 * j/64 / 8 ... grows ~6 nats per 64 keys
+        q = q * 0.2 + 8.0 * u
+        k = k * 0.2 + u[None, :] * (torch.arange(N).float()[:, None] / 64.0) * 6.0
+    elif mode == "small_steps":  # ~2.5 nats (3.6 in log2) per tile: below the threshold of 6
+        q = q * 0.2 + 8.0 * u
+        k = k * 0.2 + u[None, :] * (torch.arange(N).float()[:, None] / 64.0) * 2.5
+    else:
+        q = q * 30.0
+        k = k * 30.0
+    qkv = torch.cat([q, k, v], dim=1).to(torch.bfloat16)
+    d_o = torch.randn(N, dh, generator=g).to(torch.bfloat16)
+    o_ref, lse_ref, dqkv_ref = _attn_ref(qkv.float(), B, N, H, dh, d_o.float())
+    o, lse2 = ops.attn_fwd(qkv.cuda(), B, N, H, dh)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse2).all()
+    assert rel_fro(o, o_ref) < 1e-2, rel_fro(o, o_ref)
+    _close(lse2, lse_ref.float(), atol=5e-2, rtol=2e-3)
+    dqkv = ops.attn_bwd(qkv.cuda(), o, d_o.cuda(), lse2, B, N, H, dh)
+    assert torch.isfinite(dqkv.float()).all()
+    assert rel_fro(dqkv, dqkv_ref) < 3e-2, rel_fro(dqkv, dqkv_ref)
+
+
 def test_attention_bf16_spiked_scores(ops):
     """online-softmax rescale path: one key dominates late in the sequence (max jumps at a later tile)"""
     B, N, H, dh = 1, 256, 1, 64
