@@ -117,6 +117,19 @@ size_t avf_attn_bwd_workspace_bytes(int batch, int tokens, int heads, int dim_he
 int avf_attn_bwd(int dtype, const void* qkv, const void* o, const void* d_o, const float* lse2, void* dqkv,
                  void* workspace, int batch, int tokens, int heads, int dim_head, void* stream);
 
+/* Token-sequence plumbing of the callers either side of the stack (fp32, dim % 4 == 0, 16-byte aligned pointers).
+ *  avf_fuse_tokens:   out[b, t, :] = (t < t_video ? clip[b, t, :] : audio[b, t - t_video, :]) + pos[t, :]  (pos nullable)
+ *                     - the sequence-axis fusion torch.cat([clip, audio], 1) + pos_embedding of BASELINE.json's configs
+ *                     (feature-axis fusion of the reference: models/avformer.py:95-103).
+ *  avf_token_mean_fwd: out[b, :] = mean_t y[b, t, :]                      (x.mean(dim=1), models/tformer.py head)
+ *  avf_token_mean_bwd: dy[b, t, :] = g[b, :] / tokens, the same in bf16 (dy_bf16, nullable), and colsum[d] =
+ *                     sum_b g[b, d] (nullable) = the column sums of dy that the top layer's bias gradient needs. */
+int avf_fuse_tokens(const float* clip, const float* audio, const float* pos, float* out, int batch, int t_video,
+                    int t_audio, int dim, void* stream);
+int avf_token_mean_fwd(const float* y, float* out, int batch, int tokens, int dim, void* stream);
+int avf_token_mean_bwd(const float* g, float* dy, void* dy_bf16, float* colsum, int batch, int tokens, int dim,
+                       void* stream);
+
 /* AULoss - loss.py:63-103.  logits/labels fp32 [rows, 12] (ld given); rows whose FIRST label == ignore
  * are dropped; loss[0] = mean over kept rows x 12 of BCE-with-logits(pos_weight); grad_unit [rows,12]
  * (contiguous) = d loss / d logits.  All rows dropped => NaN (as the reference). */

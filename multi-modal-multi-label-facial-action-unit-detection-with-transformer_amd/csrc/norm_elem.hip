@@ -2,6 +2,8 @@
 // column sums (bias gradients), fp32->bf16 casts / weight transposes, AU loss.
 //
 // Reference math: models/heads.py:178-185 (PreNorm/nn.LayerNorm), models/loss.py:63-103 (AULoss).
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace avf {
@@ -639,7 +641,132 @@ __global__ __launch_bounds__(256) void au_loss_kernel(const float* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Token-sequence plumbing of the callers either side of the stack (the fused [B, T_v + T_a, dim] sequence of
+// BASELINE.json's configs; reference fusion: models/avformer.py:95-103, mean pooling: models/tformer.py head):
+// sequence fusion + positional embedding in one pass, token-mean pooling, and its backward, which writes the top
+// layer's incoming gradient in fp32 AND bf16 and its column sums analytically (= sum_b g[b,:]).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fuse_tokens_kernel(const float4* __restrict__ clip, const float4* __restrict__ audio,
+                                                         const float4* __restrict__ pos, float4* __restrict__ out, int Tv,
+                                                         int Ta, int D4, int64_t total4) {
+  const int T = Tv + Ta;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / D4;
+    const int c = (int)(i - row * D4);
+    const int64_t b = row / T;
+    const int t = (int)(row - b * T);
+    float4 v = t < Tv ? clip[(b * Tv + t) * D4 + c] : audio[(b * Ta + (t - Tv)) * D4 + c];
+    if (pos) {
+      const float4 p = pos[(int64_t)t * D4 + c];
+      v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    out[i] = v;
+  }
+}
+
+// grid (ceil(D4/16), B); 256 threads = 16 float4 column groups x 16 token lanes
+__global__ __launch_bounds__(256) void token_mean_fwd_kernel(const float4* __restrict__ y, float4* __restrict__ out, int T,
+                                                            int D4) {
+  __shared__ float4 red[16][16];
+  const int cg = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cg;
+  const int64_t b = blockIdx.y;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < D4) {
+    const float4* base = y + b * T * D4 + c;
+    int t = tl;
+    for (; t + 48 < T; t += 64) {  // four independent loads in flight
+      const float4 v0 = base[(int64_t)t * D4], v1 = base[(int64_t)(t + 16) * D4], v2 = base[(int64_t)(t + 32) * D4],
+                   v3 = base[(int64_t)(t + 48) * D4];
+      acc.x += (v0.x + v1.x) + (v2.x + v3.x); acc.y += (v0.y + v1.y) + (v2.y + v3.y);
+      acc.z += (v0.z + v1.z) + (v2.z + v3.z); acc.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; t < T; t += 16) {
+      const float4 v = base[(int64_t)t * D4];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  red[tl][cg] = acc;
+  __syncthreads();
+  if (tl == 0 && c < D4) {
+    float4 r = red[0][cg];
+#pragma unroll
+    for (int j = 1; j < 16; ++j) { r.x += red[j][cg].x; r.y += red[j][cg].y; r.z += red[j][cg].z; r.w += red[j][cg].w; }
+    const float inv = 1.0f / (float)T;
+    out[b * D4 + c] = make_float4(r.x * inv, r.y * inv, r.z * inv, r.w * inv);
+  }
+}
+
+// dy[b,t,:] = g[b,:] / T (fp32, and bf16 if dy_lo); the last blocks of the grid write colsum[d] = sum_b g[b,d]
+__global__ __launch_bounds__(256) void token_mean_bwd_kernel(const float4* __restrict__ g, float4* __restrict__ dy,
+                                                            bf16* __restrict__ dy_lo, float* __restrict__ colsum, int B,
+                                                            int T, int D4, int64_t total4, int main_blocks) {
+  if ((int)blockIdx.x >= main_blocks) {
+    const int d = ((int)blockIdx.x - main_blocks) * 256 + threadIdx.x;
+    if (d < 4 * D4) {
+      const float* gs = reinterpret_cast<const float*>(g);
+      float a = 0.f;
+      for (int b = 0; b < B; ++b) a += gs[(int64_t)b * 4 * D4 + d];
+      colsum[d] = a;
+    }
+    return;
+  }
+  const float inv = 1.0f / (float)T;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)main_blocks * 256) {
+    const int64_t row = i / D4;
+    const int c = (int)(i - row * D4);
+    const int64_t b = row / T;
+    const float4 v = g[b * D4 + c];
+    const float4 r = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+    dy[i] = r;
+    if (dy_lo) store4<bf16>(dy_lo + 4 * i, r);
+  }
+}
+
 }  // namespace avf
+
+extern "C" int avf_fuse_tokens(const float* clip, const float* audio, const float* pos, float* out, int batch, int t_video,
+                               int t_audio, int dim, void* stream) {
+  using namespace avf;
+  AVF_REQUIRE(out && batch > 0 && t_video >= 0 && t_audio >= 0 && t_video + t_audio > 0 && (clip || t_video == 0) &&
+                  (audio || t_audio == 0) && dim > 0 && dim % 4 == 0,
+              "fuse_tokens: bad arguments (dim must be a multiple of 4)");
+  AVF_REQUIRE((((uintptr_t)clip | (uintptr_t)audio | (uintptr_t)pos | (uintptr_t)out) & 15) == 0,
+              "fuse_tokens: pointers must be 16-byte aligned");
+  const int64_t total4 = (int64_t)batch * (t_video + t_audio) * (dim / 4);
+  const int blocks = (int)std::min<int64_t>((total4 + 255) / 256, 8192);
+  fuse_tokens_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((const float4*)clip, (const float4*)audio, (const float4*)pos,
+                                                              (float4*)out, t_video, t_audio, dim / 4, total4);
+  return check_launch("fuse_tokens_kernel");
+}
+
+extern "C" int avf_token_mean_fwd(const float* y, float* out, int batch, int tokens, int dim, void* stream) {
+  using namespace avf;
+  AVF_REQUIRE(y && out && batch > 0 && batch <= 65535 && tokens > 0 && dim > 0 && dim % 4 == 0,
+              "token_mean_fwd: bad arguments (dim must be a multiple of 4)");
+  AVF_REQUIRE((((uintptr_t)y | (uintptr_t)out) & 15) == 0, "token_mean_fwd: pointers must be 16-byte aligned");
+  const int D4 = dim / 4;
+  token_mean_fwd_kernel<<<dim3((D4 + 15) / 16, batch), 256, 0, (hipStream_t)stream>>>((const float4*)y, (float4*)out, tokens,
+                                                                                       D4);
+  return check_launch("token_mean_fwd_kernel");
+}
+
+extern "C" int avf_token_mean_bwd(const float* g, float* dy, void* dy_bf16, float* colsum, int batch, int tokens, int dim,
+                                  void* stream) {
+  using namespace avf;
+  AVF_REQUIRE(g && dy && batch > 0 && tokens > 0 && dim > 0 && dim % 4 == 0,
+              "token_mean_bwd: bad arguments (dim must be a multiple of 4)");
+  AVF_REQUIRE((((uintptr_t)g | (uintptr_t)dy) & 15) == 0 && ((uintptr_t)dy_bf16 & 7) == 0,
+              "token_mean_bwd: misaligned pointers");
+  const int D4 = dim / 4;
+  const int64_t total4 = (int64_t)batch * tokens * D4;
+  const int main_blocks = (int)std::min<int64_t>((total4 + 255) / 256, 8192);
+  const int extra = colsum ? (dim + 255) / 256 : 0;
+  token_mean_bwd_kernel<<<main_blocks + extra, 256, 0, (hipStream_t)stream>>>((const float4*)g, (float4*)dy, (bf16*)dy_bf16,
+                                                                              colsum, batch, tokens, D4, total4, main_blocks);
+  return check_launch("token_mean_bwd_kernel");
+}
 
 extern "C" int avf_au_loss(const float* logits, int64_t ld_logits, const float* labels, int64_t ld_labels,
                            const float* pos_weight, float ignore, int rows, int ncls, float* loss, float* grad_unit,

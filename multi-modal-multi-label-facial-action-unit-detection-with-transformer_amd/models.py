@@ -18,8 +18,10 @@ import os
 from collections import OrderedDict
 
 import torch
+import torch.nn.functional as F
 from torch import nn
 
+from . import ops
 from .heads import AU_former, TFormer, former_AU_head, tformer_AU_head  # noqa: F401
 from .loss import AULoss
 from .transformer import Transformer
@@ -103,6 +105,32 @@ class TwoStreamAuralVisualFormer(nn.Module, _TaskLossMixin):
         return out
 
 
+class _FuseTokens(torch.autograd.Function):
+    """tokens[b] = cat(clip[b], audio[b]) on the token axis + pos  (avf_fuse_tokens); d_pos = sum over the batch."""
+
+    @staticmethod
+    def forward(ctx, clip, audio, pos):
+        T = clip.shape[1] + audio.shape[1]
+        if pos.shape[-2] < T or pos.shape[-1] != clip.shape[-1]:
+            raise ValueError(f"pos_embedding {tuple(pos.shape)} does not cover {T} tokens of width {clip.shape[-1]}")
+        ctx.tv, ctx.shape_pos = clip.shape[1], pos.shape
+        p = pos.detach().reshape(pos.shape[-2], pos.shape[-1])[:T]
+        return ops.fuse_tokens(clip.detach().float(), audio.detach().float(), p)
+
+    @staticmethod
+    def backward(ctx, dy):
+        d_clip = dy[:, :ctx.tv] if ctx.needs_input_grad[0] else None
+        d_audio = dy[:, ctx.tv:] if ctx.needs_input_grad[1] else None
+        d_pos = None
+        if ctx.needs_input_grad[2]:
+            B, T, D = dy.shape
+            d_pos = ops.colsum(dy.contiguous().view(B, T * D)).view(T, D)
+            if ctx.shape_pos[-2] > T:  # embedding table longer than the sequence: the unused rows get zero gradient
+                d_pos = F.pad(d_pos, (0, 0, 0, ctx.shape_pos[-2] - T))
+            d_pos = d_pos.view(ctx.shape_pos)
+        return d_clip, d_audio, d_pos
+
+
 class SyntheticAVFormer(nn.Module, _TaskLossMixin):
     """BASELINE.json configs C2-C5: one Transformer(dim, depth, heads, dim_head, mlp_dim) over the fused
     [B, T_v + T_a, dim] token sequence, mean pooling, 12 AU logits in the reference's [B,21] layout."""
@@ -119,13 +147,11 @@ class SyntheticAVFormer(nn.Module, _TaskLossMixin):
         self.loss_AU = AULoss()
 
     def forward(self, x):
-        tokens = torch.cat([x['clip'], x['audio_features']], dim=1)  # fusion on the SEQUENCE axis
-        tokens = tokens + self.pos_embedding[:, :tokens.shape[1]]
-        y = self.transformer(tokens)
-        logits = self.au_fc(y.mean(dim=1))
-        out = torch.zeros(y.shape[0], 21, device=y.device, dtype=logits.dtype)
-        out[:, :12] = logits
-        return out
+        # fusion on the SEQUENCE axis + positional embedding in one pass: cat([clip, audio], 1) + pos_embedding
+        tokens = _FuseTokens.apply(x['clip'], x['audio_features'], self.pos_embedding)
+        pooled = self.transformer(tokens, pool='mean')  # y.mean(dim=1), pooled inside the library
+        logits = self.au_fc(pooled)
+        return F.pad(logits, (0, 21 - logits.shape[1]))  # the reference's [B,21] layout: AU logits in slots 0..11
 
 
 # name -> class, as the if/elif chain in the reference's train.py:292-315 does for --model_name

@@ -185,6 +185,45 @@ def au_loss(logits: torch.Tensor, labels: torch.Tensor, pos_weight: torch.Tensor
     return loss, grad
 
 
+def fuse_tokens(clip: torch.Tensor, audio: torch.Tensor, pos: Optional[torch.Tensor]) -> torch.Tensor:
+    """[B,Tv,D] ++ [B,Ta,D] on the token axis, + pos[Tv+Ta, D] (nullable): one pass (avf_fuse_tokens)."""
+    _need_cuda(clip, audio)
+    clip, audio = clip.contiguous(), audio.contiguous()
+    B, Tv, D = clip.shape
+    Ta = audio.shape[1]
+    assert audio.shape[0] == B and audio.shape[2] == D and clip.dtype == audio.dtype == torch.float32
+    if pos is not None:
+        pos = pos.contiguous()
+        assert pos.numel() == (Tv + Ta) * D and pos.dtype == torch.float32
+    out = torch.empty((B, Tv + Ta, D), dtype=torch.float32, device=clip.device)
+    _lib.check(_lib.load().avf_fuse_tokens(_ptr(clip), _ptr(audio), _ptr(pos), _ptr(out), B, Tv, Ta, D, _stream()),
+               "fuse_tokens")
+    return out
+
+
+def token_mean_fwd(y: torch.Tensor) -> torch.Tensor:
+    """[B,T,D] fp32 -> [B,D] mean over tokens."""
+    _need_cuda(y)
+    y = y.contiguous()
+    B, T, D = y.shape
+    out = torch.empty((B, D), dtype=torch.float32, device=y.device)
+    _lib.check(_lib.load().avf_token_mean_fwd(_ptr(y), _ptr(out), B, T, D, _stream()), "token_mean_fwd")
+    return out
+
+
+def token_mean_bwd(g: torch.Tensor, tokens: int, want_bf16: bool = False, want_colsum: bool = False):
+    """g [B,D] -> dy [B,T,D] = g/T broadcast (+ optional bf16 copy and column sums over all B*T rows)."""
+    _need_cuda(g)
+    g = g.contiguous().to(torch.float32)
+    B, D = g.shape
+    dy = torch.empty((B, tokens, D), dtype=torch.float32, device=g.device)
+    lo = torch.empty((B, tokens, D), dtype=torch.bfloat16, device=g.device) if want_bf16 else None
+    cs = torch.empty(D, dtype=torch.float32, device=g.device) if want_colsum else None
+    _lib.check(_lib.load().avf_token_mean_bwd(_ptr(g), _ptr(dy), _ptr(lo), _ptr(cs), B, tokens, D, _stream()),
+               "token_mean_bwd")
+    return dy, lo, cs
+
+
 def dropout_factors(seed: int, layer: int, site: int, p: float, rows: int, cols: int, device="cuda") -> torch.Tensor:
     """keep/(1-p) factors of dropout site `site` of layer `layer` for a [rows, cols] activation (test aid)."""
     out = torch.empty((rows, cols), dtype=torch.float32, device=device)

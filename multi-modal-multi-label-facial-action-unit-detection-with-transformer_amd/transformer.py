@@ -96,7 +96,7 @@ class _StackFn(torch.autograd.Function):
     """x -> L layers.  Saved activations live in per-layer byte buffers carved by the library."""
 
     @staticmethod
-    def forward(ctx, x, mod, *params):
+    def forward(ctx, x, mod, pool, *params):
         lib = _lib.load()
         B, N, D = x.shape
         dev = x.device
@@ -135,7 +135,12 @@ class _StackFn(torch.autograd.Function):
         ctx.saved_bufs = saved if need_grad else None
         ctx.params = params
         ctx.lowps = lowps
+        ctx.pool = pool
         _check_canaries()
+        if pool:  # token-mean pooling of the last layer's output, fused on the library side (heads that pool)
+            pooled = torch.empty((B, D), dtype=torch.float32, device=dev)
+            _lib.check(lib.avf_token_mean_fwd(_ptr(xs[-1]), _ptr(pooled), B, N, D, stream), "token_mean_fwd")
+            return pooled
         return xs[-1].view(B, N, D)
 
     @staticmethod
@@ -155,12 +160,20 @@ class _StackFn(torch.autograd.Function):
         L = mod.depth
         ws = mod._workspace(lib, cfg, dev)
         bf16 = cfg.dtype == _lib.BF16
-        dx = dy.contiguous().view(B * N, D).to(torch.float32)
-        if dx.data_ptr() == dy.data_ptr():
-            dx = dx.clone()  # layers write their input gradient in place
         lo_a = torch.empty((B * N, D), dtype=torch.bfloat16, device=dev) if bf16 else None
         lo_b = torch.empty((B * N, D), dtype=torch.bfloat16, device=dev) if bf16 else None
         have_lo = False
+        top_colsum = False
+        if ctx.pool:
+            # dy is the gradient of the pooled [B, D] output: one kernel writes the top layer's incoming gradient in fp32
+            # and (no dropout mask to apply on it) in bf16, and its column sums - the top layer's b2 gradient - directly
+            g = dy.contiguous().to(torch.float32)
+            dx = torch.empty((B * N, D), dtype=torch.float32, device=dev)
+            have_lo = top_colsum = bf16 and cfg.dropout_p == 0.0
+        else:
+            dx = dy.contiguous().view(B * N, D).to(torch.float32)
+            if dx.data_ptr() == dy.data_ptr():
+                dx = dx.clone()  # layers write their input gradient in place
         live = mod.flat_parameters()
         sizes = [p.numel() for p in ctx.params[:PARAMS_PER_LAYER]]
         hook = mod._grad_hook
@@ -175,13 +188,17 @@ class _StackFn(torch.autograd.Function):
             flats.append(flat)
             views.append(vs)
         B2 = PARAMS_PER_LAYER - 1  # index of net.3.bias: its gradient = column sums of the layer's dx_out
+        if ctx.pool:
+            _lib.check(lib.avf_token_mean_bwd(_ptr(g), _ptr(dx), _ptr(lo_a) if have_lo else None,
+                                              _ptr(views[L - 1][B2]) if top_colsum else None, B, N, D, stream),
+                       "token_mean_bwd")
         for l in reversed(range(L)):
             gp = _lib.LayerPtrs(*[v.data_ptr() for v in views[l]])
             pp = mod._param_struct(ctx.params, l)
             # LN1' of this layer writes the column sums of dx_in directly into the previous layer's b2 gradient
             _lib.check(lib.avf_layer_bwd(C.byref(cfgs[l]), C.byref(pp), _ptr(ctx.lowps[l]), _ptr(ctx.xs[l]),
                                          _ptr(ctx.saved_bufs[l]), _ptr(dx), _ptr(lo_a) if have_lo else None,
-                                         _ptr(views[l][B2]) if l < L - 1 else None, _ptr(dx), _ptr(lo_b),
+                                         _ptr(views[l][B2]) if (l < L - 1 or top_colsum) else None, _ptr(dx), _ptr(lo_b),
                                          _ptr(views[l - 1][B2]) if l > 0 else None, C.byref(gp), _ptr(ws), stream),
                        f"layer_bwd[{l}]")
             lo_a, lo_b = lo_b, lo_a
@@ -201,7 +218,7 @@ class _StackFn(torch.autograd.Function):
         _check_canaries()
         ctx.saved_bufs = None
         ctx.xs = None
-        return (dx.view(B, N, D), None, *([None] * (L * PARAMS_PER_LAYER)))
+        return (dx.view(B, N, D), None, None, *([None] * (L * PARAMS_PER_LAYER)))
 
 
 class Transformer(nn.Module):
@@ -308,7 +325,12 @@ class Transformer(nn.Module):
         self._lowp_ptrs = None
 
     # ---- forward -------------------------------------------------------------------------------
-    def forward(self, x, mask=None):
+    def forward(self, x, mask=None, pool=None):
+        """``pool='mean'`` (an addition to the reference signature) returns the token mean [B, dim] of the stack's output
+        instead of [B, N, dim]: the pooling and its backward run inside the library (heads that pool, e.g.
+        SyntheticAVFormer)."""
+        if pool not in (None, 'mean'):
+            raise ValueError(f"pool must be None or 'mean', got {pool!r}")
         if mask is not None:
             # dead branch in the reference (no caller passes a mask, SURVEY.md section 1); not built.
             raise NotImplementedError("mask is not supported by the HIP path (no reference caller uses it)")
@@ -322,4 +344,4 @@ class Transformer(nn.Module):
             if p.dtype != torch.float32 or not p.is_cuda:
                 raise RuntimeError("Transformer (HIP): parameters must be fp32 tensors on the GPU (model.to('cuda'))")
         with torch.cuda.device(x.device):  # launches go to the input's device and its current stream
-            return _StackFn.apply(x.to(torch.float32), self, *params)
+            return _StackFn.apply(x.to(torch.float32), self, pool == 'mean', *params)

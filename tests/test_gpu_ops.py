@@ -272,6 +272,34 @@ def test_attention_bf16_spiked_scores(ops):
     _close(lse2, lse_ref.float(), atol=5e-2, rtol=1e-3)
 
 
+# ---------------------------------------------------------------------------------------------- token plumbing
+@pytest.mark.parametrize("B,Tv,Ta,D", [(2, 3, 2, 8), (3, 196, 128, 512), (1, 0, 5, 12), (4, 7, 0, 36), (2, 33, 31, 260)])
+def test_fuse_tokens(ops, B, Tv, Ta, D):
+    g = torch.Generator().manual_seed(B + Tv + Ta + D)
+    clip = torch.randn(B, Tv, D, generator=g).cuda()
+    audio = torch.randn(B, Ta, D, generator=g).cuda()
+    pos = torch.randn(Tv + Ta, D, generator=g).cuda()
+    ref = torch.cat([clip, audio], 1) + pos
+    assert torch.equal(ops.fuse_tokens(clip, audio, pos), ref)       # one fp32 add per element: bit-exact
+    assert torch.equal(ops.fuse_tokens(clip, audio, None), torch.cat([clip, audio], 1))
+
+
+@pytest.mark.parametrize("B,T,D", [(2, 5, 8), (32, 324, 512), (3, 1, 12), (1, 1000, 36), (5, 77, 260), (2, 64, 768)])
+def test_token_mean_fwd_bwd(ops, B, T, D):
+    g = torch.Generator().manual_seed(B + T + D)
+    y = torch.randn(B, T, D, generator=g).cuda()
+    m = ops.token_mean_fwd(y)
+    _close(m, y.double().mean(1).float(), atol=1e-5, rtol=1e-5)
+    gr = torch.randn(B, D, generator=g).cuda()
+    dy, lo, cs = ops.token_mean_bwd(gr, T, want_bf16=True, want_colsum=True)
+    ref = (gr / T)[:, None, :].expand(B, T, D)
+    _close(dy, ref, atol=1e-7, rtol=1e-6)
+    assert torch.equal(lo, dy.to(torch.bfloat16))
+    _close(cs, gr.double().sum(0).float(), atol=1e-5, rtol=1e-5)
+    dy2, lo2, cs2 = ops.token_mean_bwd(gr, T)
+    assert lo2 is None and cs2 is None and torch.equal(dy2, dy)
+
+
 # ---------------------------------------------------------------------------------------------- AU loss
 @pytest.mark.parametrize("tag", ["all", "ign"])
 def test_au_loss_golden(ops, tag):

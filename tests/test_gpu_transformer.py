@@ -154,6 +154,67 @@ def test_full_c2_vs_oracle_bf16_and_f32():
     torch.testing.assert_close(l16.cpu(), loss_ref, rtol=5e-3, atol=5e-3)
 
 
+@pytest.mark.parametrize("mode,dropout", [("f32", 0.0), ("bf16", 0.0), ("bf16", 0.1)])
+def test_pooled_stack_and_token_fusion_match_unfused(mode, dropout):
+    """Transformer(x, pool='mean') and the fused token build of SyntheticAVFormer against the plain composition
+    cat -> + pos -> Transformer -> mean(1): same forward, same gradients for every parameter (dropout: same seed, so the
+    same masks; the pooled path then takes the unfused bf16-cast branch for the top layer)."""
+    import avformer_amd as A
+    B, Tv, Ta, D, L, H, dh, M = 3, 21, 12, 64, 2, 2, 32, 96
+    torch.manual_seed(5)
+    model = A.SyntheticAVFormer(D, L, H, dh, M, Tv, Ta, compute_dtype=mode).to(DEV)
+    model.transformer.dropout = dropout
+    model.train()
+    g = torch.Generator().manual_seed(6)
+    clip = torch.randn(B, Tv, D, generator=g).to(DEV)
+    aud = torch.randn(B, Ta, D, generator=g).to(DEV)
+    w = torch.randn(B, 21, generator=g).to(DEV)
+
+    def run(fused):
+        model.zero_grad(set_to_none=True)
+        model.transformer._seed_dev = None  # same dropout seed sequence for both runs
+        torch.manual_seed(77)
+        if fused:
+            out = model({"clip": clip, "audio_features": aud})
+        else:
+            tok = torch.cat([clip, aud], 1) + model.pos_embedding
+            out = torch.nn.functional.pad(model.au_fc(model.transformer(tok).mean(1)), (0, 9))
+        (out * w).sum().backward()
+        return out.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+
+    out_f, g_f = run(True)
+    out_u, g_u = run(False)
+    tol = dict(rtol=1e-4, atol=1e-5) if mode == "f32" else dict(rtol=2e-2, atol=2e-3)
+    torch.testing.assert_close(out_f, out_u, **tol)
+    assert set(g_f) == set(g_u)
+    for n in g_f:
+        assert rel_fro(g_f[n], g_u[n]) < (1e-4 if mode == "f32" else 2e-2), (n, rel_fro(g_f[n], g_u[n]))
+
+
+def test_synthetic_model_gradients_vs_oracle_autograd():
+    """parity mode: d loss / d (pos_embedding, au_fc, first-layer weights) of the fused model path against torch
+    autograd through the CPU oracle."""
+    import avformer_amd as A
+    B, Tv, Ta, D, L, H, dh, M = 4, 9, 7, 32, 2, 2, 16, 48
+    torch.manual_seed(9)
+    model = A.SyntheticAVFormer(D, L, H, dh, M, Tv, Ta, compute_dtype="f32").to(DEV)
+    g = torch.Generator().manual_seed(10)
+    clip = torch.randn(B, Tv, D, generator=g)
+    aud = torch.randn(B, Ta, D, generator=g)
+    labels = (torch.rand(B, 12, generator=g) > 0.5).float()
+    loss = model.get_au_loss(model({"clip": clip.to(DEV), "audio_features": aud.to(DEV)}), labels.to(DEV))
+    loss.backward()
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    tok = torch.cat([clip, aud], 1) + sd["pos_embedding"]
+    tsd = {k[len("transformer."):]: v for k, v in sd.items() if k.startswith("transformer.")}
+    y = oracle.transformer_forward(tok, tsd, L, H)
+    loss_ref = oracle.au_loss(y.mean(1) @ sd["au_fc.weight"].t() + sd["au_fc.bias"], labels)
+    loss_ref.backward()
+    torch.testing.assert_close(loss.detach().cpu(), loss_ref.detach(), rtol=1e-4, atol=1e-6)
+    for n, p in model.named_parameters():
+        assert rel_fro(p.grad, sd[n].grad) < 2e-3, (n, rel_fro(p.grad, sd[n].grad))
+
+
 # ---------------------------------------------------------------------------------------------- heads
 def _load_into(mod, params):
     res = mod.load_state_dict({k: v for k, v in params.items() if torch.is_tensor(v)}, strict=False)
