@@ -59,7 +59,6 @@ __device__ __forceinline__ int nt_off(int r, int c) { return r * 128 + ((c ^ (r 
 template <int EPI, typename CT, int MI, int NI>
 __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI][NI], int m_base, int n_base, int li,
                                             int lg, int part_row) {
-  static_assert(MI % 2 == 0, "MI must be even");
   int nn[NI], nc[NI];
   float4 bj[NI];
 #pragma unroll
@@ -75,11 +74,12 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
 #pragma unroll
     for (int r = 0; r < 4; ++r) cs[j][r] = 0.f;
 #pragma unroll
-  for (int half = 0; half < MI / 2; ++half) {
+  for (int half = 0; half < (MI + 1) / 2; ++half) {
     float4 ex[2][NI];  // residual (fp32) or saved pre-activation (bf16 -> fp32) for this pair of row blocks
     int mm[2];
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii) {
+      if (half * 2 + ii >= MI) continue;  // odd MI: the last pair has one row block
       mm[ii] = m_base + (half * 2 + ii) * 16 + li;
       const int mc = mm[ii] < p.M ? mm[ii] : p.M - 1;
 #pragma unroll
@@ -91,6 +91,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii) {
       const int i = half * 2 + ii;
+      if (i >= MI) continue;
       const bool mok = mm[ii] < p.M;
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
@@ -356,24 +357,28 @@ int launch_nt_glds(const NtParams& p, hipStream_t s, int* part_rows) {
 //   1:  64x128, 4 waves of 32x64, 2 stages (48 KiB, 3/CU)   - finer grain for grids that cannot fill the chip
 //   2: 128x128, 8 waves of 64x32, 2 stages (64 KiB, 2/CU)   - twice the waves per CU hide the DMA / epilogue
 //                                                             latency better (+5..8 % measured at K = 512..1536)
+//   3:  96x128, 4 waves of 48x64, 2 stages (56 KiB, 2/CU)   - M = 10368, N = 512: 432 workgroups fill the 512 slots in
+//                                                             one round; 8..11 % faster than (1) once K >= 1024
 // (3- and 4-stage rings, 256x128 / 256x256 tiles, 64x64 tiles and a persistent tile loop were all measured slower
 //  on this path's shapes - M = 10k..16k, N = 512..1536, K = 512..1536 - and removed: the waves wait ~55 % of their
 //  cycles (SQ_WAIT_ANY) on LDS/barrier latency, which more resident waves hide better than deeper DMA rings)
-int pick_nt_tile(int64_t M, int64_t N) {
+int pick_nt_tile(int64_t M, int64_t N, int64_t K) {
   static const int override_tile = [] {
     const char* e = getenv("AVF_NT_TILE");  // tuning aid: force one configuration
     return e ? atoi(e) : -1;
   }();
   if (override_tile >= 0) return override_tile;
   const int64_t wg128 = ceil_div(M, 128) * ceil_div(N, 128);
-  return wg128 < 512 ? 1 : 2;
+  if (wg128 >= 512) return 2;
+  return (K >= 1024 && ceil_div(M, 96) * ceil_div(N, 128) <= 512) ? 3 : 1;
 }
 
 template <int EPI, typename CT>
 int launch_nt_glds_any(const NtParams& p, hipStream_t s, int* part_rows) {
-  switch (pick_nt_tile(p.M, p.N)) {
+  switch (pick_nt_tile(p.M, p.N, p.K)) {
     case 0: return launch_nt_glds<EPI, CT, 2, 2, 4, 4, 2>(p, s, part_rows);
     case 1: return launch_nt_glds<EPI, CT, 2, 2, 2, 4, 2>(p, s, part_rows);
+    case 3: return launch_nt_glds<EPI, CT, 2, 2, 3, 4, 2>(p, s, part_rows);
     default: return launch_nt_glds<EPI, CT, 2, 4, 4, 2, 2>(p, s, part_rows);
   }
 }

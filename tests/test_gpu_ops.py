@@ -100,10 +100,10 @@ def test_gemm_f32_forms(ops, M, N, K, ta, tb):
     _close(c, _gemm_ref(a, b, ta, tb).float(), atol=1e-4 * math.sqrt(K), rtol=1e-4)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_gemm_epilogues(ops, dtype):
+@pytest.mark.parametrize("dtype,M,N,K", [(torch.float32, 200, 136, 96), (torch.bfloat16, 200, 136, 96),
+                                         (torch.bfloat16, 301, 260, 1088), (torch.bfloat16, 8200, 520, 64)])
+def test_gemm_epilogues(ops, dtype, M, N, K):
     g = torch.Generator().manual_seed(11)
-    M, N, K = 200, 136, 96
     a = torch.randn(M, K, generator=g).to(dtype)
     w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype)
     bias = torch.randn(N, generator=g)
@@ -125,7 +125,8 @@ def test_gemm_epilogues(ops, dtype):
     _close(c, ((a.double() @ w.double().t()) * uu.grad.double()).float(), **tol)
 
 
-@pytest.mark.parametrize("M,N,K", [(8, 8, 8), (64, 128, 64), (200, 136, 96), (384, 1536, 512), (1000, 48, 40)])
+@pytest.mark.parametrize("M,N,K", [(8, 8, 8), (64, 128, 64), (200, 136, 96), (384, 1536, 512), (1000, 48, 40),
+                                   (1000, 512, 1024), (301, 132, 1088), (8200, 1024, 128)])  # 96x128 / 128x128x8w tiles
 def test_gemm_bf16_nt(ops, M, N, K):
     g = torch.Generator().manual_seed(M + N + K)
     a = torch.randn(M, K, generator=g).to(torch.bfloat16)
