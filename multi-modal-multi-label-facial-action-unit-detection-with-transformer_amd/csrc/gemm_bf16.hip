@@ -359,7 +359,7 @@ int launch_nt_glds(const NtParams& p, hipStream_t s, int* part_rows) {
 //                                                             latency better (+5..8 % measured at K = 512..1536)
 //   3:  96x128, 4 waves of 48x64, 2 stages (56 KiB, 2/CU)   - M = 10368, N = 512: 432 workgroups fill the 512 slots in
 //                                                             one round; 8..11 % faster than (1) once K >= 1024
-// (3- and 4-stage rings, 256x128 / 256x256 tiles, 64x64 tiles and a persistent tile loop were all measured slower
+// (3- and 4-stage rings, 256x128 / 256x256 / 192x128 tiles, 64x64 tiles and a persistent tile loop were all measured slower
 //  on this path's shapes - M = 10k..16k, N = 512..1536, K = 512..1536 - and removed: the waves wait ~55 % of their
 //  cycles (SQ_WAIT_ANY) on LDS/barrier latency, which more resident waves hide better than deeper DMA rings)
 int pick_nt_tile(int64_t M, int64_t N, int64_t K) {
