@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+bwd(+all-reduce) only")
+    ap.add_argument("--torch-adam", action="store_true",
+                    help="step torch.optim.Adam(fused=True) instead of the library's Adam (same arithmetic; the library's "
+                         "also rewrites the bf16 weight copies in its pass)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--graph", action="store_true", help="capture the step into a HIP graph and replay it")
     args = ap.parse_args()
@@ -139,10 +142,14 @@ def main():
     batch = {"clip": clip, "audio_features": audio}
     opt = None
     if not args.no_optimizer:
-        try:
-            opt = torch.optim.Adam(model.parameters(), lr=5e-4, weight_decay=5e-5, fused=True)
-        except Exception:
-            opt = torch.optim.Adam(model.parameters(), lr=5e-4, weight_decay=5e-5)
+        # Adam(lr, weight_decay) as the reference's loop (train.py:318-322)
+        if args.torch_adam:
+            try:
+                opt = torch.optim.Adam(model.parameters(), lr=5e-4, weight_decay=5e-5, fused=True)
+            except Exception:
+                opt = torch.optim.Adam(model.parameters(), lr=5e-4, weight_decay=5e-5)
+        else:
+            opt = A.optim.FusedAdam(model, lr=5e-4, weight_decay=5e-5)
     dp = A.dp.DataParallel(model) if use_dist else None
 
     def step():
@@ -220,6 +227,7 @@ def main():
                                f"mlp={c['mlp_dim']}, T_v={Tv}+T_a={Ta} tokens, B={B}/GPU",
                    "global_batch": B * world, "seq_len": Tv + Ta, "parallelism": f"dp{world}",
                    "step": "zero_grad+fwd+AULoss+bwd" + ("+allreduce" if use_dist else "") + ("+adam" if opt else ""),
+                   "optimizer": None if opt is None else type(opt).__name__,
                    "loss": float(loss.item())},
     }
     if rank == 0:

@@ -144,6 +144,22 @@ size_t avf_layer_workspace_bytes(const avf_layer_cfg* cfg); /* scratch, reusable
 /* refresh the bf16 weight copies from the fp32 masters (no-op in AVF_F32 mode) */
 int avf_layer_prepare_weights(const avf_layer_cfg* cfg, const avf_layer_params* p, void* lowp, void* stream);
 
+/* Adam step of one layer fused with the refresh of its bf16 weight copies - torch.optim.Adam(lr, betas, eps,
+ * weight_decay) as the reference's training loop uses it (train.py:318-322; L2 decay added to the gradient, bias
+ * correction by `step`, amsgrad off), arithmetic as torch's fused kernel.  p is updated IN PLACE (the const of
+ * avf_layer_params is cast away), exp_avg / exp_avg_sq likewise; a tensor whose gradient pointer is null is not
+ * updated (its bf16 copies are still rewritten).  `step` is a device float holding the number of THIS update (>= 1),
+ * read at run time (graph-capturable); null means 1.  lowp as for avf_layer_fwd (ignored in AVF_F32 mode). */
+int avf_layer_adam_step(const avf_layer_cfg* cfg, const avf_layer_params* p, const avf_layer_grads* g,
+                        const avf_layer_grads* exp_avg, const avf_layer_grads* exp_avg_sq, void* lowp, float lr,
+                        float beta1, float beta2, float eps, float weight_decay, const float* step, void* stream);
+
+/* the same Adam update for `count` arbitrary fp32 tensors (host arrays of device pointers and element counts): the
+ * parameters around the stacks (positional embedding, AU head).  A tensor whose gradient pointer is null is skipped. */
+int avf_adam_step_tensors(int count, float* const* p, const float* const* g, float* const* exp_avg,
+                          float* const* exp_avg_sq, const int64_t* numel, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, const float* step, void* stream);
+
 /* x_out = layer(x_in); x_in, x_out fp32 [B*N, D] (may not alias). */
 int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p, const void* lowp, const float* x_in,
                   float* x_out, void* saved, void* workspace, void* stream);

@@ -1,0 +1,240 @@
+// optim.hip - Adam update of one transformer layer fused with the refresh of its bf16 weight copies.
+//
+// Reference: the training loop steps torch.optim.Adam(lr, weight_decay) (train.py:318-322, L2 weight decay added to
+// the gradient, bias-corrected, eps outside the square root).  In throughput mode the stack then needs bf16 copies W
+// and W^T of the four weight matrices (avf_layer_prepare_weights) - one more read of every master weight per step.
+// Here ONE launch per layer reads p, g, m, v once and writes p, m, v AND the two bf16 images (the transpose through a
+// 64x64 LDS tile), with 16-byte loads and 8-byte bf16 stores.  The arithmetic follows torch's fused kernel
+// (exp_avg by lerp, exp_avg_sq by the two-term form) so the two optimizers agree to rounding.
+#include "common.hpp"
+
+namespace avf {
+
+namespace {
+
+struct AdamDesc {
+  float* p;
+  const float* g;  // null: no update, the bf16 images are still refreshed
+  float* m;
+  float* v;
+  bf16* lo;  // row-major bf16 copy [R, C] (nullable)
+  bf16* t;   // transposed bf16 copy [C, R] (nullable)
+  int R, C;
+  int tile0, tiles_c;  // first work item of this tensor, tiles per row of tiles (matrices)
+};
+
+constexpr int ADAM_MAX = 11;
+
+struct AdamBatch {
+  AdamDesc d[ADAM_MAX];
+  int count;
+  float lr, b1, b2, eps, wd;
+  const float* step;  // device scalar: the step number of THIS update (>= 1)
+};
+
+struct AdamCoef {
+  float lr_c, rsq_c2, b1, b2, eps, wd;
+};
+
+__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, const AdamCoef& k) {
+  g = fmaf(k.wd, p, g);
+  const float w = 1.0f - k.b1;  // lerp(m, g, w) as torch: a + w (b - a) for w < 0.5
+  m = w < 0.5f ? fmaf(w, g - m, m) : g - (g - m) * (1.0f - w);
+  v = k.b2 * v + (1.0f - k.b2) * g * g;
+  const float denom = sqrtf(v) * k.rsq_c2 + k.eps;
+  p -= k.lr_c * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void adam_layer_kernel(AdamBatch b) {
+  __shared__ float tile[64][65];
+  int di = 0;
+#pragma unroll 1
+  for (int i = 1; i < b.count; ++i)
+    if ((int)blockIdx.x >= b.d[i].tile0) di = i;
+  const AdamDesc d = b.d[di];
+  const int item = (int)blockIdx.x - d.tile0;
+  const float step = b.step ? b.step[0] : 1.0f;
+  AdamCoef k;
+  k.b1 = b.b1; k.b2 = b.b2; k.eps = b.eps; k.wd = b.wd;
+  k.lr_c = b.lr / (1.0f - powf(b.b1, step));
+  k.rsq_c2 = 1.0f / sqrtf(1.0f - powf(b.b2, step));
+  const bool upd = d.g != nullptr;
+
+  if (d.R == 1) {  // vector: 4096 elements per work item
+    const int base = item * 4096;
+    for (int i = threadIdx.x; i < 4096 && base + i < d.C; i += 256) {
+      if (!upd) continue;
+      float p = d.p[base + i], m = d.m[base + i], v = d.v[base + i];
+      adam1(p, d.g[base + i], m, v, k);
+      d.p[base + i] = p; d.m[base + i] = m; d.v[base + i] = v;
+    }
+    return;
+  }
+  const int r0 = (item / d.tiles_c) * 64, c0 = (item % d.tiles_c) * 64;
+  const bool vec = (d.C & 3) == 0 && (d.R & 3) == 0;
+  if (vec) {
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = c0 + tx * 4;
+    // all sixteen 16-byte loads of the thread are issued before the first store (the pointers may alias as far as the
+    // compiler knows, so it would not hoist them itself)
+    float4 P[4], G[4], Mv[4], Vv[4];
+    bool ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = r0 + ty + 16 * i;
+      ok[i] = r < d.R && c < d.C;
+      const int64_t o = (int64_t)r * d.C + c;
+      P[i] = G[i] = Mv[i] = Vv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok[i]) {
+        P[i] = *reinterpret_cast<const float4*>(d.p + o);
+        if (upd) {
+          G[i] = *reinterpret_cast<const float4*>(d.g + o);
+          Mv[i] = *reinterpret_cast<const float4*>(d.m + o);
+          Vv[i] = *reinterpret_cast<const float4*>(d.v + o);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = r0 + ty + 16 * i;
+      float4 p = P[i];
+      if (ok[i]) {
+        const int64_t o = (int64_t)r * d.C + c;
+        if (upd) {
+          float4 m = Mv[i], v = Vv[i];
+          const float4 g = G[i];
+          adam1(p.x, g.x, m.x, v.x, k); adam1(p.y, g.y, m.y, v.y, k);
+          adam1(p.z, g.z, m.z, v.z, k); adam1(p.w, g.w, m.w, v.w, k);
+          *reinterpret_cast<float4*>(d.p + o) = p;
+          *reinterpret_cast<float4*>(d.m + o) = m;
+          *reinterpret_cast<float4*>(d.v + o) = v;
+        }
+        if (d.lo) store4<bf16>(d.lo + o, p);
+      }
+      tile[ty + 16 * i][tx * 4 + 0] = p.x; tile[ty + 16 * i][tx * 4 + 1] = p.y;
+      tile[ty + 16 * i][tx * 4 + 2] = p.z; tile[ty + 16 * i][tx * 4 + 3] = p.w;
+    }
+    if (!d.t) return;
+    __syncthreads();
+    const int cc = threadIdx.x >> 2, rg = (threadIdx.x & 3) * 16;  // output row c0+cc, 16 consecutive output columns
+    if (c0 + cc < d.C) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int rr = rg + 4 * q;
+        if (r0 + rr < d.R)
+          store4<bf16>(d.t + (int64_t)(c0 + cc) * d.R + r0 + rr,
+                       make_float4(tile[rr][cc], tile[rr + 1][cc], tile[rr + 2][cc], tile[rr + 3][cc]));
+      }
+    }
+    return;
+  }
+  // generic shapes: scalar accesses
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int r = r0 + (e >> 6), c = c0 + (e & 63);
+    float p = 0.f;
+    if (r < d.R && c < d.C) {
+      const int64_t o = (int64_t)r * d.C + c;
+      p = d.p[o];
+      if (upd) {
+        float m = d.m[o], v = d.v[o];
+        adam1(p, d.g[o], m, v, k);
+        d.p[o] = p; d.m[o] = m; d.v[o] = v;
+      }
+      if (d.lo) d.lo[o] = from_f32<bf16>(p);
+    }
+    tile[e >> 6][e & 63] = p;
+  }
+  if (!d.t) return;
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int cc = e >> 6, rr = e & 63;
+    if (c0 + cc < d.C && r0 + rr < d.R) d.t[(int64_t)(c0 + cc) * d.R + r0 + rr] = from_f32<bf16>(tile[rr][cc]);
+  }
+}
+
+}  // namespace
+
+}  // namespace avf
+
+extern "C" int avf_layer_adam_step(const avf_layer_cfg* cfg, const avf_layer_params* p, const avf_layer_grads* g,
+                                   const avf_layer_grads* exp_avg, const avf_layer_grads* exp_avg_sq, void* lowp, float lr,
+                                   float beta1, float beta2, float eps, float weight_decay, const float* step,
+                                   void* stream) {
+  using namespace avf;
+  AVF_REQUIRE(cfg && p && g && exp_avg && exp_avg_sq, "layer_adam_step: null pointer");
+  AVF_REQUIRE(cfg->dim > 0 && cfg->heads > 0 && cfg->dim_head > 0 && cfg->mlp_dim > 0, "layer_adam_step: bad dimensions");
+  AVF_REQUIRE(lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f,
+              "layer_adam_step: bad hyper-parameters");
+  AVF_REQUIRE(cfg->dtype == AVF_F32 || lowp, "layer_adam_step(bf16): lowp buffer missing");
+  const int D = cfg->dim, I = cfg->heads * cfg->dim_head, M = cfg->mlp_dim;
+  // the bf16 images in the order avf_layer_lowp_bytes carves them: Wqkv, Wqkv^T, Wo, Wo^T, W1, W1^T, W2, W2^T
+  bf16* img[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (cfg->dtype == AVF_BF16) {
+    size_t off = 0;
+    const size_t bytes[4] = {(size_t)3 * I * D * 2, (size_t)D * I * 2, (size_t)M * D * 2, (size_t)D * M * 2};
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 2; ++j) {
+        img[2 * i + j] = reinterpret_cast<bf16*>((char*)lowp + off);
+        off += (bytes[i] + 255) & ~(size_t)255;
+      }
+    AVF_REQUIRE(off == avf_layer_lowp_bytes(cfg), "layer_adam_step: lowp layout mismatch (%zu vs %zu)", off,
+                avf_layer_lowp_bytes(cfg));
+  }
+  AdamBatch b;
+  memset(&b, 0, sizeof(b));
+  int n = 0, tiles = 0;
+  auto add = [&](const float* pp, float* gg, float* mm, float* vv, bf16* lo, bf16* t, int R, int C) {
+    if (!pp || (!gg && !lo && !t)) return;  // absent tensor, or nothing to do for it
+    AdamDesc& d = b.d[n++];
+    d.p = const_cast<float*>(pp); d.g = gg; d.m = mm; d.v = vv; d.lo = lo; d.t = t; d.R = R; d.C = C;
+    d.tile0 = tiles;
+    d.tiles_c = R == 1 ? 1 : (C + 63) / 64;
+    tiles += R == 1 ? (C + 4095) / 4096 : ((R + 63) / 64) * d.tiles_c;
+  };
+  add(p->w_qkv, g->w_qkv, exp_avg->w_qkv, exp_avg_sq->w_qkv, img[0], img[1], 3 * I, D);
+  add(p->w_out, g->w_out, exp_avg->w_out, exp_avg_sq->w_out, img[2], img[3], D, I);
+  add(p->w1, g->w1, exp_avg->w1, exp_avg_sq->w1, img[4], img[5], M, D);
+  add(p->w2, g->w2, exp_avg->w2, exp_avg_sq->w2, img[6], img[7], D, M);
+  add(p->ln1_w, g->ln1_w, exp_avg->ln1_w, exp_avg_sq->ln1_w, nullptr, nullptr, 1, D);
+  add(p->ln1_b, g->ln1_b, exp_avg->ln1_b, exp_avg_sq->ln1_b, nullptr, nullptr, 1, D);
+  add(p->b_out, g->b_out, exp_avg->b_out, exp_avg_sq->b_out, nullptr, nullptr, 1, D);
+  add(p->ln2_w, g->ln2_w, exp_avg->ln2_w, exp_avg_sq->ln2_w, nullptr, nullptr, 1, D);
+  add(p->ln2_b, g->ln2_b, exp_avg->ln2_b, exp_avg_sq->ln2_b, nullptr, nullptr, 1, D);
+  add(p->b1, g->b1, exp_avg->b1, exp_avg_sq->b1, nullptr, nullptr, 1, M);
+  add(p->b2, g->b2, exp_avg->b2, exp_avg_sq->b2, nullptr, nullptr, 1, D);
+  if (n == 0) return 0;
+  for (int i = 0; i < n; ++i)
+    AVF_REQUIRE(!b.d[i].g || (b.d[i].m && b.d[i].v), "layer_adam_step: exp_avg / exp_avg_sq missing for an updated tensor");
+  b.count = n;
+  b.lr = lr; b.b1 = beta1; b.b2 = beta2; b.eps = eps; b.wd = weight_decay; b.step = step;
+  adam_layer_kernel<<<tiles, 256, 0, (hipStream_t)stream>>>(b);
+  return check_launch("adam_layer_kernel");
+}
+
+extern "C" int avf_adam_step_tensors(int count, float* const* p, const float* const* g, float* const* exp_avg,
+                                     float* const* exp_avg_sq, const int64_t* numel, float lr, float beta1, float beta2,
+                                     float eps, float weight_decay, const float* step, void* stream) {
+  using namespace avf;
+  AVF_REQUIRE(count >= 0 && (count == 0 || (p && g && exp_avg && exp_avg_sq && numel)), "adam_step_tensors: null pointer");
+  AVF_REQUIRE(lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f,
+              "adam_step_tensors: bad hyper-parameters");
+  for (int base = 0; base < count; base += ADAM_MAX) {
+    AdamBatch b;
+    memset(&b, 0, sizeof(b));
+    int n = 0, tiles = 0;
+    for (int i = base; i < count && i < base + ADAM_MAX; ++i) {
+      if (!g[i] || numel[i] <= 0) continue;
+      AVF_REQUIRE(p[i] && exp_avg[i] && exp_avg_sq[i] && numel[i] < (1LL << 31), "adam_step_tensors: bad tensor %d", i);
+      AdamDesc& d = b.d[n++];
+      d.p = p[i]; d.g = g[i]; d.m = exp_avg[i]; d.v = exp_avg_sq[i]; d.R = 1; d.C = (int)numel[i];
+      d.tile0 = tiles; d.tiles_c = 1;
+      tiles += (int)((numel[i] + 4095) / 4096);
+    }
+    if (n == 0) continue;
+    b.count = n;
+    b.lr = lr; b.b1 = beta1; b.b2 = beta2; b.eps = eps; b.wd = weight_decay; b.step = step;
+    adam_layer_kernel<<<tiles, 256, 0, (hipStream_t)stream>>>(b);
+    AVF_TRY(check_launch("adam_layer_kernel(tensors)"));
+  }
+  return 0;
+}

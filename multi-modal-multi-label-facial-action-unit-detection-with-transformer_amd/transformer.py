@@ -235,6 +235,7 @@ class Transformer(nn.Module):
         self._lowp_bufs = None
         self._lowp_ptrs = None
         self.cache_weights = False
+        self._lowp_ready = False  # set by optim.FusedAdam: the bf16 copies already reflect the current masters
         self._grad_hook: Optional[Callable] = None
         self._seed_dev = None
         self._last_seed_t = None
@@ -313,6 +314,10 @@ class Transformer(nn.Module):
             self._lowp_bufs = [_alloc_bytes(need, dev) for _ in range(self.depth)]
             fresh = True
         ptrs = [p.data_ptr() for p in params]
+        ready = self._lowp_ready and not fresh and self._lowp_ptrs == ptrs
+        self._lowp_ready = False  # one forward per optimizer step; anything else re-prepares (weights may have changed)
+        if ready:
+            return self._lowp_bufs
         if fresh or not self.cache_weights or self._lowp_ptrs != ptrs:
             for l in range(self.depth):
                 pp = self._param_struct(params, l)
@@ -323,6 +328,7 @@ class Transformer(nn.Module):
 
     def refresh_weights(self):
         self._lowp_ptrs = None
+        self._lowp_ready = False
 
     # ---- forward -------------------------------------------------------------------------------
     def forward(self, x, mask=None, pool=None):
@@ -331,6 +337,8 @@ class Transformer(nn.Module):
         SyntheticAVFormer)."""
         if pool not in (None, 'mean'):
             raise ValueError(f"pool must be None or 'mean', got {pool!r}")
+        if pool == 'mean' and self.dim % 4 != 0:
+            raise ValueError("pool='mean' needs dim % 4 == 0 (use .mean(dim=1) on the unpooled output otherwise)")
         if mask is not None:
             # dead branch in the reference (no caller passes a mask, SURVEY.md section 1); not built.
             raise NotImplementedError("mask is not supported by the HIP path (no reference caller uses it)")

@@ -1,0 +1,86 @@
+"""FusedAdam (avf_layer_adam_step) against torch.optim.Adam on the same model: parameters, optimizer state and the
+bf16 weight copies the next forward uses."""
+import copy
+
+import pytest
+import torch
+
+from gpu_util import DEV, rel_fro
+
+pytestmark = pytest.mark.gpu
+
+
+def _models(mode, dims=(64, 2, 2, 32, 96, 9, 7)):
+    import avformer_amd as A
+    D, L, H, dh, M, Tv, Ta = dims
+    torch.manual_seed(3)
+    a = A.SyntheticAVFormer(D, L, H, dh, M, Tv, Ta, compute_dtype=mode).to(DEV)
+    b = copy.deepcopy(a)
+    return A, a, b, (Tv, Ta, D)
+
+
+@pytest.mark.parametrize("mode,dims", [("f32", (64, 2, 2, 32, 96, 9, 7)), ("bf16", (64, 2, 2, 32, 96, 9, 7)),
+                                       ("bf16", (40, 1, 1, 32, 56, 5, 4)),   # partial 64x64 tiles
+                                       ("f32", (36, 1, 3, 16, 52, 5, 4))])   # widths 36 / 52: partial tiles, 4-element granularity
+def test_fused_adam_matches_torch_adam(mode, dims):
+    A, ma, mb, (Tv, Ta, D) = _models(mode, dims)
+    kw = dict(lr=3e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=1e-2)
+    oa = A.optim.FusedAdam(ma, **kw)
+    ob = torch.optim.Adam(mb.parameters(), **kw)
+    g = torch.Generator().manual_seed(4)
+    for it in range(4):
+        batch = {"clip": torch.randn(3, Tv, D, generator=g).to(DEV), "audio_features": torch.randn(3, Ta, D, generator=g).to(DEV)}
+        labels = (torch.rand(3, 12, generator=g) > 0.5).float().to(DEV)
+        for m, o in ((ma, oa), (mb, ob)):
+            o.zero_grad(set_to_none=True)
+            m.get_au_loss(m(batch), labels).backward()
+        # same gradients into both optimizers (removes the bf16 forward noise from the comparison)
+        for pa, pb in zip(ma.parameters(), mb.parameters()):
+            pb.grad = pa.grad.detach().clone()
+        oa.step()
+        ob.step()
+        for (n, pa), pb in zip(ma.named_parameters(), mb.parameters()):
+            assert rel_fro(pa, pb) < 2e-6, (it, n, rel_fro(pa, pb))
+    # optimizer state has torch's keys and values
+    for pa, pb in zip(ma.parameters(), mb.parameters()):
+        sa, sb = oa.state[pa], ob.state[pb]
+        assert float(sa["step"]) == float(sb["step"]) == 4.0
+        assert rel_fro(sa["exp_avg"], sb["exp_avg"]) < 1e-5
+        assert rel_fro(sa["exp_avg_sq"], sb["exp_avg_sq"]) < 1e-5
+    if mode == "bf16":
+        # the copies written by the optimizer are exactly what a fresh preparation pass produces
+        st = ma.transformer
+        assert st._lowp_ready
+        kept = [b.clone() for b in st._lowp_bufs]
+        st.refresh_weights()
+        with torch.no_grad():
+            ma(batch)
+        for x, y in zip(kept, st._lowp_bufs):
+            assert torch.equal(x, y)
+
+
+def test_fused_adam_skips_weight_prep_and_state_dict_roundtrip():
+    A, ma, mb, (Tv, Ta, D) = _models("bf16")
+    oa = A.optim.FusedAdam(ma, lr=1e-3, weight_decay=5e-5)
+    g = torch.Generator().manual_seed(5)
+    batch = {"clip": torch.randn(2, Tv, D, generator=g).to(DEV), "audio_features": torch.randn(2, Ta, D, generator=g).to(DEV)}
+    labels = (torch.rand(2, 12, generator=g) > 0.5).float().to(DEV)
+
+    def one(m, o):
+        o.zero_grad(set_to_none=True)
+        loss = m.get_au_loss(m(batch), labels)
+        loss.backward()
+        o.step()
+        return float(loss)
+
+    l0 = one(ma, oa)
+    l1 = one(ma, oa)  # this forward consumed the optimizer-written copies
+    assert l1 < l0
+    # resume: a second optimizer loaded from the state dict continues identically
+    mb.load_state_dict(ma.state_dict())
+    ob = A.optim.FusedAdam(mb, lr=1e-3, weight_decay=5e-5)
+    ob.load_state_dict(copy.deepcopy(oa.state_dict()))
+    la, lb = one(ma, oa), one(mb, ob)
+    assert abs(la - lb) < 1e-6 * max(1.0, abs(la))
+    for pa, pb in zip(ma.parameters(), mb.parameters()):
+        assert rel_fro(pa, pb) < 1e-6
