@@ -647,21 +647,30 @@ __global__ __launch_bounds__(256) void au_loss_kernel(const float* __restrict__ 
 // sequence fusion + positional embedding in one pass, token-mean pooling, and its backward, which writes the top
 // layer's incoming gradient in fp32 AND bf16 and its column sums analytically (= sum_b g[b,:]).
 // ---------------------------------------------------------------------------------------------
+constexpr int TOK_ROWS_PER_BLOCK = 4;
+
+// one workgroup per TOK_ROWS_PER_BLOCK token rows (row = b * T + t): no per-element index division
 __global__ __launch_bounds__(256) void fuse_tokens_kernel(const float4* __restrict__ clip, const float4* __restrict__ audio,
                                                          const float4* __restrict__ pos, float4* __restrict__ out, int Tv,
-                                                         int Ta, int D4, int64_t total4) {
+                                                         int Ta, int D4, int64_t rows) {
   const int T = Tv + Ta;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
-    const int64_t row = i / D4;
-    const int c = (int)(i - row * D4);
+#pragma unroll
+  for (int rr = 0; rr < TOK_ROWS_PER_BLOCK; ++rr) {
+    const int64_t row = (int64_t)blockIdx.x * TOK_ROWS_PER_BLOCK + rr;
+    if (row >= rows) return;
     const int64_t b = row / T;
     const int t = (int)(row - b * T);
-    float4 v = t < Tv ? clip[(b * Tv + t) * D4 + c] : audio[(b * Ta + (t - Tv)) * D4 + c];
-    if (pos) {
-      const float4 p = pos[(int64_t)t * D4 + c];
-      v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    const float4* src = t < Tv ? clip + (b * Tv + t) * D4 : audio + (b * Ta + (t - Tv)) * D4;
+    const float4* pr = pos ? pos + (int64_t)t * D4 : nullptr;
+    float4* dst = out + row * D4;
+    for (int c = threadIdx.x; c < D4; c += 256) {
+      float4 v = src[c];
+      if (pr) {
+        const float4 p = pr[c];
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+      }
+      dst[c] = v;
     }
-    out[i] = v;
   }
 }
 
@@ -701,7 +710,7 @@ __global__ __launch_bounds__(256) void token_mean_fwd_kernel(const float4* __res
 // dy[b,t,:] = g[b,:] / T (fp32, and bf16 if dy_lo); the last blocks of the grid write colsum[d] = sum_b g[b,d]
 __global__ __launch_bounds__(256) void token_mean_bwd_kernel(const float4* __restrict__ g, float4* __restrict__ dy,
                                                             bf16* __restrict__ dy_lo, float* __restrict__ colsum, int B,
-                                                            int T, int D4, int64_t total4, int main_blocks) {
+                                                            int T, int D4, int64_t rows, int main_blocks) {
   if ((int)blockIdx.x >= main_blocks) {
     const int d = ((int)blockIdx.x - main_blocks) * 256 + threadIdx.x;
     if (d < 4 * D4) {
@@ -713,14 +722,17 @@ __global__ __launch_bounds__(256) void token_mean_bwd_kernel(const float4* __res
     return;
   }
   const float inv = 1.0f / (float)T;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)main_blocks * 256) {
-    const int64_t row = i / D4;
-    const int c = (int)(i - row * D4);
-    const int64_t b = row / T;
-    const float4 v = g[b * D4 + c];
-    const float4 r = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
-    dy[i] = r;
-    if (dy_lo) store4<bf16>(dy_lo + 4 * i, r);
+#pragma unroll
+  for (int rr = 0; rr < TOK_ROWS_PER_BLOCK; ++rr) {
+    const int64_t row = (int64_t)blockIdx.x * TOK_ROWS_PER_BLOCK + rr;
+    if (row >= rows) return;
+    const float4* gr = g + (row / T) * D4;
+    for (int c = threadIdx.x; c < D4; c += 256) {
+      const float4 v = gr[c];
+      const float4 r = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+      dy[row * D4 + c] = r;
+      if (dy_lo) store4<bf16>(dy_lo + 4 * (row * D4 + c), r);
+    }
   }
 }
 
@@ -734,10 +746,10 @@ extern "C" int avf_fuse_tokens(const float* clip, const float* audio, const floa
               "fuse_tokens: bad arguments (dim must be a multiple of 4)");
   AVF_REQUIRE((((uintptr_t)clip | (uintptr_t)audio | (uintptr_t)pos | (uintptr_t)out) & 15) == 0,
               "fuse_tokens: pointers must be 16-byte aligned");
-  const int64_t total4 = (int64_t)batch * (t_video + t_audio) * (dim / 4);
-  const int blocks = (int)std::min<int64_t>((total4 + 255) / 256, 8192);
-  fuse_tokens_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((const float4*)clip, (const float4*)audio, (const float4*)pos,
-                                                              (float4*)out, t_video, t_audio, dim / 4, total4);
+  const int64_t rows = (int64_t)batch * (t_video + t_audio);
+  AVF_REQUIRE(ceil_div(rows, TOK_ROWS_PER_BLOCK) < (1LL << 31), "fuse_tokens: too many rows");
+  fuse_tokens_kernel<<<(unsigned)ceil_div(rows, TOK_ROWS_PER_BLOCK), 256, 0, (hipStream_t)stream>>>(
+      (const float4*)clip, (const float4*)audio, (const float4*)pos, (float4*)out, t_video, t_audio, dim / 4, rows);
   return check_launch("fuse_tokens_kernel");
 }
 
@@ -760,11 +772,12 @@ extern "C" int avf_token_mean_bwd(const float* g, float* dy, void* dy_bf16, floa
   AVF_REQUIRE((((uintptr_t)g | (uintptr_t)dy) & 15) == 0 && ((uintptr_t)dy_bf16 & 7) == 0,
               "token_mean_bwd: misaligned pointers");
   const int D4 = dim / 4;
-  const int64_t total4 = (int64_t)batch * tokens * D4;
-  const int main_blocks = (int)std::min<int64_t>((total4 + 255) / 256, 8192);
+  const int64_t rows = (int64_t)batch * tokens;
+  AVF_REQUIRE(ceil_div(rows, TOK_ROWS_PER_BLOCK) < (1LL << 30), "token_mean_bwd: too many rows");
+  const int main_blocks = (int)ceil_div(rows, TOK_ROWS_PER_BLOCK);
   const int extra = colsum ? (dim + 255) / 256 : 0;
   token_mean_bwd_kernel<<<main_blocks + extra, 256, 0, (hipStream_t)stream>>>((const float4*)g, (float4*)dy, (bf16*)dy_bf16,
-                                                                              colsum, batch, tokens, D4, total4, main_blocks);
+                                                                              colsum, batch, tokens, D4, rows, main_blocks);
   return check_launch("token_mean_bwd_kernel");
 }
 
