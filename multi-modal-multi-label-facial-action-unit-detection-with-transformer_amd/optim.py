@@ -99,25 +99,32 @@ class FusedAdam(torch.optim.Optimizer):
                     bf16 = cfg.dtype == _lib.BF16
                     if bf16 and st._lowp_bufs is None:
                         st._lowp(lib, cfg, [p.detach() for p in params], dev, stream)  # allocate (and fill) the copies
+                    lr, eps, wd = float(hip_group["lr"]), float(hip_group["eps"]), float(hip_group["weight_decay"])
                     for l in range(st.depth):
                         lp = params[l * PARAMS_PER_LAYER:(l + 1) * PARAMS_PER_LAYER]
                         m, v, mv, vv = self._layer_state(si, l, lp)
-                        grads = []
+                        # the structs of the stable pointers (parameters, moments) are built once per layer
+                        key = (si, l, "ptrs")
+                        hit = self._flat.get(key)
+                        pptr = tuple(p.data_ptr() for p in lp)
+                        if hit is None or hit[0] != pptr:
+                            hit = (pptr, _lib.LayerPtrs(*pptr), _lib.LayerPtrs(*[t.data_ptr() for t in mv]),
+                                   _lib.LayerPtrs(*[t.data_ptr() for t in vv]))
+                            self._flat[key] = hit
+                            for p in lp:
+                                self.state[p]["step"] = self._step_dev  # shared device counter (as capturable Adam)
+                        gptr = []
+                        keep = []
                         for p in lp:
                             g = p.grad if (p.requires_grad and id(p) in self._owned) else None
                             if g is not None and (g.dtype != torch.float32 or not g.is_contiguous()):
                                 g = g.to(torch.float32).contiguous()
-                            grads.append(g)
-                            if g is not None:
-                                self.state[p]["step"] = self._step_dev  # shared device counter (as capturable Adam)
-                        pp = _lib.LayerPtrs(*[p.data_ptr() for p in lp])
-                        gp = _lib.LayerPtrs(*[None if g is None else g.data_ptr() for g in grads])
-                        mp = _lib.LayerPtrs(*[t.data_ptr() for t in mv])
-                        vp = _lib.LayerPtrs(*[t.data_ptr() for t in vv])
-                        _lib.check(lib.avf_layer_adam_step(C.byref(cfg), C.byref(pp), C.byref(gp), C.byref(mp), C.byref(vp),
-                                                           _ptr(st._lowp_bufs[l]) if bf16 else None, float(hip_group["lr"]),
-                                                           float(b1), float(b2), float(hip_group["eps"]),
-                                                           float(hip_group["weight_decay"]), _ptr(self._step_dev), stream),
+                                keep.append(g)
+                            gptr.append(None if g is None else g.data_ptr())
+                        _lib.check(lib.avf_layer_adam_step(C.byref(cfg), C.byref(hit[1]), C.byref(_lib.LayerPtrs(*gptr)),
+                                                           C.byref(hit[2]), C.byref(hit[3]),
+                                                           _ptr(st._lowp_bufs[l]) if bf16 else None, lr, float(b1), float(b2),
+                                                           eps, wd, _ptr(self._step_dev), stream),
                                    f"layer_adam_step[{l}]")
                     if bf16:
                         st._lowp_ptrs = [p.data_ptr() for p in params]

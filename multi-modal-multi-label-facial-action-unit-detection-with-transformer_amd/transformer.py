@@ -177,10 +177,14 @@ class _StackFn(torch.autograd.Function):
         live = mod.flat_parameters()
         sizes = [p.numel() for p in ctx.params[:PARAMS_PER_LAYER]]
         hook = mod._grad_hook
-        # one flat fp32 gradient bucket per layer; the tensors' .grad become views of it
+        # one flat fp32 gradient bucket per layer; the tensors' .grad become views of it.  The buckets of all layers are
+        # consecutive slices of ONE allocation, so a data-parallel wrapper can reduce several adjacent layers with one
+        # collective (fewer, larger all-reduces: less host time per step, better xGMI efficiency)
         flats, views = [], []
+        per_layer = sum(sizes)
+        flat_all = torch.empty(L * per_layer, dtype=torch.float32, device=dev)
         for l in range(L):
-            flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+            flat = flat_all[l * per_layer:(l + 1) * per_layer]
             vs, off = [], 0
             for i, n in enumerate(sizes):
                 vs.append(flat[off:off + n].view_as(ctx.params[l * PARAMS_PER_LAYER + i]))
@@ -251,9 +255,18 @@ class Transformer(nn.Module):
                 f.norm.weight, f.norm.bias, f.fn.net[0].weight, f.fn.net[0].bias, f.fn.net[3].weight, f.fn.net[3].bias]
 
     def flat_parameters(self) -> List[torch.Tensor]:
+        """all layers' tensors in order; the list is cached (walking the module tree costs ~0.2 ms per call) and rebuilt
+        when a holder's Parameter object has been replaced"""
+        cache = self.__dict__.get("_flat_cache")
+        if cache is not None:
+            first = self.layers[0][0].fn.norm.weight
+            last = self.layers[self.depth - 1][1].fn.fn.net[3].bias
+            if cache[0] is first and cache[-1] is last:
+                return cache
         out = []
         for l in range(self.depth):
             out += self.layer_parameters(l)
+        self.__dict__["_flat_cache"] = out
         return out
 
     def set_grad_hook(self, hook: Optional[Callable]):
@@ -291,9 +304,16 @@ class Transformer(nn.Module):
         """the 64-bit seed the latest training forward used (host sync; for tests / mask replay)"""
         return 0 if self._last_seed_t is None else int(self._last_seed_t.item()) & 0xFFFFFFFFFFFFFFFF
 
-    @staticmethod
-    def _param_struct(params, l) -> _lib.LayerPtrs:
-        return _lib.LayerPtrs(*[p.data_ptr() for p in params[l * PARAMS_PER_LAYER:(l + 1) * PARAMS_PER_LAYER]])
+    def _param_struct(self, params, l) -> _lib.LayerPtrs:
+        """LayerPtrs of layer l; the ctypes struct is reused while the eleven data pointers are unchanged"""
+        ptrs = tuple(p.data_ptr() for p in params[l * PARAMS_PER_LAYER:(l + 1) * PARAMS_PER_LAYER])
+        cache = self.__dict__.setdefault("_pstruct_cache", {})
+        hit = cache.get(l)
+        if hit is not None and hit[0] == ptrs:
+            return hit[1]
+        st = _lib.LayerPtrs(*ptrs)
+        cache[l] = (ptrs, st)
+        return st
 
     def _workspace(self, lib, cfg, dev):
         need = lib.avf_layer_workspace_bytes(C.byref(cfg))

@@ -25,10 +25,14 @@ class OracleStack(A.Transformer):
         return oracle.transformer_forward(x, sd, self.depth, self.heads)
 
     def emulate_backward_hooks(self):
-        # what _StackFn.backward does on the GPU: per layer (reverse order) one flat fp32 bucket whose views are .grad
+        # what _StackFn.backward does on the GPU: per layer (reverse order) one flat fp32 bucket whose views are .grad;
+        # the buckets are consecutive slices of one allocation (the wrapper merges adjacent ones into one collective)
+        per_layer = sum(p.numel() for p in self.layer_parameters(0))
+        flat_all = torch.empty(self.depth * per_layer)
         for l in reversed(range(self.depth)):
             ps = self.layer_parameters(l)
-            flat = torch.cat([p.grad.reshape(-1) for p in ps])
+            flat = flat_all[l * per_layer:(l + 1) * per_layer]
+            flat.copy_(torch.cat([p.grad.reshape(-1) for p in ps]))
             off = 0
             for p in ps:
                 n = p.numel()
@@ -57,13 +61,16 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, bucket_layers=2):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.manual_seed(100 + rank)  # deliberately different init per rank: the wrapper must broadcast rank 0's
         model = TinyModel()
-        dp = A.dp.DataParallel(model)
+        dp = A.dp.DataParallel(model, bucket_layers=bucket_layers)
+        launched = []
+        real_launch = dp._launch
+        dp._launch = lambda t: (launched.append(t.numel()), real_launch(t))[1]
         g = torch.Generator().manual_seed(7)
         x = torch.randn(8, 6, D, generator=g)
         y = (torch.rand(8, 12, generator=g) > 0.5).float()
@@ -81,25 +88,28 @@ def _worker(rank, world, port, out):
         for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
             worst = max(worst, (p.grad - q.grad).abs().max().item() / (q.grad.abs().max().item() + 1e-12))
         same_w = all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), ref.state_dict().values()))
-        out.put((rank, worst, same_w, len(dp._pending)))
+        out.put((rank, worst, same_w, len(dp._pending), len(launched)))
     finally:
         dist.destroy_process_group()
 
 
-def test_dp_two_ranks_match_single_process():
+@pytest.mark.parametrize("bucket_layers", [1, 2])
+def test_dp_two_ranks_match_single_process(bucket_layers):
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out, bucket_layers)) for r in range(2)]
     for p in procs:
         p.start()
     res = [out.get(timeout=180) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, worst, same_w, pending in res:
+    for rank, worst, same_w, pending, ncoll in res:
         assert worst < 1e-5, (rank, worst)
         assert same_w and pending == 0
+        # two layers: one collective each, or one merged collective; plus the bucket of the parameters outside the stack
+        assert ncoll == (3 if bucket_layers == 1 else 2), ncoll
 
 
 def test_dp_requires_process_group():
