@@ -240,6 +240,8 @@ class Transformer(nn.Module):
         self._lowp_ptrs = None
         self.cache_weights = False
         self._lowp_ready = False  # set by optim.FusedAdam: the bf16 copies already reflect the current masters
+        # weights written behind the optimizer's back (checkpoint restore into a live model) invalidate the copies
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.refresh_weights())
         self._grad_hook: Optional[Callable] = None
         self._seed_dev = None
         self._last_seed_t = None

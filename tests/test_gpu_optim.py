@@ -84,3 +84,20 @@ def test_fused_adam_skips_weight_prep_and_state_dict_roundtrip():
     assert abs(la - lb) < 1e-6 * max(1.0, abs(la))
     for pa, pb in zip(ma.parameters(), mb.parameters()):
         assert rel_fro(pa, pb) < 1e-6
+
+
+def test_load_state_dict_after_step_invalidates_bf16_copies():
+    """optimizer step -> load_state_dict -> forward must use the LOADED weights, not the copies the step wrote"""
+    A, ma, mb, (Tv, Ta, D) = _models("bf16")
+    oa = A.optim.FusedAdam(ma, lr=1e-2)
+    g = torch.Generator().manual_seed(8)
+    batch = {"clip": torch.randn(2, Tv, D, generator=g).to(DEV), "audio_features": torch.randn(2, Ta, D, generator=g).to(DEV)}
+    labels = (torch.rand(2, 12, generator=g) > 0.5).float().to(DEV)
+    saved = copy.deepcopy(ma.state_dict())
+    ma.get_au_loss(ma(batch), labels).backward()
+    oa.step()                      # weights move; bf16 copies rewritten, marked ready
+    ma.load_state_dict(saved)      # back to the initial weights, in place (same storage)
+    with torch.no_grad():
+        out_a = ma(batch)
+        out_b = mb(batch)          # mb still holds the initial weights
+    assert torch.equal(out_a, out_b)
