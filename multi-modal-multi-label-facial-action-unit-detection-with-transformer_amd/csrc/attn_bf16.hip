@@ -1191,8 +1191,16 @@ int res_waves(int N) {
 
 template <typename K, typename... Args>
 int res_launch(K kernel, const char* name, int blocks, int waves, size_t smem, hipStream_t s, Args... args) {
-  hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  AVF_REQUIRE(e == hipSuccess, "%s: cannot raise dynamic LDS limit: %s", name, hipGetErrorString(e));
+  // raise the dynamic-LDS limit once per kernel (nine instantiations share this function template per signature)
+  static const void* raised[16];
+  static int nraised = 0;
+  bool seen = false;
+  for (int i = 0; i < nraised; ++i) seen = seen || raised[i] == (const void*)kernel;
+  if (!seen) {
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    AVF_REQUIRE(e == hipSuccess, "%s: cannot raise dynamic LDS limit: %s", name, hipGetErrorString(e));
+    if (nraised < 16) raised[nraised++] = (const void*)kernel;
+  }
   AVF_REQUIRE(smem <= 160 * 1024, "%s: %zu bytes of LDS", name, smem);
   kernel<<<blocks, waves * 64, smem, s>>>(args...);
   return check_launch(name);

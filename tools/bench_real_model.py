@@ -7,6 +7,8 @@ import avformer_amd as A
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 torch.manual_seed(0)
 model = A.build_model("avformer", task="AU").cuda().train()
+if os.environ.get("AVF_SINGLE_STREAM") == "1":
+    model.concurrent_streams = False
 opt = torch.optim.Adam(model.parameters(), lr=5e-4, weight_decay=5e-5, fused=True)
 x = {"clip": torch.randn(B, 512, device="cuda"), "audio_features": torch.randn(B, 512, device="cuda")}
 y = (torch.rand(B, 12, device="cuda") > 0.5).float()
