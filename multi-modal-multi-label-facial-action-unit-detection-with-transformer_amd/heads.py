@@ -6,6 +6,8 @@ HIP ``Transformer``:
 * ``tformer_AU_head``  - reference models/tformer.py:362-403; ``former_AU_head`` is the same structure and
                          stands in for the class models/avformer.py:19,87 imports but the reference never defines
 * ``TFormer``          - reference models/vformer.py:270-293 (= tformer.py:271-294)
+* ``ResFormerTokens``  - the token section of ``ResFormer.forward``, reference models/sformer.py:313-327
+                         (= vformer.py:245-259, tformer.py:246-260); the conv stages around it are out of scope
 
 The glue outside the block (BatchNorm1d, the 12 small projections, the 12 per-token dots, cls/pos
 assembly) is plain PyTorch on the GPU in this version ("next"); the 24
@@ -93,3 +95,25 @@ class TFormer(nn.Module):
         x = x + self.pos_embedding[:, :(n + 1)]
         x = self.spatial_transformer(x)
         return x[:, 0]
+
+
+class ResFormerTokens(nn.Module):
+    """The transformer section in the middle of the reference's ``ResFormer`` (S-Former after ResNet stage 3): the
+    stage-3 feature map [B', C, h, w] becomes h*w tokens of width C, gets the learned positional embedding, runs through
+    ``spatial_transformer`` and is folded back to [B', C, h, w] for stage 4.  Parameter names (``pos_embedding``,
+    ``spatial_transformer.*``) are ResFormer's, so its checkpoints load with ``strict=False``; defaults are its ctor's
+    (``sformer.py:240``: 49 patches, dim 256, depth 1, 8 heads of 32, mlp 512)."""
+
+    def __init__(self, num_patches=7 * 7, dim=256, depth=1, heads=8, mlp_dim=512, dim_head=32, dropout=0.0,
+                 compute_dtype="bf16"):
+        super().__init__()
+        self.pos_embedding = nn.Parameter(torch.randn(1, num_patches, dim))
+        self.spatial_transformer = Transformer(dim, depth, heads, dim_head, mlp_dim, dropout,
+                                               compute_dtype=compute_dtype)
+
+    def forward(self, x):
+        b_l, c, h, w = x.shape
+        t = x.reshape((b_l, c, h * w)).permute(0, 2, 1)
+        t = t + self.pos_embedding[:, :t.shape[1]]
+        t = self.spatial_transformer(t)
+        return t.permute(0, 2, 1).reshape((b_l, c, h, w))

@@ -23,6 +23,7 @@ from .reference_math import (  # noqa: F401
     gelu_tanh,
     layer_forward,
     layernorm,
+    resformer_tokens_forward,
     tformer_forward,
     transformer_forward,
     transformer_param_names,

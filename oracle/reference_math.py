@@ -203,6 +203,16 @@ def tformer_forward(x: Tensor, sd: Dict[str, Tensor], num_patches: int, dim: int
     return x[:, 0]
 
 
+def resformer_tokens_forward(x: Tensor, sd: Dict[str, Tensor], depth: int, heads: int, prefix: str = "") -> Tensor:
+    """models/sformer.py:313-327 (= vformer.py:245-259, tformer.py:246-260), the token section of ``ResFormer.forward``:
+    feature map [B', C, h, w] -> tokens [B', h*w, C] + pos_embedding -> spatial_transformer -> back to [B', C, h, w]."""
+    b_l, c, h, w = x.shape
+    t = x.reshape((b_l, c, h * w)).permute(0, 2, 1)
+    t = t + sd[f"{prefix}pos_embedding"][:, :t.shape[1]]
+    t = transformer_forward(t, sd, depth, heads, prefix=f"{prefix}spatial_transformer.")
+    return t.permute(0, 2, 1).reshape((b_l, c, h, w))
+
+
 def au_loss(y_pred: Tensor, y_true: Tensor, ignore: float = -1.0) -> Tensor:
     """models/loss.py:75-103 (``AULoss``): keep rows whose FIRST label != ignore; per-element
     BCE-with-logits with pos_weight; mean over kept rows x 12.  All rows dropped => NaN, as in

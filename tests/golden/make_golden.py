@@ -14,7 +14,7 @@ as fp32 ``.npz`` files.  The fixtures are data only; no reference source text is
 Fixture list: G1 attention, G2 feed-forward, G3 transformer at config C1,
 G4 transformer with inner != dim at N in {12, 17, 49}, G5 AU_former (eval), G6 tformer_AU_head
 (emb 64), G7 TFormer, G8 AULoss with/without ignored rows, G9 tiny pipeline TFormer -> AU_former
--> AULoss with gradients, G10 tanh-GELU on a grid.
+-> AULoss with gradients, G10 tanh-GELU on a grid, G11 the token section of ResFormer.forward.
 """
 import importlib.util
 import os
@@ -181,6 +181,27 @@ def main():
         if p.grad is not None:
             out["g.au." + k] = p.grad
     save("g9_pipeline", **out)
+
+    # G11: the token section of ResFormer.forward (vformer.py:245-259 = sformer.py:313-327): stage-3 feature map
+    # [B', C, h, w] -> tokens [B', h*w, C] + pos_embedding -> spatial_transformer -> back to [B', C, h, w].  The module
+    # is the reference's own ResFormer (its conv stages are constructed but not run); small dims keep the fixture small.
+    torch.manual_seed(1011)
+    rf = vformer.ResFormer(vformer.BasicBlock, [1, 1, 1, 1], num_patches=9, dim=32, depth=1, heads=8, mlp_dim=64, dim_head=32)
+    xmap = torch.randn(4, 32, 3, 3, requires_grad=True)
+    b_l, c, h, w = xmap.shape
+    t = xmap.reshape((b_l, c, h * w)).permute(0, 2, 1)
+    t = t + rf.pos_embedding[:, :t.shape[1]]
+    t = rf.spatial_transformer(t)
+    ymap = t.permute(0, 2, 1).reshape((b_l, c, h, w))
+    l = sq(ymap)
+    l.backward()
+    out = {"x": xmap.detach(), "y": ymap.detach(), "dx": xmap.grad, "loss": l.detach(),
+           "p.pos_embedding": rf.pos_embedding.detach(), "g.pos_embedding": rf.pos_embedding.grad}
+    for k, v in rf.spatial_transformer.state_dict().items():
+        out["p.spatial_transformer." + k] = v
+    for k, q in rf.spatial_transformer.named_parameters():
+        out["g.spatial_transformer." + k] = q.grad
+    save("g11_resformer_tokens", num_patches=9, dim=32, depth=1, heads=8, dim_head=32, mlp_dim=64, **out)
 
     # G10: tanh-GELU on a grid incl. large magnitudes, with its derivative
     g = heads.GELU()

@@ -269,6 +269,30 @@ def test_tformer_golden_f32():
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_resformer_tokens_golden(mode):
+    """the token section of ResFormer.forward (sformer.py:313-327) against the fixture made from the reference module"""
+    import avformer_amd as A
+    p, g, r = split_golden(load_golden("g11_resformer_tokens"))
+    m = _load_into(A.ResFormerTokens(r["num_patches"], r["dim"], r["depth"], r["heads"], r["mlp_dim"], r["dim_head"],
+                                     compute_dtype=mode), p)
+    x = r["x"].to(DEV).requires_grad_(True)
+    y = m(x)
+    assert y.shape == x.shape
+    y.pow(2).mean().backward()
+    got = dict(m.named_parameters())
+    if mode == "f32":
+        _close(y, r["y"])
+        _close(x.grad, r["dx"], atol=1e-6)
+        for k, v in g.items():
+            _close(got[k].grad, v, atol=2e-6, rtol=2e-3)
+    else:
+        assert rel_fro(y, r["y"]) < 1.5e-2
+        assert rel_fro(x.grad, r["dx"]) < 4e-2
+        for k, v in g.items():
+            assert rel_fro(got[k].grad, v) < 5e-2, (k, rel_fro(got[k].grad, v))
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
 def test_pipeline_golden(mode):
     """G9: [B,T,D] -> TFormer -> AU_former(eval) -> AULoss incl. an ignored row, all gradients."""
     import avformer_amd as A

@@ -102,6 +102,15 @@ def test_g7_tformer():
     check_grads(ps, g)
 
 
+def test_g11_resformer_tokens():
+    p, g, r = split_golden(load_golden("g11_resformer_tokens"))
+    x, ps, y = run_with_grads(lambda x, ps: oracle.resformer_tokens_forward(x, ps, r["depth"], r["heads"]), r["x"], p)
+    close(y, r["y"])
+    y.pow(2).mean().backward()
+    close(x.grad, r["dx"])
+    check_grads(ps, g)
+
+
 @pytest.mark.parametrize("tag", ["all", "ign"])
 def test_g8_au_loss(tag):
     g = load_golden("g8_au_loss")
