@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16* __res
 // cross-lane maximum from v_permlane{16,32}_swap instead of LDS permutes.  lse2 = m + log2(l) is exact whatever m is.
 // =============================================================================================
 constexpr int RES_MAX_N = 576;    // (N rounded to 32) * 256 B + the dK/dV kernel's statistics <= 160 KB
-constexpr int RES_A = 2;          // tiles whose DMA is issued before any compute
+constexpr int RES_A = 1;          // tiles whose DMA is issued before any compute (1 vs 2: -2 % backward, same forward)
 constexpr float RES_TAU = 6.0f;   // log2 of the largest probability kept before a rescale
 
 __device__ __forceinline__ void glds16(const void* g, char* l) {
