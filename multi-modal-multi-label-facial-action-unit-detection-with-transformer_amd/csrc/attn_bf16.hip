@@ -357,7 +357,7 @@ __device__ __forceinline__ bf16x8_t lds_tr_frag(const char* p) {  // rows +0 and
 // their LDS images in 8-row pieces, ordered a0 b0 a1 b1 ... (16 pieces per 64-row tile, so arrival is in tile order);
 // piece p belongs to wave p mod W and each wave walks its pieces with a cursor.  Phase 1 (the first RES_A tiles) is
 // issued up front; the rest is issued one piece at a time from hooks inside the first tile's compute, so no wave sits
-// in a full memory queue while the SIMD idles, and tile 1 covers the latency of the last pieces.
+// in a full memory queue while the SIMD idles; the second barrier (after the RES_A-th tile) waits for what is left.
 struct ResLoader {
   const bf16 *a, *b;
   int64_t lda, ldb;
