@@ -71,7 +71,7 @@ def test_fused_adam_skips_weight_prep_and_state_dict_roundtrip():
         loss = m.get_au_loss(m(batch), labels)
         loss.backward()
         o.step()
-        return float(loss)
+        return float(loss.detach())
 
     l0 = one(ma, oa)
     l1 = one(ma, oa)  # this forward consumed the optimizer-written copies
