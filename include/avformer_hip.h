@@ -117,6 +117,15 @@ size_t avf_attn_bwd_workspace_bytes(int batch, int tokens, int heads, int dim_he
 int avf_attn_bwd(int dtype, const void* qkv, const void* o, const void* d_o, const float* lse2, void* dqkv,
                  void* workspace, int batch, int tokens, int heads, int dim_head, void* stream);
 
+/* The same attention core (bf16 only) on a projection whose q columns are ALREADY multiplied by log2(e)/sqrt(dim_head):
+ * the scores leave the MFMA in the log2 domain and the subtraction of the running maximum / of lse2 rides in the MFMA's
+ * C operand (no per-score multiply-add).  This is what avf_layer_fwd / avf_layer_bwd run - they fold the factor into the
+ * query rows of the bf16 copy of to_qkv.weight (heads.py:212) - and dq, dk, dv are still the gradients with respect to
+ * the UNSCALED q, k, v.  workspace >= 2 * avf_attn_bwd_workspace_bytes(...). */
+int avf_attn_fwd_qs(const void* qkv, void* o, float* lse2, int batch, int tokens, int heads, int dim_head, void* stream);
+int avf_attn_bwd_qs(const void* qkv, const void* o, const void* d_o, const float* lse2, void* dqkv, void* workspace,
+                    int batch, int tokens, int heads, int dim_head, void* stream);
+
 /* Token-sequence plumbing of the callers either side of the stack (fp32, dim % 4 == 0, 16-byte aligned pointers).
  *  avf_fuse_tokens:   out[b, t, :] = (t < t_video ? clip[b, t, :] : audio[b, t - t_video, :]) + pos[t, :]  (pos nullable)
  *                     - the sequence-axis fusion torch.cat([clip, audio], 1) + pos_embedding of BASELINE.json's configs

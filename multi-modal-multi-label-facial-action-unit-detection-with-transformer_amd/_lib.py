@@ -55,6 +55,8 @@ SIGNATURES = {
     "avf_attn_fwd": (_int, [_int, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     "avf_attn_bwd_workspace_bytes": (_sz, [_int, _int, _int, _int]),
     "avf_attn_bwd": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
+    "avf_attn_fwd_qs": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _vp]),
+    "avf_attn_bwd_qs": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     "avf_fuse_tokens": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     "avf_token_mean_fwd": (_int, [_vp, _vp, _int, _int, _int, _vp]),
     "avf_token_mean_bwd": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _vp]),

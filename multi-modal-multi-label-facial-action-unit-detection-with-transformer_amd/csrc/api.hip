@@ -217,6 +217,21 @@ extern "C" int avf_attn_bwd(int dtype, const void* qkv, const void* o, const voi
   AVF_REQUIRE(false, "attn_bwd: bad dtype %d", dtype);
 }
 
+// bf16 attention on a projection whose q columns already carry log2(e)/sqrt(dim_head) - what avf_layer_fwd/bwd run
+// (the factor is folded into the query rows of the bf16 Wqkv image).  workspace: 2 * avf_attn_bwd_workspace_bytes.
+extern "C" int avf_attn_fwd_qs(const void* qkv, void* o, float* lse2, int batch, int tokens, int heads, int dim_head,
+                               void* stream) {
+  AVF_REQUIRE(qkv && o && lse2, "attn_fwd_qs: null pointer");
+  return attn_fwd_bf16((const bf16*)qkv, (bf16*)o, lse2, batch, tokens, heads, dim_head, (hipStream_t)stream, true);
+}
+extern "C" int avf_attn_bwd_qs(const void* qkv, const void* o, const void* d_o, const float* lse2, void* dqkv,
+                               void* workspace, int batch, int tokens, int heads, int dim_head, void* stream) {
+  AVF_REQUIRE(qkv && o && d_o && lse2 && dqkv && workspace, "attn_bwd_qs: null pointer");
+  float* w = (float*)workspace;
+  return attn_bwd_bf16((const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse2, (bf16*)dqkv, w, batch, tokens, heads,
+                       dim_head, (hipStream_t)stream, true, w + (size_t)batch * tokens * heads);
+}
+
 extern "C" int avf_selftest_mfma_bf16(const void* a, const void* b, float* c, void* stream) {
   selftest_mfma_bf16_kernel<<<1, 64, 0, (hipStream_t)stream>>>((const bf16*)a, (const bf16*)b, c);
   return check_launch("selftest_mfma_bf16");

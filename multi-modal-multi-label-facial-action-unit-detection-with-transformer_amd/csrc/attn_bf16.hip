@@ -102,7 +102,7 @@ struct TileStager {
 // =============================================================================================
 template <int DH>
 __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
-                                                            float* __restrict__ lse2, int B, int N, int H) {
+                                                            float* __restrict__ lse2, int B, int N, int H, int qs) {
   constexpr int KS = DH / 32, DB = DH / 16;
   constexpr int KLD = DH * 2 + 32;  // K tile: row reads (ds_read_b128); +32 B keeps them conflict-free (PMC-checked)
   constexpr int VLD = DH * 2 + 32;  // V tile: transposed reads, 8 consecutive rows -> 8 distinct bank windows
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16* __res
   const bf16* vbase = qbase + 2 * I;
   const int q0 = blk * 128 + wave * 32;
   const bool active = __builtin_amdgcn_readfirstlane(q0) < N;
-  const float c = LOG2E / sqrtf((float)DH);
+  const float c = qs ? 1.0f : LOG2E / sqrtf((float)DH);  // qs: q already carries log2(e)/sqrt(dh)
   AVF_PHASE_INIT();
 
   bf16x8_t fq[2][KS];
@@ -424,8 +424,10 @@ __device__ __forceinline__ void res_sweep(int N, bool first, TileFn&& tile, Sync
   if (nfull < nt && t0 <= nfull) tile(nfull, std::true_type{}, std::false_type{});
 }
 
-// MULTI: more 32-row groups than waves (each wave loops over its groups); otherwise exactly one group per wave
-template <int MAXW, bool MULTI>
+// MULTI: more 32-row groups than waves (each wave loops over its groups); otherwise exactly one group per wave.
+// QS: the q columns already carry log2(e)/sqrt(dh) (layer path) - the scores leave the MFMA in the log2 domain, and the
+// subtraction of the running maximum (forward) / of lse2 (backward) rides in the MFMA's C operand: no per-score FMA.
+template <int MAXW, bool MULTI, bool QS>
 __global__ __launch_bounds__(MAXW * 64) void attn_fwd_res_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
                                                                 float* __restrict__ lse2, int N, int H) {
   constexpr int DH = 64, KS = 2, DB = 4;
@@ -471,7 +473,9 @@ __global__ __launch_bounds__(MAXW * 64) void attn_fwd_res_kernel(const bf16* __r
 #pragma unroll
       for (int d = 0; d < DB; ++d) ot[d][qb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
-    float m[2] = {-INFINITY, -INFINITY};
+    float m[2] = {QS ? 0.f : -INFINITY, QS ? 0.f : -INFINITY};
+    f32x4_t minit[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // QS: -m, the C operand of the first score MFMA
+    bool first_tile = true;                                              // QS: the first tile centres m on its maximum
 
     auto tile = [&](int t, auto tail_tag, auto feed_tag) {
       constexpr bool TAIL = decltype(tail_tag)::value;
@@ -482,8 +486,8 @@ __global__ __launch_bounds__(MAXW * 64) void attn_fwd_res_kernel(const bf16* __r
       f32x4_t st[4][2];
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
-        st[kb][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        st[kb][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        st[kb][0] = QS ? minit[0] : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        st[kb][1] = QS ? minit[1] : f32x4_t{0.f, 0.f, 0.f, 0.f};
         if (!TAIL || kb < nkb) {
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
@@ -495,6 +499,50 @@ __global__ __launch_bounds__(MAXW * 64) void attn_fwd_res_kernel(const bf16* __r
         if (FEED) loader.issue_one();
       }
       AVF_PHASE_MARK(2);
+      if constexpr (QS) {
+        // st = log2-domain score - m.  Re-centre when a row maximum exceeds m by more than RES_TAU (and always on the
+        // first tile, which fixes m): only then are the accumulators and this tile's scores shifted.
+        float cm[2];
+        bool grow = first_tile;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+          float tmax = -INFINITY;
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if (TAIL && (t * 64 + kb * 16 + 4 * lg + r >= N)) st[kb][qb][r] = -INFINITY;
+              tmax = fmaxf(tmax, st[kb][qb][r]);
+            }
+          cm[qb] = colmax4(tmax);
+          grow = grow || (cm[qb] > RES_TAU);
+        }
+        if (__builtin_amdgcn_ballot_w64(grow) != 0) {  // wave-uniform
+#pragma unroll
+          for (int qb = 0; qb < 2; ++qb) {
+            const float shift = first_tile ? cm[qb] : fmaxf(cm[qb], 0.f);
+            const float alpha = first_tile ? 1.0f : __builtin_amdgcn_exp2f(-shift);  // accumulators are 0 on the first tile
+            m[qb] += shift;
+            minit[qb] = f32x4_t{-m[qb], -m[qb], -m[qb], -m[qb]};
+            ls[qb][0] *= alpha; ls[qb][1] *= alpha; ls[qb][2] *= alpha; ls[qb][3] *= alpha;
+#pragma unroll
+            for (int d = 0; d < DB; ++d) {
+              ot[d][qb][0] *= alpha; ot[d][qb][1] *= alpha; ot[d][qb][2] *= alpha; ot[d][qb][3] *= alpha;
+            }
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) st[kb][qb][r] -= shift;
+          }
+        }
+        first_tile = false;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[kb][qb][r] = __builtin_amdgcn_exp2f(st[kb][qb][r]);
+      } else {
       float cand[2];
       bool grow = false;
 #pragma unroll
@@ -529,6 +577,7 @@ __global__ __launch_bounds__(MAXW * 64) void attn_fwd_res_kernel(const bf16* __r
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) st[kb][qb][r] = __builtin_amdgcn_exp2f(fmaf(st[kb][qb][r], c, -m[qb]));
+      }
       AVF_PHASE_MARK(3);
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -580,12 +629,15 @@ __global__ __launch_bounds__(MAXW * 64) void attn_fwd_res_kernel(const bf16* __r
 // delta[q] = sum_d O[q,d] dO[q,d] for its rows (from the dO fragments it holds anyway) and writes it for the
 // dK/dV kernel that follows on the stream - no separate delta launch on this path.
 // ---------------------------------------------------------------------------------------------
-// MULTI: more 32-row groups than waves (each wave loops over its groups); otherwise exactly one group per wave
-template <int MAXW, bool MULTI>
+// MULTI: more 32-row groups than waves (each wave loops over its groups); otherwise exactly one group per wave.
+// QS: the q columns already carry log2(e)/sqrt(dh) (layer path) - the scores leave the MFMA in the log2 domain, and the
+// subtraction of the running maximum (forward) / of lse2 (backward) rides in the MFMA's C operand: no per-score FMA.
+template <int MAXW, bool MULTI, bool QS>
 __global__ __launch_bounds__(MAXW * 64) void attn_dq_res_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                                const bf16* __restrict__ d_o,
                                                                const float* __restrict__ lse2, float* __restrict__ delta,
-                                                               bf16* __restrict__ dqkv, int N, int H) {
+                                                               float* __restrict__ nlse, bf16* __restrict__ dqkv, int N,
+                                                               int H) {
   constexpr int DH = 64, KS = 2, DB = 4;
   extern __shared__ __attribute__((aligned(16))) char res_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -630,8 +682,12 @@ __global__ __launch_bounds__(MAXW * 64) void attn_dq_res_kernel(const bf16* __re
       for (int ks = 0; ks < KS; ++ks)
         part += dot8(load_frag_global(obase + (int64_t)q * I + ks * 32 + 8 * lg, ok), fg[qb][ks]);
       dl[qb] = colsum4(part);
-      if (ok && lg == 0) delta[(int64_t)bh * N + q] = dl[qb];
+      if (ok && lg == 0) {
+        delta[(int64_t)bh * N + q] = dl[qb];
+        if (QS) nlse[(int64_t)bh * N + q] = -L[qb];  // the dK/dV kernel feeds it to its MFMAs as the C operand
+      }
     }
+    const f32x4_t linit[2] = {{-L[0], -L[0], -L[0], -L[0]}, {-L[1], -L[1], -L[1], -L[1]}};
     if (first_pass) loader.issue_until(16 * RES_A);
 
     f32x4_t dqt[DB][2];
@@ -652,7 +708,8 @@ __global__ __launch_bounds__(MAXW * 64) void attn_dq_res_kernel(const bf16* __re
         ds[kb][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         ds[kb][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         if (!TAIL || kb < nkb) {
-          f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+          f32x4_t p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0;
+          f32x4_t s0 = QS ? linit[0] : p0, s1 = QS ? linit[1] : p0;  // QS: the MFMA returns log2-score - lse2
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
             const bf16x8_t fk = lds_row_frag(kt + kb * 2048 + off.row[ks]);
@@ -665,8 +722,8 @@ __global__ __launch_bounds__(MAXW * 64) void attn_dq_res_kernel(const bf16* __re
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const bool dead = TAIL && (t * 64 + kb * 16 + 4 * lg + r >= N);
-            const float e0 = dead ? 0.f : __builtin_amdgcn_exp2f(fmaf(s0[r], c, -L[0]));
-            const float e1 = dead ? 0.f : __builtin_amdgcn_exp2f(fmaf(s1[r], c, -L[1]));
+            const float e0 = dead ? 0.f : __builtin_amdgcn_exp2f(QS ? s0[r] : fmaf(s0[r], c, -L[0]));
+            const float e1 = dead ? 0.f : __builtin_amdgcn_exp2f(QS ? s1[r] : fmaf(s1[r], c, -L[1]));
             ds[kb][0][r] = e0 * (p0[r] - dl[0]);
             ds[kb][1][r] = e1 * (p1[r] - dl[1]);
           }
@@ -712,8 +769,10 @@ __global__ __launch_bounds__(MAXW * 64) void attn_dq_res_kernel(const bf16* __re
 // head-resident dK, dV: Q and dO images (+ the head's lse2 / delta rows, by 4-byte LDS-DMA) in LDS; 32 key rows per
 // group.  Query rows past N are copies of row N-1: their probabilities are zeroed in the tail tile.
 // ---------------------------------------------------------------------------------------------
-// MULTI: more 32-row groups than waves (each wave loops over its groups); otherwise exactly one group per wave
-template <int MAXW, bool MULTI>
+// MULTI: more 32-row groups than waves (each wave loops over its groups); otherwise exactly one group per wave.
+// QS: the q columns already carry log2(e)/sqrt(dh) (layer path) - the scores leave the MFMA in the log2 domain, and the
+// subtraction of the running maximum (forward) / of lse2 (backward) rides in the MFMA's C operand: no per-score FMA.
+template <int MAXW, bool MULTI, bool QS>
 __global__ __launch_bounds__(MAXW * 64) void attn_dkv_res_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
                                                                 const float* __restrict__ lse2,
                                                                 const float* __restrict__ delta, bf16* __restrict__ dqkv,
@@ -738,7 +797,9 @@ __global__ __launch_bounds__(MAXW * 64) void attn_dkv_res_kernel(const bf16* __r
   float* Ds = Ls + NP64;
   const float scale = 1.0f / sqrtf((float)DH);
   const float c = LOG2E * scale;
+  const float kscale = QS ? 1.0f / LOG2E : scale;  // dK = scale dS^T q = dS^T q' / log2(e)
   AVF_PHASE_INIT();
+  // QS: `lse2` points at the NEGATED statistics the dQ kernel wrote (they become the C operand of the score MFMAs)
   // the softmax statistics of the head's query rows: 64 floats per DMA piece, lse2 pieces then delta pieces
   for (int j = wave; j < NP64 / 32; j += W) {
     const int blk = j >> 1;
@@ -791,7 +852,10 @@ __global__ __launch_bounds__(MAXW * 64) void attn_dkv_res_kernel(const bf16* __r
           const int qb = 2 * s2 + h2;
           pm[h2][0] = pm[h2][1] = dsm[h2][0] = dsm[h2][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
           if (!TAIL || qb < nqb) {
-            f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+            const float4 l4 = *reinterpret_cast<const float4*>(Ls + t * 64 + qb * 16 + 4 * lg);
+            const float4 d4 = *reinterpret_cast<const float4*>(Ds + t * 64 + qb * 16 + 4 * lg);
+            f32x4_t p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0;
+            f32x4_t s0 = QS ? f32x4_t{l4.x, l4.y, l4.z, l4.w} : p0, s1 = s0;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
               const bf16x8_t fqr = lds_row_frag(qt + qb * 2048 + off.row[ks]);
@@ -801,14 +865,12 @@ __global__ __launch_bounds__(MAXW * 64) void attn_dkv_res_kernel(const bf16* __r
               p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fgr, fv[0][ks], p0, 0, 0, 0);
               p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fgr, fv[1][ks], p1, 0, 0, 0);
             }
-            const float4 l4 = *reinterpret_cast<const float4*>(Ls + t * 64 + qb * 16 + 4 * lg);
-            const float4 d4 = *reinterpret_cast<const float4*>(Ds + t * 64 + qb * 16 + 4 * lg);
             const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const bool dead = TAIL && (t * 64 + qb * 16 + 4 * lg + r >= N);
-              const float e0 = dead ? 0.f : __builtin_amdgcn_exp2f(fmaf(s0[r], c, -lv[r]));
-              const float e1 = dead ? 0.f : __builtin_amdgcn_exp2f(fmaf(s1[r], c, -lv[r]));
+              const float e0 = dead ? 0.f : __builtin_amdgcn_exp2f(QS ? s0[r] : fmaf(s0[r], c, -lv[r]));
+              const float e1 = dead ? 0.f : __builtin_amdgcn_exp2f(QS ? s1[r] : fmaf(s1[r], c, -lv[r]));
               pm[h2][0][r] = e0;
               pm[h2][1][r] = e1;
               dsm[h2][0][r] = e0 * (p0[r] - dv[r]);
@@ -852,8 +914,8 @@ __global__ __launch_bounds__(MAXW * 64) void attn_dkv_res_kernel(const bf16* __r
         bf16* outv = outk + I;
 #pragma unroll
         for (int d = 0; d < DB; ++d) {
-          store4<bf16>(outk + d * 16 + 4 * lg, make_float4(dkt[d][kb][0] * scale, dkt[d][kb][1] * scale,
-                                                           dkt[d][kb][2] * scale, dkt[d][kb][3] * scale));
+          store4<bf16>(outk + d * 16 + 4 * lg, make_float4(dkt[d][kb][0] * kscale, dkt[d][kb][1] * kscale,
+                                                           dkt[d][kb][2] * kscale, dkt[d][kb][3] * kscale));
           store4<bf16>(outv + d * 16 + 4 * lg,
                        make_float4(dvt[d][kb][0], dvt[d][kb][1], dvt[d][kb][2], dvt[d][kb][3]));
         }
@@ -871,7 +933,7 @@ template <int DH>
 __global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
                                                            const float* __restrict__ lse2,
                                                            const float* __restrict__ delta, bf16* __restrict__ dqkv,
-                                                           int B, int N, int H) {
+                                                           int B, int N, int H, int qs) {
   constexpr int KS = DH / 32, DB = DH / 16;
   constexpr int KLD = DH * 2 + 32;  // K tile: row reads AND transposed reads
   constexpr int VLD = DH * 2 + 32;  // V tile: row reads only (+32 B: conflict-free, PMC-checked)
@@ -892,7 +954,7 @@ __global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(const bf16* __rest
   const int q0 = blk * 128 + wave * 32;
   const bool active = __builtin_amdgcn_readfirstlane(q0) < N;
   const float scale = 1.0f / sqrtf((float)DH);
-  const float c = LOG2E * scale;
+  const float c = qs ? 1.0f : LOG2E * scale;
 
   bf16x8_t fq[2][KS], fg[2][KS];
   float L[2], dl[2];
@@ -1006,7 +1068,7 @@ template <int DH>
 __global__ __launch_bounds__(256, 2) void attn_dkv_bf16_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
                                                             const float* __restrict__ lse2,
                                                             const float* __restrict__ delta, bf16* __restrict__ dqkv,
-                                                            int B, int N, int H) {
+                                                            int B, int N, int H, int qs) {
   constexpr int KS = DH / 32, DB = DH / 16;
   constexpr int TLD = DH * 2 + 32;  // Q and dO tiles: row reads AND transposed reads
   constexpr int STAGE = 2 * 64 * TLD + 2 * 64 * 4;
@@ -1026,7 +1088,8 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_bf16_kernel(const bf16* __res
   const int k0 = blk * 128 + wave * 32;
   const bool active = __builtin_amdgcn_readfirstlane(k0) < N;
   const float scale = 1.0f / sqrtf((float)DH);
-  const float c = LOG2E * scale;
+  const float c = qs ? 1.0f : LOG2E * scale;
+  const float kscale = qs ? 1.0f / LOG2E : scale;  // dK = scale dS^T q = dS^T q' / log2(e) when q' = q log2(e) scale
 
   bf16x8_t fk[2][KS], fv[2][KS];
 #pragma unroll
@@ -1159,8 +1222,8 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_bf16_kernel(const bf16* __res
       bf16* outv = outk + I;
 #pragma unroll
       for (int d = 0; d < DB; ++d) {
-        store4<bf16>(outk + d * 16 + 4 * lg, make_float4(dkt[d][kb][0] * scale, dkt[d][kb][1] * scale,
-                                                         dkt[d][kb][2] * scale, dkt[d][kb][3] * scale));
+        store4<bf16>(outk + d * 16 + 4 * lg, make_float4(dkt[d][kb][0] * kscale, dkt[d][kb][1] * kscale,
+                                                         dkt[d][kb][2] * kscale, dkt[d][kb][3] * kscale));
         store4<bf16>(outv + d * 16 + 4 * lg,
                      make_float4(dvt[d][kb][0], dvt[d][kb][1], dvt[d][kb][2], dvt[d][kb][3]));
       }
@@ -1207,7 +1270,18 @@ int res_launch(K kernel, const char* name, int blocks, int waves, size_t smem, h
 }
 }  // namespace
 
-int attn_fwd_bf16(const bf16* qkv, bf16* o, float* lse2, int B, int N, int H, int dh, hipStream_t s) {
+// log2(e)/sqrt(dh): the factor the layer path folds into the query rows of its bf16 Wqkv image
+// (AVF_ATTN_QS=0, a tuning aid, turns the folding off: factor 1 and the kernels that scale the scores themselves)
+bool attn_q_prescale_on() {
+  static const int on = [] {
+    const char* e = getenv("AVF_ATTN_QS");
+    return e ? atoi(e) : 1;
+  }();
+  return on != 0;
+}
+float attn_q_prescale(int dh) { return attn_q_prescale_on() ? LOG2E / sqrtf((float)dh) : 1.0f; }
+
+int attn_fwd_bf16(const bf16* qkv, bf16* o, float* lse2, int B, int N, int H, int dh, hipStream_t s, bool q_prescaled) {
   AVF_REQUIRE(B > 0 && N > 0 && H > 0, "attn_fwd_bf16: bad shape");
   AVF_REQUIRE(ceil_div(N, 128) * B * H < (1LL << 31), "attn_fwd_bf16: grid too large");
   AVF_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)o & 7) == 0, "attn_fwd_bf16: misaligned pointers");
@@ -1215,19 +1289,27 @@ int attn_fwd_bf16(const bf16* qkv, bf16* o, float* lse2, int B, int N, int H, in
   if (use_resident(N, dh)) {
     const int W = res_waves(N);
     const size_t smem = (size_t)((N + 31) & ~31) * 128 * 2;
-    if (res_multi(N)) return res_launch(attn_fwd_res_kernel<8, true>, "attn_fwd_res<8,multi>", B * H, W, smem, s, qkv, o, lse2, N, H);
-    if (W <= 8) return res_launch(attn_fwd_res_kernel<8, false>, "attn_fwd_res<8>", B * H, W, smem, s, qkv, o, lse2, N, H);
-    return res_launch(attn_fwd_res_kernel<12, false>, "attn_fwd_res<12>", B * H, W, smem, s, qkv, o, lse2, N, H);
+#define AVF_FWD_RES(MW, MU, Q, NAME) res_launch(attn_fwd_res_kernel<MW, MU, Q>, NAME, B * H, W, smem, s, qkv, o, lse2, N, H)
+    if (q_prescaled) {
+      if (res_multi(N)) return AVF_FWD_RES(8, true, true, "attn_fwd_res<8,multi,qs>");
+      if (W <= 8) return AVF_FWD_RES(8, false, true, "attn_fwd_res<8,qs>");
+      return AVF_FWD_RES(12, false, true, "attn_fwd_res<12,qs>");
+    }
+    if (res_multi(N)) return AVF_FWD_RES(8, true, false, "attn_fwd_res<8,multi>");
+    if (W <= 8) return AVF_FWD_RES(8, false, false, "attn_fwd_res<8>");
+    return AVF_FWD_RES(12, false, false, "attn_fwd_res<12>");
+#undef AVF_FWD_RES
   }
   const unsigned grid = (unsigned)(ceil_div(N, 128) * B * H);
-  if (dh == 64) attn_fwd_bf16_kernel<64><<<grid, 256, 0, s>>>(qkv, o, lse2, B, N, H);
-  else if (dh == 32) attn_fwd_bf16_kernel<32><<<grid, 256, 0, s>>>(qkv, o, lse2, B, N, H);
+  const int qs = q_prescaled ? 1 : 0;
+  if (dh == 64) attn_fwd_bf16_kernel<64><<<grid, 256, 0, s>>>(qkv, o, lse2, B, N, H, qs);
+  else if (dh == 32) attn_fwd_bf16_kernel<32><<<grid, 256, 0, s>>>(qkv, o, lse2, B, N, H, qs);
   else AVF_REQUIRE(false, "attention (bf16): unsupported dim_head %d (32 or 64)", dh);
   return check_launch("attn_fwd_bf16_kernel");
 }
 
 int attn_bwd_bf16(const bf16* qkv, const bf16* o, const bf16* d_o, const float* lse2, bf16* dqkv, float* delta, int B,
-                  int N, int H, int dh, hipStream_t s) {
+                  int N, int H, int dh, hipStream_t s, bool q_prescaled, float* nlse) {
   AVF_REQUIRE(B > 0 && N > 0 && H > 0, "attn_bwd_bf16: bad shape");
   AVF_REQUIRE(ceil_div(N, 128) * B * H < (1LL << 31), "attn_bwd_bf16: grid too large");
   AVF_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)d_o & 15) == 0 && ((uintptr_t)dqkv & 7) == 0,
@@ -1236,25 +1318,33 @@ int attn_bwd_bf16(const bf16* qkv, const bf16* o, const bf16* d_o, const float* 
   if (use_resident(N, dh)) {  // delta comes out of the dQ kernel
     const int W = res_waves(N);
     const size_t smem = (size_t)((N + 31) & ~31) * 128 * 2, smem_kv = smem + (size_t)((N + 63) & ~63) * 8;
-    if (res_multi(N)) {
-      AVF_TRY(res_launch(attn_dq_res_kernel<8, true>, "attn_dq_res<8,multi>", B * H, W, smem, s, qkv, o, d_o, lse2, delta, dqkv, N, H));
-      return res_launch(attn_dkv_res_kernel<8, true>, "attn_dkv_res<8,multi>", B * H, W, smem_kv, s, qkv, d_o, lse2, delta, dqkv, N, H);
+    AVF_REQUIRE(!q_prescaled || nlse, "attn_bwd_bf16: scratch for the negated statistics missing");
+#define AVF_BWD_RES(MW, MU, Q, TAG)                                                                                      \
+  do {                                                                                                                   \
+    AVF_TRY(res_launch(attn_dq_res_kernel<MW, MU, Q>, "attn_dq_res" TAG, B * H, W, smem, s, qkv, o, d_o, lse2, delta,    \
+                       nlse, dqkv, N, H));                                                                               \
+    return res_launch(attn_dkv_res_kernel<MW, MU, Q>, "attn_dkv_res" TAG, B * H, W, smem_kv, s, qkv, d_o,                \
+                      Q ? (const float*)nlse : lse2, (const float*)delta, dqkv, N, H);                                   \
+  } while (0)
+    if (q_prescaled) {
+      if (res_multi(N)) AVF_BWD_RES(8, true, true, "<8,multi,qs>");
+      if (W <= 8) AVF_BWD_RES(8, false, true, "<8,qs>");
+      AVF_BWD_RES(12, false, true, "<12,qs>");
     }
-    if (W <= 8) {
-      AVF_TRY(res_launch(attn_dq_res_kernel<8, false>, "attn_dq_res<8>", B * H, W, smem, s, qkv, o, d_o, lse2, delta, dqkv, N, H));
-      return res_launch(attn_dkv_res_kernel<8, false>, "attn_dkv_res<8>", B * H, W, smem_kv, s, qkv, d_o, lse2, delta, dqkv, N, H);
-    }
-    AVF_TRY(res_launch(attn_dq_res_kernel<12, false>, "attn_dq_res<12>", B * H, W, smem, s, qkv, o, d_o, lse2, delta, dqkv, N, H));
-    return res_launch(attn_dkv_res_kernel<12, false>, "attn_dkv_res<12>", B * H, W, smem_kv, s, qkv, d_o, lse2, delta, dqkv, N, H);
+    if (res_multi(N)) AVF_BWD_RES(8, true, false, "<8,multi>");
+    if (W <= 8) AVF_BWD_RES(8, false, false, "<8>");
+    AVF_BWD_RES(12, false, false, "<12>");
+#undef AVF_BWD_RES
   }
   AVF_TRY(attn_delta(AVF_BF16, o, d_o, delta, B, N, H, dh, s));
   const unsigned grid = (unsigned)(ceil_div(N, 128) * B * H);
+  const int qs = q_prescaled ? 1 : 0;
   if (dh == 64) {
-    attn_dq_bf16_kernel<64><<<grid, 256, 0, s>>>(qkv, d_o, lse2, delta, dqkv, B, N, H);
-    attn_dkv_bf16_kernel<64><<<grid, 256, 0, s>>>(qkv, d_o, lse2, delta, dqkv, B, N, H);
+    attn_dq_bf16_kernel<64><<<grid, 256, 0, s>>>(qkv, d_o, lse2, delta, dqkv, B, N, H, qs);
+    attn_dkv_bf16_kernel<64><<<grid, 256, 0, s>>>(qkv, d_o, lse2, delta, dqkv, B, N, H, qs);
   } else if (dh == 32) {
-    attn_dq_bf16_kernel<32><<<grid, 256, 0, s>>>(qkv, d_o, lse2, delta, dqkv, B, N, H);
-    attn_dkv_bf16_kernel<32><<<grid, 256, 0, s>>>(qkv, d_o, lse2, delta, dqkv, B, N, H);
+    attn_dq_bf16_kernel<32><<<grid, 256, 0, s>>>(qkv, d_o, lse2, delta, dqkv, B, N, H, qs);
+    attn_dkv_bf16_kernel<32><<<grid, 256, 0, s>>>(qkv, d_o, lse2, delta, dqkv, B, N, H, qs);
   } else {
     AVF_REQUIRE(false, "attention (bf16): unsupported dim_head %d (32 or 64)", dh);
   }

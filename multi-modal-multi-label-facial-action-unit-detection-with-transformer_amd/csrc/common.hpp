@@ -271,7 +271,9 @@ __device__ __forceinline__ void fold_columns_vec(const FoldJob& j, int colgroup,
 // workspace bytes for the fused column-sum partials of an NT GEMM with M rows and N columns
 size_t gemm_nt_colsum_ws(int64_t M, int64_t N);
 int prep_weight_bf16(const float* w, void* w_lo, void* w_t_lo, int rows, int cols, hipStream_t s);
-struct PrepDesc { const float* w; bf16* lo; bf16* t; int R, C; };
+// lo_scale / lo_scaled_rows: the first rows of the row-major image `lo` (NOT of the transposed image) are multiplied by a
+// constant - the query rows of Wqkv carry the softmax scale (see attn_q_prescale in attn_bf16.hip)
+struct PrepDesc { const float* w; bf16* lo; bf16* t; int R, C; float lo_scale; int lo_scaled_rows; };
 struct PrepBatch { PrepDesc d[4]; };
 int prep_weights_multi(const PrepBatch& b, int count, hipStream_t s);
 
@@ -319,9 +321,15 @@ int gemm_bf16_tn_group(const TnGroupArgs& a, hipStream_t s, const FoldList* extr
 int attn_fwd_f32(const float* qkv, float* o, float* lse2, int B, int N, int H, int dh, hipStream_t s);
 int attn_bwd_f32(const float* qkv, const float* o, const float* d_o, const float* lse2, float* dqkv, float* delta,
                  int B, int N, int H, int dh, hipStream_t s);
-int attn_fwd_bf16(const bf16* qkv, bf16* o, float* lse2, int B, int N, int H, int dh, hipStream_t s);
+// q_prescaled: the q columns of qkv already hold q * log2(e)/sqrt(dh) (the layer path: folded into the bf16 copy of
+// Wqkv's query rows, attn_q_prescale); the operator-level C entry points pass false.  nlse (backward, q_prescaled
+// only): B*H*N floats of scratch next to delta.
+float attn_q_prescale(int dh);
+bool attn_q_prescale_on();
+int attn_fwd_bf16(const bf16* qkv, bf16* o, float* lse2, int B, int N, int H, int dh, hipStream_t s,
+                  bool q_prescaled = false);
 int attn_bwd_bf16(const bf16* qkv, const bf16* o, const bf16* d_o, const float* lse2, bf16* dqkv, float* delta,
-                  int B, int N, int H, int dh, hipStream_t s);
+                  int B, int N, int H, int dh, hipStream_t s, bool q_prescaled = false, float* nlse = nullptr);
 int attn_delta(int dtype, const void* o, const void* d_o, float* delta, int B, int N, int H, int dh, hipStream_t s);
 
 }  // namespace avf

@@ -142,7 +142,7 @@ size_t carve_work(const Dims& d, void* base, Work* w) {
   t.dx_mid = (float*)c.take(d.R * d.D * 4);
   t.dx_mid_lo = c.take(d.dt == AVF_BF16 ? d.R * d.D * 2 : 0);
   t.dx_out_lo = c.take(d.dt == AVF_BF16 ? d.R * d.D * 2 : 0);
-  t.delta = (float*)c.take((size_t)d.B * d.H * d.N * 4);
+  t.delta = (float*)c.take((size_t)d.B * d.H * d.N * 4 * 2);  // delta, then the negated lse2 rows (bf16 backward)
   t.ln_ws = c.take(layernorm_bwd_ws(d.R, d.D));
   t.ln_ws1 = c.take(layernorm_bwd_ws(d.R, d.D));  // LN1 partials (its fold may be deferred past LN2's)
   const int maxc = d.M > d.D ? d.M : d.D;
@@ -254,10 +254,12 @@ extern "C" int avf_layer_prepare_weights(const avf_layer_cfg* cfg, const avf_lay
   LowP l;
   carve_lowp(d, lowp, &l);
   PrepBatch b;
-  b.d[0] = PrepDesc{p->w_qkv, (bf16*)l.wqkv, (bf16*)l.wqkv_t, 3 * d.I, d.D};
-  b.d[1] = PrepDesc{p->w_out, (bf16*)l.wo, (bf16*)l.wo_t, d.D, d.I};
-  b.d[2] = PrepDesc{p->w1, (bf16*)l.w1, (bf16*)l.w1_t, d.M, d.D};
-  b.d[3] = PrepDesc{p->w2, (bf16*)l.w2, (bf16*)l.w2_t, d.D, d.M};
+  // the query rows of the forward image of Wqkv carry the softmax scale (the transposed image, which backward
+  // multiplies dqkv with, does not): q' = h1 (c Wq)^T, so the attention kernels get log2-domain scores from the MFMA
+  b.d[0] = PrepDesc{p->w_qkv, (bf16*)l.wqkv, (bf16*)l.wqkv_t, 3 * d.I, d.D, attn_q_prescale(d.dh), d.I};
+  b.d[1] = PrepDesc{p->w_out, (bf16*)l.wo, (bf16*)l.wo_t, d.D, d.I, 1.0f, 0};
+  b.d[2] = PrepDesc{p->w1, (bf16*)l.w1, (bf16*)l.w1_t, d.M, d.D, 1.0f, 0};
+  b.d[3] = PrepDesc{p->w2, (bf16*)l.w2, (bf16*)l.w2_t, d.D, d.M, 1.0f, 0};
   return prep_weights_multi(b, 4, s);
 }
 
@@ -281,7 +283,7 @@ extern "C" int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p
 
   AVF_TRY(layernorm_fwd(x_in, p->ln1_w, p->ln1_b, sv.h1, d.dt, sv.mean1, sv.rstd1, d.R, d.D, cfg->ln_eps, s));
   AVF_TRY(linear_fwd(d, sv.h1, d.D, wqkv, 3 * d.I, sv.qkv, d.dt, AVF_EPI_NONE, nullptr, nullptr, nullptr, s));
-  if (lo) AVF_TRY(attn_fwd_bf16((const bf16*)sv.qkv, (bf16*)sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s));
+  if (lo) AVF_TRY(attn_fwd_bf16((const bf16*)sv.qkv, (bf16*)sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s, attn_q_prescale_on()));
   else AVF_TRY(attn_fwd_f32((const float*)sv.qkv, (float*)sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s));
   const DropCfg dr0 = make_drop(d.p, d.seed, d.layer, 0, d.seed_dev), dr1 = make_drop(d.p, d.seed, d.layer, 1, d.seed_dev),
                 dr2 = make_drop(d.p, d.seed, d.layer, 2, d.seed_dev);
@@ -366,7 +368,7 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   AVF_TRY(linear_dx(d, gm, d.D, p->w_out, l.wo_t, d.I, w.d_o, AVF_EPI_NONE, nullptr, s));
   if (lo)
     AVF_TRY(attn_bwd_bf16((const bf16*)sv.qkv, (const bf16*)sv.o, (const bf16*)w.d_o, sv.lse2, (bf16*)w.dqkv, w.delta,
-                          d.B, d.N, d.H, d.dh, s));
+                          d.B, d.N, d.H, d.dh, s, attn_q_prescale_on(), w.delta + (size_t)d.B * d.H * d.N));
   else
     AVF_TRY(attn_bwd_f32((const float*)sv.qkv, (const float*)sv.o, (const float*)w.d_o, sv.lse2, (float*)w.dqkv,
                          w.delta, d.B, d.N, d.H, d.dh, s));

@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256) void prep_weights_multi_kernel(PrepBatch b) {
     int r = r0 + ty + 8 * i, c = c0 + tx;
     float v = (r < d.R && c < d.C) ? d.w[(int64_t)r * d.C + c] : 0.f;
     tile[ty + 8 * i][tx] = v;
-    if (r < d.R && c < d.C) d.lo[(int64_t)r * d.C + c] = from_f32<bf16>(v);
+    if (r < d.R && c < d.C) d.lo[(int64_t)r * d.C + c] = from_f32<bf16>(r < d.lo_scaled_rows ? v * d.lo_scale : v);
   }
   __syncthreads();
 #pragma unroll

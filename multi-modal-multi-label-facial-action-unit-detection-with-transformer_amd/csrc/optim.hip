@@ -20,6 +20,8 @@ struct AdamDesc {
   bf16* lo;  // row-major bf16 copy [R, C] (nullable)
   bf16* t;   // transposed bf16 copy [C, R] (nullable)
   int R, C;
+  float lo_scale;      // rows < lo_scaled_rows of `lo` (only) are written multiplied by this: the query rows of Wqkv carry
+  int lo_scaled_rows;  // the softmax scale (attn_q_prescale)
   int tile0, tiles_c;  // first work item of this tensor, tiles per row of tiles (matrices)
 };
 
@@ -109,7 +111,10 @@ __global__ __launch_bounds__(256) void adam_layer_kernel(AdamBatch b) {
           *reinterpret_cast<float4*>(d.m + o) = m;
           *reinterpret_cast<float4*>(d.v + o) = v;
         }
-        if (d.lo) store4<bf16>(d.lo + o, p);
+        if (d.lo) {
+          const float sc = r < d.lo_scaled_rows ? d.lo_scale : 1.0f;
+          store4<bf16>(d.lo + o, make_float4(p.x * sc, p.y * sc, p.z * sc, p.w * sc));
+        }
       }
       tile[ty + 16 * i][tx * 4 + 0] = p.x; tile[ty + 16 * i][tx * 4 + 1] = p.y;
       tile[ty + 16 * i][tx * 4 + 2] = p.z; tile[ty + 16 * i][tx * 4 + 3] = p.w;
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(256) void adam_layer_kernel(AdamBatch b) {
         adam1(p, d.g[o], m, v, k);
         d.p[o] = p; d.m[o] = m; d.v[o] = v;
       }
-      if (d.lo) d.lo[o] = from_f32<bf16>(p);
+      if (d.lo) d.lo[o] = from_f32<bf16>(r < d.lo_scaled_rows ? p * d.lo_scale : p);
     }
     tile[e >> 6][e & 63] = p;
   }
@@ -183,15 +188,17 @@ extern "C" int avf_layer_adam_step(const avf_layer_cfg* cfg, const avf_layer_par
   AdamBatch b;
   memset(&b, 0, sizeof(b));
   int n = 0, tiles = 0;
-  auto add = [&](const float* pp, float* gg, float* mm, float* vv, bf16* lo, bf16* t, int R, int C) {
+  auto add = [&](const float* pp, float* gg, float* mm, float* vv, bf16* lo, bf16* t, int R, int C, float lo_scale = 1.0f,
+                 int lo_scaled_rows = 0) {
     if (!pp || (!gg && !lo && !t)) return;  // absent tensor, or nothing to do for it
     AdamDesc& d = b.d[n++];
     d.p = const_cast<float*>(pp); d.g = gg; d.m = mm; d.v = vv; d.lo = lo; d.t = t; d.R = R; d.C = C;
+    d.lo_scale = lo_scale; d.lo_scaled_rows = lo_scaled_rows;
     d.tile0 = tiles;
     d.tiles_c = R == 1 ? 1 : (C + 63) / 64;
     tiles += R == 1 ? (C + 4095) / 4096 : ((R + 63) / 64) * d.tiles_c;
   };
-  add(p->w_qkv, g->w_qkv, exp_avg->w_qkv, exp_avg_sq->w_qkv, img[0], img[1], 3 * I, D);
+  add(p->w_qkv, g->w_qkv, exp_avg->w_qkv, exp_avg_sq->w_qkv, img[0], img[1], 3 * I, D, attn_q_prescale(cfg->dim_head), I);
   add(p->w_out, g->w_out, exp_avg->w_out, exp_avg_sq->w_out, img[2], img[3], D, I);
   add(p->w1, g->w1, exp_avg->w1, exp_avg_sq->w1, img[4], img[5], M, D);
   add(p->w2, g->w2, exp_avg->w2, exp_avg_sq->w2, img[6], img[7], D, M);

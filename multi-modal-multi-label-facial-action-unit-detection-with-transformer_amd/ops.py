@@ -147,27 +147,38 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool 
     return c
 
 
-def attn_fwd(qkv: torch.Tensor, batch: int, tokens: int, heads: int, dim_head: int):
-    """Attention core on the packed QKV projection [B*N, 3*H*dh] -> (o [B*N, H*dh], lse2 [B,H,N])."""
+def attn_fwd(qkv: torch.Tensor, batch: int, tokens: int, heads: int, dim_head: int, q_prescaled: bool = False):
+    """Attention core on the packed QKV projection [B*N, 3*H*dh] -> (o [B*N, H*dh], lse2 [B,H,N]).
+    q_prescaled (bf16 only): the q columns already carry log2(e)/sqrt(dim_head) (avf_attn_fwd_qs)."""
     _need_cuda(qkv)
     qkv = qkv.contiguous()
     inner = heads * dim_head
     assert qkv.shape == (batch * tokens, 3 * inner)
     o = torch.empty((batch * tokens, inner), dtype=qkv.dtype, device=qkv.device)
     lse2 = torch.empty((batch, heads, tokens), dtype=torch.float32, device=qkv.device)
-    _lib.check(_lib.load().avf_attn_fwd(avf_dtype(qkv.dtype), _ptr(qkv), _ptr(o), _ptr(lse2), batch, tokens, heads,
-                                        dim_head, _stream()), "attn_fwd")
+    if q_prescaled:
+        assert qkv.dtype == torch.bfloat16
+        _lib.check(_lib.load().avf_attn_fwd_qs(_ptr(qkv), _ptr(o), _ptr(lse2), batch, tokens, heads, dim_head, _stream()),
+                   "attn_fwd_qs")
+    else:
+        _lib.check(_lib.load().avf_attn_fwd(avf_dtype(qkv.dtype), _ptr(qkv), _ptr(o), _ptr(lse2), batch, tokens, heads,
+                                            dim_head, _stream()), "attn_fwd")
     return o, lse2
 
 
-def attn_bwd(qkv, o, d_o, lse2, batch: int, tokens: int, heads: int, dim_head: int) -> torch.Tensor:
+def attn_bwd(qkv, o, d_o, lse2, batch: int, tokens: int, heads: int, dim_head: int, q_prescaled: bool = False) -> torch.Tensor:
     _need_cuda(qkv, o, d_o, lse2)
     lib = _lib.load()
     qkv, o, d_o = qkv.contiguous(), o.contiguous(), d_o.contiguous()
     dqkv = torch.empty_like(qkv)
-    ws = _bytes(lib.avf_attn_bwd_workspace_bytes(batch, tokens, heads, dim_head), qkv.device)
-    _lib.check(lib.avf_attn_bwd(avf_dtype(qkv.dtype), _ptr(qkv), _ptr(o), _ptr(d_o), _ptr(lse2), _ptr(dqkv), _ptr(ws),
-                                batch, tokens, heads, dim_head, _stream()), "attn_bwd")
+    ws = _bytes(lib.avf_attn_bwd_workspace_bytes(batch, tokens, heads, dim_head) * (2 if q_prescaled else 1), qkv.device)
+    if q_prescaled:
+        assert qkv.dtype == torch.bfloat16
+        _lib.check(lib.avf_attn_bwd_qs(_ptr(qkv), _ptr(o), _ptr(d_o), _ptr(lse2), _ptr(dqkv), _ptr(ws), batch, tokens, heads,
+                                       dim_head, _stream()), "attn_bwd_qs")
+    else:
+        _lib.check(lib.avf_attn_bwd(avf_dtype(qkv.dtype), _ptr(qkv), _ptr(o), _ptr(d_o), _ptr(lse2), _ptr(dqkv), _ptr(ws),
+                                    batch, tokens, heads, dim_head, _stream()), "attn_bwd")
     return dqkv
 
 

@@ -184,17 +184,33 @@ def test_attention_f32(ops, B, N, H, dh):
     _close(dqkv, dqkv_ref.float(), atol=5e-5, rtol=1e-4)
 
 
+def _prescale_q(qkv, H, dh):
+    """bf16 projection with q' = bf16(q * log2(e)/sqrt(dh)) in the q columns, and the fp32 projection it stands for:
+    (q'/c | k | v) exactly, so that the reference sees the very numbers the kernels see"""
+    c = math.log2(math.e) / math.sqrt(dh)
+    I = H * dh
+    dev = qkv.float().clone()
+    dev[:, :I] = (dev[:, :I] * c).to(torch.bfloat16).float()
+    ref = dev.clone()
+    ref[:, :I] = ref[:, :I] / c
+    return dev.to(torch.bfloat16), ref
+
+
+@pytest.mark.parametrize("qs", [False, True], ids=["raw_q", "prescaled_q"])
 @pytest.mark.parametrize("B,N,H,dh", [(1, 64, 2, 32), (2, 49, 8, 32), (3, 17, 8, 64), (2, 130, 3, 64), (1, 324, 2, 64),
                                       (2, 12, 8, 32), (1, 512, 2, 64), (1, 200, 1, 32)])
-def test_attention_bf16(ops, B, N, H, dh):
+def test_attention_bf16(ops, B, N, H, dh, qs):
     g = torch.Generator().manual_seed(B * 100 + N + dh + 1)
     qkv = torch.randn(B * N, 3 * H * dh, generator=g).to(torch.bfloat16)
     d_o = torch.randn(B * N, H * dh, generator=g).to(torch.bfloat16)
-    o_ref, lse_ref, dqkv_ref = _attn_ref(qkv.float(), B, N, H, dh, d_o.float())
-    o, lse2 = ops.attn_fwd(qkv.cuda(), B, N, H, dh)
+    ref_in = qkv.float()
+    if qs:
+        qkv, ref_in = _prescale_q(qkv, H, dh)
+    o_ref, lse_ref, dqkv_ref = _attn_ref(ref_in, B, N, H, dh, d_o.float())
+    o, lse2 = ops.attn_fwd(qkv.cuda(), B, N, H, dh, q_prescaled=qs)
     assert rel_fro(o, o_ref) < 1e-2, rel_fro(o, o_ref)
     _close(lse2, lse_ref.float(), atol=2e-2, rtol=1e-3)
-    dqkv = ops.attn_bwd(qkv.cuda(), o, d_o.cuda(), lse2, B, N, H, dh)
+    dqkv = ops.attn_bwd(qkv.cuda(), o, d_o.cuda(), lse2, B, N, H, dh, q_prescaled=qs)
     I = H * dh
     for name, sl in (("dq", slice(0, I)), ("dk", slice(I, 2 * I)), ("dv", slice(2 * I, 3 * I))):
         e = rel_fro(dqkv[:, sl], dqkv_ref[:, sl])
@@ -203,19 +219,23 @@ def test_attention_bf16(ops, B, N, H, dh):
 
 @pytest.mark.parametrize("N", [1, 15, 16, 31, 33, 63, 64, 65, 96, 127, 128, 200, 256, 320, 383, 384, 385, 448, 500, 512,
                                575, 576, 577, 640])
-def test_attention_bf16_dh64_lengths(ops, N):
+@pytest.mark.parametrize("qs", [False, True], ids=["raw_q", "prescaled_q"])
+def test_attention_bf16_dh64_lengths(ops, N, qs):
     """dim_head 64 over the sequence lengths where the kernel family changes: one group per wave (N <= 384, 8- and
     12-wave builds), several groups per wave (385..576), the streaming kernels (> 576); tails of 1..63 rows."""
     B, H, dh = 2, 2, 64
     g = torch.Generator().manual_seed(1000 + N)
     qkv = torch.randn(B * N, 3 * H * dh, generator=g).to(torch.bfloat16)
     d_o = torch.randn(B * N, H * dh, generator=g).to(torch.bfloat16)
-    o_ref, lse_ref, dqkv_ref = _attn_ref(qkv.float(), B, N, H, dh, d_o.float())
-    o, lse2 = ops.attn_fwd(qkv.cuda(), B, N, H, dh)
+    ref_in = qkv.float()
+    if qs:
+        qkv, ref_in = _prescale_q(qkv, H, dh)
+    o_ref, lse_ref, dqkv_ref = _attn_ref(ref_in, B, N, H, dh, d_o.float())
+    o, lse2 = ops.attn_fwd(qkv.cuda(), B, N, H, dh, q_prescaled=qs)
     assert torch.isfinite(o.float()).all() and torch.isfinite(lse2).all()
     assert rel_fro(o, o_ref) < 1e-2, rel_fro(o, o_ref)
     _close(lse2, lse_ref.float(), atol=2e-2, rtol=1e-3)
-    dqkv = ops.attn_bwd(qkv.cuda(), o, d_o.cuda(), lse2, B, N, H, dh)
+    dqkv = ops.attn_bwd(qkv.cuda(), o, d_o.cuda(), lse2, B, N, H, dh, q_prescaled=qs)
     assert torch.isfinite(dqkv.float()).all()
     I = H * dh
     for name, sl in (("dq", slice(0, I)), ("dk", slice(I, 2 * I)), ("dv", slice(2 * I, 3 * I))):
@@ -226,8 +246,9 @@ def test_attention_bf16_dh64_lengths(ops, N):
         assert e < 2e-2, (name, e)
 
 
-@pytest.mark.parametrize("mode", ["ramp", "small_steps", "huge"])
-def test_attention_bf16_rescale_paths(ops, mode):
+@pytest.mark.parametrize("qs", [False, True], ids=["raw_q", "prescaled_q"])
+@pytest.mark.parametrize("mode", ["ramp", "small_steps", "huge", "descending", "very_negative"])
+def test_attention_bf16_rescale_paths(ops, mode, qs):
     """lazy rescaling of the head-resident forward: 'ramp' = the row maximum grows by much more than the threshold in
     every key tile (rescale each tile); 'small_steps' = it grows by less than the threshold per tile (stale maximum,
     probabilities above 1 in the accumulators); 'huge' = scores of magnitude ~1e3 (log2 domain ~1.4e3)."""
@@ -244,17 +265,26 @@ def test_attention_bf16_rescale_paths(ops, mode):
     elif mode == "small_steps":  # ~2.5 nats (3.6 in log2) per tile: below the threshold of 6
         q = q * 0.2 + 8.0 * u
         k = k * 0.2 + u[None, :] * (torch.arange(N).float()[:, None] / 64.0) * 2.5
+    elif mode == "descending":  # the first tile holds the row maxima; later tiles fall by ~6 nats per 64 keys
+        q = q * 0.2 + 8.0 * u
+        k = k * 0.2 - u[None, :] * (torch.arange(N).float()[:, None] / 64.0) * 6.0
+    elif mode == "very_negative":  # every score ~ -250 nats: the first tile must centre the maximum far below zero
+        q = q * 0.2 + 40.0 * u
+        k = k * 0.2 - 50.0 * u[None, :]
     else:
         q = q * 30.0
         k = k * 30.0
     qkv = torch.cat([q, k, v], dim=1).to(torch.bfloat16)
     d_o = torch.randn(N, dh, generator=g).to(torch.bfloat16)
-    o_ref, lse_ref, dqkv_ref = _attn_ref(qkv.float(), B, N, H, dh, d_o.float())
-    o, lse2 = ops.attn_fwd(qkv.cuda(), B, N, H, dh)
+    ref_in = qkv.float()
+    if qs:
+        qkv, ref_in = _prescale_q(qkv, H, dh)
+    o_ref, lse_ref, dqkv_ref = _attn_ref(ref_in, B, N, H, dh, d_o.float())
+    o, lse2 = ops.attn_fwd(qkv.cuda(), B, N, H, dh, q_prescaled=qs)
     assert torch.isfinite(o.float()).all() and torch.isfinite(lse2).all()
     assert rel_fro(o, o_ref) < 1e-2, rel_fro(o, o_ref)
     _close(lse2, lse_ref.float(), atol=5e-2, rtol=2e-3)
-    dqkv = ops.attn_bwd(qkv.cuda(), o, d_o.cuda(), lse2, B, N, H, dh)
+    dqkv = ops.attn_bwd(qkv.cuda(), o, d_o.cuda(), lse2, B, N, H, dh, q_prescaled=qs)
     assert torch.isfinite(dqkv.float()).all()
     assert rel_fro(dqkv, dqkv_ref) < 3e-2, rel_fro(dqkv, dqkv_ref)
 

@@ -74,14 +74,14 @@ int main(int argc, char** argv) {
   hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
   K<<<grid, W * 64, smem>>>(__VA_ARGS__)
       typedef avf::bf16 T;
-      if (mode == 2 && passes > 1) { AVF_DIAG_LAUNCH((avf::attn_dkv_res_kernel<8, true>), q, g, lse, lse, (T*)dqkv, N, H); }
-      else if (mode == 2 && W <= 8) { AVF_DIAG_LAUNCH((avf::attn_dkv_res_kernel<8, false>), q, g, lse, lse, (T*)dqkv, N, H); }
-      else if (mode == 2) { AVF_DIAG_LAUNCH((avf::attn_dkv_res_kernel<12, false>), q, g, lse, lse, (T*)dqkv, N, H); }
-      else if (passes > 1) { AVF_DIAG_LAUNCH((avf::attn_fwd_res_kernel<8, true>), q, (T*)o, lse, N, H); }
-      else if (W <= 8) { AVF_DIAG_LAUNCH((avf::attn_fwd_res_kernel<8, false>), q, (T*)o, lse, N, H); }
-      else { AVF_DIAG_LAUNCH((avf::attn_fwd_res_kernel<12, false>), q, (T*)o, lse, N, H); }
+      if (mode == 2 && passes > 1) { AVF_DIAG_LAUNCH((avf::attn_dkv_res_kernel<8, true, false>), q, g, lse, lse, (T*)dqkv, N, H); }
+      else if (mode == 2 && W <= 8) { AVF_DIAG_LAUNCH((avf::attn_dkv_res_kernel<8, false, false>), q, g, lse, lse, (T*)dqkv, N, H); }
+      else if (mode == 2) { AVF_DIAG_LAUNCH((avf::attn_dkv_res_kernel<12, false, false>), q, g, lse, lse, (T*)dqkv, N, H); }
+      else if (passes > 1) { AVF_DIAG_LAUNCH((avf::attn_fwd_res_kernel<8, true, false>), q, (T*)o, lse, N, H); }
+      else if (W <= 8) { AVF_DIAG_LAUNCH((avf::attn_fwd_res_kernel<8, false, false>), q, (T*)o, lse, N, H); }
+      else { AVF_DIAG_LAUNCH((avf::attn_fwd_res_kernel<12, false, false>), q, (T*)o, lse, N, H); }
     } else {
-      avf::attn_fwd_bf16_kernel<64><<<grid, 256>>>((const avf::bf16*)qkv, (avf::bf16*)o, lse, B, N, H);
+      avf::attn_fwd_bf16_kernel<64><<<grid, 256>>>((const avf::bf16*)qkv, (avf::bf16*)o, lse, B, N, H, 0);
     }
     hipEventRecord(e1);
   }
