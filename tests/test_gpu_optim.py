@@ -101,3 +101,34 @@ def test_load_state_dict_after_step_invalidates_bf16_copies():
         out_a = ma(batch)
         out_b = mb(batch)          # mb still holds the initial weights
     assert torch.equal(out_a, out_b)
+
+
+def test_training_trajectory_bf16_library_adam_tracks_f32_torch_adam():
+    """40 optimisation steps on a fixed batch: the throughput path (bf16 kernels, pre-scaled q, bf16 weight copies written by
+    the library's Adam and consumed by the next forward) must follow the parity path (f32 kernels, torch.optim.Adam) -
+    a stale or mis-scaled weight copy anywhere in that loop shows up as a diverging loss curve."""
+    import avformer_amd as A
+    D, L, H, dh, M, Tv, Ta = 64, 2, 2, 32, 128, 20, 12
+    torch.manual_seed(21)
+    m32 = A.SyntheticAVFormer(D, L, H, dh, M, Tv, Ta, compute_dtype="f32").to(DEV)
+    m16 = A.SyntheticAVFormer(D, L, H, dh, M, Tv, Ta, compute_dtype="bf16").to(DEV)
+    m16.load_state_dict(m32.state_dict())
+    o32 = torch.optim.Adam(m32.parameters(), lr=2e-3, weight_decay=5e-5)
+    o16 = A.optim.FusedAdam(m16, lr=2e-3, weight_decay=5e-5)
+    g = torch.Generator().manual_seed(22)
+    batch = {"clip": torch.randn(16, Tv, D, generator=g).to(DEV), "audio_features": torch.randn(16, Ta, D, generator=g).to(DEV)}
+    labels = (torch.rand(16, 12, generator=g) > 0.5).float().to(DEV)
+    curves = {}
+    for name, m, o in (("f32", m32, o32), ("bf16", m16, o16)):
+        losses = []
+        for _ in range(40):
+            o.zero_grad(set_to_none=True)
+            loss = m.get_au_loss(m(batch), labels)
+            loss.backward()
+            o.step()
+            losses.append(float(loss.detach()))
+        curves[name] = losses
+    a, b = curves["f32"], curves["bf16"]
+    assert a[-1] < 0.6 * a[0] and b[-1] < 0.6 * b[0], (a[0], a[-1], b[0], b[-1])  # both fit the batch
+    for i in (0, 5, 10, 20, 39):
+        assert abs(a[i] - b[i]) < 0.05 * a[i] + 5e-3, (i, a[i], b[i])
