@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--torch-adam", action="store_true",
                     help="step torch.optim.Adam(fused=True) instead of the library's Adam (same arithmetic; the library's "
                          "also rewrites the bf16 weight copies in its pass)")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--graph", action="store_true", help="capture the step into a HIP graph and replay it")
     args = ap.parse_args()
 
