@@ -324,6 +324,13 @@ int attn_bwd_f32(const float* qkv, const float* o, const float* d_o, const float
 // q_prescaled: the q columns of qkv already hold q * log2(e)/sqrt(dh) (the layer path: folded into the bf16 copy of
 // Wqkv's query rows, attn_q_prescale); the operator-level C entry points pass false.  nlse (backward, q_prescaled
 // only): B*H*N floats of scratch next to delta.
+// single-launch forward of one layer for short sequences (layer_small.hip)
+bool small_layer_ok(int dtype, int tokens, int dim, int heads, int dim_head, int mlp_dim);
+int layer_fwd_small(int B, int N, int D, int H, int M, float eps, float score_scale, const avf_layer_params* p,
+                    const void* wqkv, const void* wo, const void* w1, const void* w2, const float* x_in, float* x_out,
+                    void* h1, float* mean1, float* rstd1, void* qkv, void* o, float* lse2, float* x_mid, void* h2,
+                    float* mean2, float* rstd2, void* u, void* g, const DropCfg& dr0, const DropCfg& dr1,
+                    const DropCfg& dr2, hipStream_t s);
 float attn_q_prescale(int dh);
 bool attn_q_prescale_on();
 int attn_fwd_bf16(const bf16* qkv, bf16* o, float* lse2, int B, int N, int H, int dh, hipStream_t s,

@@ -281,6 +281,13 @@ extern "C" int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   const void* w1 = lo ? l.w1 : (const void*)p->w1;
   const void* w2 = lo ? l.w2 : (const void*)p->w2;
 
+  if (small_layer_ok(d.dt, d.N, d.D, d.H, d.dh, d.M)) {  // short sequences: the whole layer in one launch
+    const float sc = attn_q_prescale_on() ? 1.0f : 1.4426950408889634f / sqrtf((float)d.dh);
+    return layer_fwd_small(d.B, d.N, d.D, d.H, d.M, cfg->ln_eps, sc, p, wqkv, wo, w1, w2, x_in, x_out, sv.h1, sv.mean1,
+                           sv.rstd1, sv.qkv, sv.o, sv.lse2, sv.x_mid, sv.h2, sv.mean2, sv.rstd2, sv.u, sv.g,
+                           make_drop(d.p, d.seed, d.layer, 0, d.seed_dev), make_drop(d.p, d.seed, d.layer, 1, d.seed_dev),
+                           make_drop(d.p, d.seed, d.layer, 2, d.seed_dev), s);
+  }
   AVF_TRY(layernorm_fwd(x_in, p->ln1_w, p->ln1_b, sv.h1, d.dt, sv.mean1, sv.rstd1, d.R, d.D, cfg->ln_eps, s));
   AVF_TRY(linear_fwd(d, sv.h1, d.D, wqkv, 3 * d.I, sv.qkv, d.dt, AVF_EPI_NONE, nullptr, nullptr, nullptr, s));
   if (lo) AVF_TRY(attn_fwd_bf16((const bf16*)sv.qkv, (bf16*)sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s, attn_q_prescale_on()));

@@ -1,0 +1,368 @@
+// layer_small.hip - one transformer layer, FORWARD, as a single launch for short sequences.
+//
+// The reference's real head shapes (AU_former / former_AU_head stacks over 12 tokens; dim 128 or 256,
+// 8 heads of 32, mlp 256) are launch-bound: seven forward launches per layer of a few
+// microseconds of work each.  Here ONE workgroup (8 or 16 wavefronts) per clip runs the whole layer - LN1, QKV, attention,
+// out-projection + residual, LN2, MLP1 + GELU, MLP2 + residual (heads.py:246-255) - writing exactly the saved-activation
+// block the per-operator backward reads (h1, stats, qkv, o, lse2, x_mid, h2, stats, u, g), so backward is unchanged.
+// Activations travel between the phases through those global buffers (L2-resident: a clip's block is a few hundred KB)
+// with a workgroup barrier between phases; the GEMMs keep the clip's A rows in registers (<= 64 rows x K <= 256) and read
+// the bf16 weight images straight from L2 as MFMA operands - no LDS staging at all; LDS only holds each head's V for the
+// transposed fragment reads.  Same arithmetic as the per-operator path (bf16 MFMA, fp32 accumulate / LayerNorm / softmax,
+// counter-based dropout with the same element indices), except that the softmax is single-pass (all keys at once).
+//
+// Eligibility (small_layer_ok): bf16, dim_head 32, tokens <= 16, dim / inner / mlp_dim in {128, 256} - the reference's
+// AU_former / former_AU_head stacks.  Measured on the real avformer head model (B=64, 12 tokens, three stacks): -3 % per
+// step under hipGraph replay (0.97 vs 1.00 ms), -5..10 % in the host-bound eager loop (42 fewer launches per step).  The
+// phases are latency-bound chains through L2 (store -> barrier -> load), so the gain is the launch overhead only; keeping
+// the clip's activations in LDS between the phases is the next step.
+#include "common.hpp"
+
+namespace avf {
+
+namespace {
+
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+constexpr float LOG2E_S = 1.4426950408889634f;
+constexpr int VLD = 32 * 2 + 32;  // bytes per staged V row (dim_head 32) + 32 B: conflict-free transposed reads
+
+struct SmallArgs {
+  const float* x_in;
+  float* x_out;
+  // parameters (fp32 vectors) and bf16 weight images [out, in]
+  const float *ln1_w, *ln1_b, *b_out, *ln2_w, *ln2_b, *b1, *b2;
+  const bf16 *wqkv, *wo, *w1, *w2;
+  // saved-activation block
+  bf16 *h1, *qkv, *o, *h2, *u, *g;
+  float *mean1, *rstd1, *lse2, *x_mid, *mean2, *rstd2;
+  int N, H;
+  float eps, score_scale;  // score_scale: 1 when the q rows of wqkv carry log2(e)/sqrt(dh), that factor otherwise
+  DropCfg dr0, dr1, dr2;
+};
+
+__device__ __forceinline__ bf16x8_t ldg_frag(const bf16* p) {
+  return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p));
+}
+
+__device__ __forceinline__ bf16x8_t pack_pair_s(const f32x4_t& a, const f32x4_t& b) {
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+  u32x4_t r = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+
+__device__ __forceinline__ bf16x8_t tr_frag_s(const lds_char* tile, int row_base, int col_base, int li, int lg) {
+  const lds_char* p0 = tile + (row_base + 4 * lg + (li >> 2)) * VLD + (col_base + 4 * (li & 3)) * 2;
+  s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
+  s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0 + 16 * VLD));
+  s16x8_t r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+
+// max / sum over the four lanes {li, li+16, li+32, li+48}
+__device__ __forceinline__ float quad_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+// LayerNorm of the clip's rows: wave w takes rows w, w+NW, ...; D = 128 or 256 (one or two float4 per lane... D/4 <= 64)
+template <int D32, int NW>
+__device__ __forceinline__ void small_ln(const float* x, const float* gamma, const float* beta, bf16* y, float* mean,
+                                         float* rstd, int64_t row0, int N, float eps, int wave, int lane) {
+  constexpr int D = D32 * 32;
+  const int c = lane * 4;
+  const bool act = c < D;
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f), b = g;
+  if (act) {
+    g = *reinterpret_cast<const float4*>(gamma + c);
+    b = *reinterpret_cast<const float4*>(beta + c);
+  }
+  for (int r = wave; r < N; r += NW) {
+    const int64_t row = row0 + r;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (act) v = *reinterpret_cast<const float4*>(x + row * D + c);
+    const float mu = wave_sum((v.x + v.y) + (v.z + v.w)) / (float)D;
+    float q = 0.f;
+    if (act) {
+      const float a0 = v.x - mu, a1 = v.y - mu, a2 = v.z - mu, a3 = v.w - mu;
+      q = (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+    }
+    const float rs = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0) {
+      mean[row] = mu;
+      rstd[row] = rs;
+    }
+    if (act)
+      store4<bf16>(y + row * D + c, make_float4((v.x - mu) * rs * g.x + b.x, (v.y - mu) * rs * g.y + b.y,
+                                                (v.z - mu) * rs * g.z + b.z, (v.w - mu) * rs * g.w + b.w));
+  }
+}
+
+// C[rows of the clip, Nout] = A[rows, K] W[Nout, K]^T; the clip's A fragments stay in registers, wave w takes the
+// 16-column blocks w, w+NW, ...; epi(cb, acc): lane holds C[16 i + li][16 cb + 4 lg + 0..3] in acc[i]
+template <int MB, int K32, int NW, typename Epi>
+__device__ __forceinline__ void small_gemm(const bf16* A, int64_t row0, int N, const bf16* W, int Nout, int wave, int li, int lg,
+                                           Epi&& epi) {
+  constexpr int K = K32 * 32;
+  bf16x8_t fa[MB][K32];
+#pragma unroll
+  for (int i = 0; i < MB; ++i) {
+    int r = 16 * i + li;
+    r = r < N ? r : N - 1;
+#pragma unroll
+    for (int ks = 0; ks < K32; ++ks) fa[i][ks] = ldg_frag(A + (row0 + r) * K + ks * 32 + 8 * lg);
+  }
+  // the weight fragments of a column block are all requested before its first MFMA, and the next block's while this one
+  // computes (the loop is latency-bound: a few MFMAs per L2 round trip)
+  bf16x8_t fb[K32], fn[K32];
+  int cb = wave;
+  if (cb < Nout / 16) {
+    const bf16* wrow = W + (int64_t)(cb * 16 + li) * K + 8 * lg;
+#pragma unroll
+    for (int ks = 0; ks < K32; ++ks) fb[ks] = ldg_frag(wrow + ks * 32);
+  }
+  for (; cb < Nout / 16; cb += NW) {
+    const bool more = cb + NW < Nout / 16;
+    if (more) {
+      const bf16* wrow = W + (int64_t)((cb + NW) * 16 + li) * K + 8 * lg;
+#pragma unroll
+      for (int ks = 0; ks < K32; ++ks) fn[ks] = ldg_frag(wrow + ks * 32);
+    }
+    f32x4_t acc[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < K32; ++ks)
+#pragma unroll
+      for (int i = 0; i < MB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks], fa[i][ks], acc[i], 0, 0, 0);
+    epi(cb, acc);
+    if (more) {
+#pragma unroll
+      for (int ks = 0; ks < K32; ++ks) fb[ks] = fn[ks];
+    }
+  }
+}
+
+// NW wavefronts per clip: 16 for <= 16 tokens (the GEMM column blocks, LayerNorm rows and heads spread over more waves:
+// the kernel is a chain of latency-bound phases), 8 otherwise (register budget of the A fragments)
+template <int MB, int D32, int I32, int M32, int NW>
+__global__ __launch_bounds__(NW * 64) void layer_fwd_small_kernel(SmallArgs a) {
+  constexpr int D = D32 * 32, I = I32 * 32, M = M32 * 32;
+  constexpr int KB = 2 * ((MB + 1) / 2);  // key blocks of 16, padded to pairs (one MFMA k-step = 32 keys)
+  __shared__ __attribute__((aligned(16))) char vstage[NW][KB * 16 * VLD];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int N = a.N, H = a.H;
+  const int64_t b = blockIdx.x, row0 = b * N;
+
+  // ---- LN1
+  small_ln<D32, NW>(a.x_in, a.ln1_w, a.ln1_b, a.h1, a.mean1, a.rstd1, row0, N, a.eps, wave, lane);
+  __syncthreads();
+
+  // ---- QKV projection (no bias)
+  small_gemm<MB, D32, NW>(a.h1, row0, N, a.wqkv, 3 * I, wave, li, lg, [&](int cb, f32x4_t(&acc)[MB]) {
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+      const int r = 16 * i + li;
+      if (r < N)
+        store4<bf16>(a.qkv + (row0 + r) * (3 * I) + cb * 16 + 4 * lg, make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]));
+    }
+  });
+  __syncthreads();
+
+  // ---- attention: wave w takes heads w, w+NW, ...; single-pass softmax over the clip's keys
+  {
+    char* vt = vstage[wave];
+    for (int h = wave; h < H; h += NW) {
+      const bf16* qb_ = a.qkv + row0 * (3 * I) + h * 32;
+      // stage V of this head: rows past N are zero (their probabilities are zero, but 0 * garbage must not be NaN)
+      for (int e = lane; e < KB * 16 * 4; e += 64) {
+        const int r = e >> 2, c = e & 3;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r < N) v = *reinterpret_cast<const uint4*>(qb_ + (int64_t)r * (3 * I) + 2 * I + c * 8);
+        *reinterpret_cast<uint4*>(vt + r * VLD + c * 16) = v;
+      }
+      bf16x8_t fq[MB], fk[KB];
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        int r = 16 * i + li;
+        r = r < N ? r : N - 1;
+        fq[i] = ldg_frag(qb_ + (int64_t)r * (3 * I) + 8 * lg);
+      }
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        int r = 16 * kb + li;
+        r = r < N ? r : N - 1;
+        fk[kb] = ldg_frag(qb_ + (int64_t)r * (3 * I) + I + 8 * lg);
+      }
+#pragma unroll
+      for (int qb = 0; qb < MB; ++qb) {
+        // S^T[key][query]: lane owns query column 16 qb + li, keys 16 kb + 4 lg + r
+        f32x4_t st[KB];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[kb], fq[qb], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float s = (16 * kb + 4 * lg + r < N) ? st[kb][r] * a.score_scale : -INFINITY;
+            st[kb][r] = s;
+            mx = fmaxf(mx, s);
+          }
+        }
+        mx = quad_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            st[kb][r] = __builtin_amdgcn_exp2f(st[kb][r] - mx);
+            sum += st[kb][r];
+          }
+        sum = quad_sum(sum);
+        f32x4_t ot[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s2 = 0; s2 < KB / 2; ++s2) {
+          const bf16x8_t pp = pack_pair_s(st[2 * s2], st[2 * s2 + 1]);
+#pragma unroll
+          for (int d = 0; d < 2; ++d)
+            ot[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag_s((const lds_char*)vt, 32 * s2, 16 * d, li, lg), pp, ot[d], 0, 0,
+                                                            0);
+        }
+        const int q = 16 * qb + li;
+        if (q < N) {
+          const float inv = 1.0f / sum;
+#pragma unroll
+          for (int d = 0; d < 2; ++d)
+            store4<bf16>(a.o + (row0 + q) * I + h * 32 + 16 * d + 4 * lg,
+                         make_float4(ot[d][0] * inv, ot[d][1] * inv, ot[d][2] * inv, ot[d][3] * inv));
+          if (lg == 0) a.lse2[(b * H + h) * N + q] = mx + log2f(sum);
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- out-projection + bias, dropout site 0, + residual -> x_mid (fp32)
+  {
+    const uint64_t key = a.dr0.thresh16 ? drop_key(a.dr0) : 0;
+    small_gemm<MB, I32, NW>(a.o, row0, N, a.wo, D, wave, li, lg, [&](int cb, f32x4_t(&acc)[MB]) {
+      const int n = cb * 16 + 4 * lg;
+      const float4 bj = *reinterpret_cast<const float4*>(a.b_out + n);
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        const int r = 16 * i + li;
+        if (r >= N) continue;
+        const int64_t row = row0 + r;
+        float4 df = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (a.dr0.thresh16) df = drop_factor4(a.dr0, key, (uint64_t)row * D + n);
+        const float4 x = *reinterpret_cast<const float4*>(a.x_in + row * D + n);
+        *reinterpret_cast<float4*>(a.x_mid + row * D + n) =
+            make_float4((acc[i][0] + bj.x) * df.x + x.x, (acc[i][1] + bj.y) * df.y + x.y, (acc[i][2] + bj.z) * df.z + x.z,
+                        (acc[i][3] + bj.w) * df.w + x.w);
+      }
+    });
+  }
+  __syncthreads();
+
+  // ---- LN2
+  small_ln<D32, NW>(a.x_mid, a.ln2_w, a.ln2_b, a.h2, a.mean2, a.rstd2, row0, N, a.eps, wave, lane);
+  __syncthreads();
+
+  // ---- MLP1 + bias -> u (saved, unmasked), Dropout(GELU(u)) -> g
+  {
+    const uint64_t key = a.dr1.thresh16 ? drop_key(a.dr1) : 0;
+    small_gemm<MB, D32, NW>(a.h2, row0, N, a.w1, M, wave, li, lg, [&](int cb, f32x4_t(&acc)[MB]) {
+      const int n = cb * 16 + 4 * lg;
+      const float4 bj = *reinterpret_cast<const float4*>(a.b1 + n);
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        const int r = 16 * i + li;
+        if (r >= N) continue;
+        const int64_t row = row0 + r;
+        const float v0 = acc[i][0] + bj.x, v1 = acc[i][1] + bj.y, v2 = acc[i][2] + bj.z, v3 = acc[i][3] + bj.w;
+        store4<bf16>(a.u + row * M + n, make_float4(v0, v1, v2, v3));
+        float4 df = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (a.dr1.thresh16) df = drop_factor4(a.dr1, key, (uint64_t)row * M + n);
+        store4<bf16>(a.g + row * M + n, make_float4(gelu_tanh_fast(v0) * df.x, gelu_tanh_fast(v1) * df.y,
+                                                    gelu_tanh_fast(v2) * df.z, gelu_tanh_fast(v3) * df.w));
+      }
+    });
+  }
+  __syncthreads();
+
+  // ---- MLP2 + bias, dropout site 2, + residual -> x_out (fp32)
+  {
+    const uint64_t key = a.dr2.thresh16 ? drop_key(a.dr2) : 0;
+    small_gemm<MB, M32, NW>(a.g, row0, N, a.w2, D, wave, li, lg, [&](int cb, f32x4_t(&acc)[MB]) {
+      const int n = cb * 16 + 4 * lg;
+      const float4 bj = *reinterpret_cast<const float4*>(a.b2 + n);
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        const int r = 16 * i + li;
+        if (r >= N) continue;
+        const int64_t row = row0 + r;
+        float4 df = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (a.dr2.thresh16) df = drop_factor4(a.dr2, key, (uint64_t)row * D + n);
+        const float4 x = *reinterpret_cast<const float4*>(a.x_mid + row * D + n);
+        *reinterpret_cast<float4*>(a.x_out + row * D + n) =
+            make_float4((acc[i][0] + bj.x) * df.x + x.x, (acc[i][1] + bj.y) * df.y + x.y, (acc[i][2] + bj.z) * df.z + x.z,
+                        (acc[i][3] + bj.w) * df.w + x.w);
+      }
+    });
+  }
+}
+
+template <int D32, int I32, int M32>
+int launch_small(const SmallArgs& a, int B, hipStream_t s) {
+  // one 16-row block, 16 wavefronts.  (The kernel is written for up to four row blocks, but measured on B=4 x 64 tokens
+  // - BASELINE's C1 - the single launch is SLOWER than the seven per-operator ones under graph replay, 0.31 vs 0.25 ms per
+  // step: with few clips the per-operator kernels spread over more CUs.  So only the 12-token shapes take this path.)
+  AVF_REQUIRE(a.N <= 16, "layer_fwd_small: at most 16 tokens");
+  layer_fwd_small_kernel<1, D32, I32, M32, 16><<<B, 1024, 0, s>>>(a);
+  return check_launch("layer_fwd_small_kernel");
+}
+
+}  // namespace
+
+// shapes the single-launch forward covers (AVF_LAYER_SMALL=0 turns it off: tuning / A-B aid)
+bool small_layer_ok(int dtype, int tokens, int dim, int heads, int dim_head, int mlp_dim) {
+  static const int on = [] {
+    const char* e = getenv("AVF_LAYER_SMALL");
+    return e ? atoi(e) : 1;
+  }();
+  const int inner = heads * dim_head;
+  auto ok = [](int v) { return v == 128 || v == 256; };
+  return on && dtype == AVF_BF16 && dim_head == 32 && tokens >= 1 && tokens <= 16 && ok(dim) && ok(inner) && ok(mlp_dim);
+}
+
+int layer_fwd_small(int B, int N, int D, int H, int M, float eps, float score_scale, const avf_layer_params* p,
+                    const void* wqkv, const void* wo, const void* w1, const void* w2, const float* x_in, float* x_out,
+                    void* h1, float* mean1, float* rstd1, void* qkv, void* o, float* lse2, float* x_mid, void* h2,
+                    float* mean2, float* rstd2, void* u, void* g, const DropCfg& dr0, const DropCfg& dr1,
+                    const DropCfg& dr2, hipStream_t s) {
+  SmallArgs a;
+  a.x_in = x_in; a.x_out = x_out;
+  a.ln1_w = p->ln1_w; a.ln1_b = p->ln1_b; a.b_out = p->b_out; a.ln2_w = p->ln2_w; a.ln2_b = p->ln2_b; a.b1 = p->b1; a.b2 = p->b2;
+  a.wqkv = (const bf16*)wqkv; a.wo = (const bf16*)wo; a.w1 = (const bf16*)w1; a.w2 = (const bf16*)w2;
+  a.h1 = (bf16*)h1; a.qkv = (bf16*)qkv; a.o = (bf16*)o; a.h2 = (bf16*)h2; a.u = (bf16*)u; a.g = (bf16*)g;
+  a.mean1 = mean1; a.rstd1 = rstd1; a.lse2 = lse2; a.x_mid = x_mid; a.mean2 = mean2; a.rstd2 = rstd2;
+  a.N = N; a.H = H; a.eps = eps; a.score_scale = score_scale;
+  a.dr0 = dr0; a.dr1 = dr1; a.dr2 = dr2;
+  const int I = H * 32;
+  AVF_REQUIRE(((uintptr_t)x_in & 15) == 0 && ((uintptr_t)x_out & 15) == 0, "layer_fwd_small: misaligned activations");
+#define AVF_SMALL(DD, II, MM) \
+  if (D == DD * 32 && I == II * 32 && M == MM * 32) return launch_small<DD, II, MM>(a, B, s)
+  AVF_SMALL(4, 4, 4); AVF_SMALL(4, 4, 8); AVF_SMALL(4, 8, 4); AVF_SMALL(4, 8, 8);
+  AVF_SMALL(8, 4, 4); AVF_SMALL(8, 4, 8); AVF_SMALL(8, 8, 4); AVF_SMALL(8, 8, 8);
+#undef AVF_SMALL
+  AVF_REQUIRE(false, "layer_fwd_small: unsupported shape D=%d I=%d M=%d", D, I, M);
+}
+
+}  // namespace avf

@@ -58,7 +58,11 @@ CONFIGS = {
     "c1": (4, 64, 128, 2, 8, 32, 256),
     "odd_tokens": (3, 77, 256, 1, 8, 32, 512),
     "tformer_real": (5, 17, 512, 3, 8, 64, 1024),
-    "au_head_real": (6, 12, 256, 3, 8, 32, 256),
+    "au_head_real": (6, 12, 256, 3, 8, 32, 256),          # <= 16 tokens, dim_head 32: the single-launch forward (bf16)
+    "au_former_real": (5, 12, 128, 2, 8, 32, 256),        # AU_former.corr_transformer (heads.py:277), same path
+    "small_16_tokens": (3, 16, 128, 1, 4, 32, 128),       # full 16-row block, 4 heads, mlp 128
+    "small_1_token": (2, 1, 256, 2, 8, 32, 128),          # a single token per clip
+    "small_7_tokens_dh32_h4": (70, 7, 128, 1, 4, 32, 256),  # more clips than a first wave of workgroups fills
     "c2_small_batch": (4, 324, 512, 6, 8, 64, 1024),
     "c4_model_short": (2, 200, 768, 2, 12, 64, 1536),   # BASELINE.json configs[3] model (d=768, 12 heads), short clip
     "wide_tformer": (3, 17, 1536, 1, 8, 64, 1024),       # tformer.py:301 TFormer(dim=128*12): D=1536, I=512
