@@ -5,17 +5,14 @@
 // microseconds of work each.  Here ONE workgroup (8 or 16 wavefronts) per clip runs the whole layer - LN1, QKV, attention,
 // out-projection + residual, LN2, MLP1 + GELU, MLP2 + residual (heads.py:246-255) - writing exactly the saved-activation
 // block the per-operator backward reads (h1, stats, qkv, o, lse2, x_mid, h2, stats, u, g), so backward is unchanged.
-// Activations travel between the phases through those global buffers (L2-resident: a clip's block is a few hundred KB)
-// with a workgroup barrier between phases; the GEMMs keep the clip's A rows in registers (<= 64 rows x K <= 256) and read
-// the bf16 weight images straight from L2 as MFMA operands - no LDS staging at all; LDS only holds each head's V for the
-// transposed fragment reads.  Same arithmetic as the per-operator path (bf16 MFMA, fp32 accumulate / LayerNorm / softmax,
+// Between the phases (a workgroup barrier each) the clip's activations stay in LDS (<= 60 KB) and are ALSO stored into the
+// saved block; the GEMMs keep the clip's A rows in registers and read the bf16 weight images straight from L2 as MFMA
+// operands (no LDS staging of weights).  Same arithmetic as the per-operator path (bf16 MFMA, fp32 accumulate / LayerNorm / softmax,
 // counter-based dropout with the same element indices), except that the softmax is single-pass (all keys at once).
 //
 // Eligibility (small_layer_ok): bf16, dim_head 32, tokens <= 16, dim / inner / mlp_dim in {128, 256} - the reference's
 // AU_former / former_AU_head stacks.  Measured on the real avformer head model (B=64, 12 tokens, three stacks): -3 % per
-// step under hipGraph replay (0.97 vs 1.00 ms), -5..10 % in the host-bound eager loop (42 fewer launches per step).  The
-// phases are latency-bound chains through L2 (store -> barrier -> load), so the gain is the launch overhead only; keeping
-// the clip's activations in LDS between the phases is the next step.
+// step under hipGraph replay, -5..10 % in the host-bound eager loop (42 fewer launches per step).
 #include "common.hpp"
 
 namespace avf {
@@ -26,7 +23,6 @@ typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 
 constexpr float LOG2E_S = 1.4426950408889634f;
-constexpr int VLD = 32 * 2 + 32;  // bytes per staged V row (dim_head 32) + 32 B: conflict-free transposed reads
 
 struct SmallArgs {
   const float* x_in;
@@ -52,10 +48,11 @@ __device__ __forceinline__ bf16x8_t pack_pair_s(const f32x4_t& a, const f32x4_t&
   return __builtin_bit_cast(bf16x8_t, r);
 }
 
+template <int LD>  // LD: row stride in bytes of the image the fragment is read from
 __device__ __forceinline__ bf16x8_t tr_frag_s(const lds_char* tile, int row_base, int col_base, int li, int lg) {
-  const lds_char* p0 = tile + (row_base + 4 * lg + (li >> 2)) * VLD + (col_base + 4 * (li & 3)) * 2;
+  const lds_char* p0 = tile + (row_base + 4 * lg + (li >> 2)) * LD + (col_base + 4 * (li & 3)) * 2;
   s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
-  s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0 + 16 * VLD));
+  s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0 + 16 * LD));
   s16x8_t r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8_t, r);
 }
@@ -70,10 +67,13 @@ __device__ __forceinline__ float quad_sum(float v) {
   return v + __shfl_xor(v, 32, 64);
 }
 
-// LayerNorm of the clip's rows: wave w takes rows w, w+NW, ...; D = 128 or 256 (one or two float4 per lane... D/4 <= 64)
-template <int D32, int NW>
-__device__ __forceinline__ void small_ln(const float* x, const float* gamma, const float* beta, bf16* y, float* mean,
-                                         float* rstd, int64_t row0, int N, float eps, int wave, int lane) {
+// LayerNorm of the clip's rows: wave w takes rows w, w+NW, ... of the R-row block; x is fp32 with row stride ldx (global
+// or LDS); the bf16 result goes to the LDS operand buffer ylds (row stride ldy elements; rows past N are zeroed, so that
+// everything computed from them stays finite) and, for the rows of the clip, to the saved block in global memory.
+template <int D32, int NW, int R>
+__device__ __forceinline__ void small_ln(const float* x, int64_t ldx, const float* gamma, const float* beta, bf16* ylds,
+                                         int ldy, bf16* ysave, float* mean, float* rstd, int64_t row0, int N, float eps,
+                                         int wave, int lane) {
   constexpr int D = D32 * 32;
   const int c = lane * 4;
   const bool act = c < D;
@@ -82,10 +82,13 @@ __device__ __forceinline__ void small_ln(const float* x, const float* gamma, con
     g = *reinterpret_cast<const float4*>(gamma + c);
     b = *reinterpret_cast<const float4*>(beta + c);
   }
-  for (int r = wave; r < N; r += NW) {
-    const int64_t row = row0 + r;
+  for (int r = wave; r < R; r += NW) {
+    if (r >= N) {
+      if (act) store4<bf16>(ylds + r * ldy + c, make_float4(0.f, 0.f, 0.f, 0.f));
+      continue;
+    }
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (act) v = *reinterpret_cast<const float4*>(x + row * D + c);
+    if (act) v = *reinterpret_cast<const float4*>(x + r * ldx + c);
     const float mu = wave_sum((v.x + v.y) + (v.z + v.w)) / (float)D;
     float q = 0.f;
     if (act) {
@@ -94,29 +97,30 @@ __device__ __forceinline__ void small_ln(const float* x, const float* gamma, con
     }
     const float rs = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
     if (lane == 0) {
-      mean[row] = mu;
-      rstd[row] = rs;
+      mean[row0 + r] = mu;
+      rstd[row0 + r] = rs;
     }
-    if (act)
-      store4<bf16>(y + row * D + c, make_float4((v.x - mu) * rs * g.x + b.x, (v.y - mu) * rs * g.y + b.y,
-                                                (v.z - mu) * rs * g.z + b.z, (v.w - mu) * rs * g.w + b.w));
+    if (act) {
+      const float4 y = make_float4((v.x - mu) * rs * g.x + b.x, (v.y - mu) * rs * g.y + b.y, (v.z - mu) * rs * g.z + b.z,
+                                   (v.w - mu) * rs * g.w + b.w);
+      store4<bf16>(ylds + r * ldy + c, y);
+      store4<bf16>(ysave + (row0 + r) * D + c, y);
+    }
   }
 }
 
-// C[rows of the clip, Nout] = A[rows, K] W[Nout, K]^T; the clip's A fragments stay in registers, wave w takes the
-// 16-column blocks w, w+NW, ...; epi(cb, acc): lane holds C[16 i + li][16 cb + 4 lg + 0..3] in acc[i]
+// C[R rows, Nout] = A[R, K] W[Nout, K]^T; A comes from an LDS operand buffer (row stride lda elements) and stays in
+// registers, wave w takes the 16-column blocks w, w+NW, ...; epi(cb, acc): lane holds C[16 i + li][16 cb + 4 lg + 0..3]
 template <int MB, int K32, int NW, typename Epi>
-__device__ __forceinline__ void small_gemm(const bf16* A, int64_t row0, int N, const bf16* W, int Nout, int wave, int li, int lg,
+__device__ __forceinline__ void small_gemm(const bf16* A, int lda, const bf16* W, int Nout, int wave, int li, int lg,
                                            Epi&& epi) {
   constexpr int K = K32 * 32;
   bf16x8_t fa[MB][K32];
 #pragma unroll
-  for (int i = 0; i < MB; ++i) {
-    int r = 16 * i + li;
-    r = r < N ? r : N - 1;
+  for (int i = 0; i < MB; ++i)
 #pragma unroll
-    for (int ks = 0; ks < K32; ++ks) fa[i][ks] = ldg_frag(A + (row0 + r) * K + ks * 32 + 8 * lg);
-  }
+    for (int ks = 0; ks < K32; ++ks)
+      fa[i][ks] = *reinterpret_cast<const bf16x8_t*>(A + (16 * i + li) * lda + ks * 32 + 8 * lg);
   // the weight fragments of a column block are all requested before its first MFMA, and the next block's while this one
   // computes (the loop is latency-bound: a few MFMAs per L2 round trip)
   bf16x8_t fb[K32], fn[K32];
@@ -148,103 +152,100 @@ __device__ __forceinline__ void small_gemm(const bf16* A, int64_t row0, int N, c
   }
 }
 
-// NW wavefronts per clip: 16 for <= 16 tokens (the GEMM column blocks, LayerNorm rows and heads spread over more waves:
-// the kernel is a chain of latency-bound phases), 8 otherwise (register budget of the A fragments)
+// NW wavefronts per clip (the GEMM column blocks, LayerNorm rows and heads spread over the waves: the kernel is a chain of
+// latency-bound phases).  Between the phases the clip's activations stay in LDS - operand buffer (h1 -> o -> h2), qkv,
+// x_mid (fp32), g - and every phase ALSO stores its result into the saved-activation block for backward; only the weight
+// images and the layer input come from global memory.
 template <int MB, int D32, int I32, int M32, int NW>
 __global__ __launch_bounds__(NW * 64) void layer_fwd_small_kernel(SmallArgs a) {
-  constexpr int D = D32 * 32, I = I32 * 32, M = M32 * 32;
-  constexpr int KB = 2 * ((MB + 1) / 2);  // key blocks of 16, padded to pairs (one MFMA k-step = 32 keys)
-  __shared__ __attribute__((aligned(16))) char vstage[NW][KB * 16 * VLD];
+  constexpr int D = D32 * 32, I = I32 * 32, M = M32 * 32, R = MB * 16;
+  constexpr int KB = 2 * ((MB + 1) / 2);   // key blocks of 16, padded to pairs (one MFMA k-step = 32 keys)
+  constexpr int RK = KB * 16;              // rows of the qkv buffer (>= R)
+  constexpr int AMAX = (D > I ? D : I);    // widest operand that lives in abuf (h1, o, h2)
+  constexpr int LDA = AMAX + 8, LDG = M + 8, LDQ = 3 * I + 16, LDX = D + 4;  // row strides: +16 B (bf16) keeps the 16-row
+  // fragment reads conflict-free; +32 B on the qkv rows does the same for the transposed V reads
+  __shared__ __attribute__((aligned(16))) bf16 abuf[R * LDA];
+  __shared__ __attribute__((aligned(16))) bf16 gbuf[R * LDG];
+  __shared__ __attribute__((aligned(16))) bf16 qbuf[RK * LDQ];
+  __shared__ __attribute__((aligned(16))) float xmid[R * LDX];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lg = lane >> 4;
   const int N = a.N, H = a.H;
   const int64_t b = blockIdx.x, row0 = b * N;
 
+  // rows of the qkv buffer beyond the row blocks the GEMM writes (odd MB): V must be finite there
+  for (int e = tid; e < (RK - R) * LDQ / 8; e += NW * 64) reinterpret_cast<uint4*>(qbuf + R * LDQ)[e] = make_uint4(0, 0, 0, 0);
+
   // ---- LN1
-  small_ln<D32, NW>(a.x_in, a.ln1_w, a.ln1_b, a.h1, a.mean1, a.rstd1, row0, N, a.eps, wave, lane);
+  small_ln<D32, NW, R>(a.x_in + row0 * D, D, a.ln1_w, a.ln1_b, abuf, LDA, a.h1, a.mean1, a.rstd1, row0, N, a.eps, wave, lane);
   __syncthreads();
 
   // ---- QKV projection (no bias)
-  small_gemm<MB, D32, NW>(a.h1, row0, N, a.wqkv, 3 * I, wave, li, lg, [&](int cb, f32x4_t(&acc)[MB]) {
+  small_gemm<MB, D32, NW>(abuf, LDA, a.wqkv, 3 * I, wave, li, lg, [&](int cb, f32x4_t(&acc)[MB]) {
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
       const int r = 16 * i + li;
-      if (r < N)
-        store4<bf16>(a.qkv + (row0 + r) * (3 * I) + cb * 16 + 4 * lg, make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]));
+      const float4 v = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+      store4<bf16>(qbuf + r * LDQ + cb * 16 + 4 * lg, v);
+      if (r < N) store4<bf16>(a.qkv + (row0 + r) * (3 * I) + cb * 16 + 4 * lg, v);
     }
   });
   __syncthreads();
 
-  // ---- attention: wave w takes heads w, w+NW, ...; single-pass softmax over the clip's keys
-  {
-    char* vt = vstage[wave];
-    for (int h = wave; h < H; h += NW) {
-      const bf16* qb_ = a.qkv + row0 * (3 * I) + h * 32;
-      // stage V of this head: rows past N are zero (their probabilities are zero, but 0 * garbage must not be NaN)
-      for (int e = lane; e < KB * 16 * 4; e += 64) {
-        const int r = e >> 2, c = e & 3;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (r < N) v = *reinterpret_cast<const uint4*>(qb_ + (int64_t)r * (3 * I) + 2 * I + c * 8);
-        *reinterpret_cast<uint4*>(vt + r * VLD + c * 16) = v;
-      }
-      bf16x8_t fq[MB], fk[KB];
+  // ---- attention: wave w takes heads w, w+NW, ...; single-pass softmax over the clip's keys; o -> abuf (h1 is dead)
+  for (int h = wave; h < H; h += NW) {
+    const bf16* qh = qbuf + h * 32;
+    bf16x8_t fq[MB], fk[KB];
 #pragma unroll
-      for (int i = 0; i < MB; ++i) {
-        int r = 16 * i + li;
-        r = r < N ? r : N - 1;
-        fq[i] = ldg_frag(qb_ + (int64_t)r * (3 * I) + 8 * lg);
-      }
+    for (int i = 0; i < MB; ++i) fq[i] = *reinterpret_cast<const bf16x8_t*>(qh + (16 * i + li) * LDQ + 8 * lg);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) fk[kb] = *reinterpret_cast<const bf16x8_t*>(qh + (16 * kb + li) * LDQ + I + 8 * lg);
+#pragma unroll
+    for (int qb = 0; qb < MB; ++qb) {
+      // S^T[key][query]: lane owns query column 16 qb + li, keys 16 kb + 4 lg + r
+      f32x4_t st[KB];
+      float mx = -INFINITY;
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
-        int r = 16 * kb + li;
-        r = r < N ? r : N - 1;
-        fk[kb] = ldg_frag(qb_ + (int64_t)r * (3 * I) + I + 8 * lg);
+        st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[kb], fq[qb], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float sc = (16 * kb + 4 * lg + r < N) ? st[kb][r] * a.score_scale : -INFINITY;
+          st[kb][r] = sc;
+          mx = fmaxf(mx, sc);
+        }
       }
+      mx = quad_max(mx);
+      float sum = 0.f;
 #pragma unroll
-      for (int qb = 0; qb < MB; ++qb) {
-        // S^T[key][query]: lane owns query column 16 qb + li, keys 16 kb + 4 lg + r
-        f32x4_t st[KB];
-        float mx = -INFINITY;
+      for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-          st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[kb], fq[qb], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float s = (16 * kb + 4 * lg + r < N) ? st[kb][r] * a.score_scale : -INFINITY;
-            st[kb][r] = s;
-            mx = fmaxf(mx, s);
-          }
+        for (int r = 0; r < 4; ++r) {
+          st[kb][r] = __builtin_amdgcn_exp2f(st[kb][r] - mx);
+          sum += st[kb][r];
         }
-        mx = quad_max(mx);
-        float sum = 0.f;
+      sum = quad_sum(sum);
+      f32x4_t ot[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
+      for (int s2 = 0; s2 < KB / 2; ++s2) {
+        const bf16x8_t pp = pack_pair_s(st[2 * s2], st[2 * s2 + 1]);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            st[kb][r] = __builtin_amdgcn_exp2f(st[kb][r] - mx);
-            sum += st[kb][r];
-          }
-        sum = quad_sum(sum);
-        f32x4_t ot[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        for (int d = 0; d < 2; ++d)
+          ot[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              tr_frag_s<LDQ * 2>((const lds_char*)(qh + 2 * I), 32 * s2, 16 * d, li, lg), pp, ot[d], 0, 0, 0);
+      }
+      const int q = 16 * qb + li;
+      const float inv = 1.0f / sum;
 #pragma unroll
-        for (int s2 = 0; s2 < KB / 2; ++s2) {
-          const bf16x8_t pp = pack_pair_s(st[2 * s2], st[2 * s2 + 1]);
-#pragma unroll
-          for (int d = 0; d < 2; ++d)
-            ot[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag_s((const lds_char*)vt, 32 * s2, 16 * d, li, lg), pp, ot[d], 0, 0,
-                                                            0);
-        }
-        const int q = 16 * qb + li;
+      for (int d = 0; d < 2; ++d) {
+        const float4 v = make_float4(ot[d][0] * inv, ot[d][1] * inv, ot[d][2] * inv, ot[d][3] * inv);
         if (q < N) {
-          const float inv = 1.0f / sum;
-#pragma unroll
-          for (int d = 0; d < 2; ++d)
-            store4<bf16>(a.o + (row0 + q) * I + h * 32 + 16 * d + 4 * lg,
-                         make_float4(ot[d][0] * inv, ot[d][1] * inv, ot[d][2] * inv, ot[d][3] * inv));
-          if (lg == 0) a.lse2[(b * H + h) * N + q] = mx + log2f(sum);
+          store4<bf16>(abuf + q * LDA + h * 32 + 16 * d + 4 * lg, v);
+          store4<bf16>(a.o + (row0 + q) * I + h * 32 + 16 * d + 4 * lg, v);
         }
       }
+      if (q < N && lg == 0) a.lse2[(b * H + h) * N + q] = mx + log2f(sum);
     }
   }
   __syncthreads();
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(NW * 64) void layer_fwd_small_kernel(SmallArgs a) {
   // ---- out-projection + bias, dropout site 0, + residual -> x_mid (fp32)
   {
     const uint64_t key = a.dr0.thresh16 ? drop_key(a.dr0) : 0;
-    small_gemm<MB, I32, NW>(a.o, row0, N, a.wo, D, wave, li, lg, [&](int cb, f32x4_t(&acc)[MB]) {
+    small_gemm<MB, I32, NW>(abuf, LDA, a.wo, D, wave, li, lg, [&](int cb, f32x4_t(&acc)[MB]) {
       const int n = cb * 16 + 4 * lg;
       const float4 bj = *reinterpret_cast<const float4*>(a.b_out + n);
 #pragma unroll
@@ -263,35 +264,39 @@ __global__ __launch_bounds__(NW * 64) void layer_fwd_small_kernel(SmallArgs a) {
         float4 df = make_float4(1.f, 1.f, 1.f, 1.f);
         if (a.dr0.thresh16) df = drop_factor4(a.dr0, key, (uint64_t)row * D + n);
         const float4 x = *reinterpret_cast<const float4*>(a.x_in + row * D + n);
-        *reinterpret_cast<float4*>(a.x_mid + row * D + n) =
-            make_float4((acc[i][0] + bj.x) * df.x + x.x, (acc[i][1] + bj.y) * df.y + x.y, (acc[i][2] + bj.z) * df.z + x.z,
-                        (acc[i][3] + bj.w) * df.w + x.w);
+        const float4 v = make_float4((acc[i][0] + bj.x) * df.x + x.x, (acc[i][1] + bj.y) * df.y + x.y,
+                                     (acc[i][2] + bj.z) * df.z + x.z, (acc[i][3] + bj.w) * df.w + x.w);
+        *reinterpret_cast<float4*>(xmid + r * LDX + n) = v;
+        *reinterpret_cast<float4*>(a.x_mid + row * D + n) = v;
       }
     });
   }
   __syncthreads();
 
-  // ---- LN2
-  small_ln<D32, NW>(a.x_mid, a.ln2_w, a.ln2_b, a.h2, a.mean2, a.rstd2, row0, N, a.eps, wave, lane);
+  // ---- LN2 (o in abuf is dead: h2 takes its place)
+  small_ln<D32, NW, R>(xmid, LDX, a.ln2_w, a.ln2_b, abuf, LDA, a.h2, a.mean2, a.rstd2, row0, N, a.eps, wave, lane);
   __syncthreads();
 
   // ---- MLP1 + bias -> u (saved, unmasked), Dropout(GELU(u)) -> g
   {
     const uint64_t key = a.dr1.thresh16 ? drop_key(a.dr1) : 0;
-    small_gemm<MB, D32, NW>(a.h2, row0, N, a.w1, M, wave, li, lg, [&](int cb, f32x4_t(&acc)[MB]) {
+    small_gemm<MB, D32, NW>(abuf, LDA, a.w1, M, wave, li, lg, [&](int cb, f32x4_t(&acc)[MB]) {
       const int n = cb * 16 + 4 * lg;
       const float4 bj = *reinterpret_cast<const float4*>(a.b1 + n);
 #pragma unroll
       for (int i = 0; i < MB; ++i) {
         const int r = 16 * i + li;
-        if (r >= N) continue;
-        const int64_t row = row0 + r;
+        const int64_t row = row0 + (r < N ? r : 0);
         const float v0 = acc[i][0] + bj.x, v1 = acc[i][1] + bj.y, v2 = acc[i][2] + bj.z, v3 = acc[i][3] + bj.w;
-        store4<bf16>(a.u + row * M + n, make_float4(v0, v1, v2, v3));
         float4 df = make_float4(1.f, 1.f, 1.f, 1.f);
         if (a.dr1.thresh16) df = drop_factor4(a.dr1, key, (uint64_t)row * M + n);
-        store4<bf16>(a.g + row * M + n, make_float4(gelu_tanh_fast(v0) * df.x, gelu_tanh_fast(v1) * df.y,
-                                                    gelu_tanh_fast(v2) * df.z, gelu_tanh_fast(v3) * df.w));
+        const float4 gv = make_float4(gelu_tanh_fast(v0) * df.x, gelu_tanh_fast(v1) * df.y, gelu_tanh_fast(v2) * df.z,
+                                      gelu_tanh_fast(v3) * df.w);
+        store4<bf16>(gbuf + r * LDG + n, gv);  // rows past N: finite values nobody stores
+        if (r < N) {
+          store4<bf16>(a.u + row * M + n, make_float4(v0, v1, v2, v3));
+          store4<bf16>(a.g + row * M + n, gv);
+        }
       }
     });
   }
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(NW * 64) void layer_fwd_small_kernel(SmallArgs a) {
   // ---- MLP2 + bias, dropout site 2, + residual -> x_out (fp32)
   {
     const uint64_t key = a.dr2.thresh16 ? drop_key(a.dr2) : 0;
-    small_gemm<MB, M32, NW>(a.g, row0, N, a.w2, D, wave, li, lg, [&](int cb, f32x4_t(&acc)[MB]) {
+    small_gemm<MB, M32, NW>(gbuf, LDG, a.w2, D, wave, li, lg, [&](int cb, f32x4_t(&acc)[MB]) {
       const int n = cb * 16 + 4 * lg;
       const float4 bj = *reinterpret_cast<const float4*>(a.b2 + n);
 #pragma unroll
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(NW * 64) void layer_fwd_small_kernel(SmallArgs a) {
         const int64_t row = row0 + r;
         float4 df = make_float4(1.f, 1.f, 1.f, 1.f);
         if (a.dr2.thresh16) df = drop_factor4(a.dr2, key, (uint64_t)row * D + n);
-        const float4 x = *reinterpret_cast<const float4*>(a.x_mid + row * D + n);
+        const float4 x = *reinterpret_cast<const float4*>(xmid + r * LDX + n);
         *reinterpret_cast<float4*>(a.x_out + row * D + n) =
             make_float4((acc[i][0] + bj.x) * df.x + x.x, (acc[i][1] + bj.y) * df.y + x.y, (acc[i][2] + bj.z) * df.z + x.z,
                         (acc[i][3] + bj.w) * df.w + x.w);
