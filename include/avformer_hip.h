@@ -163,6 +163,12 @@ int avf_layer_adam_step(const avf_layer_cfg* cfg, const avf_layer_params* p, con
                         const avf_layer_grads* exp_avg, const avf_layer_grads* exp_avg_sq, void* lowp, float lr,
                         float beta1, float beta2, float eps, float weight_decay, const float* step, void* stream);
 
+/* the same for `layers` consecutive layers of one stack (arrays of `layers` structs, lowp[l] per layer): three layers per
+ * launch */
+int avf_stack_adam_step(const avf_layer_cfg* cfg, int layers, const avf_layer_params* p, const avf_layer_grads* g,
+                        const avf_layer_grads* exp_avg, const avf_layer_grads* exp_avg_sq, void* const* lowp, float lr,
+                        float beta1, float beta2, float eps, float weight_decay, const float* step, void* stream);
+
 /* the same Adam update for `count` arbitrary fp32 tensors (host arrays of device pointers and element counts): the
  * parameters around the stacks (positional embedding, AU head).  A tensor whose gradient pointer is null is skipped. */
 int avf_adam_step_tensors(int count, float* const* p, const float* const* g, float* const* exp_avg,

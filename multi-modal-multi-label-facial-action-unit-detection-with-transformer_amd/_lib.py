@@ -70,6 +70,8 @@ SIGNATURES = {
                              C.POINTER(LayerPtrs), _vp, _vp]),
     "avf_layer_adam_step": (_int, [C.POINTER(LayerCfg), C.POINTER(LayerPtrs), C.POINTER(LayerPtrs), C.POINTER(LayerPtrs),
                                    C.POINTER(LayerPtrs), _vp, _f, _f, _f, _f, _f, _vp, _vp]),
+    "avf_stack_adam_step": (_int, [C.POINTER(LayerCfg), _int, C.POINTER(LayerPtrs), C.POINTER(LayerPtrs), C.POINTER(LayerPtrs),
+                                   C.POINTER(LayerPtrs), _vp, _f, _f, _f, _f, _f, _vp, _vp]),
     "avf_adam_step_tensors": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _vp, _vp]),
     "avf_dropout_factors": (_int, [C.c_uint32, C.c_uint32, _int, _int, _f, _i64, _int, _vp, _vp]),
     "avf_timing_enable": (_int, [_int]),

@@ -25,7 +25,7 @@ struct AdamDesc {
   int tile0, tiles_c;  // first work item of this tensor, tiles per row of tiles (matrices)
 };
 
-constexpr int ADAM_MAX = 11;
+constexpr int ADAM_MAX = 33;  // three layers per launch (the descriptor table travels as a kernel argument: < 4 KB)
 
 struct AdamBatch {
   AdamDesc d[ADAM_MAX];
@@ -161,15 +161,11 @@ __global__ __launch_bounds__(256) void adam_layer_kernel(AdamBatch b) {
 
 }  // namespace avf
 
-extern "C" int avf_layer_adam_step(const avf_layer_cfg* cfg, const avf_layer_params* p, const avf_layer_grads* g,
-                                   const avf_layer_grads* exp_avg, const avf_layer_grads* exp_avg_sq, void* lowp, float lr,
-                                   float beta1, float beta2, float eps, float weight_decay, const float* step,
-                                   void* stream) {
-  using namespace avf;
-  AVF_REQUIRE(cfg && p && g && exp_avg && exp_avg_sq, "layer_adam_step: null pointer");
-  AVF_REQUIRE(cfg->dim > 0 && cfg->heads > 0 && cfg->dim_head > 0 && cfg->mlp_dim > 0, "layer_adam_step: bad dimensions");
-  AVF_REQUIRE(lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f,
-              "layer_adam_step: bad hyper-parameters");
+namespace avf {
+namespace {
+// append the eleven tensors of one layer to a batch; returns 0 / non-zero
+int adam_add_layer(AdamBatch& b, int& n, int& tiles, const avf_layer_cfg* cfg, const avf_layer_params* p,
+                   const avf_layer_grads* g, const avf_layer_grads* exp_avg, const avf_layer_grads* exp_avg_sq, void* lowp) {
   AVF_REQUIRE(cfg->dtype == AVF_F32 || lowp, "layer_adam_step(bf16): lowp buffer missing");
   const int D = cfg->dim, I = cfg->heads * cfg->dim_head, M = cfg->mlp_dim;
   // the bf16 images in the order avf_layer_lowp_bytes carves them: Wqkv, Wqkv^T, Wo, Wo^T, W1, W1^T, W2, W2^T
@@ -185,9 +181,7 @@ extern "C" int avf_layer_adam_step(const avf_layer_cfg* cfg, const avf_layer_par
     AVF_REQUIRE(off == avf_layer_lowp_bytes(cfg), "layer_adam_step: lowp layout mismatch (%zu vs %zu)", off,
                 avf_layer_lowp_bytes(cfg));
   }
-  AdamBatch b;
-  memset(&b, 0, sizeof(b));
-  int n = 0, tiles = 0;
+  const int first = n;
   auto add = [&](const float* pp, float* gg, float* mm, float* vv, bf16* lo, bf16* t, int R, int C, float lo_scale = 1.0f,
                  int lo_scaled_rows = 0) {
     if (!pp || (!gg && !lo && !t)) return;  // absent tensor, or nothing to do for it
@@ -209,13 +203,45 @@ extern "C" int avf_layer_adam_step(const avf_layer_cfg* cfg, const avf_layer_par
   add(p->ln2_b, g->ln2_b, exp_avg->ln2_b, exp_avg_sq->ln2_b, nullptr, nullptr, 1, D);
   add(p->b1, g->b1, exp_avg->b1, exp_avg_sq->b1, nullptr, nullptr, 1, M);
   add(p->b2, g->b2, exp_avg->b2, exp_avg_sq->b2, nullptr, nullptr, 1, D);
-  if (n == 0) return 0;
-  for (int i = 0; i < n; ++i)
+  for (int i = first; i < n; ++i)
     AVF_REQUIRE(!b.d[i].g || (b.d[i].m && b.d[i].v), "layer_adam_step: exp_avg / exp_avg_sq missing for an updated tensor");
-  b.count = n;
-  b.lr = lr; b.b1 = beta1; b.b2 = beta2; b.eps = eps; b.wd = weight_decay; b.step = step;
-  adam_layer_kernel<<<tiles, 256, 0, (hipStream_t)stream>>>(b);
-  return check_launch("adam_layer_kernel");
+  return 0;
+}
+}  // namespace
+}  // namespace avf
+
+extern "C" int avf_stack_adam_step(const avf_layer_cfg* cfg, int layers, const avf_layer_params* p, const avf_layer_grads* g,
+                                   const avf_layer_grads* exp_avg, const avf_layer_grads* exp_avg_sq, void* const* lowp,
+                                   float lr, float beta1, float beta2, float eps, float weight_decay, const float* step,
+                                   void* stream) {
+  using namespace avf;
+  AVF_REQUIRE(cfg && layers >= 0 && (layers == 0 || (p && g && exp_avg && exp_avg_sq)), "stack_adam_step: null pointer");
+  AVF_REQUIRE(cfg->dim > 0 && cfg->heads > 0 && cfg->dim_head > 0 && cfg->mlp_dim > 0, "stack_adam_step: bad dimensions");
+  AVF_REQUIRE(lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f,
+              "stack_adam_step: bad hyper-parameters");
+  AVF_REQUIRE(cfg->dtype == AVF_F32 || lowp, "stack_adam_step(bf16): lowp buffers missing");
+  constexpr int PER_LAUNCH = ADAM_MAX / 11;
+  for (int l0 = 0; l0 < layers; l0 += PER_LAUNCH) {
+    AdamBatch b;
+    memset(&b, 0, sizeof(b));
+    int n = 0, tiles = 0;
+    for (int l = l0; l < layers && l < l0 + PER_LAUNCH; ++l)
+      AVF_TRY(adam_add_layer(b, n, tiles, cfg, p + l, g + l, exp_avg + l, exp_avg_sq + l, lowp ? lowp[l] : nullptr));
+    if (n == 0) continue;
+    b.count = n;
+    b.lr = lr; b.b1 = beta1; b.b2 = beta2; b.eps = eps; b.wd = weight_decay; b.step = step;
+    adam_layer_kernel<<<tiles, 256, 0, (hipStream_t)stream>>>(b);
+    AVF_TRY(check_launch("adam_layer_kernel"));
+  }
+  return 0;
+}
+
+extern "C" int avf_layer_adam_step(const avf_layer_cfg* cfg, const avf_layer_params* p, const avf_layer_grads* g,
+                                   const avf_layer_grads* exp_avg, const avf_layer_grads* exp_avg_sq, void* lowp, float lr,
+                                   float beta1, float beta2, float eps, float weight_decay, const float* step,
+                                   void* stream) {
+  void* lp[1] = {lowp};
+  return avf_stack_adam_step(cfg, 1, p, g, exp_avg, exp_avg_sq, lp, lr, beta1, beta2, eps, weight_decay, step, stream);
 }
 
 extern "C" int avf_adam_step_tensors(int count, float* const* p, const float* const* g, float* const* exp_avg,

@@ -100,32 +100,39 @@ class FusedAdam(torch.optim.Optimizer):
                     if bf16 and st._lowp_bufs is None:
                         st._lowp(lib, cfg, [p.detach() for p in params], dev, stream)  # allocate (and fill) the copies
                     lr, eps, wd = float(hip_group["lr"]), float(hip_group["eps"]), float(hip_group["weight_decay"])
-                    for l in range(st.depth):
-                        lp = params[l * PARAMS_PER_LAYER:(l + 1) * PARAMS_PER_LAYER]
-                        m, v, mv, vv = self._layer_state(si, l, lp)
-                        # the structs of the stable pointers (parameters, moments) are built once per layer
-                        key = (si, l, "ptrs")
-                        hit = self._flat.get(key)
-                        pptr = tuple(p.data_ptr() for p in lp)
-                        if hit is None or hit[0] != pptr:
-                            hit = (pptr, _lib.LayerPtrs(*pptr), _lib.LayerPtrs(*[t.data_ptr() for t in mv]),
-                                   _lib.LayerPtrs(*[t.data_ptr() for t in vv]))
-                            self._flat[key] = hit
+                    L = st.depth
+                    # ctypes arrays of per-layer structs; the ones of the stable pointers (parameters, moments, bf16
+                    # images) are built once per stack, the gradient one every step
+                    key = (si, "arrays")
+                    pptr = tuple(p.data_ptr() for p in params)
+                    hit = self._flat.get(key)
+                    if hit is None or hit[0] != pptr:
+                        P_, M_, V_ = (_lib.LayerPtrs * L)(), (_lib.LayerPtrs * L)(), (_lib.LayerPtrs * L)()
+                        for l in range(L):
+                            lp = params[l * PARAMS_PER_LAYER:(l + 1) * PARAMS_PER_LAYER]
+                            m, v, mv, vv = self._layer_state(si, l, lp)
+                            P_[l] = _lib.LayerPtrs(*[t.data_ptr() for t in lp])
+                            M_[l] = _lib.LayerPtrs(*[t.data_ptr() for t in mv])
+                            V_[l] = _lib.LayerPtrs(*[t.data_ptr() for t in vv])
                             for p in lp:
                                 self.state[p]["step"] = self._step_dev  # shared device counter (as capturable Adam)
+                        lows = (C.c_void_p * L)(*[(b.data_ptr() if bf16 else None) for b in (st._lowp_bufs or [None] * L)]) \
+                            if bf16 else None
+                        hit = (pptr, P_, M_, V_, lows)
+                        self._flat[key] = hit
+                    G_ = (_lib.LayerPtrs * L)()
+                    keep = []
+                    for l in range(L):
                         gptr = []
-                        keep = []
-                        for p in lp:
+                        for p in params[l * PARAMS_PER_LAYER:(l + 1) * PARAMS_PER_LAYER]:
                             g = p.grad if (p.requires_grad and id(p) in self._owned) else None
                             if g is not None and (g.dtype != torch.float32 or not g.is_contiguous()):
                                 g = g.to(torch.float32).contiguous()
                                 keep.append(g)
                             gptr.append(None if g is None else g.data_ptr())
-                        _lib.check(lib.avf_layer_adam_step(C.byref(cfg), C.byref(hit[1]), C.byref(_lib.LayerPtrs(*gptr)),
-                                                           C.byref(hit[2]), C.byref(hit[3]),
-                                                           _ptr(st._lowp_bufs[l]) if bf16 else None, lr, float(b1), float(b2),
-                                                           eps, wd, _ptr(self._step_dev), stream),
-                                   f"layer_adam_step[{l}]")
+                        G_[l] = _lib.LayerPtrs(*gptr)
+                    _lib.check(lib.avf_stack_adam_step(C.byref(cfg), L, hit[1], G_, hit[2], hit[3], hit[4], lr, float(b1),
+                                                       float(b2), eps, wd, _ptr(self._step_dev), stream), "stack_adam_step")
                     if bf16:
                         st._lowp_ptrs = [p.data_ptr() for p in params]
                         st._lowp_ready = True  # the next forward may skip its weight-preparation pass
