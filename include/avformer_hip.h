@@ -108,6 +108,17 @@ int avf_gemm(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K,
              const void* B, int64_t ldb, void* C, int64_t ldc, int c_dtype, int epilogue, const float* bias,
              const float* residual, int64_t ldres, void* aux, int64_t ldaux, void* workspace, void* stream);
 
+/* MX-FP8 operands (OCP microscaling: e4m3 elements, one E8M0 scale byte per 32 consecutive elements of a row) for the
+ * forward nn.Linear GEMMs (heads.py:191,195,212) on v_mfma_scale_f32_16x16x128_f8f6f4 - BASELINE config 5.
+ *   avf_quant_mx8:   x [rows,cols] (AVF_F32 | AVF_BF16, cols % 32 == 0) -> q [rows,cols] bytes, scales [rows,cols/32] bytes;
+ *                    scale = floor(log2(block amax)) - 8 (+127), q = rne_e4m3(clamp(x * 2^-(scale-127), +-448)).
+ *   avf_gemm_mx8_nt: C[M,N] = A[M,K] * B[N,K]^T from two such images (K % 128 == 0), fp32 accumulate, epilogues
+ *                    AVF_EPI_NONE / BIAS_RES / BIAS_GELU as avf_gemm. */
+int avf_quant_mx8(int dtype, const void* x, int64_t rows, int64_t cols, void* q, void* scales, void* stream);
+int avf_gemm_mx8_nt(int64_t M, int64_t N, int64_t K, const void* a_q, const void* a_scales, const void* b_q,
+                    const void* b_scales, void* C, int64_t ldc, int c_dtype, int epilogue, const float* bias,
+                    const float* residual, int64_t ldres, void* aux, int64_t ldaux, void* stream);
+
 /* Multi-head self-attention core - heads.py:222-237.  qkv [B*N, 3I] (q|k|v, head-major columns),
  * o [B*N, I], lse2 fp32 [B,H,N] = log2-domain log-sum-exp of the scaled scores (saved for backward). */
 int avf_attn_fwd(int dtype, const void* qkv, void* o, float* lse2, int batch, int tokens, int heads,
@@ -196,7 +207,7 @@ int avf_dropout_factors(uint32_t seed_lo, uint32_t seed_hi, int layer_index, int
                         float* out, void* stream);
 
 /* ---- optional HIP-event timing per kernel class (bench.py's roofline line) --------------------------
- * classes: 0 gemm_bf16_nt, 1 gemm_bf16_tn(+fold), 2 gemm_f32, 3 attn_fwd, 4 attn_bwd, 5 layernorm.
+ * classes: 0 gemm_bf16_nt, 1 gemm_bf16_tn(+fold), 2 gemm_f32, 3 attn_fwd, 4 attn_bwd, 5 layernorm, 6 other, 7 gemm_mx8_nt.
  * enable(1) resets the records; read() synchronises the recorded events and sums them. */
 int avf_timing_enable(int on);
 int avf_timing_read(int cls, double* total_ms, int64_t* launches, double* flops, double* bytes);

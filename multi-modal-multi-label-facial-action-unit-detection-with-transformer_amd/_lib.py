@@ -52,6 +52,9 @@ SIGNATURES = {
     "avf_gemm_workspace_bytes": (_sz, [_int, _int, _int, _i64, _i64, _i64]),
     "avf_gemm": (_int, [_int, _int, _int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _int, _int, _vp, _vp,
                         _i64, _vp, _i64, _vp, _vp]),
+    "avf_quant_mx8": (_int, [_int, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "avf_gemm_mx8_nt": (_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _i64, _vp, _i64,
+                               _vp]),
     "avf_attn_fwd": (_int, [_int, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     "avf_attn_bwd_workspace_bytes": (_sz, [_int, _int, _int, _int]),
     "avf_attn_bwd": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
@@ -127,7 +130,7 @@ def load(build_if_missing: bool = True):
     return _lib
 
 
-KERNEL_CLASSES = ("gemm_bf16_nt", "gemm_bf16_tn", "gemm_f32", "attn_fwd", "attn_bwd", "layernorm")
+KERNEL_CLASSES = ("gemm_bf16_nt", "gemm_bf16_tn", "gemm_f32", "attn_fwd", "attn_bwd", "layernorm", "other", "gemm_mx8_nt")
 
 
 def timing_enable(on: bool):

@@ -33,7 +33,7 @@ int check_launch(const char* what);
 // optional per-kernel-class HIP-event timing (bench.py's roofline line); off by default
 // ---------------------------------------------------------------------------------------------
 enum KernelClass {
-  KC_GEMM_BF16_NT = 0, KC_GEMM_BF16_TN, KC_GEMM_F32, KC_ATTN_FWD, KC_ATTN_BWD, KC_LAYERNORM, KC_OTHER, KC_COUNT
+  KC_GEMM_BF16_NT = 0, KC_GEMM_BF16_TN, KC_GEMM_F32, KC_ATTN_FWD, KC_ATTN_BWD, KC_LAYERNORM, KC_OTHER, KC_GEMM_MX8_NT, KC_COUNT
 };
 struct TimingScope {  // records a start/stop event pair around the launches issued during its lifetime
   int slot;
@@ -53,6 +53,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;  // MFMA A/B fragme
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // MFMA 16x16 accumulator
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
 
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
@@ -66,6 +67,35 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
   const f32x2_t v = {lo, hi};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+
+// MX-FP8 block encoder (OCP microscaling v1.0, e4m3 elements): the 4 lanes 4k .. 4k+3 hold 8 consecutive elements
+// each of one 32-element block and must all be active.  scale = E8M0 byte of 2^(floor(log2 amax) - 8); elements are
+// x * 2^-(scale-127), clamped to +-448, rounded to nearest even by v_cvt_pk_fp8_f32.
+struct MxBlock {
+  uint2 q;         // this lane's 8 e4m3 bytes
+  uint32_t scale;  // the block's E8M0 byte (same on the 4 lanes)
+};
+__device__ __forceinline__ MxBlock mx8_encode(const float (&v)[8]) {
+  float am = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) am = fmaxf(am, fabsf(v[i]));
+  am = fmaxf(am, __shfl_xor(am, 1, 64));
+  am = fmaxf(am, __shfl_xor(am, 2, 64));
+  const uint32_t eb = (__float_as_uint(am) >> 23) & 255u;  // biased exponent of the block maximum
+  const uint32_t sb = eb > 8u ? eb - 8u : 0u;
+  const float inv = __uint_as_float((254u - sb) << 23);    // 2^(127 - sb)
+  float t[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t[i] = fminf(fmaxf(v[i] * inv, -448.f), 448.f);
+  int lo = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], 0, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], lo, true);
+  int hi = __builtin_amdgcn_cvt_pk_fp8_f32(t[4], t[5], 0, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(t[6], t[7], hi, true);
+  MxBlock b;
+  b.q = make_uint2((uint32_t)lo, (uint32_t)hi);
+  b.scale = sb;
+  return b;
 }
 
 template <typename T>
@@ -303,6 +333,9 @@ int gemm(const GemmArgs& a, hipStream_t s);
 int gemm_f32(const GemmArgs& a, hipStream_t s);
 int gemm_bf16_nt(const GemmArgs& a, hipStream_t s);
 int gemm_bf16_tn(const GemmArgs& a, hipStream_t s);
+// MX-FP8 NT GEMM (gemm_mx8.hip): A, B are e4m3 byte images (lda, ldb in bytes), scales [rows][K/32] E8M0 bytes
+int gemm_mx8_nt(const GemmArgs& a, const void* a_scales, const void* b_scales, hipStream_t s);
+int quant_mx8(const void* x, int dtype, int64_t ldx, int64_t R, int64_t K, void* q, int64_t ldq, void* scales, hipStream_t s);
 size_t gemm_bf16_tn_ws(int64_t M, int64_t N, int64_t K);
 // up to four C_i[M_i,N_i] = A_i[K,M_i]^T B_i[K,N_i] sharing K, one launch (weight gradients of one layer)
 struct TnGroupArgs {

@@ -1,0 +1,290 @@
+// gemm_mx8.hip - MX-FP8 (OCP microscaling: e4m3 elements, one E8M0 scale per 32 consecutive K) operands on
+// v_mfma_scale_f32_16x16x128_f8f6f4, fp32 accumulate: the CDNA4 fp8 path of BASELINE config 5 for the forward
+// nn.Linear GEMMs of the layer (heads.py:191,195,212).
+//
+//   quant:  x[R,K] (bf16 | fp32)  ->  q[R,K] e4m3 bytes + s[R,K/32] E8M0 bytes
+//           s = floor(log2(amax of the block)) - 8 (+127), q = rne_e4m3(clamp(x * 2^-(s-127), +-448))     (OCP MX v1.0 6.3)
+//   NT:     C[M,N] = (A_q, A_s)[M,K] * (B_q, B_s)[N,K]^T with the epilogues of the bf16 NT kernel (gemm_nt.hpp)
+//
+// Operand map of the instruction, pinned on hardware by tools/diag/mfma_fp8_probe.hip: lane (i = l & 15, g = l >> 4)
+// holds row i's bytes k = 16 g .. 16 g + 15 and k = 64 + 16 g .. 64 + 16 g + 15 - the 16-byte chunks g and 4 + g of a
+// 128-byte tile row, which is the same pair of ds_read_b128 the bf16 kernel issues for its two k-halves, so the LDS
+// image, its XOR swizzle and the LDS-DMA source permutation are shared with gemm_bf16.hip - and supplies the scale
+// byte of block k = 32 g .. 32 g + 31 of its row.  A K-step is therefore 128 deep at the LDS bytes, DMA instructions
+// and fragment reads of a 64-deep bf16 step, with half as many (twice as long) MFMAs per unit of K.
+// The scale bytes of a K-step ([row][4], one dword per row) ride along as one 4-byte LDS-DMA per 64 rows.
+//
+// The matrix core adds the 128 products of one instruction with a shared alignment (terms more than ~2^17 below the
+// largest are truncated; measured by tools/diag/mfma_fp8_probe3.hip), so results differ from an fp32 dot product of the
+// dequantised operands by up to ~1e-3 of the largest product: the tests state that tolerance.
+#include "common.hpp"
+#include "gemm_nt.hpp"
+
+namespace avf {
+
+namespace {
+
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+
+struct Mx8Params {
+  NtParams nt;        // A, B are byte images here; lda, ldb in bytes
+  const uint8_t* As;  // [M][K/32]
+  const uint8_t* Bs;  // [N][K/32]
+};
+
+__device__ __forceinline__ void glds4(const void* g, char* l) {
+  __builtin_amdgcn_global_load_lds((gptr_t*)g, (lptr_t*)l, 4, 0, 0);
+}
+
+template <int EPI, typename CT, int WM, int WN, int MI, int NI>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_mx8_nt_kernel(Mx8Params q, int tiles_n, int nwg) {
+  const NtParams& p = q.nt;
+  constexpr int WTM = 16 * MI, WTN = 16 * NI;
+  constexpr int BMT = WTM * WM, BNT = WTN * WN, NW = WM * WN;
+  static_assert((BMT / 8) % NW == 0 && (BNT / 8) % NW == 0, "tile rows must split evenly over the waves");
+  constexpr int A_BYTES = BMT * 128, B_BYTES = BNT * 128;
+  constexpr int S_PIECES = (BMT + BNT + 63) / 64;       // scale dwords: 64 rows per 4-byte DMA instruction
+  constexpr int S_BYTES = S_PIECES * 256;               // [A rows | B rows], padded to whole pieces
+  constexpr int S_INS = (S_PIECES + NW - 1) / NW;       // per wave (pieces wrap: a duplicate writes the same bytes)
+  constexpr int STAGE = A_BYTES + B_BYTES + S_BYTES;
+  constexpr int A_INS = (BMT / 8) / NW, B_INS = (BNT / 8) / NW;
+  constexpr int INS = A_INS + B_INS + S_INS;
+  constexpr int KS = 128;
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 15, lg = lane >> 4;
+  const int wg = xcd_remap(blockIdx.x, nwg);
+  const int m0 = (wg / tiles_n) * BMT, n0 = (wg % tiles_n) * BNT;
+  const int kb = p.K >> 5;  // scale bytes per row
+
+  const int lrow = lane >> 3, lchunk = (lane & 7) ^ (lane >> 3);
+  const char* ga[A_INS];
+  const char* gb[B_INS];
+  const uint8_t* gs[S_INS];
+  int spiece[S_INS];
+#pragma unroll
+  for (int j = 0; j < A_INS; ++j) {
+    int r = m0 + (wave * A_INS + j) * 8 + lrow;
+    r = r < p.M ? r : p.M - 1;
+    ga[j] = (const char*)p.A + (int64_t)r * p.lda + lchunk * 16;
+  }
+#pragma unroll
+  for (int j = 0; j < B_INS; ++j) {
+    int r = n0 + (wave * B_INS + j) * 8 + lrow;
+    r = r < p.N ? r : p.N - 1;
+    gb[j] = (const char*)p.B + (int64_t)r * p.ldb + lchunk * 16;
+  }
+#pragma unroll
+  for (int j = 0; j < S_INS; ++j) {
+    spiece[j] = (wave * S_INS + j) % S_PIECES;
+    const int rho = spiece[j] * 64 + lane;  // row of the combined [A | B] scale block
+    if (rho < BMT) {
+      int r = m0 + rho;
+      r = r < p.M ? r : p.M - 1;
+      gs[j] = q.As + (int64_t)r * kb;
+    } else {
+      int r = n0 + rho - BMT;
+      r = r < n0 + BNT ? r : n0 + BNT - 1;  // padding lanes of the last piece
+      r = r < p.N ? r : p.N - 1;
+      gs[j] = q.Bs + (int64_t)r * kb;
+    }
+  }
+  auto stage = [&](int st, int t) {
+    char* sa = dsm + st * STAGE;
+    char* sb = sa + A_BYTES;
+    char* ss = sb + B_BYTES;
+#pragma unroll
+    for (int j = 0; j < A_INS; ++j) glds16(ga[j] + t * KS, sa + (wave * A_INS + j) * 1024);
+#pragma unroll
+    for (int j = 0; j < B_INS; ++j) glds16(gb[j] + t * KS, sb + (wave * B_INS + j) * 1024);
+#pragma unroll
+    for (int j = 0; j < S_INS; ++j) glds4(gs[j] + t * 4, ss + spiece[j] * 256);
+  };
+
+  f32x4_t acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nt = p.K / KS;
+  stage(0, 0);
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (t + 1 < nt) stage(cur ^ 1, t + 1);
+    const char* sa = dsm + cur * STAGE;
+    const char* sb = sa + A_BYTES;
+    const char* ss = sb + B_BYTES;
+    i32x4_t fa[2][MI], fb[2][NI];
+    uint32_t sca[MI], scb[NI];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        fa[h][i] = *reinterpret_cast<const i32x4_t*>(sa + nt_off(wm * WTM + i * 16 + li, h * 4 + lg));
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        fb[h][j] = *reinterpret_cast<const i32x4_t*>(sb + nt_off(wn * WTN + j * 16 + li, h * 4 + lg));
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+      sca[i] = (*reinterpret_cast<const uint32_t*>(ss + (wm * WTM + i * 16 + li) * 4) >> (8 * lg)) & 255u;
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+      scb[j] = (*reinterpret_cast<const uint32_t*>(ss + (BMT + wn * WTN + j * 16 + li) * 4) >> (8 * lg)) & 255u;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const v8i_t va = {fa[0][i][0], fa[0][i][1], fa[0][i][2], fa[0][i][3], fa[1][i][0], fa[1][i][1], fa[1][i][2], fa[1][i][3]};
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const v8i_t vb = {fb[0][j][0], fb[0][j][1], fb[0][j][2], fb[0][j][3], fb[1][j][0], fb[1][j][1], fb[1][j][2], fb[1][j][3]};
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(vb, va, acc[i][j], 0, 0, 0, (int)scb[j], 0, (int)sca[i]);
+      }
+    }
+    cur ^= 1;
+  }
+
+  nt_epilogue<EPI, CT, MI, NI>(p, acc, m0 + wm * WTM, n0 + wn * WTN, li, lg,
+                               p.cs_partial ? (wg / tiles_n) * WM + wm : -1);
+}
+
+template <int EPI, typename CT, int WM, int WN, int MI, int NI>
+int launch_mx8(const Mx8Params& q, hipStream_t s, int* part_rows) {
+  constexpr int BMT = 16 * MI * WM, BNT = 16 * NI * WN;
+  constexpr int SMEM = 2 * ((BMT + BNT) * 128 + ((BMT + BNT + 63) / 64) * 256);
+  static_assert(SMEM <= 160 * 1024, "LDS budget");
+  static bool raised = false;
+  if (!raised && SMEM > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_mx8_nt_kernel<EPI, CT, WM, WN, MI, NI>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    AVF_REQUIRE(e == hipSuccess, "gemm_mx8_nt: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
+    raised = true;
+  }
+  const int tiles_m = (q.nt.M + BMT - 1) / BMT, tiles_n = (q.nt.N + BNT - 1) / BNT;
+  const int nwg = tiles_m * tiles_n;
+  *part_rows = tiles_m * WM;
+  gemm_mx8_nt_kernel<EPI, CT, WM, WN, MI, NI><<<nwg, WM * WN * 64, SMEM, s>>>(q, tiles_n, nwg);
+  return 0;
+}
+
+template <int EPI, typename CT>
+int launch_mx8_any(const Mx8Params& q, hipStream_t s, int* part_rows) {
+  switch (pick_nt_tile(q.nt.M, q.nt.N, q.nt.K / 2)) {  // K/2: the same LDS bytes per row as a bf16 problem of that depth
+    case 0: return launch_mx8<EPI, CT, 2, 2, 4, 4>(q, s, part_rows);
+    case 1: return launch_mx8<EPI, CT, 2, 2, 2, 4>(q, s, part_rows);
+    case 3: return launch_mx8<EPI, CT, 2, 2, 3, 4>(q, s, part_rows);
+    default: return launch_mx8<EPI, CT, 2, 4, 4, 2>(q, s, part_rows);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// quantiser: 8 elements per lane, 4 lanes per 32-block
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void load8(const bf16* p, float (&v)[8]) {
+  const uint4 u = *reinterpret_cast<const uint4*>(p);
+  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = __uint_as_float(w[i] << 16);
+    v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void quant_mx8_kernel(const T* __restrict__ x, int64_t ldx, uint8_t* __restrict__ qo,
+                                                        int64_t ldq, uint8_t* __restrict__ so, int64_t R, int K) {
+  const int per_row = K >> 3;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = R * per_row;
+  const bool live = idx < total;
+  const int64_t row = live ? idx / per_row : 0;
+  const int c8 = live ? (int)(idx - row * per_row) : 0;
+  float v[8];
+  load8(x + row * ldx + c8 * 8, v);
+  const MxBlock b = mx8_encode(v);
+  if (live) {
+    *reinterpret_cast<uint2*>(qo + row * ldq + c8 * 8) = b.q;
+    if ((c8 & 3) == 0) so[row * (K >> 5) + (c8 >> 2)] = b.scale;
+  }
+}
+
+}  // namespace
+
+int quant_mx8(const void* x, int dtype, int64_t ldx, int64_t R, int64_t K, void* q, int64_t ldq, void* scales, hipStream_t s) {
+  AVF_REQUIRE(R > 0 && K > 0 && K % 32 == 0 && K < (1LL << 31), "quant_mx8: K must be a positive multiple of 32");
+  AVF_REQUIRE(dtype == AVF_F32 || dtype == AVF_BF16, "quant_mx8: source must be f32 or bf16");
+  AVF_REQUIRE(ldx % 8 == 0 && ldq % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)q & 7) == 0,
+              "quant_mx8: rows must be 16-byte (source) / 8-byte (image) aligned");
+  const int64_t total = R * (K >> 3);
+  const unsigned blocks = (unsigned)ceil_div(total, (int64_t)256);
+  if (dtype == AVF_F32)
+    quant_mx8_kernel<float><<<blocks, 256, 0, s>>>((const float*)x, ldx, (uint8_t*)q, ldq, (uint8_t*)scales, R, (int)K);
+  else
+    quant_mx8_kernel<bf16><<<blocks, 256, 0, s>>>((const bf16*)x, ldx, (uint8_t*)q, ldq, (uint8_t*)scales, R, (int)K);
+  return check_launch("quant_mx8_kernel");
+}
+
+int gemm_mx8_nt(const GemmArgs& a, const void* a_scales, const void* b_scales, hipStream_t s) {
+  AVF_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm_mx8_nt: bad shape");
+  AVF_REQUIRE(a.K % 128 == 0 && a.N % 4 == 0, "gemm_mx8_nt: K%%128 and N%%4 must be 0 (K=%lld N=%lld)", (long long)a.K,
+              (long long)a.N);
+  AVF_REQUIRE(a.lda % 16 == 0 && a.ldb % 16 == 0 && a.ldc % 4 == 0, "gemm_mx8_nt: leading dimensions must be 16-byte multiples");
+  AVF_REQUIRE(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.B & 15) == 0 && ((uintptr_t)a.C & 15) == 0,
+              "gemm_mx8_nt: operands must be 16-byte aligned");
+  AVF_REQUIRE(a_scales && b_scales && ((uintptr_t)a_scales & 3) == 0 && ((uintptr_t)b_scales & 3) == 0,
+              "gemm_mx8_nt: scale images missing or not 4-byte aligned");
+  AVF_REQUIRE(a.M < (1LL << 31) && a.N < (1LL << 31) && a.K < (1LL << 31), "gemm_mx8_nt: shape too large");
+  Mx8Params q;
+  NtParams& p = q.nt;
+  TimingScope ts(KC_GEMM_MX8_NT, 2.0 * a.M * a.N * a.K,
+                 1.0 * (a.M * a.K + a.N * a.K) * (1.0 + 1.0 / 32) + (a.c_dtype == AVF_F32 ? 4.0 : 2.0) * a.M * a.N, s);
+  p.A = (const bf16*)a.A; p.lda = a.lda; p.B = (const bf16*)a.B; p.ldb = a.ldb;
+  p.C = a.C; p.ldc = a.ldc; p.bias = a.bias; p.residual = a.residual; p.ldres = a.ldres;
+  p.aux = (bf16*)a.aux; p.ldaux = a.ldaux;
+  p.drop = a.drop;
+  AVF_REQUIRE(!a.drop.thresh16 || a.epilogue != AVF_EPI_NONE, "gemm_mx8_nt: dropout needs a fused epilogue");
+  p.M = (int)a.M; p.N = (int)a.N; p.K = (int)a.K;
+  q.As = (const uint8_t*)a_scales; q.Bs = (const uint8_t*)b_scales;
+  const bool cf32 = a.c_dtype == AVF_F32;
+  AVF_REQUIRE(cf32 || a.c_dtype == AVF_BF16, "gemm_mx8_nt: bad c_dtype");
+  int part_rows = 0;
+  p.cs_partial = nullptr;
+  if (a.colsum) {
+    AVF_REQUIRE(a.workspace, "gemm_mx8_nt: column-sum workspace missing");
+    p.cs_partial = (float*)a.workspace;
+  }
+#define LAUNCH(E)                                                     \
+  do {                                                                \
+    if (cf32) AVF_TRY((launch_mx8_any<E, float>(q, s, &part_rows)));   \
+    else AVF_TRY((launch_mx8_any<E, bf16>(q, s, &part_rows)));        \
+  } while (0)
+  switch (a.epilogue) {
+    case AVF_EPI_NONE: LAUNCH(AVF_EPI_NONE); break;
+    case AVF_EPI_BIAS_RES:
+      AVF_REQUIRE(a.residual && cf32 && a.ldres % 4 == 0, "gemm_mx8_nt: BIAS_RES needs fp32 C and residual");
+      LAUNCH(AVF_EPI_BIAS_RES);
+      break;
+    case AVF_EPI_BIAS_GELU:
+      AVF_REQUIRE(a.aux && a.ldaux % 4 == 0, "gemm_mx8_nt: aux missing");
+      LAUNCH(AVF_EPI_BIAS_GELU);
+      break;
+    default: AVF_REQUIRE(false, "gemm_mx8_nt: bad epilogue %d", a.epilogue);
+  }
+#undef LAUNCH
+  AVF_TRY(check_launch("gemm_mx8_nt_kernel"));
+  AVF_REQUIRE(!a.colsum || (size_t)part_rows * a.N * sizeof(float) <= gemm_nt_colsum_ws(a.M, a.N),
+              "gemm_mx8_nt: column-sum partials exceed their workspace (internal error)");
+  if (a.colsum) AVF_TRY(fold_partials(p.cs_partial, part_rows, (int)a.N, a.colsum, s));
+  return 0;
+}
+
+}  // namespace avf

@@ -1,0 +1,166 @@
+// gemm_nt.hpp - pieces shared by the NT GEMM kernels (gemm_bf16.hip: bf16 operands; gemm_mx8.hip: MX-FP8 operands):
+// parameter block, LDS tile addressing, the fused epilogue, LDS-DMA and launch-order helpers.
+#pragma once
+#include <stdlib.h>
+
+#include "common.hpp"
+
+namespace avf {
+namespace {
+
+typedef __attribute__((address_space(3))) char lds_char;
+
+constexpr int TB = 128;            // block tile (both M and N)
+constexpr int TK = 64;             // bf16 K per stage (128 bytes per tile row)
+constexpr int NT_STAGE = TB * TK * 2;  // bytes per operand per stage = 16 KiB
+
+struct NtParams {
+  const bf16* A;
+  int64_t lda;
+  const bf16* B;
+  int64_t ldb;
+  void* C;
+  int64_t ldc;
+  const float* bias;
+  const float* residual;
+  int64_t ldres;
+  bf16* aux;
+  int64_t ldaux;
+  float* cs_partial;  // optional [tiles_m * WM][N] column-sum partials of the stored C values (bias gradients)
+  DropCfg drop;       // dropout site fused in the epilogue (thresh16 == 0: none); element index = m * N + n
+  int M, N, K;
+};
+
+// 16-byte chunk c (0..7) of tile row r lives at chunk slot c ^ (r & 7): conflict-free ds_read_b128
+__device__ __forceinline__ int nt_off(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
+
+// Shared epilogue.  A lane holds C[m = m_base + 16 i + li][n = n_base + 16 j + 4 lg + 0..3] in acc[i][j].
+// All global reads of the epilogue (bias, fp32 residual, saved pre-activation) are issued up front from CLAMPED
+// addresses - no branch sits between them, so their latencies overlap instead of serialising - and only the
+// stores are predicated on the tile edge.
+// part_row >= 0: also emit the column sums of this wave's 64 rows into cs_partial[part_row][n] (plain stores;
+// a fold kernel adds the tiles_m*WM partial rows) - fuses the bias gradient "db = sum_rows dY" into the GEMM.
+template <int EPI, typename CT, int MI, int NI>
+__device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI][NI], int m_base, int n_base, int li,
+                                            int lg, int part_row) {
+  int nn[NI], nc[NI];
+  float4 bj[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    nn[j] = n_base + j * 16 + 4 * lg;
+    nc[j] = nn[j] < p.N ? nn[j] : 0;
+    bj[j] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nc[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const uint64_t dkey = p.drop.thresh16 ? drop_key(p.drop) : 0;
+  float cs[NI][4];
+#pragma unroll
+  for (int j = 0; j < NI; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cs[j][r] = 0.f;
+#pragma unroll
+  for (int half = 0; half < (MI + 1) / 2; ++half) {
+    float4 ex[2][NI];  // residual (fp32) or saved pre-activation (bf16 -> fp32) for this pair of row blocks
+    int mm[2];
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+      if (half * 2 + ii >= MI) continue;  // odd MI: the last pair has one row block
+      mm[ii] = m_base + (half * 2 + ii) * 16 + li;
+      const int mc = mm[ii] < p.M ? mm[ii] : p.M - 1;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        if (EPI == AVF_EPI_BIAS_RES) ex[ii][j] = *reinterpret_cast<const float4*>(p.residual + (int64_t)mc * p.ldres + nc[j]);
+        else if (EPI == AVF_EPI_DGELU) ex[ii][j] = load4<bf16>(p.aux + (int64_t)mc * p.ldaux + nc[j]);
+      }
+    }
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+      const int i = half * 2 + ii;
+      if (i >= MI) continue;
+      const bool mok = mm[ii] < p.M;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        float v[4] = {acc[i][j][0] + bj[j].x, acc[i][j][1] + bj[j].y, acc[i][j][2] + bj[j].z, acc[i][j][3] + bj[j].w};
+        const bool ok = mok && nn[j] < p.N;
+        float4 df = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (p.drop.thresh16) df = drop_factor4(p.drop, dkey, (uint64_t)mm[ii] * p.N + nn[j]);  // wave-uniform branch
+        if (EPI == AVF_EPI_BIAS_RES) {  // x + Dropout(Linear(.))
+          v[0] = v[0] * df.x + ex[ii][j].x; v[1] = v[1] * df.y + ex[ii][j].y;
+          v[2] = v[2] * df.z + ex[ii][j].z; v[3] = v[3] * df.w + ex[ii][j].w;
+        } else if (EPI == AVF_EPI_BIAS_GELU) {  // Dropout(GELU(u)); u is saved unmasked
+          if (ok) store4<bf16>(p.aux + (int64_t)mm[ii] * p.ldaux + nn[j], make_float4(v[0], v[1], v[2], v[3]));
+          v[0] = gelu_tanh_fast(v[0]) * df.x; v[1] = gelu_tanh_fast(v[1]) * df.y;
+          v[2] = gelu_tanh_fast(v[2]) * df.z; v[3] = gelu_tanh_fast(v[3]) * df.w;
+        } else if (EPI == AVF_EPI_DGELU) {  // backward through Dropout then GELU
+          v[0] *= df.x * dgelu_tanh_fast(ex[ii][j].x); v[1] *= df.y * dgelu_tanh_fast(ex[ii][j].y);
+          v[2] *= df.z * dgelu_tanh_fast(ex[ii][j].z); v[3] *= df.w * dgelu_tanh_fast(ex[ii][j].w);
+        }
+        if (ok) {
+          store4<CT>((CT*)p.C + (int64_t)mm[ii] * p.ldc + nn[j], make_float4(v[0], v[1], v[2], v[3]));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cs[j][r] += v[r];
+        }
+      }
+    }
+  }
+  if (part_row >= 0) {  // wave-uniform
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t = cs[j][r];
+        t += __shfl_xor(t, 1, 64);
+        t += __shfl_xor(t, 2, 64);
+        t += __shfl_xor(t, 4, 64);
+        t += __shfl_xor(t, 8, 64);
+        cs[j][r] = t;
+      }
+    if (li == 0) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        if (nn[j] < p.N)
+          *reinterpret_cast<float4*>(p.cs_partial + (int64_t)part_row * p.N + nn[j]) =
+              make_float4(cs[j][0], cs[j][1], cs[j][2], cs[j][3]);
+    }
+  }
+}
+
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+__device__ __forceinline__ void glds16(const void* g, char* l) {
+  __builtin_amdgcn_global_load_lds((gptr_t*)g, (lptr_t*)l, 16, 0, 0);
+}
+
+__device__ __forceinline__ int xcd_remap(int id, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = id & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// tile configurations (block tile, wavefronts, LDS stages, resident blocks per CU):
+//   0: 128x128, 4 waves of 64x64, 2 stages (64 KiB, 2/CU)
+//   1:  64x128, 4 waves of 32x64, 2 stages (48 KiB, 3/CU)   - finer grain for grids that cannot fill the chip
+//   2: 128x128, 8 waves of 64x32, 2 stages (64 KiB, 2/CU)   - twice the waves per CU hide the DMA / epilogue
+//                                                             latency better (+5..8 % measured at K = 512..1536)
+//   3:  96x128, 4 waves of 48x64, 2 stages (56 KiB, 2/CU)   - M = 10368, N = 512: 432 workgroups fill the 512 slots in
+//                                                             one round; 8..11 % faster than (1) once K >= 1024
+// (3- and 4-stage rings, 256x128 / 256x256 / 192x128 tiles, 64x64 tiles and a persistent tile loop were all measured slower
+//  on this path's shapes - M = 10k..16k, N = 512..1536, K = 512..1536 - and removed: the waves wait ~55 % of their
+//  cycles (SQ_WAIT_ANY) on LDS/barrier latency, which more resident waves hide better than deeper DMA rings)
+int pick_nt_tile(int64_t M, int64_t N, int64_t K) {
+  static const int override_tile = [] {
+    const char* e = getenv("AVF_NT_TILE");  // tuning aid: force one configuration
+    return e ? atoi(e) : -1;
+  }();
+  if (override_tile >= 0) return override_tile;
+  const int64_t wg128 = ceil_div(M, 128) * ceil_div(N, 128);
+  if (wg128 >= 512) return 2;
+  return (K >= 1024 && ceil_div(M, 96) * ceil_div(N, 128) <= 512) ? 3 : 1;
+}
+
+}  // namespace
+}  // namespace avf

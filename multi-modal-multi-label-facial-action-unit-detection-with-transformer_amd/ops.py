@@ -147,6 +147,34 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool 
     return c
 
 
+def quant_mx8(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """[rows, cols] f32|bf16 -> (e4m3 bytes [rows, cols] uint8, E8M0 scale bytes [rows, cols/32] uint8)."""
+    _need_cuda(x)
+    x = x.contiguous()
+    rows, cols = x.shape
+    q = torch.empty((rows, cols), dtype=torch.uint8, device=x.device)
+    s = torch.empty((rows, cols // 32), dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.load().avf_quant_mx8(avf_dtype(x.dtype), _ptr(x), rows, cols, _ptr(q), _ptr(s), _stream()), "quant_mx8")
+    return q, s
+
+
+def gemm_mx8(a_q: torch.Tensor, a_s: torch.Tensor, b_q: torch.Tensor, b_s: torch.Tensor, out_dtype=torch.float32,
+             epilogue: int = EPI_NONE, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None):
+    """C[M,N] = A[M,K] B[N,K]^T from MX-FP8 images (quant_mx8).  Returns C (and the saved pre-activation for
+    EPI_BIAS_GELU)."""
+    _need_cuda(a_q, a_s, b_q, b_s, bias, residual)
+    M, K = a_q.shape
+    N = b_q.shape[0]
+    assert b_q.shape[1] == K and a_s.shape == (M, K // 32) and b_s.shape == (N, K // 32)
+    c = torch.empty((M, N), dtype=out_dtype, device=a_q.device)
+    aux = torch.empty((M, N), dtype=out_dtype, device=a_q.device) if epilogue == EPI_BIAS_GELU else None
+    _lib.check(_lib.load().avf_gemm_mx8_nt(M, N, K, _ptr(a_q.contiguous()), _ptr(a_s.contiguous()), _ptr(b_q.contiguous()),
+                                           _ptr(b_s.contiguous()), _ptr(c), N, avf_dtype(out_dtype), epilogue, _ptr(bias),
+                                           _ptr(residual.contiguous() if residual is not None else None), N,
+                                           _ptr(aux), N, _stream()), "gemm_mx8_nt")
+    return (c, aux) if aux is not None else c
+
+
 def attn_fwd(qkv: torch.Tensor, batch: int, tokens: int, heads: int, dim_head: int, q_prescaled: bool = False):
     """Attention core on the packed QKV projection [B*N, 3*H*dh] -> (o [B*N, H*dh], lse2 [B,H,N]).
     q_prescaled (bf16 only): the q columns already carry log2(e)/sqrt(dim_head) (avf_attn_fwd_qs)."""

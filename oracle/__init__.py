@@ -29,3 +29,4 @@ from .reference_math import (  # noqa: F401
     transformer_param_names,
     init_transformer_state,
 )
+from .mx8 import mx8_dequant, mx8_quant  # noqa: F401,E402
