@@ -29,8 +29,10 @@ CONFIGS = {
     "c2": dict(dim=512, depth=6, heads=8, dim_head=64, mlp_dim=1024, t_video=196, t_audio=128, batch=32),
     "c3": dict(dim=512, depth=6, heads=8, dim_head=64, mlp_dim=1024, t_video=384, t_audio=128, batch=32),
     "c4": dict(dim=768, depth=12, heads=12, dim_head=64, mlp_dim=1536, t_video=768, t_audio=256, batch=16),
+    "c5": dict(dim=512, depth=6, heads=8, dim_head=64, mlp_dim=1024, t_video=384, t_audio=128, batch=64),  # with --dtype mx8
 }
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "mx8": 2500.0}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+MX8_PEAK_TFLOPS = 5000.0  # the MX-scaled fp8 MFMA (kernel class gemm_mx8_nt only; mx8 mode keeps backward on bf16)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -89,7 +91,8 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "mx8"],
+                    help="mx8: bf16 path with MX-FP8 operands on the forward qkv / mlp GEMMs (BASELINE config 5)")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
@@ -242,7 +245,7 @@ def main():
             d = mfma[dom]
             if d["launches"] > 0 and d["ms"] > 0:
                 ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-                peak = MFMA_PEAK_TFLOPS[args.dtype]
+                peak = MX8_PEAK_TFLOPS if dom == "gemm_mx8_nt" else MFMA_PEAK_TFLOPS[args.dtype]
                 result["roofline"] = {
                     "kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom),

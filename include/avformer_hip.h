@@ -54,6 +54,9 @@ typedef struct avf_layer_cfg {
   const void* seed_dev; /* optional device pointer to a uint64 seed; when non-null it replaces seed_lo/hi and is read
                           by the kernels at run time, so a captured hipGraph draws fresh masks on every replay
                           (the caller advances the value between forwards, e.g. with a captured add)            */
+  int32_t mx8_fwd;     /* 1 (AVF_BF16 only; dim, mlp_dim % 128 == 0): the forward GEMMs of to_qkv, net.0 and net.3 take MX-FP8
+                          operands (BASELINE config 5).  The bf16 weight-image buffer then also holds their e4m3 images:
+                          refresh them with avf_stack_quant_weights_mx8 whenever the bf16 images changed.          */
 } avf_layer_cfg;
 
 /* fp32 master parameters of one layer, in state_dict order:
@@ -113,11 +116,19 @@ int avf_gemm(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K,
  *   avf_quant_mx8:   x [rows,cols] (AVF_F32 | AVF_BF16, cols % 32 == 0) -> q [rows,cols] bytes, scales [rows,cols/32] bytes;
  *                    scale = floor(log2(block amax)) - 8 (+127), q = rne_e4m3(clamp(x * 2^-(scale-127), +-448)).
  *   avf_gemm_mx8_nt: C[M,N] = A[M,K] * B[N,K]^T from two such images (K % 128 == 0), fp32 accumulate, epilogues
- *                    AVF_EPI_NONE / BIAS_RES / BIAS_GELU as avf_gemm. */
+ *                    AVF_EPI_NONE / BIAS_RES / BIAS_GELU as avf_gemm; c_q / c_scales (optional, BIAS_GELU, N % 32 == 0):
+ *                    also the MX-FP8 image of the stored C, ready to be the next GEMM's A operand. */
+/* e4m3 images of Wqkv, W1, W2 of every layer of a stack from their bf16 images, one launch (cfg.mx8_fwd = 1);
+ * lowp[i] = the avf_layer_lowp_bytes buffer of layer i, after avf_layer_prepare_weights / the library Adam wrote it */
+int avf_stack_quant_weights_mx8(const avf_layer_cfg* cfg, int layers, void* const* lowp, void* stream);
 int avf_quant_mx8(int dtype, const void* x, int64_t rows, int64_t cols, void* q, void* scales, void* stream);
 int avf_gemm_mx8_nt(int64_t M, int64_t N, int64_t K, const void* a_q, const void* a_scales, const void* b_q,
                     const void* b_scales, void* C, int64_t ldc, int c_dtype, int epilogue, const float* bias,
-                    const float* residual, int64_t ldres, void* aux, int64_t ldaux, void* stream);
+                    const float* residual, int64_t ldres, void* aux, int64_t ldaux, void* c_q, void* c_scales,
+                    void* stream);
+/* nn.LayerNorm forward (heads.py:178-185) writing the bf16 output AND its MX-FP8 image (dim % 32 == 0, dim <= 1536) */
+int avf_layernorm_fwd_mx8(const float* x, const float* gamma, const float* beta, void* y_bf16, float* mean, float* rstd,
+                          void* y_q, void* y_scales, int64_t rows, int dim, float eps, void* stream);
 
 /* Multi-head self-attention core - heads.py:222-237.  qkv [B*N, 3I] (q|k|v, head-major columns),
  * o [B*N, I], lse2 fp32 [B,H,N] = log2-domain log-sum-exp of the scaled scores (saved for backward). */

@@ -26,7 +26,7 @@ class LayerCfg(C.Structure):
     _fields_ = [("batch", C.c_int32), ("tokens", C.c_int32), ("dim", C.c_int32), ("heads", C.c_int32),
                 ("dim_head", C.c_int32), ("mlp_dim", C.c_int32), ("dtype", C.c_int32), ("project_out", C.c_int32),
                 ("ln_eps", C.c_float), ("dropout_p", C.c_float), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32),
-                ("layer_index", C.c_int32), ("seed_dev", C.c_void_p)]
+                ("layer_index", C.c_int32), ("seed_dev", C.c_void_p), ("mx8_fwd", C.c_int32)]
 
 
 PARAM_FIELDS = ("ln1_w", "ln1_b", "w_qkv", "w_out", "b_out", "ln2_w", "ln2_b", "w1", "b1", "w2", "b2")
@@ -52,9 +52,11 @@ SIGNATURES = {
     "avf_gemm_workspace_bytes": (_sz, [_int, _int, _int, _i64, _i64, _i64]),
     "avf_gemm": (_int, [_int, _int, _int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _int, _int, _vp, _vp,
                         _i64, _vp, _i64, _vp, _vp]),
+    "avf_stack_quant_weights_mx8": (_int, [_vp, _int, _vp, _vp]),
     "avf_quant_mx8": (_int, [_int, _vp, _i64, _i64, _vp, _vp, _vp]),
     "avf_gemm_mx8_nt": (_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _i64, _vp, _i64,
-                               _vp]),
+                               _vp, _vp, _vp]),
+    "avf_layernorm_fwd_mx8": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _f, _vp]),
     "avf_attn_fwd": (_int, [_int, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     "avf_attn_bwd_workspace_bytes": (_sz, [_int, _int, _int, _int]),
     "avf_attn_bwd": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),

@@ -192,13 +192,19 @@ extern "C" int avf_gemm(int dtype, int transA, int transB, int64_t M, int64_t N,
   return gemm(a, (hipStream_t)stream);
 }
 
+extern "C" int avf_layernorm_fwd_mx8(const float* x, const float* gamma, const float* beta, void* y_bf16, float* mean,
+                                     float* rstd, void* y_q, void* y_scales, int64_t rows, int dim, float eps, void* stream) {
+  AVF_REQUIRE(x && gamma && beta && y_bf16 && mean && rstd && y_q && y_scales, "layernorm_fwd_mx8: null pointer");
+  return layernorm_fwd(x, gamma, beta, y_bf16, AVF_BF16, mean, rstd, rows, dim, eps, (hipStream_t)stream, y_q, y_scales);
+}
 extern "C" int avf_quant_mx8(int dtype, const void* x, int64_t rows, int64_t cols, void* q, void* scales, void* stream) {
   AVF_REQUIRE(x && q && scales, "quant_mx8: null pointer");
   return quant_mx8(x, dtype, cols, rows, cols, q, cols, scales, (hipStream_t)stream);
 }
 extern "C" int avf_gemm_mx8_nt(int64_t M, int64_t N, int64_t K, const void* a_q, const void* a_scales, const void* b_q,
                                const void* b_scales, void* C, int64_t ldc, int c_dtype, int epilogue, const float* bias,
-                               const float* residual, int64_t ldres, void* aux, int64_t ldaux, void* stream) {
+                               const float* residual, int64_t ldres, void* aux, int64_t ldaux, void* c_q, void* c_scales,
+                               void* stream) {
   AVF_REQUIRE(a_q && a_scales && b_q && b_scales && C, "gemm_mx8_nt: null pointer");
   GemmArgs a;
   a.dtype = AVF_BF16; a.transA = 0; a.transB = 1;
@@ -206,7 +212,7 @@ extern "C" int avf_gemm_mx8_nt(int64_t M, int64_t N, int64_t K, const void* a_q,
   a.A = a_q; a.lda = K; a.B = b_q; a.ldb = K; a.C = C; a.ldc = ldc;
   a.c_dtype = c_dtype; a.epilogue = epilogue; a.bias = bias; a.residual = residual; a.ldres = ldres;
   a.aux = aux; a.ldaux = ldaux; a.workspace = nullptr; a.colsum = nullptr; a.drop = kNoDrop; a.defer_fold = nullptr;
-  return gemm_mx8_nt(a, a_scales, b_scales, (hipStream_t)stream);
+  return gemm_mx8_nt(a, a_scales, b_scales, (hipStream_t)stream, c_q, c_scales);
 }
 
 extern "C" int avf_attn_fwd(int dtype, const void* qkv, void* o, float* lse2, int batch, int tokens, int heads,

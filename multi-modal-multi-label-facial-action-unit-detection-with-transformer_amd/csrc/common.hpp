@@ -69,6 +69,32 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
+// the scale byte and its reciprocal as a float, from a block maximum
+__device__ __forceinline__ uint32_t mx8_scale_byte(float amax, float* inv) {
+  const uint32_t eb = (__float_as_uint(amax) >> 23) & 255u;
+  const uint32_t sb = eb > 8u ? eb - 8u : 0u;
+  *inv = __uint_as_float((254u - sb) << 23);
+  return sb;
+}
+__device__ __forceinline__ uint32_t mx8_pack4(const float (&v)[4], float inv) {
+  float t[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t[i] = fminf(fmaxf(v[i] * inv, -448.f), 448.f);
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], w, true);
+  return (uint32_t)w;
+}
+// 4 consecutive elements per lane, the 8 lanes 8k .. 8k+7 form a block (LayerNorm rows)
+__device__ __forceinline__ uint32_t mx8_encode4(const float (&v)[4], uint32_t* scale) {
+  float am = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  am = fmaxf(am, __shfl_xor(am, 1, 64));
+  am = fmaxf(am, __shfl_xor(am, 2, 64));
+  am = fmaxf(am, __shfl_xor(am, 4, 64));
+  float inv;
+  *scale = mx8_scale_byte(am, &inv);
+  return mx8_pack4(v, inv);
+}
+
 // MX-FP8 block encoder (OCP microscaling v1.0, e4m3 elements): the 4 lanes 4k .. 4k+3 hold 8 consecutive elements
 // each of one 32-element block and must all be active.  scale = E8M0 byte of 2^(floor(log2 amax) - 8); elements are
 // x * 2^-(scale-127), clamped to +-448, rounded to nearest even by v_cvt_pk_fp8_f32.
@@ -82,19 +108,11 @@ __device__ __forceinline__ MxBlock mx8_encode(const float (&v)[8]) {
   for (int i = 0; i < 8; ++i) am = fmaxf(am, fabsf(v[i]));
   am = fmaxf(am, __shfl_xor(am, 1, 64));
   am = fmaxf(am, __shfl_xor(am, 2, 64));
-  const uint32_t eb = (__float_as_uint(am) >> 23) & 255u;  // biased exponent of the block maximum
-  const uint32_t sb = eb > 8u ? eb - 8u : 0u;
-  const float inv = __uint_as_float((254u - sb) << 23);    // 2^(127 - sb)
-  float t[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) t[i] = fminf(fmaxf(v[i] * inv, -448.f), 448.f);
-  int lo = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], 0, false);
-  lo = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], lo, true);
-  int hi = __builtin_amdgcn_cvt_pk_fp8_f32(t[4], t[5], 0, false);
-  hi = __builtin_amdgcn_cvt_pk_fp8_f32(t[6], t[7], hi, true);
+  float inv;
   MxBlock b;
-  b.q = make_uint2((uint32_t)lo, (uint32_t)hi);
-  b.scale = sb;
+  b.scale = mx8_scale_byte(am, &inv);  // biased exponent of the block maximum - 8; inv = 2^(127 - scale)
+  const float lo[4] = {v[0], v[1], v[2], v[3]}, hi[4] = {v[4], v[5], v[6], v[7]};
+  b.q = make_uint2(mx8_pack4(lo, inv), mx8_pack4(hi, inv));
   return b;
 }
 
@@ -232,8 +250,9 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // internal launchers shared between translation units (all return 0 / non-zero)
 // ---------------------------------------------------------------------------------------------
 struct FoldJob;
+// mx_q / mx_s (optional, bf16 output only): also write the MX-FP8 image of y ([rows,dim] e4m3 + [rows,dim/32] E8M0)
 int layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype, float* mean,
-                  float* rstd, int64_t rows, int dim, float eps, hipStream_t s);
+                  float* rstd, int64_t rows, int dim, float eps, hipStream_t s, void* mx_q = nullptr, void* mx_s = nullptr);
 size_t layernorm_bwd_ws(int64_t rows, int dim);
 // drop: mask applied to the bf16 copy dx_lo AND to the column sums (they feed the Linear behind a dropout site);
 // dx itself (the residual stream gradient) is never masked.
@@ -334,7 +353,16 @@ int gemm_f32(const GemmArgs& a, hipStream_t s);
 int gemm_bf16_nt(const GemmArgs& a, hipStream_t s);
 int gemm_bf16_tn(const GemmArgs& a, hipStream_t s);
 // MX-FP8 NT GEMM (gemm_mx8.hip): A, B are e4m3 byte images (lda, ldb in bytes), scales [rows][K/32] E8M0 bytes
-int gemm_mx8_nt(const GemmArgs& a, const void* a_scales, const void* b_scales, hipStream_t s);
+// mx_q / mx_s (optional, BIAS_GELU only): also write the MX-FP8 image of C ([M,N] e4m3 + [M,N/32] E8M0)
+int gemm_mx8_nt(const GemmArgs& a, const void* a_scales, const void* b_scales, hipStream_t s, void* mx_q = nullptr,
+                void* mx_s = nullptr);
+struct MxQuantJob {
+  const void* x;  // bf16 [R,K]
+  void* q;        // e4m3 [R,K]
+  void* s;        // E8M0 [R,K/32]
+  int64_t R, K;
+};
+int quant_mx8_multi(const MxQuantJob* jobs, int n, hipStream_t s);
 int quant_mx8(const void* x, int dtype, int64_t ldx, int64_t R, int64_t K, void* q, int64_t ldq, void* scales, hipStream_t s);
 size_t gemm_bf16_tn_ws(int64_t M, int64_t N, int64_t K);
 // up to four C_i[M_i,N_i] = A_i[K,M_i]^T B_i[K,N_i] sharing K, one launch (weight gradients of one layer)

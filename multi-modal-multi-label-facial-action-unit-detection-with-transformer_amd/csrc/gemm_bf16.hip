@@ -552,6 +552,7 @@ int gemm_bf16_nt(const GemmArgs& a, hipStream_t s) {
   p.C = a.C; p.ldc = a.ldc; p.bias = a.bias; p.residual = a.residual; p.ldres = a.ldres;
   p.aux = (bf16*)a.aux; p.ldaux = a.ldaux;
   p.drop = a.drop;
+  p.mxq = nullptr; p.mxs = nullptr;
   AVF_REQUIRE(!a.drop.thresh16 || a.epilogue != AVF_EPI_NONE, "gemm_bf16_nt: dropout needs a fused epilogue");
   p.M = (int)a.M; p.N = (int)a.N; p.K = (int)a.K;
   dim3 grid((unsigned)ceil_div(a.N, TB), (unsigned)ceil_div(a.M, TB));

@@ -48,7 +48,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mx8_nt_kernel(Mx8Params q, 
   constexpr int S_INS = (S_PIECES + NW - 1) / NW;       // per wave (pieces wrap: a duplicate writes the same bytes)
   constexpr int STAGE = A_BYTES + B_BYTES + S_BYTES;
   constexpr int A_INS = (BMT / 8) / NW, B_INS = (BNT / 8) / NW;
-  constexpr int INS = A_INS + B_INS + S_INS;
   constexpr int KS = 128;
   extern __shared__ __attribute__((aligned(16))) char dsm[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -213,11 +212,60 @@ __global__ __launch_bounds__(256) void quant_mx8_kernel(const T* __restrict__ x,
   const MxBlock b = mx8_encode(v);
   if (live) {
     *reinterpret_cast<uint2*>(qo + row * ldq + c8 * 8) = b.q;
-    if ((c8 & 3) == 0) so[row * (K >> 5) + (c8 >> 2)] = b.scale;
+    if ((c8 & 3) == 0) so[row * (K >> 5) + (c8 >> 2)] = (uint8_t)b.scale;
+  }
+}
+
+// several bf16 matrices in one launch (the forward weight images of a stack, once per step)
+constexpr int MX_MAX = 24;
+struct MxDesc {
+  const bf16* x;
+  uint8_t* q;
+  uint8_t* s;
+  int R, K, block0;
+};
+struct MxBatch {
+  MxDesc d[MX_MAX];
+  int n;
+};
+__global__ __launch_bounds__(256) void quant_mx8_multi_kernel(MxBatch b) {
+  int i = 0;
+  while (i + 1 < b.n && (int)blockIdx.x >= b.d[i + 1].block0) ++i;
+  const MxDesc& d = b.d[i];
+  const int per_row = d.K >> 3;
+  const int64_t idx = (int64_t)((int)blockIdx.x - d.block0) * 256 + threadIdx.x;
+  const int64_t total = (int64_t)d.R * per_row;
+  const bool live = idx < total;
+  const int64_t row = live ? idx / per_row : 0;
+  const int c8 = live ? (int)(idx - row * per_row) : 0;
+  float v[8];
+  load8(d.x + row * d.K + c8 * 8, v);
+  const MxBlock blk = mx8_encode(v);
+  if (live) {
+    *reinterpret_cast<uint2*>(d.q + row * d.K + c8 * 8) = blk.q;
+    if ((c8 & 3) == 0) d.s[row * (d.K >> 5) + (c8 >> 2)] = (uint8_t)blk.scale;
   }
 }
 
 }  // namespace
+
+int quant_mx8_multi(const MxQuantJob* jobs, int n, hipStream_t s) {
+  for (int base = 0; base < n; base += MX_MAX) {
+    MxBatch b;
+    b.n = n - base < MX_MAX ? n - base : MX_MAX;
+    int blocks = 0;
+    for (int i = 0; i < b.n; ++i) {
+      const MxQuantJob& j = jobs[base + i];
+      AVF_REQUIRE(j.x && j.q && j.s && j.R > 0 && j.K > 0 && j.K % 32 == 0 && j.R * j.K < (1LL << 31),
+                  "quant_mx8_multi: bad job %d", base + i);
+      b.d[i] = MxDesc{(const bf16*)j.x, (uint8_t*)j.q, (uint8_t*)j.s, (int)j.R, (int)j.K, blocks};
+      blocks += (int)ceil_div(j.R * (j.K >> 3), (int64_t)256);
+    }
+    quant_mx8_multi_kernel<<<blocks, 256, 0, s>>>(b);
+    AVF_TRY(check_launch("quant_mx8_multi_kernel"));
+  }
+  return 0;
+}
 
 int quant_mx8(const void* x, int dtype, int64_t ldx, int64_t R, int64_t K, void* q, int64_t ldq, void* scales, hipStream_t s) {
   AVF_REQUIRE(R > 0 && K > 0 && K % 32 == 0 && K < (1LL << 31), "quant_mx8: K must be a positive multiple of 32");
@@ -233,7 +281,7 @@ int quant_mx8(const void* x, int dtype, int64_t ldx, int64_t R, int64_t K, void*
   return check_launch("quant_mx8_kernel");
 }
 
-int gemm_mx8_nt(const GemmArgs& a, const void* a_scales, const void* b_scales, hipStream_t s) {
+int gemm_mx8_nt(const GemmArgs& a, const void* a_scales, const void* b_scales, hipStream_t s, void* mx_q, void* mx_s) {
   AVF_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm_mx8_nt: bad shape");
   AVF_REQUIRE(a.K % 128 == 0 && a.N % 4 == 0, "gemm_mx8_nt: K%%128 and N%%4 must be 0 (K=%lld N=%lld)", (long long)a.K,
               (long long)a.N);
@@ -251,6 +299,9 @@ int gemm_mx8_nt(const GemmArgs& a, const void* a_scales, const void* b_scales, h
   p.C = a.C; p.ldc = a.ldc; p.bias = a.bias; p.residual = a.residual; p.ldres = a.ldres;
   p.aux = (bf16*)a.aux; p.ldaux = a.ldaux;
   p.drop = a.drop;
+  p.mxq = (uint8_t*)mx_q; p.mxs = (uint8_t*)mx_s;
+  AVF_REQUIRE(!mx_q || (mx_s && a.epilogue == AVF_EPI_BIAS_GELU && a.N % 32 == 0 && ((uintptr_t)mx_q & 3) == 0),
+              "gemm_mx8_nt: the MX-FP8 output image needs the BIAS_GELU epilogue and N %% 32 == 0");
   AVF_REQUIRE(!a.drop.thresh16 || a.epilogue != AVF_EPI_NONE, "gemm_mx8_nt: dropout needs a fused epilogue");
   p.M = (int)a.M; p.N = (int)a.N; p.K = (int)a.K;
   q.As = (const uint8_t*)a_scales; q.Bs = (const uint8_t*)b_scales;

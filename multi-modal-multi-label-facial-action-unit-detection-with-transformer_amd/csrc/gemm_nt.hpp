@@ -28,6 +28,8 @@ struct NtParams {
   int64_t ldaux;
   float* cs_partial;  // optional [tiles_m * WM][N] column-sum partials of the stored C values (bias gradients)
   DropCfg drop;       // dropout site fused in the epilogue (thresh16 == 0: none); element index = m * N + n
+  uint8_t* mxq;       // optional (BIAS_GELU, N % 32 == 0): MX-FP8 image of the stored C, [M][N] e4m3 bytes ...
+  uint8_t* mxs;       // ... and [M][N/32] E8M0 scale bytes - the A operand of the next forward GEMM in the fp8 mode
   int M, N, K;
 };
 
@@ -77,6 +79,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
       const int i = half * 2 + ii;
       if (i >= MI) continue;
       const bool mok = mm[ii] < p.M;
+      float mxv[NI][4];
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         float v[4] = {acc[i][j][0] + bj[j].x, acc[i][j][1] + bj[j].y, acc[i][j][2] + bj[j].z, acc[i][j][3] + bj[j].w};
@@ -98,6 +101,29 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
           store4<CT>((CT*)p.C + (int64_t)mm[ii] * p.ldc + nn[j], make_float4(v[0], v[1], v[2], v[3]));
 #pragma unroll
           for (int r = 0; r < 4; ++r) cs[j][r] += v[r];
+        }
+        if (EPI == AVF_EPI_BIAS_GELU && (NI & 1) == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mxv[j][r] = v[r];
+        }
+      }
+      // MX-FP8 image of the row segment: a 32-block is the column blocks (j, j+1) x the 4 lane groups x 4 registers
+      if (EPI == AVF_EPI_BIAS_GELU && (NI & 1) == 0 && p.mxq) {  // wave-uniform
+#pragma unroll
+        for (int j = 0; j < NI; j += 2) {
+          float am = 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) am = fmaxf(am, fmaxf(fabsf(mxv[j][r]), fabsf(mxv[j + 1][r])));
+          am = fmaxf(am, __shfl_xor(am, 16, 64));
+          am = fmaxf(am, __shfl_xor(am, 32, 64));
+          float inv;
+          const uint32_t sb = mx8_scale_byte(am, &inv);
+          if (mok && nn[j] < p.N) {
+            uint8_t* qrow = p.mxq + (int64_t)mm[ii] * p.N;
+            *reinterpret_cast<uint32_t*>(qrow + nn[j]) = mx8_pack4(mxv[j], inv);
+            *reinterpret_cast<uint32_t*>(qrow + nn[j + 1]) = mx8_pack4(mxv[j + 1], inv);
+            if (lg == 0) p.mxs[(int64_t)mm[ii] * (p.N >> 5) + (nn[j] >> 5)] = (uint8_t)sb;
+          }
         }
       }
     }

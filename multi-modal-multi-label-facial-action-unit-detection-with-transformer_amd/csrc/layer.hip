@@ -27,6 +27,7 @@ struct Dims {
   uint64_t seed;
   const uint64_t* seed_dev;
   int layer;
+  bool mx;    // forward nn.Linear GEMMs fed by LayerNorm / GELU (qkv, mlp1, mlp2) take MX-FP8 operands (config 5)
 };
 
 int make_dims(const avf_layer_cfg* c, Dims* d) {
@@ -47,6 +48,10 @@ int make_dims(const avf_layer_cfg* c, Dims* d) {
   d->dt = c->dtype; d->es = c->dtype == AVF_BF16 ? 2 : 4;
   d->p = c->dropout_p; d->seed = ((uint64_t)c->seed_hi << 32) | c->seed_lo; d->layer = c->layer_index;
   d->seed_dev = (const uint64_t*)c->seed_dev;
+  d->mx = c->mx8_fwd != 0;
+  AVF_REQUIRE(!d->mx || (c->dtype == AVF_BF16 && c->dim % 128 == 0 && c->mlp_dim % 128 == 0 && c->dim <= 1536),
+              "layer: mx8_fwd needs the bf16 path with dim and mlp_dim multiples of 128 (dim=%d mlp_dim=%d)", c->dim,
+              c->mlp_dim);
   if (c->dtype == AVF_BF16) {
     AVF_REQUIRE(d->D % 8 == 0 && d->I % 8 == 0 && d->M % 8 == 0, "layer(bf16): dim, inner and mlp_dim must be multiples of 8");
     AVF_REQUIRE(d->dh == 32 || d->dh == 64, "layer(bf16): dim_head must be 32 or 64 (got %d)", d->dh);
@@ -92,6 +97,7 @@ size_t carve_saved(const Dims& d, void* base, Saved* s) {
 
 struct LowP {
   void *wqkv, *wqkv_t, *wo, *wo_t, *w1, *w1_t, *w2, *w2_t;
+  void *wqkv_q, *wqkv_s, *w1_q, *w1_s, *w2_q, *w2_s;  // mx8_fwd only
 };
 size_t carve_lowp(const Dims& d, void* base, LowP* l) {
   if (d.dt != AVF_BF16) {
@@ -108,6 +114,13 @@ size_t carve_lowp(const Dims& d, void* base, LowP* l) {
   t.w1_t = c.take((size_t)d.M * d.D * 2);
   t.w2 = c.take((size_t)d.D * d.M * 2);
   t.w2_t = c.take((size_t)d.D * d.M * 2);
+  if (d.mx) {  // MX-FP8 forward images (e4m3 bytes + one scale byte per 32) of Wqkv, W1, W2
+    t.wqkv_q = c.take((size_t)3 * d.I * d.D); t.wqkv_s = c.take((size_t)3 * d.I * d.D / 32);
+    t.w1_q = c.take((size_t)d.M * d.D);       t.w1_s = c.take((size_t)d.M * d.D / 32);
+    t.w2_q = c.take((size_t)d.D * d.M);       t.w2_s = c.take((size_t)d.D * d.M / 32);
+  } else {
+    t.wqkv_q = t.wqkv_s = t.w1_q = t.w1_s = t.w2_q = t.w2_s = nullptr;
+  }
   if (l) *l = t;
   return c.off;
 }
@@ -131,6 +144,7 @@ TnGroupArgs dw_group(const Dims& d, const void* gy, const void* g_act, const voi
 struct Work {
   void *du, *dh, *d_o, *dqkv, *dx_mid_lo, *dx_out_lo, *ln_ws, *ln_ws1, *cs_ws, *gemm_ws;
   float *dx_mid, *delta;
+  void *hq, *hs, *gq, *gs;  // mx8_fwd only: MX-FP8 images of the LayerNorm output and of gelu(u), forward scratch
 };
 size_t carve_work(const Dims& d, void* base, Work* w) {
   Carver c(base);
@@ -161,6 +175,12 @@ size_t carve_work(const Dims& d, void* base, Work* w) {
     g = g > gg ? g : gg;
   }
   t.gemm_ws = c.take(g);
+  if (d.mx) {
+    t.hq = c.take(d.R * d.D); t.hs = c.take(d.R * d.D / 32);
+    t.gq = c.take(d.R * d.M); t.gs = c.take(d.R * d.M / 32);
+  } else {
+    t.hq = t.hs = t.gq = t.gs = nullptr;
+  }
   if (w) *w = t;
   return c.off;
 }
@@ -176,6 +196,20 @@ int linear_fwd(const Dims& d, const void* A, int in, const void* W, int out, voi
   a.bias = bias; a.residual = res; a.ldres = out; a.aux = aux; a.ldaux = out; a.workspace = nullptr; a.colsum = nullptr;
   a.drop = drop; a.defer_fold = nullptr;
   return gemm(a, s);
+}
+
+// the same from MX-FP8 images of A and W; mx_q / mx_s: also emit the image of C (BIAS_GELU)
+int linear_fwd_mx(const Dims& d, const void* Aq, const void* As, int in, const void* Wq, const void* Ws, int out, void* C,
+                  int c_dtype, int epi, const float* bias, const float* res, void* aux, hipStream_t s, const DropCfg& drop,
+                  void* mx_q = nullptr, void* mx_s = nullptr) {
+  GemmArgs a;
+  a.dtype = AVF_BF16; a.transA = 0; a.transB = 1;
+  a.M = d.R; a.N = out; a.K = in;
+  a.A = Aq; a.lda = in; a.B = Wq; a.ldb = in;
+  a.C = C; a.ldc = out; a.c_dtype = c_dtype; a.epilogue = epi;
+  a.bias = bias; a.residual = res; a.ldres = out; a.aux = aux; a.ldaux = out; a.workspace = nullptr; a.colsum = nullptr;
+  a.drop = drop; a.defer_fold = nullptr;
+  return gemm_mx8_nt(a, As, Ws, s, mx_q, mx_s);
 }
 
 // dX[R, in] = dY[R, out] * W[out, in].  bf16 mode consumes the transposed copy Wt[in, out] as an NT GEMM.
@@ -263,9 +297,25 @@ extern "C" int avf_layer_prepare_weights(const avf_layer_cfg* cfg, const avf_lay
   return prep_weights_multi(b, 4, s);
 }
 
+extern "C" int avf_stack_quant_weights_mx8(const avf_layer_cfg* cfg, int layers, void* const* lowp, void* stream) {
+  Dims d;
+  AVF_TRY(make_dims(cfg, &d));
+  AVF_REQUIRE(d.mx, "stack_quant_weights_mx8: cfg.mx8_fwd is not set");
+  AVF_REQUIRE(layers > 0 && layers <= 64 && lowp, "stack_quant_weights_mx8: bad arguments");
+  MxQuantJob jobs[64 * 3];
+  for (int i = 0; i < layers; ++i) {
+    AVF_REQUIRE(lowp[i], "stack_quant_weights_mx8: null image buffer (layer %d)", i);
+    LowP l;
+    carve_lowp(d, lowp[i], &l);
+    jobs[3 * i + 0] = MxQuantJob{l.wqkv, l.wqkv_q, l.wqkv_s, 3 * d.I, d.D};
+    jobs[3 * i + 1] = MxQuantJob{l.w1, l.w1_q, l.w1_s, d.M, d.D};
+    jobs[3 * i + 2] = MxQuantJob{l.w2, l.w2_q, l.w2_s, d.D, d.M};
+  }
+  return quant_mx8_multi(jobs, 3 * layers, (hipStream_t)stream);
+}
+
 extern "C" int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p, const void* lowp, const float* x_in,
                              float* x_out, void* saved, void* workspace, void* stream) {
-  (void)workspace;
   Dims d;
   AVF_TRY(make_dims(cfg, &d));
   AVF_REQUIRE(p && x_in && x_out && saved, "layer_fwd: null pointer");
@@ -281,6 +331,27 @@ extern "C" int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   const void* w1 = lo ? l.w1 : (const void*)p->w1;
   const void* w2 = lo ? l.w2 : (const void*)p->w2;
 
+  if (d.mx) {
+    // config 5: the three GEMMs whose A operand leaves a row-wise producer (LayerNorm, GELU epilogue) run on the MX-FP8
+    // matrix path; the producers emit the e4m3 image beside the bf16 tensor backward needs, the weights' images come
+    // from avf_stack_quant_weights_mx8.  out-proj (A = attention output) and all of backward stay bf16.
+    AVF_REQUIRE(workspace, "layer_fwd(mx8): workspace missing");
+    Work w;
+    carve_work(d, workspace, &w);
+    const DropCfg dr0 = make_drop(d.p, d.seed, d.layer, 0, d.seed_dev), dr1 = make_drop(d.p, d.seed, d.layer, 1, d.seed_dev),
+                  dr2 = make_drop(d.p, d.seed, d.layer, 2, d.seed_dev);
+    AVF_TRY(layernorm_fwd(x_in, p->ln1_w, p->ln1_b, sv.h1, d.dt, sv.mean1, sv.rstd1, d.R, d.D, cfg->ln_eps, s, w.hq, w.hs));
+    AVF_TRY(linear_fwd_mx(d, w.hq, w.hs, d.D, l.wqkv_q, l.wqkv_s, 3 * d.I, sv.qkv, d.dt, AVF_EPI_NONE, nullptr, nullptr,
+                          nullptr, s, kNoDrop));
+    AVF_TRY(attn_fwd_bf16((const bf16*)sv.qkv, (bf16*)sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s, attn_q_prescale_on()));
+    AVF_TRY(linear_fwd(d, sv.o, d.I, wo, d.D, sv.x_mid, AVF_F32, AVF_EPI_BIAS_RES, p->b_out, x_in, nullptr, s, dr0));
+    AVF_TRY(layernorm_fwd(sv.x_mid, p->ln2_w, p->ln2_b, sv.h2, d.dt, sv.mean2, sv.rstd2, d.R, d.D, cfg->ln_eps, s, w.hq, w.hs));
+    AVF_TRY(linear_fwd_mx(d, w.hq, w.hs, d.D, l.w1_q, l.w1_s, d.M, sv.g, d.dt, AVF_EPI_BIAS_GELU, p->b1, nullptr, sv.u, s, dr1,
+                          w.gq, w.gs));
+    AVF_TRY(linear_fwd_mx(d, w.gq, w.gs, d.M, l.w2_q, l.w2_s, d.D, x_out, AVF_F32, AVF_EPI_BIAS_RES, p->b2, sv.x_mid, nullptr,
+                          s, dr2));
+    return 0;
+  }
   if (small_layer_ok(d.dt, d.N, d.D, d.H, d.dh, d.M)) {  // short sequences: the whole layer in one launch
     const float sc = attn_q_prescale_on() ? 1.0f : 1.4426950408889634f / sqrtf((float)d.dh);
     return layer_fwd_small(d.B, d.N, d.D, d.H, d.M, cfg->ln_eps, sc, p, wqkv, wo, w1, w2, x_in, x_out, sv.h1, sv.mean1,

@@ -69,11 +69,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 }
 
 // D % 4 == 0 and D <= 256*NV: the row lives in registers (one HBM read, no re-reads from cache)
-template <typename OutT, int NV>
+// MX: also emit the MX-FP8 image of the row (common.hpp mx8_encode4: D % 32 == 0, so the 8 lanes of a block are
+// live together) - the A operand of the following forward GEMM in the fp8 mode (layer.hip)
+template <typename OutT, int NV, bool MX = false>
 __global__ __launch_bounds__(256) void ln_fwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, OutT* __restrict__ y,
                                                          float* __restrict__ mean, float* __restrict__ rstd,
-                                                         int64_t rows, int D, float eps) {
+                                                         int64_t rows, int D, float eps, uint8_t* __restrict__ yq = nullptr,
+                                                         uint8_t* __restrict__ ys = nullptr) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -106,18 +109,42 @@ __global__ __launch_bounds__(256) void ln_fwd_reg_kernel(const float* __restrict
     if (c < D) {
       const float4 g = *reinterpret_cast<const float4*>(gamma + c);
       const float4 b = *reinterpret_cast<const float4*>(beta + c);
-      store4<OutT>(y + row * D + c, make_float4((v[i].x - mu) * rs * g.x + b.x, (v[i].y - mu) * rs * g.y + b.y,
-                                                (v[i].z - mu) * rs * g.z + b.z, (v[i].w - mu) * rs * g.w + b.w));
+      const float4 o = make_float4((v[i].x - mu) * rs * g.x + b.x, (v[i].y - mu) * rs * g.y + b.y,
+                                   (v[i].z - mu) * rs * g.z + b.z, (v[i].w - mu) * rs * g.w + b.w);
+      store4<OutT>(y + row * D + c, o);
+      if (MX) {
+        const float ov[4] = {o.x, o.y, o.z, o.w};
+        uint32_t sb;
+        const uint32_t qw = mx8_encode4(ov, &sb);
+        *reinterpret_cast<uint32_t*>(yq + row * D + c) = qw;
+        if ((lane & 7) == 0) ys[row * (D >> 5) + (c >> 5)] = (uint8_t)sb;
+      }
     }
   }
 }
 
 int layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype, float* mean,
-                  float* rstd, int64_t rows, int dim, float eps, hipStream_t s) {
+                  float* rstd, int64_t rows, int dim, float eps, hipStream_t s, void* mx_q, void* mx_s) {
   AVF_REQUIRE(rows > 0 && dim > 0, "layernorm_fwd: bad shape rows=%lld dim=%d", (long long)rows, dim);
   AVF_REQUIRE(y_dtype == AVF_F32 || y_dtype == AVF_BF16, "layernorm_fwd: bad dtype %d", y_dtype);
-  TimingScope ts(KC_LAYERNORM, 0.0, (double)rows * dim * (4.0 + (y_dtype == AVF_BF16 ? 2.0 : 4.0)), s);
+  TimingScope ts(KC_LAYERNORM, 0.0, (double)rows * dim * (4.0 + (y_dtype == AVF_BF16 ? 2.0 : 4.0) + (mx_q ? 1.03125 : 0.0)), s);
   dim3 grid((unsigned)ceil_div(rows, 4)), block(256);
+  if (mx_q) {
+    AVF_REQUIRE(mx_s && y_dtype == AVF_BF16 && dim % 32 == 0 && dim <= 1536,
+                "layernorm_fwd: the MX-FP8 image needs bf16 output, dim %% 32 == 0 and dim <= 1536 (dim=%d)", dim);
+#define LAUNCH_MX(NVV)                                                                                              \
+  ln_fwd_reg_kernel<bf16, NVV, true><<<grid, block, 0, s>>>(x, gamma, beta, (bf16*)y, mean, rstd, rows, dim, eps, \
+                                                            (uint8_t*)mx_q, (uint8_t*)mx_s)
+    switch ((dim + 255) / 256) {
+      case 1: LAUNCH_MX(1); break;
+      case 2: LAUNCH_MX(2); break;
+      case 3: LAUNCH_MX(3); break;
+      case 4: LAUNCH_MX(4); break;
+      default: LAUNCH_MX(6); break;
+    }
+#undef LAUNCH_MX
+    return check_launch("ln_fwd_reg_kernel(mx)");
+  }
   if (dim % 4 == 0 && dim <= 1536) {
     const int nv = (dim + 255) / 256;
 #define LAUNCH_NV(T, NVV) ln_fwd_reg_kernel<T, NVV><<<grid, block, 0, s>>>(x, gamma, beta, (T*)y, mean, rstd, rows, dim, eps)

@@ -158,21 +158,42 @@ def quant_mx8(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     return q, s
 
 
+def layernorm_fwd_mx8(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5):
+    """LayerNorm rows -> (y bf16, mean, rstd, e4m3 image of y, its scale bytes)."""
+    _need_cuda(x, weight, bias)
+    x = x.contiguous()
+    rows, dim = x.shape
+    y = torch.empty((rows, dim), dtype=torch.bfloat16, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    q = torch.empty((rows, dim), dtype=torch.uint8, device=x.device)
+    s = torch.empty((rows, dim // 32), dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.load().avf_layernorm_fwd_mx8(_ptr(x), _ptr(weight), _ptr(bias), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(q),
+                                                 _ptr(s), rows, dim, eps, _stream()), "layernorm_fwd_mx8")
+    return y, mean, rstd, q, s
+
+
 def gemm_mx8(a_q: torch.Tensor, a_s: torch.Tensor, b_q: torch.Tensor, b_s: torch.Tensor, out_dtype=torch.float32,
-             epilogue: int = EPI_NONE, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None):
+             epilogue: int = EPI_NONE, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+             want_image: bool = False):
     """C[M,N] = A[M,K] B[N,K]^T from MX-FP8 images (quant_mx8).  Returns C (and the saved pre-activation for
-    EPI_BIAS_GELU)."""
+    EPI_BIAS_GELU; and with want_image the MX-FP8 image (q, scales) of C)."""
     _need_cuda(a_q, a_s, b_q, b_s, bias, residual)
     M, K = a_q.shape
     N = b_q.shape[0]
     assert b_q.shape[1] == K and a_s.shape == (M, K // 32) and b_s.shape == (N, K // 32)
     c = torch.empty((M, N), dtype=out_dtype, device=a_q.device)
     aux = torch.empty((M, N), dtype=out_dtype, device=a_q.device) if epilogue == EPI_BIAS_GELU else None
+    cq = torch.empty((M, N), dtype=torch.uint8, device=a_q.device) if want_image else None
+    cs = torch.empty((M, N // 32), dtype=torch.uint8, device=a_q.device) if want_image else None
     _lib.check(_lib.load().avf_gemm_mx8_nt(M, N, K, _ptr(a_q.contiguous()), _ptr(a_s.contiguous()), _ptr(b_q.contiguous()),
                                            _ptr(b_s.contiguous()), _ptr(c), N, avf_dtype(out_dtype), epilogue, _ptr(bias),
                                            _ptr(residual.contiguous() if residual is not None else None), N,
-                                           _ptr(aux), N, _stream()), "gemm_mx8_nt")
-    return (c, aux) if aux is not None else c
+                                           _ptr(aux), N, _ptr(cq), _ptr(cs), _stream()), "gemm_mx8_nt")
+    out = (c, aux) if aux is not None else (c,)
+    if want_image:
+        out = out + (cq, cs)
+    return out if len(out) > 1 else out[0]
 
 
 def attn_fwd(qkv: torch.Tensor, batch: int, tokens: int, heads: int, dim_head: int, q_prescaled: bool = False):

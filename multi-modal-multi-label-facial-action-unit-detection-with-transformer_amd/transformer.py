@@ -8,7 +8,8 @@ dual_sformer.py/vggformer.py): same constructor, same ``forward(x[B,N,dim], mask
 the reference would get).  The holders only own parameters: all math runs in
 ``libavformer_hip.so`` through one forward and one backward C call per layer.
 
-Extra keyword ``compute_dtype``: ``"bf16"`` (throughput mode: bf16 MFMA, fp32 accumulate / LayerNorm /
+Extra keyword ``compute_dtype``: ``"mx8"`` (the bf16 mode with MX-FP8 operands on the forward GEMMs of to_qkv, net.0 and
+net.3 - BASELINE config 5; tolerance against the bf16 mode stated in tests/test_gpu_mx8.py), ``"bf16"`` (throughput mode: bf16 MFMA, fp32 accumulate / LayerNorm /
 softmax statistics / residual stream) or ``"f32"`` (parity mode: fp32 MFMA + fp32 attention; matches the
 fp32 CPU reference to ~1e-5).
 """
@@ -232,7 +233,12 @@ class Transformer(nn.Module):
         super().__init__()
         self.dim, self.depth, self.heads, self.dim_head, self.mlp_dim = dim, depth, heads, dim_head, mlp_dim
         self.dropout = float(dropout)
-        self.compute_dtype = avf_dtype(compute_dtype)
+        # "mx8": the bf16 path with MX-FP8 operands for the forward GEMMs of to_qkv, net.0 and net.3 (BASELINE config 5)
+        self.mx8 = isinstance(compute_dtype, str) and compute_dtype.lower() in ("mx8", "fp8", "mxfp8")
+        if self.mx8 and (dim % 128 or mlp_dim % 128 or dim > 1536):
+            raise ValueError(f"compute_dtype='mx8' needs dim and mlp_dim to be multiples of 128 and dim <= 1536 "
+                             f"(dim={dim}, mlp_dim={mlp_dim})")
+        self.compute_dtype = _lib.BF16 if self.mx8 else avf_dtype(compute_dtype)
         self.project_out = not (heads == 1 and dim_head == dim)
         self.layers = nn.ModuleList([_make_layer(dim, heads, dim_head, mlp_dim, dropout) for _ in range(depth)])
         self._ws = None
@@ -285,7 +291,7 @@ class Transformer(nn.Module):
                 f"p=0 / eval() (SURVEY.md section 7)")
         return _lib.LayerCfg(B, N, self.dim, self.heads, self.dim_head, self.mlp_dim, self.compute_dtype,
                              int(self.project_out), 1e-5, float(p), 0, 0, layer,
-                             seed_t.data_ptr() if (seed_t is not None and p != 0.0) else None)
+                             seed_t.data_ptr() if (seed_t is not None and p != 0.0) else None, int(self.mx8))
 
     def _advance_seed(self, dev) -> Optional[torch.Tensor]:
         """Dropout seed of this forward, as a DEVICE tensor: the module's counter (initialised from torch.initial_seed(),
@@ -338,14 +344,19 @@ class Transformer(nn.Module):
         ptrs = [p.data_ptr() for p in params]
         ready = self._lowp_ready and not fresh and self._lowp_ptrs == ptrs
         self._lowp_ready = False  # one forward per optimizer step; anything else re-prepares (weights may have changed)
-        if ready:
-            return self._lowp_bufs
-        if fresh or not self.cache_weights or self._lowp_ptrs != ptrs:
+        changed = ready  # the optimizer rewrote the bf16 images
+        if not ready and (fresh or not self.cache_weights or self._lowp_ptrs != ptrs):
             for l in range(self.depth):
                 pp = self._param_struct(params, l)
                 _lib.check(lib.avf_layer_prepare_weights(C.byref(cfg), C.byref(pp), _ptr(self._lowp_bufs[l]), stream),
                            f"prepare_weights[{l}]")
             self._lowp_ptrs = ptrs
+            changed = True
+        if self.mx8 and changed:  # the e4m3 images follow the bf16 ones: one launch for the stack
+            if fresh or self.__dict__.get("_mx_ptr_array") is None:
+                self._mx_ptr_array = (C.c_void_p * self.depth)(*[b.data_ptr() for b in self._lowp_bufs])
+            _lib.check(lib.avf_stack_quant_weights_mx8(C.byref(cfg), self.depth, self._mx_ptr_array, stream),
+                       "stack_quant_weights_mx8")
         return self._lowp_bufs
 
     def refresh_weights(self):

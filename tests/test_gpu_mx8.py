@@ -106,9 +106,134 @@ def test_gemm_against_fp32_product(ops, M, N, K):
 
 
 def test_rejects_bad_shapes(ops):
-    import avformer_amd as A
-    with pytest.raises(A._lib.HipLibraryError):
+    with pytest.raises(RuntimeError, match="multiple of 32"):
         ops.quant_mx8(torch.zeros(4, 48, device="cuda"))
     aq, as_ = ops.quant_mx8(torch.zeros(4, 64, device="cuda"))
-    with pytest.raises(A._lib.HipLibraryError):
+    with pytest.raises(RuntimeError, match="K%128"):
         ops.gemm_mx8(aq, as_, aq, as_)  # K % 128 != 0
+
+
+# ---------------------------------------------------------------------------------------------- fused producers
+@pytest.mark.parametrize("rows,D", [(5, 128), (324, 512), (77, 1536), (9, 256)])
+def test_layernorm_emits_the_image_of_its_output(ops, rows, D):
+    g = torch.Generator().manual_seed(rows + D)
+    x = (torch.randn(rows, D, generator=g) * 3 + 1).cuda()
+    w = torch.randn(D, generator=g).cuda()
+    b = torch.randn(D, generator=g).cuda()
+    y, mean, rstd, q, s = ops.layernorm_fwd_mx8(x, w, b)
+    y32, mean32, rstd32 = ops.layernorm_fwd(x, w, b, 1e-5, torch.float32)  # the same kernel arithmetic, fp32 store
+    assert torch.equal(y.float(), y32.bfloat16().float()) and torch.equal(mean, mean32)
+    q_ref, s_ref = oracle.mx8_quant(y32)
+    assert torch.equal(s.cpu(), s_ref)
+    assert torch.equal(q.cpu(), q_ref)
+
+
+@pytest.mark.parametrize("M,N,K", [(648, 1024, 512), (100, 256, 128), (1296, 128, 256)])
+def test_gelu_epilogue_emits_the_image_of_its_output(ops, M, N, K):
+    import avformer_amd as A
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(N, K, generator=g) * 0.1
+    bias = torch.randn(N, generator=g)
+    aq, as_ = ops.quant_mx8(a.cuda())
+    bq, bs = ops.quant_mx8(b.cuda())
+    c, u, cq, cs = ops.gemm_mx8(aq, as_, bq, bs, out_dtype=torch.float32, epilogue=A.ops.EPI_BIAS_GELU, bias=bias.cuda(),
+                                want_image=True)
+    q_ref, s_ref = oracle.mx8_quant(c)  # the image of exactly the values the kernel stored
+    assert torch.equal(cs.cpu(), s_ref)
+    assert torch.equal(cq.cpu(), q_ref)
+
+
+# ---------------------------------------------------------------------------------------------- the layer path
+CFG = dict(dim=256, depth=2, heads=8, dim_head=32, mlp_dim=512)
+
+
+def _pair(cfg, dropout=0.0):
+    import avformer_amd as A
+    torch.manual_seed(3)
+    ref = A.Transformer(cfg["dim"], cfg["depth"], cfg["heads"], cfg["dim_head"], cfg["mlp_dim"], dropout,
+                        compute_dtype="bf16").cuda()
+    mx = A.Transformer(cfg["dim"], cfg["depth"], cfg["heads"], cfg["dim_head"], cfg["mlp_dim"], dropout,
+                       compute_dtype="mx8").cuda()
+    mx.load_state_dict(ref.state_dict())
+    return ref, mx
+
+
+@pytest.mark.parametrize("cfg,B,N", [(CFG, 3, 40), (dict(dim=512, depth=2, heads=8, dim_head=64, mlp_dim=1024), 2, 324),
+                                     (dict(dim=128, depth=2, heads=8, dim_head=32, mlp_dim=256), 4, 12)])
+def test_stack_forward_backward_against_bf16_mode(cfg, B, N):
+    """Config-5 tolerance for the stack: output within 3 %, input gradient within 6 %, every parameter gradient within
+    10 % (relative Frobenius; observed <= 7.3 %, largest on to_out.weight, whose operand is the attention output of the
+    fp8-fed q/k/v) of the bf16 mode on the same weights; the fp32 oracle output is within 4 %."""
+    ref, mx = _pair(cfg)
+    x = torch.randn(B, N, cfg["dim"], generator=torch.Generator().manual_seed(1)).cuda()
+    outs = []
+    for t in (ref, mx):
+        xi = x.clone().requires_grad_(True)
+        y = t(xi)
+        (y.float() ** 2).mean().backward()
+        outs.append((y.detach(), xi.grad, {k: p.grad.clone() for k, p in t.named_parameters()}))
+    (y0, dx0, g0), (y1, dx1, g1) = outs
+    assert rel_fro(y1, y0) < 0.03
+    assert rel_fro(dx1, dx0) < 0.06
+    for k in g0:
+        assert rel_fro(g1[k], g0[k]) < 0.10, k
+    sd = {k: v.detach().cpu() for k, v in ref.state_dict().items()}
+    y_cpu = oracle.transformer_forward(x.cpu(), sd, cfg["depth"], cfg["heads"])
+    assert rel_fro(y1, y_cpu) < 0.04
+
+
+def test_rejects_unsupported_widths():
+    import avformer_amd as A
+    with pytest.raises(ValueError):
+        A.Transformer(192, 1, 8, 32, 256, compute_dtype="mx8")
+
+
+def test_training_trajectory_tracks_bf16_mode():
+    """40 Adam steps on a fixed regression batch (the loss falls 2.1 -> 0.05): the mx8 run's loss stays within 1 % of the
+    INITIAL loss of the bf16 run's at every step (observed 0.45 %; same initial weights; the weight images are re-quantised
+    after every optimizer step) and ends within 20 % of it in relative terms (observed 13 %: the e4m3 noise floor shows
+    once the batch is nearly memorised)."""
+    import avformer_amd as A
+    ref, mx = _pair(CFG)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(8, 24, CFG["dim"], generator=g).cuda()
+    target = torch.randn(8, 24, CFG["dim"], generator=g).cuda()
+    losses = []
+    for t in (ref, mx):
+        opt = A.optim.FusedAdam(t, lr=1e-3)
+        ls = []
+        for _ in range(40):
+            opt.zero_grad(set_to_none=True)
+            loss = ((t(x) - target) ** 2).mean()
+            loss.backward()
+            opt.step()
+            ls.append(loss.item())
+        losses.append(ls)
+    a, b = torch.tensor(losses[0]), torch.tensor(losses[1])
+    assert b[-1] < 0.9 * b[0]  # it trains
+    assert ((a - b).abs().max() / a[0]).item() < 0.01
+    assert abs(b[-1] - a[-1]) / a[-1] < 0.20
+
+
+def test_dropout_masks_replay_in_backward():
+    """dropout sites ride in the mx8 epilogues exactly as in the bf16 ones: a seeded forward is reproducible and its
+    backward sees the same masks (gradient of a linear functional equals the finite-difference-free identity check
+    against a second run with the same seed)."""
+    _, mx = _pair(CFG, dropout=0.2)
+    mx.train()
+    x = torch.randn(2, 20, CFG["dim"], generator=torch.Generator().manual_seed(4)).cuda()
+    mx._seed_dev = None
+    torch.manual_seed(77)
+    xi = x.clone().requires_grad_(True)
+    y1 = mx(xi)
+    y1.sum().backward()
+    g1 = xi.grad.clone()
+    mx._seed_dev = None
+    torch.manual_seed(77)
+    xj = x.clone().requires_grad_(True)
+    y2 = mx(xj)
+    y2.sum().backward()
+    assert torch.equal(y1, y2) and torch.equal(g1, xj.grad)
+    mx.eval()
+    assert rel_fro(mx(x), y1) > 0.05  # the masks were live
