@@ -553,6 +553,7 @@ int gemm_bf16_nt(const GemmArgs& a, hipStream_t s) {
   p.aux = (bf16*)a.aux; p.ldaux = a.ldaux;
   p.drop = a.drop;
   p.mxq = nullptr; p.mxs = nullptr;
+  p.wide = nt_wide_stores();
   AVF_REQUIRE(!a.drop.thresh16 || a.epilogue != AVF_EPI_NONE, "gemm_bf16_nt: dropout needs a fused epilogue");
   p.M = (int)a.M; p.N = (int)a.N; p.K = (int)a.K;
   dim3 grid((unsigned)ceil_div(a.N, TB), (unsigned)ceil_div(a.M, TB));

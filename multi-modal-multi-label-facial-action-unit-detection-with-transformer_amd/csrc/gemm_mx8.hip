@@ -300,6 +300,7 @@ int gemm_mx8_nt(const GemmArgs& a, const void* a_scales, const void* b_scales, h
   p.aux = (bf16*)a.aux; p.ldaux = a.ldaux;
   p.drop = a.drop;
   p.mxq = (uint8_t*)mx_q; p.mxs = (uint8_t*)mx_s;
+  p.wide = nt_wide_stores();
   AVF_REQUIRE(!mx_q || (mx_s && a.epilogue == AVF_EPI_BIAS_GELU && a.N % 32 == 0 && ((uintptr_t)mx_q & 3) == 0),
               "gemm_mx8_nt: the MX-FP8 output image needs the BIAS_GELU epilogue and N %% 32 == 0");
   AVF_REQUIRE(!a.drop.thresh16 || a.epilogue != AVF_EPI_NONE, "gemm_mx8_nt: dropout needs a fused epilogue");

@@ -28,6 +28,7 @@ struct NtParams {
   int64_t ldaux;
   float* cs_partial;  // optional [tiles_m * WM][N] column-sum partials of the stored C values (bias gradients)
   DropCfg drop;       // dropout site fused in the epilogue (thresh16 == 0: none); element index = m * N + n
+  int wide;           // 1: 2-byte outputs are stored 16 bytes per lane after a lane-pair exchange (store_pair16)
   uint8_t* mxq;       // optional (BIAS_GELU, N % 32 == 0): MX-FP8 image of the stored C, [M][N] e4m3 bytes ...
   uint8_t* mxs;       // ... and [M][N/32] E8M0 scale bytes - the A operand of the next forward GEMM in the fp8 mode
   int M, N, K;
@@ -35,6 +36,24 @@ struct NtParams {
 
 // 16-byte chunk c (0..7) of tile row r lives at chunk slot c ^ (r & 7): conflict-free ds_read_b128
 __device__ __forceinline__ int nt_off(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
+
+// Two column blocks (j, j+1) of one output row in a 2-byte type.  A lane holds columns 4 lg .. 4 lg + 3 of each block as two
+// packed dwords; v_permlane16_swap trades the (j+1) words of the even lane groups for the j words of the odd ones, after
+// which a lane owns EIGHT consecutive columns (even groups: block j, columns 4 lg .. 4 lg + 7; odd groups: block j+1,
+// columns 4 (lg-1) .. 4 (lg-1) + 7): one 16-byte store where the plain path issues two 8-byte ones to other rows' segments.
+__device__ __forceinline__ void store_pair16(bf16* row, int n_j, int n_j1, int lg, uint32_t a0, uint32_t a1, uint32_t b0,
+                                             uint32_t b1, bool row_ok, int N) {
+  const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+  const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+  const int col = (lg & 1) ? n_j1 - 4 : n_j;
+  if (row_ok && col < N) *reinterpret_cast<uint4*>(row + col) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+}
+// the same for one dword per block (4 e4m3 bytes): one 8-byte store
+__device__ __forceinline__ void store_pair8(uint8_t* row, int n_j, int n_j1, int lg, uint32_t a, uint32_t b, bool row_ok, int N) {
+  const auto s = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+  const int col = (lg & 1) ? n_j1 - 4 : n_j;
+  if (row_ok && col < N) *reinterpret_cast<uint2*>(row + col) = make_uint2(s[0], s[1]);
+}
 
 // Shared epilogue.  A lane holds C[m = m_base + 16 i + li][n = n_base + 16 j + 4 lg + 0..3] in acc[i][j].
 // All global reads of the epilogue (bias, fp32 residual, saved pre-activation) are issued up front from CLAMPED
@@ -54,6 +73,9 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
     bj[j] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nc[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const uint64_t dkey = p.drop.thresh16 ? drop_key(p.drop) : 0;
+  // 2-byte outputs: lane pairs trade words so that every store is 16 bytes (wave-uniform conditions)
+  const bool wide_c = (NI & 1) == 0 && sizeof(CT) == 2 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && p.wide;
+  const bool wide_aux = (NI & 1) == 0 && EPI == AVF_EPI_BIAS_GELU && (p.N & 7) == 0 && (p.ldaux & 7) == 0 && p.wide;
   float cs[NI][4];
 #pragma unroll
   for (int j = 0; j < NI; ++j)
@@ -80,6 +102,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
       if (i >= MI) continue;
       const bool mok = mm[ii] < p.M;
       float mxv[NI][4];
+      uint32_t cw[NI][2], aw[NI][2];  // packed bf16 words of C / aux when a lane pair shares its stores (store_pair16)
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         float v[4] = {acc[i][j][0] + bj[j].x, acc[i][j][1] + bj[j].y, acc[i][j][2] + bj[j].z, acc[i][j][3] + bj[j].w};
@@ -90,21 +113,43 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
           v[0] = v[0] * df.x + ex[ii][j].x; v[1] = v[1] * df.y + ex[ii][j].y;
           v[2] = v[2] * df.z + ex[ii][j].z; v[3] = v[3] * df.w + ex[ii][j].w;
         } else if (EPI == AVF_EPI_BIAS_GELU) {  // Dropout(GELU(u)); u is saved unmasked
-          if (ok) store4<bf16>(p.aux + (int64_t)mm[ii] * p.ldaux + nn[j], make_float4(v[0], v[1], v[2], v[3]));
+          if (wide_aux) {
+            aw[j][0] = pack_bf16x2(v[0], v[1]); aw[j][1] = pack_bf16x2(v[2], v[3]);
+          } else if (ok) {
+            store4<bf16>(p.aux + (int64_t)mm[ii] * p.ldaux + nn[j], make_float4(v[0], v[1], v[2], v[3]));
+          }
           v[0] = gelu_tanh_fast(v[0]) * df.x; v[1] = gelu_tanh_fast(v[1]) * df.y;
           v[2] = gelu_tanh_fast(v[2]) * df.z; v[3] = gelu_tanh_fast(v[3]) * df.w;
         } else if (EPI == AVF_EPI_DGELU) {  // backward through Dropout then GELU
           v[0] *= df.x * dgelu_tanh_fast(ex[ii][j].x); v[1] *= df.y * dgelu_tanh_fast(ex[ii][j].y);
           v[2] *= df.z * dgelu_tanh_fast(ex[ii][j].z); v[3] *= df.w * dgelu_tanh_fast(ex[ii][j].w);
         }
-        if (ok) {
+        if (wide_c) {
+          cw[j][0] = pack_bf16x2(v[0], v[1]); cw[j][1] = pack_bf16x2(v[2], v[3]);
+        } else if (ok) {
           store4<CT>((CT*)p.C + (int64_t)mm[ii] * p.ldc + nn[j], make_float4(v[0], v[1], v[2], v[3]));
+        }
+        if (ok) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) cs[j][r] += v[r];
         }
         if (EPI == AVF_EPI_BIAS_GELU && (NI & 1) == 0) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) mxv[j][r] = v[r];
+        }
+      }
+      if ((NI & 1) == 0) {
+        if (wide_c) {
+#pragma unroll
+          for (int j = 0; j < NI; j += 2)
+            store_pair16((bf16*)p.C + (int64_t)mm[ii] * p.ldc, nn[j], nn[j + 1], lg, cw[j][0], cw[j][1], cw[j + 1][0],
+                         cw[j + 1][1], mok, p.N);
+        }
+        if (EPI == AVF_EPI_BIAS_GELU && wide_aux) {
+#pragma unroll
+          for (int j = 0; j < NI; j += 2)
+            store_pair16(p.aux + (int64_t)mm[ii] * p.ldaux, nn[j], nn[j + 1], lg, aw[j][0], aw[j][1], aw[j + 1][0],
+                         aw[j + 1][1], mok, p.N);
         }
       }
       // MX-FP8 image of the row segment: a 32-block is the column blocks (j, j+1) x the 4 lane groups x 4 registers
@@ -118,12 +163,9 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
           am = fmaxf(am, __shfl_xor(am, 32, 64));
           float inv;
           const uint32_t sb = mx8_scale_byte(am, &inv);
-          if (mok && nn[j] < p.N) {
-            uint8_t* qrow = p.mxq + (int64_t)mm[ii] * p.N;
-            *reinterpret_cast<uint32_t*>(qrow + nn[j]) = mx8_pack4(mxv[j], inv);
-            *reinterpret_cast<uint32_t*>(qrow + nn[j + 1]) = mx8_pack4(mxv[j + 1], inv);
-            if (lg == 0) p.mxs[(int64_t)mm[ii] * (p.N >> 5) + (nn[j] >> 5)] = (uint8_t)sb;
-          }
+          store_pair8(p.mxq + (int64_t)mm[ii] * p.N, nn[j], nn[j + 1], lg, mx8_pack4(mxv[j], inv), mx8_pack4(mxv[j + 1], inv),
+                      mok, p.N);
+          if (lg == 0 && mok && nn[j] < p.N) p.mxs[(int64_t)mm[ii] * (p.N >> 5) + (nn[j] >> 5)] = (uint8_t)sb;
         }
       }
     }
@@ -177,6 +219,14 @@ __device__ __forceinline__ void wait_vmcnt() {
 // (3- and 4-stage rings, 256x128 / 256x256 / 192x128 tiles, 64x64 tiles and a persistent tile loop were all measured slower
 //  on this path's shapes - M = 10k..16k, N = 512..1536, K = 512..1536 - and removed: the waves wait ~55 % of their
 //  cycles (SQ_WAIT_ANY) on LDS/barrier latency, which more resident waves hide better than deeper DMA rings)
+int nt_wide_stores() {
+  static const int on = [] {
+    const char* e = getenv("AVF_NT_WIDE");  // tuning aid: 0 = the plain per-block stores
+    return e ? atoi(e) : 1;
+  }();
+  return on;
+}
+
 int pick_nt_tile(int64_t M, int64_t N, int64_t K) {
   static const int override_tile = [] {
     const char* e = getenv("AVF_NT_TILE");  // tuning aid: force one configuration

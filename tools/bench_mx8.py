@@ -45,10 +45,13 @@ def main():
         bq, bs = ops.quant_mx8(b)
         t16 = timeit(lambda: ops.gemm(a16, b16, out_dtype=od, epilogue=epi, bias=bias, residual=res))
         t8 = timeit(lambda: ops.gemm_mx8(aq, as_, bq, bs, out_dtype=od, epilogue=epi, bias=bias, residual=res))
+        timg = timeit(lambda: ops.gemm_mx8(aq, as_, bq, bs, out_dtype=od, epilogue=epi, bias=bias, want_image=True)) \
+            if epi == ops.EPI_BIAS_GELU else None
         tq = timeit(lambda: ops.quant_mx8(a16))
         fl = 2.0 * M * N * K
         print(f"{name:10s} N={N:5d} K={K:5d}  bf16 {t16:7.1f} us ({fl / t16 / 1e6:6.0f} TF)   mx8 {t8:7.1f} us ({fl / t8 / 1e6:6.0f} TF)"
-              f"   x{t16 / t8:4.2f}   standalone quant of A {tq:6.1f} us")
+              f"   x{t16 / t8:4.2f}   standalone quant of A {tq:6.1f} us"
+              + (f"   mx8 + image of C {timg:6.1f} us" if timg is not None else ""))
 
 
 if __name__ == "__main__":
