@@ -72,6 +72,10 @@ typedef struct avf_layer_grads {
 } avf_layer_grads;
 
 int avf_version(void);
+/* sizeof(avf_layer_cfg) / sizeof(avf_layer_params) as this library was compiled: a binding checks its own struct
+ * declarations against them before the first call (a shorter caller-side struct would be read past its end) */
+size_t avf_sizeof_layer_cfg(void);
+size_t avf_sizeof_layer_params(void);
 const char* avf_last_error(void);
 /* 1 if a gfx950 device is usable by this process */
 int avf_device_ok(void);

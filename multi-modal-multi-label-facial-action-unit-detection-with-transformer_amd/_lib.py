@@ -40,6 +40,8 @@ class LayerPtrs(C.Structure):
 # name -> (restype, argtypes); every symbol declared in include/avformer_hip.h
 SIGNATURES = {
     "avf_version": (_int, []),
+    "avf_sizeof_layer_cfg": (_sz, []),
+    "avf_sizeof_layer_params": (_sz, []),
     "avf_last_error": (C.c_char_p, []),
     "avf_device_ok": (_int, []),
     "avf_layernorm_fwd": (_int, [_vp, _vp, _vp, _vp, _int, _vp, _vp, _i64, _int, _f, _vp]),
@@ -128,6 +130,12 @@ def load(build_if_missing: bool = True):
                 raise HipLibraryError(f"{path} does not export {name}") from e
             fn.restype = res
             fn.argtypes = args
+        # a stale .so (or an edited struct) must not be called with structs of another layout
+        if lib.avf_sizeof_layer_cfg() != C.sizeof(LayerCfg) or lib.avf_sizeof_layer_params() != C.sizeof(LayerPtrs):
+            raise HipLibraryError(
+                f"{path}: avf_layer_cfg / avf_layer_params are {lib.avf_sizeof_layer_cfg()} / "
+                f"{lib.avf_sizeof_layer_params()} bytes in the library but {C.sizeof(LayerCfg)} / {C.sizeof(LayerPtrs)} "
+                f"in this binding - rebuild with python __graft_entry__.py")
         _lib = lib
     return _lib
 

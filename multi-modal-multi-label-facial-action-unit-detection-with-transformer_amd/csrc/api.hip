@@ -100,6 +100,8 @@ __global__ void selftest_tr16_kernel(const bf16* tile, bf16* out) {
 using namespace avf;
 
 extern "C" int avf_version(void) { return 1; }
+extern "C" size_t avf_sizeof_layer_cfg(void) { return sizeof(avf_layer_cfg); }
+extern "C" size_t avf_sizeof_layer_params(void) { return sizeof(avf_layer_params); }
 
 extern "C" int avf_timing_enable(int on) {
   g_timing_on = on != 0;

@@ -28,6 +28,9 @@ def test_header_symbols_all_exported(lib):
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.avf_version() == 1
+    # the binding's struct declarations match the compiled header
+    assert lib.avf_sizeof_layer_cfg() == ctypes.sizeof(A._lib.LayerCfg)
+    assert lib.avf_sizeof_layer_params() == ctypes.sizeof(A._lib.LayerPtrs)
 
 
 def test_size_queries_and_config_validation(lib):
