@@ -550,7 +550,7 @@ int gemm_bf16_nt(const GemmArgs& a, hipStream_t s) {
                  2.0 * (a.M * a.K + a.N * a.K) + (a.c_dtype == AVF_F32 ? 4.0 : 2.0) * a.M * a.N, s);
   p.A = (const bf16*)a.A; p.lda = a.lda; p.B = (const bf16*)a.B; p.ldb = a.ldb;
   p.C = a.C; p.ldc = a.ldc; p.bias = a.bias; p.residual = a.residual; p.ldres = a.ldres;
-  p.aux = (bf16*)a.aux; p.ldaux = a.ldaux;
+  p.aux = a.aux; p.ldaux = a.ldaux;
   p.drop = a.drop;
   p.mxq = nullptr; p.mxs = nullptr;
   p.wide = nt_wide_stores();

@@ -297,7 +297,7 @@ int gemm_mx8_nt(const GemmArgs& a, const void* a_scales, const void* b_scales, h
                  1.0 * (a.M * a.K + a.N * a.K) * (1.0 + 1.0 / 32) + (a.c_dtype == AVF_F32 ? 4.0 : 2.0) * a.M * a.N, s);
   p.A = (const bf16*)a.A; p.lda = a.lda; p.B = (const bf16*)a.B; p.ldb = a.ldb;
   p.C = a.C; p.ldc = a.ldc; p.bias = a.bias; p.residual = a.residual; p.ldres = a.ldres;
-  p.aux = (bf16*)a.aux; p.ldaux = a.ldaux;
+  p.aux = a.aux; p.ldaux = a.ldaux;
   p.drop = a.drop;
   p.mxq = (uint8_t*)mx_q; p.mxs = (uint8_t*)mx_s;
   p.wide = nt_wide_stores();

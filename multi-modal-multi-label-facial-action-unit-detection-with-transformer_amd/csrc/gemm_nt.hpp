@@ -24,7 +24,7 @@ struct NtParams {
   const float* bias;
   const float* residual;
   int64_t ldres;
-  bf16* aux;
+  void* aux;          // saved pre-activation, stored in C's type (BIAS_GELU writes it, DGELU reads it)
   int64_t ldaux;
   float* cs_partial;  // optional [tiles_m * WM][N] column-sum partials of the stored C values (bias gradients)
   DropCfg drop;       // dropout site fused in the epilogue (thresh16 == 0: none); element index = m * N + n
@@ -75,7 +75,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
   const uint64_t dkey = p.drop.thresh16 ? drop_key(p.drop) : 0;
   // 2-byte outputs: lane pairs trade words so that every store is 16 bytes (wave-uniform conditions)
   const bool wide_c = (NI & 1) == 0 && sizeof(CT) == 2 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && p.wide;
-  const bool wide_aux = (NI & 1) == 0 && EPI == AVF_EPI_BIAS_GELU && (p.N & 7) == 0 && (p.ldaux & 7) == 0 && p.wide;
+  const bool wide_aux = (NI & 1) == 0 && sizeof(CT) == 2 && EPI == AVF_EPI_BIAS_GELU && (p.N & 7) == 0 && (p.ldaux & 7) == 0 && p.wide;
   float cs[NI][4];
 #pragma unroll
   for (int j = 0; j < NI; ++j)
@@ -93,7 +93,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         if (EPI == AVF_EPI_BIAS_RES) ex[ii][j] = *reinterpret_cast<const float4*>(p.residual + (int64_t)mc * p.ldres + nc[j]);
-        else if (EPI == AVF_EPI_DGELU) ex[ii][j] = load4<bf16>(p.aux + (int64_t)mc * p.ldaux + nc[j]);
+        else if (EPI == AVF_EPI_DGELU) ex[ii][j] = load4<CT>((const CT*)p.aux + (int64_t)mc * p.ldaux + nc[j]);
       }
     }
 #pragma unroll
@@ -116,7 +116,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
           if (wide_aux) {
             aw[j][0] = pack_bf16x2(v[0], v[1]); aw[j][1] = pack_bf16x2(v[2], v[3]);
           } else if (ok) {
-            store4<bf16>(p.aux + (int64_t)mm[ii] * p.ldaux + nn[j], make_float4(v[0], v[1], v[2], v[3]));
+            store4<CT>((CT*)p.aux + (int64_t)mm[ii] * p.ldaux + nn[j], make_float4(v[0], v[1], v[2], v[3]));
           }
           v[0] = gelu_tanh_fast(v[0]) * df.x; v[1] = gelu_tanh_fast(v[1]) * df.y;
           v[2] = gelu_tanh_fast(v[2]) * df.z; v[3] = gelu_tanh_fast(v[3]) * df.w;
@@ -148,7 +148,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
         if (EPI == AVF_EPI_BIAS_GELU && wide_aux) {
 #pragma unroll
           for (int j = 0; j < NI; j += 2)
-            store_pair16(p.aux + (int64_t)mm[ii] * p.ldaux, nn[j], nn[j + 1], lg, aw[j][0], aw[j][1], aw[j + 1][0],
+            store_pair16((bf16*)p.aux + (int64_t)mm[ii] * p.ldaux, nn[j], nn[j + 1], lg, aw[j][0], aw[j][1], aw[j + 1][0],
                          aw[j + 1][1], mok, p.N);
         }
       }

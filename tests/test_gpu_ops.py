@@ -125,6 +125,26 @@ def test_gemm_epilogues(ops, dtype, M, N, K):
     _close(c, ((a.double() @ w.double().t()) * uu.grad.double()).float(), **tol)
 
 
+@pytest.mark.parametrize("M,N,K", [(500, 96, 256), (130, 260, 72)])
+def test_gemm_bf16_operands_fp32_outputs_keep_aux_in_fp32(ops, M, N, K):
+    """bf16 operands with c_dtype fp32: the saved pre-activation is stored / read in C's type (found by tools/fuzz_gemm.py:
+    it used to be written as bf16 into the caller's fp32 buffer)"""
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16()
+    bias = torch.randn(N, generator=g)
+    base = (a.double() @ w.double().t() + bias.double()).float()
+    c, aux = ops.gemm(a.cuda(), w.cuda(), out_dtype=torch.float32, epilogue=ops.EPI_BIAS_GELU, bias=bias.cuda())
+    assert aux.dtype == torch.float32
+    _close(aux, base, atol=1e-3, rtol=1e-4)
+    _close(c, oracle.gelu_tanh(base), atol=3e-3, rtol=2e-3)  # gelu_tanh_fast
+    u = torch.randn(M, N, generator=g)
+    uu = u.clone().requires_grad_(True)
+    oracle.gelu_tanh(uu).sum().backward()
+    c = ops.gemm(a.cuda(), w.cuda(), out_dtype=torch.float32, epilogue=ops.EPI_DGELU, aux=u.cuda())
+    _close(c, ((a.double() @ w.double().t()) * uu.grad.double()).float(), atol=3e-3, rtol=2e-3)
+
+
 @pytest.mark.parametrize("M,N,K", [(8, 8, 8), (64, 128, 64), (200, 136, 96), (384, 1536, 512), (1000, 48, 40),
                                    (1000, 512, 1024), (301, 132, 1088), (8200, 1024, 128)])  # 96x128 / 128x128x8w tiles
 def test_gemm_bf16_nt(ops, M, N, K):
