@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Random stack configurations (any dim / inner / mlp widths the modes accept, 1..700 tokens, with and without pooling):
+fp32 parity mode against the CPU oracle's autograd (tight), bf16 and - where the widths allow - mx8 against the parity mode.
+usage: python tools/fuzz_layer.py [count] [seed]"""
+import os, random, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import avformer_amd as A
+import oracle
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+count = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+for it in range(count):
+    dh = rng.choice([32, 64])
+    H = rng.choice([1, 2, 4, 8, 12])
+    I = H * dh
+    D = rng.choice([32, 64, 96, 128, 256, 384, 512])
+    M = rng.choice([64, 128, 200, 256, 512, 1024])
+    N = rng.choice([1, 2, 7, 12, 17, 31, 32, 33, 49, 64, 100, 196, 324, 400, 577, 640])
+    B = rng.choice([1, 2, 3, 5])
+    if H == 1 and dh == D:
+        continue  # nn.Identity to_out: not supported by the HIP path
+    L = rng.randint(1, 2)
+    pool = rng.random() < 0.3 and D % 4 == 0
+    torch.manual_seed(rng.randint(0, 1 << 30))
+    t32 = A.Transformer(D, L, H, dh, M, compute_dtype="f32").cuda()
+    sd = t32.state_dict()
+    x = torch.randn(B, N, D, device="cuda")
+    # oracle (CPU autograd)
+    xc = x.cpu().clone().requires_grad_(True)
+    ps = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in sd.items()}
+    yc = oracle.transformer_forward(xc, ps, L, H)
+    if pool:
+        yc = yc.mean(dim=1)
+    yc.pow(2).mean().backward()
+    modes = ["f32", "bf16"] + (["mx8"] if D % 128 == 0 and M % 128 == 0 else [])
+    line = []
+    ok = True
+    for mode in modes:
+        t = t32 if mode == "f32" else A.Transformer(D, L, H, dh, M, compute_dtype=mode).cuda()
+        if mode != "f32":
+            t.load_state_dict(sd)
+        xi = x.clone().requires_grad_(True)
+        y = t(xi, pool="mean" if pool else None)
+        y.pow(2).mean().backward()
+        ey, ed = rel(y, yc), rel(xi.grad, xc.grad)
+        eg = max(rel(p.grad, ps[n].grad) for n, p in t.named_parameters())
+        lim = {"f32": (2e-5, 1e-4, 2e-4), "bf16": (1.5e-2, 3e-2, 6e-2), "mx8": (5e-2, 9e-2, 1.5e-1)}[mode]
+        good = ey < lim[0] and ed < lim[1] and eg < lim[2]
+        ok = ok and good
+        line.append(f"{mode}{'' if good else '!'} y {ey:.1e} dx {ed:.1e} g {eg:.1e}")
+    print(f"{'ok ' if ok else 'BAD'} B={B} N={N} D={D} H={H} dh={dh} M={M} L={L} pool={int(pool)}: " + " | ".join(line))
+    if not ok:
+        sys.exit(1)
+print("all ok")
