@@ -36,7 +36,7 @@ TimingRec* g_recs = nullptr;
 int g_created = 0, g_used = 0;
 }  // namespace
 
-TimingScope::TimingScope(int cls, double flops, double bytes, hipStream_t s) : slot(-1), stream(s) {
+TimingScope::TimingScope(int cls, double flops, double bytes, hipStream_t s, bool pk) : slot(-1), stream(s), per_kernel(pk) {
   if (!g_timing_on || g_used >= TIMING_POOL) return;
   if (!g_recs) g_recs = new TimingRec[TIMING_POOL];
   if (g_used >= g_created) {
@@ -45,10 +45,16 @@ TimingScope::TimingScope(int cls, double flops, double bytes, hipStream_t s) : s
   }
   slot = g_used++;
   g_recs[slot].cls = cls; g_recs[slot].flops = flops; g_recs[slot].bytes = bytes;
-  (void)hipEventRecord(g_recs[slot].start, s);
+  if (!per_kernel) (void)hipEventRecord(g_recs[slot].start, s);
 }
 TimingScope::~TimingScope() {
-  if (slot >= 0) (void)hipEventRecord(g_recs[slot].stop, stream);
+  if (slot >= 0 && !per_kernel) (void)hipEventRecord(g_recs[slot].stop, stream);
+}
+bool TimingScope::events(hipEvent_t* start, hipEvent_t* stop) const {
+  if (slot < 0 || !per_kernel) return false;
+  *start = g_recs[slot].start;
+  *stop = g_recs[slot].stop;
+  return true;
 }
 
 // ---------------------------------------------------------------------------------------------

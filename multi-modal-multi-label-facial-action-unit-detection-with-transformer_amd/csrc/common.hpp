@@ -1,6 +1,7 @@
 // common.hpp - shared device/host helpers for libavformer_hip (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -38,9 +39,22 @@ enum KernelClass {
 struct TimingScope {  // records a start/stop event pair around the launches issued during its lifetime
   int slot;
   hipStream_t stream;
-  TimingScope(int cls, double flops, double bytes, hipStream_t s);
+  bool per_kernel;
+  // per_kernel: the scope records nothing itself; its ONE kernel launch goes through hipExtLaunchKernelGGL with the pair
+  // from events(), which then carry the dispatch's own begin / end timestamps - the duration rocprofv3 reports, without the
+  // ~2 us of command-processor time an event pair around a launch includes
+  TimingScope(int cls, double flops, double bytes, hipStream_t s, bool per_kernel = false);
   ~TimingScope();
+  bool events(hipEvent_t* start, hipEvent_t* stop) const;
 };
+// launch `kernel` inside a per_kernel scope (ts may be null or a plain scope: ordinary launch)
+template <typename... Args, typename F = void (*)(Args...)>
+inline void launch_in_scope(const TimingScope* ts, F kernel, dim3 grid, dim3 block, uint32_t smem, hipStream_t stream,
+                            Args... args) {
+  hipEvent_t e0, e1;
+  if (ts && ts->events(&e0, &e1)) hipExtLaunchKernelGGL(kernel, grid, block, smem, stream, e0, e1, 0, args...);
+  else kernel<<<grid, block, smem, stream>>>(args...);
+}
 
 // ---------------------------------------------------------------------------------------------
 // element types

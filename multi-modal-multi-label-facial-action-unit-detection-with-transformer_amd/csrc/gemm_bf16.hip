@@ -199,7 +199,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(NtParam
 }
 
 template <int EPI, typename CT, int WM, int WN, int MI, int NI, int NS>
-int launch_nt_glds(const NtParams& p, hipStream_t s, int* part_rows) {
+int launch_nt_glds(const NtParams& p, hipStream_t s, int* part_rows, TimingScope* ts) {
   constexpr int BMT = 16 * MI * WM, BNT = 16 * NI * WN;
   constexpr int SMEM = NS * (BMT + BNT) * 128;
   static_assert(NS >= 2 && NS <= 4 && SMEM <= 160 * 1024, "stage count / LDS budget");
@@ -213,17 +213,18 @@ int launch_nt_glds(const NtParams& p, hipStream_t s, int* part_rows) {
   const int tiles_m = (p.M + BMT - 1) / BMT, tiles_n = (p.N + BNT - 1) / BNT;
   const int nwg = tiles_m * tiles_n;
   *part_rows = tiles_m * WM;
-  gemm_bf16_nt_glds_kernel<EPI, CT, WM, WN, MI, NI, NS><<<nwg, WM * WN * 64, SMEM, s>>>(p, tiles_n, nwg);
+  launch_in_scope(ts, gemm_bf16_nt_glds_kernel<EPI, CT, WM, WN, MI, NI, NS>, dim3(nwg), dim3(WM * WN * 64), SMEM, s, p, tiles_n,
+                  nwg);
   return 0;
 }
 
 template <int EPI, typename CT>
-int launch_nt_glds_any(const NtParams& p, hipStream_t s, int* part_rows) {
+int launch_nt_glds_any(const NtParams& p, hipStream_t s, int* part_rows, TimingScope* ts) {
   switch (pick_nt_tile(p.M, p.N, p.K)) {
-    case 0: return launch_nt_glds<EPI, CT, 2, 2, 4, 4, 2>(p, s, part_rows);
-    case 1: return launch_nt_glds<EPI, CT, 2, 2, 2, 4, 2>(p, s, part_rows);
-    case 3: return launch_nt_glds<EPI, CT, 2, 2, 3, 4, 2>(p, s, part_rows);
-    default: return launch_nt_glds<EPI, CT, 2, 4, 4, 2, 2>(p, s, part_rows);
+    case 0: return launch_nt_glds<EPI, CT, 2, 2, 4, 4, 2>(p, s, part_rows, ts);
+    case 1: return launch_nt_glds<EPI, CT, 2, 2, 2, 4, 2>(p, s, part_rows, ts);
+    case 3: return launch_nt_glds<EPI, CT, 2, 2, 3, 4, 2>(p, s, part_rows, ts);
+    default: return launch_nt_glds<EPI, CT, 2, 4, 4, 2, 2>(p, s, part_rows, ts);
   }
 }
 
@@ -547,7 +548,7 @@ int gemm_bf16_nt(const GemmArgs& a, hipStream_t s) {
   AVF_REQUIRE(a.M < (1LL << 31) && a.N < (1LL << 31) && a.K < (1LL << 31), "gemm_bf16_nt: shape too large");
   NtParams p;
   TimingScope ts(KC_GEMM_BF16_NT, 2.0 * a.M * a.N * a.K,
-                 2.0 * (a.M * a.K + a.N * a.K) + (a.c_dtype == AVF_F32 ? 4.0 : 2.0) * a.M * a.N, s);
+                 2.0 * (a.M * a.K + a.N * a.K) + (a.c_dtype == AVF_F32 ? 4.0 : 2.0) * a.M * a.N, s, /*per_kernel=*/true);
   p.A = (const bf16*)a.A; p.lda = a.lda; p.B = (const bf16*)a.B; p.ldb = a.ldb;
   p.C = a.C; p.ldc = a.ldc; p.bias = a.bias; p.residual = a.residual; p.ldres = a.ldres;
   p.aux = a.aux; p.ldaux = a.ldaux;
@@ -570,10 +571,10 @@ int gemm_bf16_nt(const GemmArgs& a, hipStream_t s) {
 #define LAUNCH(E)                                                         \
   do {                                                                    \
     if (dma) {                                                            \
-      if (cf32) AVF_TRY((launch_nt_glds_any<E, float>(p, s, &part_rows))); \
-      else AVF_TRY((launch_nt_glds_any<E, bf16>(p, s, &part_rows)));      \
-    } else if (cf32) gemm_bf16_nt_kernel<E, float><<<grid, 256, 0, s>>>(p); \
-    else gemm_bf16_nt_kernel<E, bf16><<<grid, 256, 0, s>>>(p);            \
+      if (cf32) AVF_TRY((launch_nt_glds_any<E, float>(p, s, &part_rows, &ts))); \
+      else AVF_TRY((launch_nt_glds_any<E, bf16>(p, s, &part_rows, &ts)));      \
+    } else if (cf32) launch_in_scope(&ts, gemm_bf16_nt_kernel<E, float>, grid, dim3(256), 0, s, p); \
+    else launch_in_scope(&ts, gemm_bf16_nt_kernel<E, bf16>, grid, dim3(256), 0, s, p); \
   } while (0)
   switch (a.epilogue) {
     case AVF_EPI_NONE: LAUNCH(AVF_EPI_NONE); break;

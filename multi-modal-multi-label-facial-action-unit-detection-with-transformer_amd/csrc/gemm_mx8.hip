@@ -153,7 +153,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mx8_nt_kernel(Mx8Params q, 
 }
 
 template <int EPI, typename CT, int WM, int WN, int MI, int NI>
-int launch_mx8(const Mx8Params& q, hipStream_t s, int* part_rows) {
+int launch_mx8(const Mx8Params& q, hipStream_t s, int* part_rows, TimingScope* ts) {
   constexpr int BMT = 16 * MI * WM, BNT = 16 * NI * WN;
   constexpr int SMEM = 2 * ((BMT + BNT) * 128 + ((BMT + BNT + 63) / 64) * 256);
   static_assert(SMEM <= 160 * 1024, "LDS budget");
@@ -167,17 +167,17 @@ int launch_mx8(const Mx8Params& q, hipStream_t s, int* part_rows) {
   const int tiles_m = (q.nt.M + BMT - 1) / BMT, tiles_n = (q.nt.N + BNT - 1) / BNT;
   const int nwg = tiles_m * tiles_n;
   *part_rows = tiles_m * WM;
-  gemm_mx8_nt_kernel<EPI, CT, WM, WN, MI, NI><<<nwg, WM * WN * 64, SMEM, s>>>(q, tiles_n, nwg);
+  launch_in_scope(ts, gemm_mx8_nt_kernel<EPI, CT, WM, WN, MI, NI>, dim3(nwg), dim3(WM * WN * 64), SMEM, s, q, tiles_n, nwg);
   return 0;
 }
 
 template <int EPI, typename CT>
-int launch_mx8_any(const Mx8Params& q, hipStream_t s, int* part_rows) {
+int launch_mx8_any(const Mx8Params& q, hipStream_t s, int* part_rows, TimingScope* ts) {
   switch (pick_nt_tile(q.nt.M, q.nt.N, q.nt.K / 2)) {  // K/2: the same LDS bytes per row as a bf16 problem of that depth
-    case 0: return launch_mx8<EPI, CT, 2, 2, 4, 4>(q, s, part_rows);
-    case 1: return launch_mx8<EPI, CT, 2, 2, 2, 4>(q, s, part_rows);
-    case 3: return launch_mx8<EPI, CT, 2, 2, 3, 4>(q, s, part_rows);
-    default: return launch_mx8<EPI, CT, 2, 4, 4, 2>(q, s, part_rows);
+    case 0: return launch_mx8<EPI, CT, 2, 2, 4, 4>(q, s, part_rows, ts);
+    case 1: return launch_mx8<EPI, CT, 2, 2, 2, 4>(q, s, part_rows, ts);
+    case 3: return launch_mx8<EPI, CT, 2, 2, 3, 4>(q, s, part_rows, ts);
+    default: return launch_mx8<EPI, CT, 2, 4, 4, 2>(q, s, part_rows, ts);
   }
 }
 
@@ -294,7 +294,7 @@ int gemm_mx8_nt(const GemmArgs& a, const void* a_scales, const void* b_scales, h
   Mx8Params q;
   NtParams& p = q.nt;
   TimingScope ts(KC_GEMM_MX8_NT, 2.0 * a.M * a.N * a.K,
-                 1.0 * (a.M * a.K + a.N * a.K) * (1.0 + 1.0 / 32) + (a.c_dtype == AVF_F32 ? 4.0 : 2.0) * a.M * a.N, s);
+                 1.0 * (a.M * a.K + a.N * a.K) * (1.0 + 1.0 / 32) + (a.c_dtype == AVF_F32 ? 4.0 : 2.0) * a.M * a.N, s, /*per_kernel=*/true);
   p.A = (const bf16*)a.A; p.lda = a.lda; p.B = (const bf16*)a.B; p.ldb = a.ldb;
   p.C = a.C; p.ldc = a.ldc; p.bias = a.bias; p.residual = a.residual; p.ldres = a.ldres;
   p.aux = a.aux; p.ldaux = a.ldaux;
@@ -316,8 +316,8 @@ int gemm_mx8_nt(const GemmArgs& a, const void* a_scales, const void* b_scales, h
   }
 #define LAUNCH(E)                                                     \
   do {                                                                \
-    if (cf32) AVF_TRY((launch_mx8_any<E, float>(q, s, &part_rows)));   \
-    else AVF_TRY((launch_mx8_any<E, bf16>(q, s, &part_rows)));        \
+    if (cf32) AVF_TRY((launch_mx8_any<E, float>(q, s, &part_rows, &ts)));   \
+    else AVF_TRY((launch_mx8_any<E, bf16>(q, s, &part_rows, &ts)));        \
   } while (0)
   switch (a.epilogue) {
     case AVF_EPI_NONE: LAUNCH(AVF_EPI_NONE); break;
