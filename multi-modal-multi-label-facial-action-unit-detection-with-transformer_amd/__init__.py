@@ -5,7 +5,7 @@ The compute lives in ``lib/libavformer_hip.so`` (hand-written HIP for gfx950, C 
 ``include/avformer_hip.h``); this package is the host-side mirror of the reference's
 ``Transformer`` / head / loss / model-registry surface.
 """
-from . import _build, _lib, checkpoint, dp, graphs, metrics, ops, optim  # noqa: F401
+from . import _build, _lib, audio, checkpoint, dp, graphs, metrics, ops, optim  # noqa: F401
 from .heads import AU_former, ResFormerTokens, TFormer, former_AU_head, tformer_AU_head  # noqa: F401
 from .loss import AULoss  # noqa: F401
 from .models import (MODEL_REGISTRY, AudioFormer, SyntheticAVFormer, TwoStreamAuralVisualFormer,  # noqa: F401
