@@ -547,8 +547,13 @@ int gemm_bf16_nt(const GemmArgs& a, hipStream_t s) {
               "gemm_bf16_nt: operands must be 16-byte aligned");
   AVF_REQUIRE(a.M < (1LL << 31) && a.N < (1LL << 31) && a.K < (1LL << 31), "gemm_bf16_nt: shape too large");
   NtParams p;
-  TimingScope ts(KC_GEMM_BF16_NT, 2.0 * a.M * a.N * a.K,
-                 2.0 * (a.M * a.K + a.N * a.K) + (a.c_dtype == AVF_F32 ? 4.0 : 2.0) * a.M * a.N, s, /*per_kernel=*/true);
+  // algorithmic bytes: both operands once, C once, plus what the fused epilogue reads / writes beside C (fp32 residual;
+  // the saved pre-activation, in C's type)
+  const double csz = a.c_dtype == AVF_F32 ? 4.0 : 2.0;
+  const double epi_bytes = a.epilogue == AVF_EPI_BIAS_RES ? 4.0 * a.M * a.N
+                           : (a.epilogue == AVF_EPI_BIAS_GELU || a.epilogue == AVF_EPI_DGELU) ? csz * a.M * a.N : 0.0;
+  TimingScope ts(KC_GEMM_BF16_NT, 2.0 * a.M * a.N * a.K, 2.0 * (a.M * a.K + a.N * a.K) + csz * a.M * a.N + epi_bytes, s,
+                 /*per_kernel=*/true);
   p.A = (const bf16*)a.A; p.lda = a.lda; p.B = (const bf16*)a.B; p.ldb = a.ldb;
   p.C = a.C; p.ldc = a.ldc; p.bias = a.bias; p.residual = a.residual; p.ldres = a.ldres;
   p.aux = a.aux; p.ldaux = a.ldaux;

@@ -293,8 +293,11 @@ int gemm_mx8_nt(const GemmArgs& a, const void* a_scales, const void* b_scales, h
   AVF_REQUIRE(a.M < (1LL << 31) && a.N < (1LL << 31) && a.K < (1LL << 31), "gemm_mx8_nt: shape too large");
   Mx8Params q;
   NtParams& p = q.nt;
+  const double csz = a.c_dtype == AVF_F32 ? 4.0 : 2.0;
+  const double epi_bytes = a.epilogue == AVF_EPI_BIAS_RES ? 4.0 * a.M * a.N : a.epilogue == AVF_EPI_BIAS_GELU ? csz * a.M * a.N : 0.0;
   TimingScope ts(KC_GEMM_MX8_NT, 2.0 * a.M * a.N * a.K,
-                 1.0 * (a.M * a.K + a.N * a.K) * (1.0 + 1.0 / 32) + (a.c_dtype == AVF_F32 ? 4.0 : 2.0) * a.M * a.N, s, /*per_kernel=*/true);
+                 1.0 * (a.M * a.K + a.N * a.K) * (1.0 + 1.0 / 32) + csz * a.M * a.N + epi_bytes + (mx_q ? a.M * a.N * (1.0 + 1.0 / 32) : 0.0),
+                 s, /*per_kernel=*/true);
   p.A = (const bf16*)a.A; p.lda = a.lda; p.B = (const bf16*)a.B; p.ldb = a.ldb;
   p.C = a.C; p.ldc = a.ldc; p.bias = a.bias; p.residual = a.residual; p.ldres = a.ldres;
   p.aux = a.aux; p.ldaux = a.ldaux;
