@@ -253,7 +253,7 @@ def main():
                     "flops_per_launch": d["flops"] / d["launches"],
                     "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                     "algorithmic_GBps": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1),
-                    "measured": "HIP events attached to every dispatch of this kernel class on the launch stream "
+                    "measured": "HIP events attached to every dispatch of the hot-path kernel classes on the launch stream "
                                 "(hipExtLaunchKernelGGL start/stop events: the dispatch's own begin/end timestamps), over "
                                 "K instrumented steps run right after the timed region (same process, same inputs)",
                 }

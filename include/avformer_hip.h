@@ -223,9 +223,9 @@ int avf_dropout_factors(uint32_t seed_lo, uint32_t seed_hi, int layer_index, int
 
 /* ---- optional HIP-event timing per kernel class (bench.py's roofline line) --------------------------
  * classes: 0 gemm_bf16_nt, 1 gemm_bf16_tn(+fold), 2 gemm_f32, 3 attn_fwd, 4 attn_bwd, 5 layernorm, 6 other, 7 gemm_mx8_nt.
- * enable(1) resets the records; read() synchronises the recorded events and sums them.  Classes 0 and 7 attach the
- * event pair to the kernel dispatch itself (its begin / end timestamps, as a profiler reports them); the others record a
- * pair around the launches of one call, which includes ~2 us of command-processor time per pair. */
+ * enable(1) resets the records; read() synchronises the recorded events and sums them.  Every class but 2 and 6
+ * attaches one event pair to each kernel dispatch (its own begin / end timestamps, as a profiler reports them; `launches`
+ * counts dispatches); 2 and 6 record a pair around the launches of one call (~2 us of command-processor time each). */
 int avf_timing_enable(int on);
 int avf_timing_read(int cls, double* total_ms, int64_t* launches, double* flops, double* bytes);
 

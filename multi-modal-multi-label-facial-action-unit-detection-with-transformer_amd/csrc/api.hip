@@ -36,24 +36,36 @@ TimingRec* g_recs = nullptr;
 int g_created = 0, g_used = 0;
 }  // namespace
 
-TimingScope::TimingScope(int cls, double flops, double bytes, hipStream_t s, bool pk) : slot(-1), stream(s), per_kernel(pk) {
-  if (!g_timing_on || g_used >= TIMING_POOL) return;
+namespace {
+int timing_take_slot(int cls, double flops, double bytes) {
+  if (!g_timing_on || g_used >= TIMING_POOL) return -1;
   if (!g_recs) g_recs = new TimingRec[TIMING_POOL];
   if (g_used >= g_created) {
-    if (hipEventCreate(&g_recs[g_created].start) != hipSuccess || hipEventCreate(&g_recs[g_created].stop) != hipSuccess) return;
+    if (hipEventCreate(&g_recs[g_created].start) != hipSuccess || hipEventCreate(&g_recs[g_created].stop) != hipSuccess) return -1;
     ++g_created;
   }
-  slot = g_used++;
+  const int slot = g_used++;
   g_recs[slot].cls = cls; g_recs[slot].flops = flops; g_recs[slot].bytes = bytes;
-  if (!per_kernel) (void)hipEventRecord(g_recs[slot].start, s);
+  return slot;
+}
+}  // namespace
+
+TimingScope::TimingScope(int c, double f, double b, hipStream_t s, bool pk)
+    : slot(-1), stream(s), per_kernel(pk), cls(c), flops(f), bytes(b), issued(0) {
+  if (per_kernel) return;  // records are taken per launch
+  slot = timing_take_slot(cls, flops, bytes);
+  if (slot >= 0) (void)hipEventRecord(g_recs[slot].start, s);
 }
 TimingScope::~TimingScope() {
   if (slot >= 0 && !per_kernel) (void)hipEventRecord(g_recs[slot].stop, stream);
 }
 bool TimingScope::events(hipEvent_t* start, hipEvent_t* stop) const {
-  if (slot < 0 || !per_kernel) return false;
-  *start = g_recs[slot].start;
-  *stop = g_recs[slot].stop;
+  if (!per_kernel) return false;
+  const int sl = timing_take_slot(cls, issued ? 0.0 : flops, issued ? 0.0 : bytes);
+  if (sl < 0) return false;
+  ++issued;
+  *start = g_recs[sl].start;
+  *stop = g_recs[sl].stop;
   return true;
 }
 

@@ -1253,7 +1253,7 @@ int res_waves(int N) {
 }
 
 template <typename K, typename... Args>
-int res_launch(K kernel, const char* name, int blocks, int waves, size_t smem, hipStream_t s, Args... args) {
+int res_launch(const TimingScope* ts, K kernel, const char* name, int blocks, int waves, size_t smem, hipStream_t s, Args... args) {
   // raise the dynamic-LDS limit once per kernel (nine instantiations share this function template per signature)
   static const void* raised[16];
   static int nraised = 0;
@@ -1265,7 +1265,7 @@ int res_launch(K kernel, const char* name, int blocks, int waves, size_t smem, h
     if (nraised < 16) raised[nraised++] = (const void*)kernel;
   }
   AVF_REQUIRE(smem <= 160 * 1024, "%s: %zu bytes of LDS", name, smem);
-  kernel<<<blocks, waves * 64, smem, s>>>(args...);
+  launch_in_scope(ts, kernel, dim3(blocks), dim3(waves * 64), (uint32_t)smem, s, args...);
   return check_launch(name);
 }
 }  // namespace
@@ -1285,11 +1285,11 @@ int attn_fwd_bf16(const bf16* qkv, bf16* o, float* lse2, int B, int N, int H, in
   AVF_REQUIRE(B > 0 && N > 0 && H > 0, "attn_fwd_bf16: bad shape");
   AVF_REQUIRE(ceil_div(N, 128) * B * H < (1LL << 31), "attn_fwd_bf16: grid too large");
   AVF_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)o & 7) == 0, "attn_fwd_bf16: misaligned pointers");
-  TimingScope ts(KC_ATTN_FWD, 4.0 * B * H * (double)N * N * dh, 2.0 * 4.0 * B * N * H * dh, s);
+  TimingScope ts(KC_ATTN_FWD, 4.0 * B * H * (double)N * N * dh, 2.0 * 4.0 * B * N * H * dh, s, /*per_kernel=*/true);
   if (use_resident(N, dh)) {
     const int W = res_waves(N);
     const size_t smem = (size_t)((N + 31) & ~31) * 128 * 2;
-#define AVF_FWD_RES(MW, MU, Q, NAME) res_launch(attn_fwd_res_kernel<MW, MU, Q>, NAME, B * H, W, smem, s, qkv, o, lse2, N, H)
+#define AVF_FWD_RES(MW, MU, Q, NAME) res_launch(&ts, attn_fwd_res_kernel<MW, MU, Q>, NAME, B * H, W, smem, s, qkv, o, lse2, N, H)
     if (q_prescaled) {
       if (res_multi(N)) return AVF_FWD_RES(8, true, true, "attn_fwd_res<8,multi,qs>");
       if (W <= 8) return AVF_FWD_RES(8, false, true, "attn_fwd_res<8,qs>");
@@ -1302,8 +1302,8 @@ int attn_fwd_bf16(const bf16* qkv, bf16* o, float* lse2, int B, int N, int H, in
   }
   const unsigned grid = (unsigned)(ceil_div(N, 128) * B * H);
   const int qs = q_prescaled ? 1 : 0;
-  if (dh == 64) attn_fwd_bf16_kernel<64><<<grid, 256, 0, s>>>(qkv, o, lse2, B, N, H, qs);
-  else if (dh == 32) attn_fwd_bf16_kernel<32><<<grid, 256, 0, s>>>(qkv, o, lse2, B, N, H, qs);
+  if (dh == 64) launch_in_scope(&ts, attn_fwd_bf16_kernel<64>, dim3(grid), dim3(256), 0, s, qkv, o, lse2, B, N, H, qs);
+  else if (dh == 32) launch_in_scope(&ts, attn_fwd_bf16_kernel<32>, dim3(grid), dim3(256), 0, s, qkv, o, lse2, B, N, H, qs);
   else AVF_REQUIRE(false, "attention (bf16): unsupported dim_head %d (32 or 64)", dh);
   return check_launch("attn_fwd_bf16_kernel");
 }
@@ -1314,16 +1314,16 @@ int attn_bwd_bf16(const bf16* qkv, const bf16* o, const bf16* d_o, const float* 
   AVF_REQUIRE(ceil_div(N, 128) * B * H < (1LL << 31), "attn_bwd_bf16: grid too large");
   AVF_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)d_o & 15) == 0 && ((uintptr_t)dqkv & 7) == 0,
               "attn_bwd_bf16: misaligned pointers");
-  TimingScope ts(KC_ATTN_BWD, 10.0 * B * H * (double)N * N * dh, 2.0 * 8.0 * B * N * H * dh, s);
+  TimingScope ts(KC_ATTN_BWD, 10.0 * B * H * (double)N * N * dh, 2.0 * 8.0 * B * N * H * dh, s, /*per_kernel=*/true);
   if (use_resident(N, dh)) {  // delta comes out of the dQ kernel
     const int W = res_waves(N);
     const size_t smem = (size_t)((N + 31) & ~31) * 128 * 2, smem_kv = smem + (size_t)((N + 63) & ~63) * 8;
     AVF_REQUIRE(!q_prescaled || nlse, "attn_bwd_bf16: scratch for the negated statistics missing");
 #define AVF_BWD_RES(MW, MU, Q, TAG)                                                                                      \
   do {                                                                                                                   \
-    AVF_TRY(res_launch(attn_dq_res_kernel<MW, MU, Q>, "attn_dq_res" TAG, B * H, W, smem, s, qkv, o, d_o, lse2, delta,    \
+    AVF_TRY(res_launch(&ts, attn_dq_res_kernel<MW, MU, Q>, "attn_dq_res" TAG, B * H, W, smem, s, qkv, o, d_o, lse2, delta, \
                        nlse, dqkv, N, H));                                                                               \
-    return res_launch(attn_dkv_res_kernel<MW, MU, Q>, "attn_dkv_res" TAG, B * H, W, smem_kv, s, qkv, d_o,                \
+    return res_launch(&ts, attn_dkv_res_kernel<MW, MU, Q>, "attn_dkv_res" TAG, B * H, W, smem_kv, s, qkv, d_o,           \
                       Q ? (const float*)nlse : lse2, (const float*)delta, dqkv, N, H);                                   \
   } while (0)
     if (q_prescaled) {
@@ -1340,11 +1340,11 @@ int attn_bwd_bf16(const bf16* qkv, const bf16* o, const bf16* d_o, const float* 
   const unsigned grid = (unsigned)(ceil_div(N, 128) * B * H);
   const int qs = q_prescaled ? 1 : 0;
   if (dh == 64) {
-    attn_dq_bf16_kernel<64><<<grid, 256, 0, s>>>(qkv, d_o, lse2, delta, dqkv, B, N, H, qs);
-    attn_dkv_bf16_kernel<64><<<grid, 256, 0, s>>>(qkv, d_o, lse2, delta, dqkv, B, N, H, qs);
+    launch_in_scope(&ts, attn_dq_bf16_kernel<64>, dim3(grid), dim3(256), 0, s, qkv, d_o, lse2, (const float*)delta, dqkv, B, N, H, qs);
+    launch_in_scope(&ts, attn_dkv_bf16_kernel<64>, dim3(grid), dim3(256), 0, s, qkv, d_o, lse2, (const float*)delta, dqkv, B, N, H, qs);
   } else if (dh == 32) {
-    attn_dq_bf16_kernel<32><<<grid, 256, 0, s>>>(qkv, d_o, lse2, delta, dqkv, B, N, H, qs);
-    attn_dkv_bf16_kernel<32><<<grid, 256, 0, s>>>(qkv, d_o, lse2, delta, dqkv, B, N, H, qs);
+    launch_in_scope(&ts, attn_dq_bf16_kernel<32>, dim3(grid), dim3(256), 0, s, qkv, d_o, lse2, (const float*)delta, dqkv, B, N, H, qs);
+    launch_in_scope(&ts, attn_dkv_bf16_kernel<32>, dim3(grid), dim3(256), 0, s, qkv, d_o, lse2, (const float*)delta, dqkv, B, N, H, qs);
   } else {
     AVF_REQUIRE(false, "attention (bf16): unsupported dim_head %d (32 or 64)", dh);
   }

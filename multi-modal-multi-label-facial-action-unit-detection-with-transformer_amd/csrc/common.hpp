@@ -36,13 +36,17 @@ int check_launch(const char* what);
 enum KernelClass {
   KC_GEMM_BF16_NT = 0, KC_GEMM_BF16_TN, KC_GEMM_F32, KC_ATTN_FWD, KC_ATTN_BWD, KC_LAYERNORM, KC_OTHER, KC_GEMM_MX8_NT, KC_COUNT
 };
-struct TimingScope {  // records a start/stop event pair around the launches issued during its lifetime
+struct TimingScope {  // HIP-event timing of the launches issued during its lifetime (off unless avf_timing_enable(1))
   int slot;
   hipStream_t stream;
   bool per_kernel;
-  // per_kernel: the scope records nothing itself; its ONE kernel launch goes through hipExtLaunchKernelGGL with the pair
-  // from events(), which then carry the dispatch's own begin / end timestamps - the duration rocprofv3 reports, without the
-  // ~2 us of command-processor time an event pair around a launch includes
+  int cls;
+  double flops, bytes;
+  mutable int issued;
+  // plain scope: one start/stop event pair recorded AROUND everything launched while it lives (includes ~2 us of
+  // command-processor time per pair).  per_kernel scope: records nothing itself; every launch made through
+  // launch_in_scope() gets its own pair ATTACHED to the dispatch (hipExtLaunchKernelGGL: the kernel's own begin / end
+  // timestamps, the duration rocprofv3 reports); the first one carries the scope's flops / bytes.
   TimingScope(int cls, double flops, double bytes, hipStream_t s, bool per_kernel = false);
   ~TimingScope();
   bool events(hipEvent_t* start, hipEvent_t* stop) const;

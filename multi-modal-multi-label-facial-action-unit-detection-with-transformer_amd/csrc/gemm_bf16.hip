@@ -626,21 +626,22 @@ int gemm_bf16_tn(const GemmArgs& a, hipStream_t s) {
   const int S = tn_splits(a.M, a.N, a.K);
   AVF_REQUIRE(S == 1 || a.workspace, "gemm_bf16_tn: split-K workspace missing");
   TnParams p;
-  TimingScope ts(KC_GEMM_BF16_TN, 2.0 * a.M * a.N * a.K, 2.0 * (a.M * a.K + a.N * a.K) + 4.0 * a.M * a.N, s);
+  TimingScope ts(KC_GEMM_BF16_TN, 2.0 * a.M * a.N * a.K, 2.0 * (a.M * a.K + a.N * a.K) + 4.0 * a.M * a.N, s, /*per_kernel=*/true);
   p.A = (const bf16*)a.A; p.lda = a.lda; p.B = (const bf16*)a.B; p.ldb = a.ldb;
   p.M = (int)a.M; p.N = (int)a.N; p.K = (int)a.K;
   p.kchunk = (int)(ceil_div(ceil_div(a.K, S), TR) * TR);
   if (S > 1) { p.C = (float*)a.workspace; p.ldc = a.N; p.slab = a.M * a.N; }
   else { p.C = (float*)a.C; p.ldc = a.ldc; p.slab = 0; }
   dim3 grid((unsigned)ceil_div(a.N, TB), (unsigned)ceil_div(a.M, TB), (unsigned)S);
-  gemm_bf16_tn_kernel<<<grid, 256, TN_SMEM, s>>>(p);
+  launch_in_scope(&ts, gemm_bf16_tn_kernel, grid, dim3(256), TN_SMEM, s, p);
   AVF_TRY(check_launch("gemm_bf16_tn_kernel"));
   if (S > 1) {
     AVF_REQUIRE(a.ldc == a.N, "gemm_bf16_tn: split-K path needs a dense C (ldc == N)");
     const int64_t n4 = a.M * a.N / 4;
     int64_t blocks = ceil_div(n4, 256);
     if (blocks > 2048) blocks = 2048;
-    fold_slabs_kernel<<<(unsigned)blocks, 256, 0, s>>>((const float*)a.workspace, S, a.M * a.N, (float*)a.C, n4);
+    launch_in_scope(&ts, fold_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)a.workspace, S, (int64_t)(a.M * a.N),
+                    (float*)a.C, n4);
     AVF_TRY(check_launch("fold_slabs_kernel"));
   }
   return 0;
@@ -695,13 +696,13 @@ int gemm_bf16_tn_group(const TnGroupArgs& a, hipStream_t s, const FoldList* extr
       w += (size_t)g.S * a.M[i] * a.N[i];
     }
   }
-  TimingScope ts(KC_GEMM_BF16_TN, flops, bytes, s);
+  TimingScope ts(KC_GEMM_BF16_TN, flops, bytes, s, /*per_kernel=*/true);
   static const int tn_waves = [] {
     const char* e = getenv("AVF_TN_WAVES");  // tuning aid
     return e ? atoi(e) : 4;  // 8 waves measured 5 % slower here (unlike the NT kernel)
   }();
-  if (tn_waves == 4) gemm_bf16_tn_group_kernel<2><<<tiles * g.S, 256, 0, s>>>(g);
-  else gemm_bf16_tn_group_kernel<4><<<tiles * g.S, 512, 0, s>>>(g);
+  if (tn_waves == 4) launch_in_scope(&ts, gemm_bf16_tn_group_kernel<2>, dim3(tiles * g.S), dim3(256), 0, s, g);
+  else launch_in_scope(&ts, gemm_bf16_tn_group_kernel<4>, dim3(tiles * g.S), dim3(512), 0, s, g);
   AVF_TRY(check_launch("gemm_bf16_tn_group_kernel"));
   FoldList fl;
   memset(&fl, 0, sizeof(fl));
@@ -709,7 +710,7 @@ int gemm_bf16_tn_group(const TnGroupArgs& a, hipStream_t s, const FoldList* extr
   const int nslab = g.S > 1 ? a.count : 0;
   if (nslab + fl.count > 0) {
     dim3 grid(256, nslab + fl.count);
-    fold_group_kernel<<<grid, 256, 0, s>>>(g, nslab, fl);
+    launch_in_scope(&ts, fold_group_kernel, grid, dim3(256), 0, s, g, nslab, fl);
     AVF_TRY(check_launch("fold_group_kernel"));
   }
   return 0;

@@ -127,14 +127,15 @@ int layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y
                   float* rstd, int64_t rows, int dim, float eps, hipStream_t s, void* mx_q, void* mx_s) {
   AVF_REQUIRE(rows > 0 && dim > 0, "layernorm_fwd: bad shape rows=%lld dim=%d", (long long)rows, dim);
   AVF_REQUIRE(y_dtype == AVF_F32 || y_dtype == AVF_BF16, "layernorm_fwd: bad dtype %d", y_dtype);
-  TimingScope ts(KC_LAYERNORM, 0.0, (double)rows * dim * (4.0 + (y_dtype == AVF_BF16 ? 2.0 : 4.0) + (mx_q ? 1.03125 : 0.0)), s);
+  TimingScope ts(KC_LAYERNORM, 0.0, (double)rows * dim * (4.0 + (y_dtype == AVF_BF16 ? 2.0 : 4.0) + (mx_q ? 1.03125 : 0.0)), s,
+                 /*per_kernel=*/true);
   dim3 grid((unsigned)ceil_div(rows, 4)), block(256);
   if (mx_q) {
     AVF_REQUIRE(mx_s && y_dtype == AVF_BF16 && dim % 32 == 0 && dim <= 1536,
                 "layernorm_fwd: the MX-FP8 image needs bf16 output, dim %% 32 == 0 and dim <= 1536 (dim=%d)", dim);
 #define LAUNCH_MX(NVV)                                                                                              \
-  ln_fwd_reg_kernel<bf16, NVV, true><<<grid, block, 0, s>>>(x, gamma, beta, (bf16*)y, mean, rstd, rows, dim, eps, \
-                                                            (uint8_t*)mx_q, (uint8_t*)mx_s)
+  launch_in_scope(&ts, ln_fwd_reg_kernel<bf16, NVV, true>, grid, block, 0, s, x, gamma, beta, (bf16*)y, mean, rstd, rows, dim, eps, \
+                  (uint8_t*)mx_q, (uint8_t*)mx_s)
     switch ((dim + 255) / 256) {
       case 1: LAUNCH_MX(1); break;
       case 2: LAUNCH_MX(2); break;
@@ -147,7 +148,9 @@ int layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y
   }
   if (dim % 4 == 0 && dim <= 1536) {
     const int nv = (dim + 255) / 256;
-#define LAUNCH_NV(T, NVV) ln_fwd_reg_kernel<T, NVV><<<grid, block, 0, s>>>(x, gamma, beta, (T*)y, mean, rstd, rows, dim, eps)
+#define LAUNCH_NV(T, NVV)                                                                                             \
+  launch_in_scope(&ts, ln_fwd_reg_kernel<T, NVV, false>, grid, block, 0, s, x, gamma, beta, (T*)y, mean, rstd, rows, dim, eps, \
+                  (uint8_t*)nullptr, (uint8_t*)nullptr)
 #define LAUNCH_T(T)                 \
   switch (nv) {                     \
     case 1: LAUNCH_NV(T, 1); break; \
@@ -160,9 +163,9 @@ int layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y
 #undef LAUNCH_T
 #undef LAUNCH_NV
   } else if (y_dtype == AVF_F32) {
-    ln_fwd_kernel<float><<<grid, block, 0, s>>>(x, gamma, beta, (float*)y, mean, rstd, rows, dim, eps);
+    launch_in_scope(&ts, ln_fwd_kernel<float>, grid, block, 0, s, x, gamma, beta, (float*)y, mean, rstd, rows, dim, eps);
   } else {
-    ln_fwd_kernel<bf16><<<grid, block, 0, s>>>(x, gamma, beta, (bf16*)y, mean, rstd, rows, dim, eps);
+    launch_in_scope(&ts, ln_fwd_kernel<bf16>, grid, block, 0, s, x, gamma, beta, (bf16*)y, mean, rstd, rows, dim, eps);
   }
   return check_launch("ln_fwd_kernel");
 }
@@ -403,7 +406,8 @@ int layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gam
   AVF_REQUIRE(!drop.thresh16 || (dim % 4 == 0 && dim <= 1536), "layernorm_bwd: dropout needs dim %% 4 == 0 and dim <= 1536");
   AVF_REQUIRE((size_t)3 * dim * sizeof(float) <= 64 * 1024, "layernorm_bwd: dim %d too large", dim);
   TimingScope ts(KC_LAYERNORM, 0.0,
-                 (double)rows * dim * ((dy_dtype == AVF_BF16 ? 2.0 : 4.0) + 4.0 + (dres ? 4.0 : 0.0) + 4.0 + (dx_lo ? 2.0 : 0.0)), s);
+                 (double)rows * dim * ((dy_dtype == AVF_BF16 ? 2.0 : 4.0) + 4.0 + (dres ? 4.0 : 0.0) + 4.0 + (dx_lo ? 2.0 : 0.0)), s,
+                 /*per_kernel=*/true);
   float* partial = (float*)ws;
   const int wc = dcolsum ? 1 : 0;
   int nb;
@@ -424,8 +428,8 @@ int layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gam
       }
     }
 #define LAUNCH_NV(T, NVV)                                                                                          \
-  ln_bwd_reg_kernel<T, NVV><<<nb, 256, lds, s>>>((const T*)dy, x, gamma, mean, rstd, dres, dx, (bf16*)dx_lo, partial, \
-                                                 rows, dim, wc, drop)
+  launch_in_scope(&ts, ln_bwd_reg_kernel<T, NVV>, dim3(nb), dim3(256), (uint32_t)lds, s, (const T*)dy, x, gamma, mean, rstd, \
+                  dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop)
 #define LAUNCH_T(T)                                   \
   switch (nv) {                                       \
     case 1: LAUNCH_NV(T, 1); break;                   \
@@ -443,8 +447,8 @@ int layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gam
     const size_t lds = (size_t)3 * dim * sizeof(float);
     const bool vec = (dim & 3) == 0;
 #define LAUNCH(T, V)                                                                                            \
-  ln_bwd_kernel<T, V><<<nb, 256, lds, s>>>((const T*)dy, x, gamma, mean, rstd, dres, dx, (bf16*)dx_lo, partial, \
-                                           rows, dim, wc)
+  launch_in_scope(&ts, ln_bwd_kernel<T, V>, dim3(nb), dim3(256), (uint32_t)lds, s, (const T*)dy, x, gamma, mean, rstd, dres, \
+                  dx, (bf16*)dx_lo, partial, rows, dim, wc)
     if (dy_dtype == AVF_F32) {
       if (vec) LAUNCH(float, true); else LAUNCH(float, false);
     } else if (dy_dtype == AVF_BF16) {
