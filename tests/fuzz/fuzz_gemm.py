@@ -1,7 +1,7 @@
 """Random-shape check of the NT GEMM kernels (bf16 and MX-FP8 operands, every fused epilogue, both output types)
 against an fp32 product of the same (rounded / dequantised) operands.
 
-    python tools/fuzz_gemm.py [--cases 300] [--seed 0]
+    python tests/fuzz/fuzz_gemm.py [--cases 300] [--seed 0]
 """
 import argparse
 import os
@@ -10,7 +10,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import avformer_amd as A  # noqa: E402
 import oracle  # noqa: E402
 

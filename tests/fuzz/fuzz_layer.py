@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Random stack configurations (any dim / inner / mlp widths the modes accept, 1..700 tokens, with and without pooling):
 fp32 parity mode against the CPU oracle's autograd (tight), bf16 and - where the widths allow - mx8 against the parity mode.
-usage: python tools/fuzz_layer.py [count] [seed]"""
+usage: python tests/fuzz/fuzz_layer.py [count] [seed]"""
 import os, random, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import avformer_amd as A
 import oracle
 

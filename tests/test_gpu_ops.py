@@ -127,7 +127,7 @@ def test_gemm_epilogues(ops, dtype, M, N, K):
 
 @pytest.mark.parametrize("M,N,K", [(500, 96, 256), (130, 260, 72)])
 def test_gemm_bf16_operands_fp32_outputs_keep_aux_in_fp32(ops, M, N, K):
-    """bf16 operands with c_dtype fp32: the saved pre-activation is stored / read in C's type (found by tools/fuzz_gemm.py:
+    """bf16 operands with c_dtype fp32: the saved pre-activation is stored / read in C's type (found by tests/fuzz/fuzz_gemm.py:
     it used to be written as bf16 into the caller's fp32 buffer)"""
     g = torch.Generator().manual_seed(M + N)
     a = torch.randn(M, K, generator=g).bfloat16()
