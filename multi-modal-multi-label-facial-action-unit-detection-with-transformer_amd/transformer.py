@@ -380,6 +380,11 @@ class Transformer(nn.Module):
                                "use oracle/ only as a test checker")
         if x.dim() != 3 or x.shape[-1] != self.dim:
             raise ValueError(f"expected [B, N, {self.dim}], got {tuple(x.shape)}")
+        if x.shape[0] == 0 or x.shape[1] == 0:
+            # empty batch / empty sequence: nothing to launch.  As in the reference (every op is per token), the result is
+            # the empty tensor of the right shape; parameters receive zero gradients through the zero-weight sum
+            out = x.to(torch.float32) if pool is None else x.to(torch.float32).mean(dim=1)
+            return out + sum(p.sum() for p in self.parameters()) * 0.0
         params = self.flat_parameters()
         for p in params:
             if p.dtype != torch.float32 or not p.is_cuda:

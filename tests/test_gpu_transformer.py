@@ -414,3 +414,18 @@ print("CANARIES_OK")
     env = dict(os.environ, AVF_DEBUG_CANARY="1")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "CANARIES_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_empty_batch_and_empty_sequence():
+    """ragged extremes: B = 0 and N = 0 return the empty tensor of the right shape (as the per-token ops of the
+    reference do) and leave well-defined (zero) parameter gradients"""
+    import avformer_amd as A
+    t = A.Transformer(64, 2, 4, 32, 128).cuda()
+    for shape in ((0, 7, 64), (3, 0, 64)):
+        x = torch.zeros(shape, device="cuda", requires_grad=True)
+        y = t(x)
+        assert y.shape == shape
+        y.sum().backward()
+        assert all(p.grad is not None and float(p.grad.abs().sum()) == 0.0 for p in t.parameters())
+        t.zero_grad()
+    assert t(torch.zeros((0, 7, 64), device="cuda"), pool="mean").shape == (0, 64)
