@@ -54,6 +54,11 @@ typedef struct avf_layer_cfg {
   const void* seed_dev; /* optional device pointer to a uint64 seed; when non-null it replaces seed_lo/hi and is read
                           by the kernels at run time, so a captured hipGraph draws fresh masks on every replay
                           (the caller advances the value between forwards, e.g. with a captured add)            */
+  int32_t grad_stream_bf16; /* 1 (AVF_BF16, dropout_p == 0, dim <= 1536): avf_layer_bwd keeps the residual gradient stream in
+                          bf16 - it reads the incoming gradient from dx_out_lo (dx_out may be null; if only dx_out is given it
+                          is cast first), the two LayerNorm backward kernels exchange bf16 only, and the fp32 dx_in is written
+                          only when the pointer is non-null (a caller passes it where it consumes fp32, e.g. for the bottom
+                          layer).  Per-layer parameter gradients stay fp32.                                            */
   int32_t mx8_fwd;     /* 1 (AVF_BF16 only; dim, mlp_dim % 128 == 0): the forward GEMMs of to_qkv, net.0 and net.3 take MX-FP8
                           operands (BASELINE config 5).  The bf16 weight-image buffer then also holds their e4m3 images:
                           refresh them with avf_stack_quant_weights_mx8 whenever the bf16 images changed.          */
@@ -157,7 +162,7 @@ int avf_attn_bwd_qs(const void* qkv, const void* o, const void* d_o, const float
  *                     - the sequence-axis fusion torch.cat([clip, audio], 1) + pos_embedding of BASELINE.json's configs
  *                     (feature-axis fusion of the reference: models/avformer.py:95-103).
  *  avf_token_mean_fwd: out[b, :] = mean_t y[b, t, :]                      (x.mean(dim=1), models/tformer.py head)
- *  avf_token_mean_bwd: dy[b, t, :] = g[b, :] / tokens, the same in bf16 (dy_bf16, nullable), and colsum[d] =
+ *  avf_token_mean_bwd: dy[b, t, :] = g[b, :] / tokens (nullable when dy_bf16 is given), the same in bf16 (dy_bf16, nullable), and colsum[d] =
  *                     sum_b g[b, d] (nullable) = the column sums of dy that the top layer's bias gradient needs. */
 int avf_fuse_tokens(const float* clip, const float* audio, const float* pos, float* out, int batch, int t_video,
                     int t_audio, int dim, void* stream);

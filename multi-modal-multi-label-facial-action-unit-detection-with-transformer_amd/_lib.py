@@ -26,7 +26,7 @@ class LayerCfg(C.Structure):
     _fields_ = [("batch", C.c_int32), ("tokens", C.c_int32), ("dim", C.c_int32), ("heads", C.c_int32),
                 ("dim_head", C.c_int32), ("mlp_dim", C.c_int32), ("dtype", C.c_int32), ("project_out", C.c_int32),
                 ("ln_eps", C.c_float), ("dropout_p", C.c_float), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32),
-                ("layer_index", C.c_int32), ("seed_dev", C.c_void_p), ("mx8_fwd", C.c_int32)]
+                ("layer_index", C.c_int32), ("seed_dev", C.c_void_p), ("grad_stream_bf16", C.c_int32), ("mx8_fwd", C.c_int32)]
 
 
 PARAM_FIELDS = ("ln1_w", "ln1_b", "w_qkv", "w_out", "b_out", "ln2_w", "ln2_b", "w1", "b1", "w2", "b2")

@@ -274,10 +274,11 @@ int layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y
 size_t layernorm_bwd_ws(int64_t rows, int dim);
 // drop: mask applied to the bf16 copy dx_lo AND to the column sums (they feed the Linear behind a dropout site);
 // dx itself (the residual stream gradient) is never masked.
+// dres_dtype AVF_BF16 (bf16 gradient stream): dres is read as bf16, dx may be null (dx_lo is then the only output).
 int layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean,
-                  const float* rstd, const float* dres, float* dx, void* dx_lo, float* dgamma, float* dbeta,
+                  const float* rstd, const void* dres, float* dx, void* dx_lo, float* dgamma, float* dbeta,
                   float* dcolsum, void* ws, int64_t rows, int dim, hipStream_t s, const DropCfg& drop = kNoDrop,
-                  FoldJob* defer_fold = nullptr);
+                  FoldJob* defer_fold = nullptr, int dres_dtype = AVF_F32);
 size_t colsum_ws(int64_t rows, int cols);
 int colsum(const void* in, int in_dtype, int64_t rows, int cols, int64_t ld, float* out, void* ws, hipStream_t s);
 int cast_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t s, const DropCfg& drop = kNoDrop);

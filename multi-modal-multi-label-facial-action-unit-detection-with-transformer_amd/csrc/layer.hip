@@ -27,6 +27,7 @@ struct Dims {
   uint64_t seed;
   const uint64_t* seed_dev;
   int layer;
+  bool gs16;  // backward keeps the residual gradient stream in bf16 (no fp32 dx between the LayerNorm backward kernels)
   bool mx;    // forward nn.Linear GEMMs fed by LayerNorm / GELU (qkv, mlp1, mlp2) take MX-FP8 operands (config 5)
 };
 
@@ -48,6 +49,9 @@ int make_dims(const avf_layer_cfg* c, Dims* d) {
   d->dt = c->dtype; d->es = c->dtype == AVF_BF16 ? 2 : 4;
   d->p = c->dropout_p; d->seed = ((uint64_t)c->seed_hi << 32) | c->seed_lo; d->layer = c->layer_index;
   d->seed_dev = (const uint64_t*)c->seed_dev;
+  d->gs16 = c->grad_stream_bf16 != 0;
+  AVF_REQUIRE(!d->gs16 || (c->dtype == AVF_BF16 && c->dropout_p == 0.0f && c->dim <= 1536),
+              "layer: grad_stream_bf16 needs the bf16 path, dropout_p == 0 and dim <= 1536");
   d->mx = c->mx8_fwd != 0;
   AVF_REQUIRE(!d->mx || (c->dtype == AVF_BF16 && c->dim % 128 == 0 && c->mlp_dim % 128 == 0 && c->dim <= 1536),
               "layer: mx8_fwd needs the bf16 path with dim and mlp_dim multiples of 128 (dim=%d mlp_dim=%d)", c->dim,
@@ -378,7 +382,11 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
                              const avf_layer_grads* g, void* workspace, void* stream) {
   Dims d;
   AVF_TRY(make_dims(cfg, &d));
-  AVF_REQUIRE(p && x_in && saved && dx_out && dx_in && g && workspace, "layer_bwd: null pointer");
+  AVF_REQUIRE(p && x_in && saved && g && workspace, "layer_bwd: null pointer");
+  // bf16 gradient stream: the incoming gradient may come as its bf16 image alone, and the fp32 dx_in is optional (a caller
+  // asks for it only where it consumes it, e.g. below the bottom layer)
+  AVF_REQUIRE(d.gs16 ? (dx_out || dx_out_lo) && (dx_in || dx_in_lo) : (dx_out && dx_in), "layer_bwd: null gradient pointer");
+  AVF_REQUIRE(!d.gs16 || dx_in_lo, "layer_bwd(grad_stream_bf16): dx_in_lo missing");
   AVF_REQUIRE(d.dt == AVF_F32 || lowp, "layer_bwd(bf16): lowp weights missing");
   hipStream_t s = (hipStream_t)stream;
   Saved sv;
@@ -424,8 +432,10 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
     if (d.p > 0.f) {  // db2 sums the MASKED gradient
       AVF_REQUIRE(own_copy, "layer_bwd: with dropout pass dx_out_colsum together with dx_out_lo");
       AVF_TRY(colsum(gy, AVF_BF16, d.R, d.D, d.D, g->b2, w.cs_ws, s));
-    } else {
+    } else if (dx_out) {
       AVF_TRY(colsum(dx_out, AVF_F32, d.R, d.D, d.D, g->b2, w.cs_ws, s));
+    } else {
+      AVF_TRY(colsum(gy, AVF_BF16, d.R, d.D, d.D, g->b2, w.cs_ws, s));
     }
   }
   if (!grouped) AVF_TRY(linear_dw(d, gy, d.D, sv.g, d.M, g->w2, w.gemm_ws, s));
@@ -438,9 +448,13 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   }
   if (!grouped) AVF_TRY(linear_dw(d, w.du, d.M, sv.h2, d.D, g->w1, w.gemm_ws, s));
   AVF_TRY(linear_dx(d, w.du, d.M, p->w1, l.w1_t, d.D, w.dh, AVF_EPI_NONE, nullptr, s));
-  AVF_TRY(layernorm_bwd(w.dh, d.dt, sv.x_mid, p->ln2_w, sv.mean2, sv.rstd2, dx_out, w.dx_mid,
-                        lo ? w.dx_mid_lo : nullptr, g->ln2_w, g->ln2_b, g->b_out, w.ln_ws, d.R, d.D, s, dr0,
-                        grouped ? &folds.job[1] : nullptr));
+  if (d.gs16)  // residual gradient in: the bf16 image the GEMMs read; out: the bf16 dx_mid only
+    AVF_TRY(layernorm_bwd(w.dh, d.dt, sv.x_mid, p->ln2_w, sv.mean2, sv.rstd2, gy, nullptr, w.dx_mid_lo, g->ln2_w, g->ln2_b,
+                          g->b_out, w.ln_ws, d.R, d.D, s, dr0, grouped ? &folds.job[1] : nullptr, AVF_BF16));
+  else
+    AVF_TRY(layernorm_bwd(w.dh, d.dt, sv.x_mid, p->ln2_w, sv.mean2, sv.rstd2, dx_out, w.dx_mid,
+                          lo ? w.dx_mid_lo : nullptr, g->ln2_w, g->ln2_b, g->b_out, w.ln_ws, d.R, d.D, s, dr0,
+                          grouped ? &folds.job[1] : nullptr));
   // ---- attention half ----------------------------------------------------------------------
   if (!grouped) AVF_TRY(linear_dw(d, gm, d.D, sv.o, d.I, g->w_out, w.gemm_ws, s));
   AVF_TRY(linear_dx(d, gm, d.D, p->w_out, l.wo_t, d.I, w.d_o, AVF_EPI_NONE, nullptr, s));
@@ -453,9 +467,13 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   if (!grouped) AVF_TRY(linear_dw(d, w.dqkv, 3 * d.I, sv.h1, d.D, g->w_qkv, w.gemm_ws, s));
   AVF_TRY(linear_dx(d, w.dqkv, 3 * d.I, p->w_qkv, l.wqkv_t, d.D, w.dh, AVF_EPI_NONE, nullptr, s));
   // dx_in may alias dx_out, which the grouped dW2 GEMM does not read (it uses the bf16 copy gy)
-  AVF_TRY(layernorm_bwd(w.dh, d.dt, x_in, p->ln1_w, sv.mean1, sv.rstd1, w.dx_mid, dx_in, lo ? dx_in_lo : nullptr,
-                        g->ln1_w, g->ln1_b, dx_in_colsum, w.ln_ws1, d.R, d.D, s, dr_prev2,
-                        grouped ? &folds.job[2] : nullptr));
+  if (d.gs16)
+    AVF_TRY(layernorm_bwd(w.dh, d.dt, x_in, p->ln1_w, sv.mean1, sv.rstd1, w.dx_mid_lo, dx_in, dx_in_lo, g->ln1_w, g->ln1_b,
+                          dx_in_colsum, w.ln_ws1, d.R, d.D, s, dr_prev2, grouped ? &folds.job[2] : nullptr, AVF_BF16));
+  else
+    AVF_TRY(layernorm_bwd(w.dh, d.dt, x_in, p->ln1_w, sv.mean1, sv.rstd1, w.dx_mid, dx_in, lo ? dx_in_lo : nullptr,
+                          g->ln1_w, g->ln1_b, dx_in_colsum, w.ln_ws1, d.R, d.D, s, dr_prev2,
+                          grouped ? &folds.job[2] : nullptr));
   // one launch folds the split-K slabs of the four weight gradients and the three deferred column folds
   // (db1; dgamma2/dbeta2/dbo; dgamma1/dbeta1/previous layer's db2)
   if (grouped) AVF_TRY(gemm_bf16_tn_group(grp, s, &folds));

@@ -268,11 +268,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DyT* __restrict__ dy,
 // four waves of a block are combined through LDS with plain adds (deterministic), one partial per block.
 constexpr int LNR_ROWS_PER_BLOCK = 16;
 
-template <typename DyT, int NV>
+// ResT: storage type of the incoming residual gradient dres (fp32, or bf16 when the gradient stream is kept in bf16:
+// then dx is null and dx_lo is the stream the next LayerNorm backward reads as ITS dres)
+template <typename DyT, int NV, typename ResT = float>
 __global__ __launch_bounds__(256) void ln_bwd_reg_kernel(const DyT* __restrict__ dy, const float* __restrict__ x,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                         const float* __restrict__ dres, float* __restrict__ dx,
+                                                         const ResT* __restrict__ dres, float* __restrict__ dx,
                                                          bf16* __restrict__ dx_lo, float* __restrict__ partial,
                                                          int64_t rows, int D, int want_colsum, DropCfg drop) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [4 waves][3][D]
@@ -315,13 +317,13 @@ __global__ __launch_bounds__(256) void ln_bwd_reg_kernel(const DyT* __restrict__
       if (!act[i]) continue;
       const int c = lane * 4 + 256 * i;
       float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (dres) r = *reinterpret_cast<const float4*>(dres + row * D + c);
+      if (dres) r = load4<ResT>(dres + row * D + c);
       float4 o;
       o.x = rs * (d[i].x * g[i].x - s1 - xh[i].x * s2) + r.x;
       o.y = rs * (d[i].y * g[i].y - s1 - xh[i].y * s2) + r.y;
       o.z = rs * (d[i].z * g[i].z - s1 - xh[i].z * s2) + r.z;
       o.w = rs * (d[i].w * g[i].w - s1 - xh[i].w * s2) + r.w;
-      *reinterpret_cast<float4*>(dx + row * D + c) = o;
+      if (dx) *reinterpret_cast<float4*>(dx + row * D + c) = o;
       if (drop.thresh16) {  // what the Linear behind the dropout site sees: masked, rescaled
         const float4 f = drop_factor4(drop, dkey, (uint64_t)row * D + c);
         o.x *= f.x; o.y *= f.y; o.z *= f.z; o.w *= f.w;
@@ -399,15 +401,19 @@ size_t layernorm_bwd_ws(int64_t rows, int dim) {
 }
 
 int layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean,
-                  const float* rstd, const float* dres, float* dx, void* dx_lo, float* dgamma, float* dbeta,
+                  const float* rstd, const void* dres, float* dx, void* dx_lo, float* dgamma, float* dbeta,
                   float* dcolsum, void* ws, int64_t rows, int dim, hipStream_t s, const DropCfg& drop,
-                  FoldJob* defer_fold) {
+                  FoldJob* defer_fold, int dres_dtype) {
   AVF_REQUIRE(rows > 0 && dim > 0 && ws, "layernorm_bwd: bad arguments");
+  AVF_REQUIRE(dres_dtype == AVF_F32 || (dres_dtype == AVF_BF16 && dy_dtype == AVF_BF16 && dim % 4 == 0 && dim <= 1536 &&
+                                         !drop.thresh16 && dx_lo),
+              "layernorm_bwd: a bf16 residual gradient needs bf16 dy, a bf16 output, dim %% 4 == 0, dim <= 1536, no dropout");
+  AVF_REQUIRE(dx || dx_lo, "layernorm_bwd: no output");
   AVF_REQUIRE(!drop.thresh16 || (dim % 4 == 0 && dim <= 1536), "layernorm_bwd: dropout needs dim %% 4 == 0 and dim <= 1536");
   AVF_REQUIRE((size_t)3 * dim * sizeof(float) <= 64 * 1024, "layernorm_bwd: dim %d too large", dim);
   TimingScope ts(KC_LAYERNORM, 0.0,
-                 (double)rows * dim * ((dy_dtype == AVF_BF16 ? 2.0 : 4.0) + 4.0 + (dres ? 4.0 : 0.0) + 4.0 + (dx_lo ? 2.0 : 0.0)), s,
-                 /*per_kernel=*/true);
+                 (double)rows * dim * ((dy_dtype == AVF_BF16 ? 2.0 : 4.0) + 4.0 + (dres ? (dres_dtype == AVF_BF16 ? 2.0 : 4.0) : 0.0) +
+                                       (dx ? 4.0 : 0.0) + (dx_lo ? 2.0 : 0.0)), s, /*per_kernel=*/true);
   float* partial = (float*)ws;
   const int wc = dcolsum ? 1 : 0;
   int nb;
@@ -423,13 +429,21 @@ int layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gam
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 3 * 1536 * 4);
         hipError_t e2 = hipFuncSetAttribute((const void*)ln_bwd_reg_kernel<bf16, 6>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 3 * 1536 * 4);
-        AVF_REQUIRE(e1 == hipSuccess && e2 == hipSuccess, "layernorm_bwd: cannot raise dynamic LDS limit");
+        hipError_t e3 = hipFuncSetAttribute((const void*)ln_bwd_reg_kernel<bf16, 6, bf16>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 3 * 1536 * 4);
+        AVF_REQUIRE(e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess, "layernorm_bwd: cannot raise dynamic LDS limit");
         raised = true;
       }
     }
-#define LAUNCH_NV(T, NVV)                                                                                          \
-  launch_in_scope(&ts, ln_bwd_reg_kernel<T, NVV>, dim3(nb), dim3(256), (uint32_t)lds, s, (const T*)dy, x, gamma, mean, rstd, \
-                  dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop)
+#define LAUNCH_NV(T, NVV)                                                                                                   \
+  do {                                                                                                                      \
+    if (dres_dtype == AVF_BF16)                                                                                             \
+      launch_in_scope(&ts, ln_bwd_reg_kernel<bf16, NVV, bf16>, dim3(nb), dim3(256), (uint32_t)lds, s, (const bf16*)dy, x, gamma, \
+                      mean, rstd, (const bf16*)dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop);                       \
+    else                                                                                                                    \
+      launch_in_scope(&ts, ln_bwd_reg_kernel<T, NVV, float>, dim3(nb), dim3(256), (uint32_t)lds, s, (const T*)dy, x, gamma, mean, \
+                      rstd, (const float*)dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop);                            \
+  } while (0)
 #define LAUNCH_T(T)                                   \
   switch (nv) {                                       \
     case 1: LAUNCH_NV(T, 1); break;                   \
@@ -447,7 +461,7 @@ int layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gam
     const size_t lds = (size_t)3 * dim * sizeof(float);
     const bool vec = (dim & 3) == 0;
 #define LAUNCH(T, V)                                                                                            \
-  launch_in_scope(&ts, ln_bwd_kernel<T, V>, dim3(nb), dim3(256), (uint32_t)lds, s, (const T*)dy, x, gamma, mean, rstd, dres, \
+  launch_in_scope(&ts, ln_bwd_kernel<T, V>, dim3(nb), dim3(256), (uint32_t)lds, s, (const T*)dy, x, gamma, mean, rstd, (const float*)dres, \
                   dx, (bf16*)dx_lo, partial, rows, dim, wc)
     if (dy_dtype == AVF_F32) {
       if (vec) LAUNCH(float, true); else LAUNCH(float, false);
@@ -761,7 +775,7 @@ __global__ __launch_bounds__(256) void token_mean_bwd_kernel(const float4* __res
     for (int c = threadIdx.x; c < D4; c += 256) {
       const float4 v = gr[c];
       const float4 r = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
-      dy[row * D4 + c] = r;
+      if (dy) dy[row * D4 + c] = r;
       if (dy_lo) store4<bf16>(dy_lo + 4 * (row * D4 + c), r);
     }
   }
@@ -798,8 +812,8 @@ extern "C" int avf_token_mean_fwd(const float* y, float* out, int batch, int tok
 extern "C" int avf_token_mean_bwd(const float* g, float* dy, void* dy_bf16, float* colsum, int batch, int tokens, int dim,
                                   void* stream) {
   using namespace avf;
-  AVF_REQUIRE(g && dy && batch > 0 && tokens > 0 && dim > 0 && dim % 4 == 0,
-              "token_mean_bwd: bad arguments (dim must be a multiple of 4)");
+  AVF_REQUIRE(g && (dy || dy_bf16) && batch > 0 && tokens > 0 && dim > 0 && dim % 4 == 0,
+              "token_mean_bwd: bad arguments (dim must be a multiple of 4; one of dy / dy_bf16 is required)");
   AVF_REQUIRE((((uintptr_t)g | (uintptr_t)dy) & 15) == 0 && ((uintptr_t)dy_bf16 & 7) == 0,
               "token_mean_bwd: misaligned pointers");
   const int D4 = dim / 4;

@@ -16,6 +16,7 @@ fp32 CPU reference to ~1e-5).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Callable, List, Optional
 
 import torch
@@ -193,17 +194,23 @@ class _StackFn(torch.autograd.Function):
             flats.append(flat)
             views.append(vs)
         B2 = PARAMS_PER_LAYER - 1  # index of net.3.bias: its gradient = column sums of the layer's dx_out
+        gs16 = bool(cfg.grad_stream_bf16)
         if ctx.pool:
-            _lib.check(lib.avf_token_mean_bwd(_ptr(g), _ptr(dx), _ptr(lo_a) if have_lo else None,
+            _lib.check(lib.avf_token_mean_bwd(_ptr(g), None if (gs16 and have_lo) else _ptr(dx),
+                                              _ptr(lo_a) if have_lo else None,
                                               _ptr(views[L - 1][B2]) if top_colsum else None, B, N, D, stream),
                        "token_mean_bwd")
         for l in reversed(range(L)):
             gp = _lib.LayerPtrs(*[v.data_ptr() for v in views[l]])
             pp = mod._param_struct(ctx.params, l)
             # LN1' of this layer writes the column sums of dx_in directly into the previous layer's b2 gradient
+            # bf16 gradient stream: the fp32 buffer carries the gradient only into the top layer (when no bf16 image came
+            # with it) and out of the bottom one; in between the layers hand each other the bf16 image alone
+            dx_out_p = None if (gs16 and have_lo) else _ptr(dx)
+            dx_in_p = None if (gs16 and l > 0) else _ptr(dx)
             _lib.check(lib.avf_layer_bwd(C.byref(cfgs[l]), C.byref(pp), _ptr(ctx.lowps[l]), _ptr(ctx.xs[l]),
-                                         _ptr(ctx.saved_bufs[l]), _ptr(dx), _ptr(lo_a) if have_lo else None,
-                                         _ptr(views[l][B2]) if (l < L - 1 or top_colsum) else None, _ptr(dx), _ptr(lo_b),
+                                         _ptr(ctx.saved_bufs[l]), dx_out_p, _ptr(lo_a) if have_lo else None,
+                                         _ptr(views[l][B2]) if (l < L - 1 or top_colsum) else None, dx_in_p, _ptr(lo_b),
                                          _ptr(views[l - 1][B2]) if l > 0 else None, C.byref(gp), _ptr(ws), stream),
                        f"layer_bwd[{l}]")
             lo_a, lo_b = lo_b, lo_a
@@ -291,7 +298,15 @@ class Transformer(nn.Module):
                 f"p=0 / eval() (SURVEY.md section 7)")
         return _lib.LayerCfg(B, N, self.dim, self.heads, self.dim_head, self.mlp_dim, self.compute_dtype,
                              int(self.project_out), 1e-5, float(p), 0, 0, layer,
-                             seed_t.data_ptr() if (seed_t is not None and p != 0.0) else None, int(self.mx8))
+                             seed_t.data_ptr() if (seed_t is not None and p != 0.0) else None,
+                             int(self._grad_stream_bf16(p)), int(self.mx8))
+
+    def _grad_stream_bf16(self, p: float) -> bool:
+        """backward keeps the residual gradient between the LayerNorm backward kernels in bf16 (the GEMMs read that image
+        anyway): no fp32 dx write / read per sublayer.  Throughput mode without live dropout only; AVF_GRAD_STREAM=f32
+        restores the fp32 stream."""
+        return (self.compute_dtype == _lib.BF16 and p == 0.0 and self.dim <= 1536 and self.dim % 4 == 0
+                and os.environ.get("AVF_GRAD_STREAM", "bf16") != "f32")
 
     def _advance_seed(self, dev) -> Optional[torch.Tensor]:
         """Dropout seed of this forward, as a DEVICE tensor: the module's counter (initialised from torch.initial_seed(),
