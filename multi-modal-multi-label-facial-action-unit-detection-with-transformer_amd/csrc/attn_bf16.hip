@@ -683,11 +683,13 @@ __global__ __launch_bounds__(MAXW * 64) void attn_dq_res_kernel(const bf16* __re
         part += dot8(load_frag_global(obase + (int64_t)q * I + ks * 32 + 8 * lg, ok), fg[qb][ks]);
       dl[qb] = colsum4(part);
       if (ok && lg == 0) {
-        delta[(int64_t)bh * N + q] = dl[qb];
-        if (QS) nlse[(int64_t)bh * N + q] = -L[qb];  // the dK/dV kernel feeds it to its MFMAs as the C operand
+        delta[(int64_t)bh * N + q] = -dl[qb];        // NEGATED: the dK/dV kernel feeds it to its dP MFMAs as the C operand
+        if (QS) nlse[(int64_t)bh * N + q] = -L[qb];  // likewise for the score MFMAs
       }
     }
     const f32x4_t linit[2] = {{-L[0], -L[0], -L[0], -L[0]}, {-L[1], -L[1], -L[1], -L[1]}};
+    // dP - delta leaves the MFMA directly: -delta of the lane's query row rides in the C operand (no per-score subtract)
+    const f32x4_t dinit[2] = {{-dl[0], -dl[0], -dl[0], -dl[0]}, {-dl[1], -dl[1], -dl[1], -dl[1]}};
     if (first_pass) loader.issue_until(16 * RES_A);
 
     f32x4_t dqt[DB][2];
@@ -708,8 +710,9 @@ __global__ __launch_bounds__(MAXW * 64) void attn_dq_res_kernel(const bf16* __re
         ds[kb][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         ds[kb][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         if (!TAIL || kb < nkb) {
-          f32x4_t p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0;
-          f32x4_t s0 = QS ? linit[0] : p0, s1 = QS ? linit[1] : p0;  // QS: the MFMA returns log2-score - lse2
+          const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+          f32x4_t p0 = dinit[0], p1 = dinit[1];
+          f32x4_t s0 = QS ? linit[0] : zero, s1 = QS ? linit[1] : zero;  // QS: the MFMA returns log2-score - lse2
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
             const bf16x8_t fk = lds_row_frag(kt + kb * 2048 + off.row[ks]);
@@ -724,8 +727,8 @@ __global__ __launch_bounds__(MAXW * 64) void attn_dq_res_kernel(const bf16* __re
             const bool dead = TAIL && (t * 64 + kb * 16 + 4 * lg + r >= N);
             const float e0 = dead ? 0.f : __builtin_amdgcn_exp2f(QS ? s0[r] : fmaf(s0[r], c, -L[0]));
             const float e1 = dead ? 0.f : __builtin_amdgcn_exp2f(QS ? s1[r] : fmaf(s1[r], c, -L[1]));
-            ds[kb][0][r] = e0 * (p0[r] - dl[0]);
-            ds[kb][1][r] = e1 * (p1[r] - dl[1]);
+            ds[kb][0][r] = e0 * p0[r];
+            ds[kb][1][r] = e1 * p1[r];
           }
         }
         if (FEED) loader.issue_one();
@@ -854,8 +857,9 @@ __global__ __launch_bounds__(MAXW * 64) void attn_dkv_res_kernel(const bf16* __r
           if (!TAIL || qb < nqb) {
             const float4 l4 = *reinterpret_cast<const float4*>(Ls + t * 64 + qb * 16 + 4 * lg);
             const float4 d4 = *reinterpret_cast<const float4*>(Ds + t * 64 + qb * 16 + 4 * lg);
-            f32x4_t p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0;
-            f32x4_t s0 = QS ? f32x4_t{l4.x, l4.y, l4.z, l4.w} : p0, s1 = s0;
+            const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+            f32x4_t p0 = {d4.x, d4.y, d4.z, d4.w}, p1 = p0;  // Ds holds -delta (written negated by the dQ kernel)
+            f32x4_t s0 = QS ? f32x4_t{l4.x, l4.y, l4.z, l4.w} : zero, s1 = s0;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
               const bf16x8_t fqr = lds_row_frag(qt + qb * 2048 + off.row[ks]);
@@ -865,7 +869,7 @@ __global__ __launch_bounds__(MAXW * 64) void attn_dkv_res_kernel(const bf16* __r
               p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fgr, fv[0][ks], p0, 0, 0, 0);
               p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fgr, fv[1][ks], p1, 0, 0, 0);
             }
-            const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+            const float lv[4] = {l4.x, l4.y, l4.z, l4.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const bool dead = TAIL && (t * 64 + qb * 16 + 4 * lg + r >= N);
@@ -873,8 +877,8 @@ __global__ __launch_bounds__(MAXW * 64) void attn_dkv_res_kernel(const bf16* __r
               const float e1 = dead ? 0.f : __builtin_amdgcn_exp2f(QS ? s1[r] : fmaf(s1[r], c, -lv[r]));
               pm[h2][0][r] = e0;
               pm[h2][1][r] = e1;
-              dsm[h2][0][r] = e0 * (p0[r] - dv[r]);
-              dsm[h2][1][r] = e1 * (p1[r] - dv[r]);
+              dsm[h2][0][r] = e0 * p0[r];
+              dsm[h2][1][r] = e1 * p1[r];
             }
           }
           if (FEED) loader.issue_one();
