@@ -107,9 +107,12 @@ template <int EPI, typename CT, int WM, int WN, int MI, int NI, int NS>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(NtParams p, int tiles_n, int nwg) {
   constexpr int WTM = 16 * MI, WTN = 16 * NI;  // per-wave output tile
   constexpr int BMT = WTM * WM, BNT = WTN * WN, NW = WM * WN;
-  static_assert((BMT / 8) % NW == 0 && (BNT / 8) % NW == 0, "tile rows must split evenly over the waves");
   constexpr int A_BYTES = BMT * 128, B_BYTES = BNT * 128, STAGE = A_BYTES + B_BYTES;
-  constexpr int A_INS = (BMT / 8) / NW, B_INS = (BNT / 8) / NW;  // wave-instructions (8 rows each) per wave
+  // wave-instructions (8 tile rows each) are dealt to the waves round-robin; a wave's last one may not exist (96-row tiles
+  // on 8 waves: 12 instructions), which is fine with two stages - every K-step drains vmcnt to 0
+  constexpr int A_TOT = BMT / 8, B_TOT = BNT / 8;
+  constexpr int A_INS = (A_TOT + NW - 1) / NW, B_INS = (B_TOT + NW - 1) / NW;
+  static_assert(NS == 2 || (A_TOT % NW == 0 && B_TOT % NW == 0), "deeper rings count instructions: even split required");
   extern __shared__ __attribute__((aligned(16))) char dsm[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -124,13 +127,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(NtParam
   const bf16* gb[B_INS];
 #pragma unroll
   for (int j = 0; j < A_INS; ++j) {
-    int r = m0 + (wave * A_INS + j) * 8 + lrow;
+    int r = m0 + (wave + j * NW) * 8 + lrow;
     r = r < p.M ? r : p.M - 1;
     ga[j] = p.A + (int64_t)r * p.lda + lchunk * 8;
   }
 #pragma unroll
   for (int j = 0; j < B_INS; ++j) {
-    int r = n0 + (wave * B_INS + j) * 8 + lrow;
+    int r = n0 + (wave + j * NW) * 8 + lrow;
     r = r < p.N ? r : p.N - 1;
     gb[j] = p.B + (int64_t)r * p.ldb + lchunk * 8;
   }
@@ -138,9 +141,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(NtParam
     char* sa = dsm + st * STAGE;
     char* sb = sa + A_BYTES;
 #pragma unroll
-    for (int j = 0; j < A_INS; ++j) glds16(ga[j] + k0, sa + (wave * A_INS + j) * 1024);
+    for (int j = 0; j < A_INS; ++j)
+      if (A_TOT % NW == 0 || wave + j * NW < A_TOT) glds16(ga[j] + k0, sa + (wave + j * NW) * 1024);
 #pragma unroll
-    for (int j = 0; j < B_INS; ++j) glds16(gb[j] + k0, sb + (wave * B_INS + j) * 1024);
+    for (int j = 0; j < B_INS; ++j)
+      if (B_TOT % NW == 0 || wave + j * NW < B_TOT) glds16(gb[j] + k0, sb + (wave + j * NW) * 1024);
   };
 
   f32x4_t acc[MI][NI];
@@ -224,6 +229,7 @@ int launch_nt_glds_any(const NtParams& p, hipStream_t s, int* part_rows, TimingS
     case 0: return launch_nt_glds<EPI, CT, 2, 2, 4, 4, 2>(p, s, part_rows, ts);
     case 1: return launch_nt_glds<EPI, CT, 2, 2, 2, 4, 2>(p, s, part_rows, ts);
     case 3: return launch_nt_glds<EPI, CT, 2, 2, 3, 4, 2>(p, s, part_rows, ts);
+    case 5: return launch_nt_glds<EPI, CT, 2, 4, 3, 2, 2>(p, s, part_rows, ts);
     default: return launch_nt_glds<EPI, CT, 2, 4, 4, 2, 2>(p, s, part_rows, ts);
   }
 }

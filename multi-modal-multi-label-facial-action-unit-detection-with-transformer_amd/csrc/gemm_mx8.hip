@@ -41,13 +41,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mx8_nt_kernel(Mx8Params q, 
   const NtParams& p = q.nt;
   constexpr int WTM = 16 * MI, WTN = 16 * NI;
   constexpr int BMT = WTM * WM, BNT = WTN * WN, NW = WM * WN;
-  static_assert((BMT / 8) % NW == 0 && (BNT / 8) % NW == 0, "tile rows must split evenly over the waves");
+
   constexpr int A_BYTES = BMT * 128, B_BYTES = BNT * 128;
   constexpr int S_PIECES = (BMT + BNT + 63) / 64;       // scale dwords: 64 rows per 4-byte DMA instruction
   constexpr int S_BYTES = S_PIECES * 256;               // [A rows | B rows], padded to whole pieces
   constexpr int S_INS = (S_PIECES + NW - 1) / NW;       // per wave (pieces wrap: a duplicate writes the same bytes)
   constexpr int STAGE = A_BYTES + B_BYTES + S_BYTES;
-  constexpr int A_INS = (BMT / 8) / NW, B_INS = (BNT / 8) / NW;
+  constexpr int A_TOT = BMT / 8, B_TOT = BNT / 8;  // 8-row DMA instructions, dealt round-robin to the waves
+  constexpr int A_INS = (A_TOT + NW - 1) / NW, B_INS = (B_TOT + NW - 1) / NW;
   constexpr int KS = 128;
   extern __shared__ __attribute__((aligned(16))) char dsm[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -65,13 +66,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mx8_nt_kernel(Mx8Params q, 
   int spiece[S_INS];
 #pragma unroll
   for (int j = 0; j < A_INS; ++j) {
-    int r = m0 + (wave * A_INS + j) * 8 + lrow;
+    int r = m0 + (wave + j * NW) * 8 + lrow;
     r = r < p.M ? r : p.M - 1;
     ga[j] = (const char*)p.A + (int64_t)r * p.lda + lchunk * 16;
   }
 #pragma unroll
   for (int j = 0; j < B_INS; ++j) {
-    int r = n0 + (wave * B_INS + j) * 8 + lrow;
+    int r = n0 + (wave + j * NW) * 8 + lrow;
     r = r < p.N ? r : p.N - 1;
     gb[j] = (const char*)p.B + (int64_t)r * p.ldb + lchunk * 16;
   }
@@ -95,9 +96,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mx8_nt_kernel(Mx8Params q, 
     char* sb = sa + A_BYTES;
     char* ss = sb + B_BYTES;
 #pragma unroll
-    for (int j = 0; j < A_INS; ++j) glds16(ga[j] + t * KS, sa + (wave * A_INS + j) * 1024);
+    for (int j = 0; j < A_INS; ++j)
+      if (A_TOT % NW == 0 || wave + j * NW < A_TOT) glds16(ga[j] + t * KS, sa + (wave + j * NW) * 1024);
 #pragma unroll
-    for (int j = 0; j < B_INS; ++j) glds16(gb[j] + t * KS, sb + (wave * B_INS + j) * 1024);
+    for (int j = 0; j < B_INS; ++j)
+      if (B_TOT % NW == 0 || wave + j * NW < B_TOT) glds16(gb[j] + t * KS, sb + (wave + j * NW) * 1024);
 #pragma unroll
     for (int j = 0; j < S_INS; ++j) glds4(gs[j] + t * 4, ss + spiece[j] * 256);
   };
@@ -177,6 +180,7 @@ int launch_mx8_any(const Mx8Params& q, hipStream_t s, int* part_rows, TimingScop
     case 0: return launch_mx8<EPI, CT, 2, 2, 4, 4>(q, s, part_rows, ts);
     case 1: return launch_mx8<EPI, CT, 2, 2, 2, 4>(q, s, part_rows, ts);
     case 3: return launch_mx8<EPI, CT, 2, 2, 3, 4>(q, s, part_rows, ts);
+    case 5: return launch_mx8<EPI, CT, 2, 4, 3, 2>(q, s, part_rows, ts);
     default: return launch_mx8<EPI, CT, 2, 4, 4, 2>(q, s, part_rows, ts);
   }
 }

@@ -216,6 +216,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 //                                                             latency better (+5..8 % measured at K = 512..1536)
 //   3:  96x128, 4 waves of 48x64, 2 stages (56 KiB, 2/CU)   - M = 10368, N = 512: 432 workgroups fill the 512 slots in
 //                                                             one round; 8..11 % faster than (1) once K >= 1024
+//   5:  96x128, 8 waves of 48x32, 2 stages (56 KiB, 2/CU)   - the same tile with twice the waves (12 DMA instructions per
+//                                                             operand dealt round-robin to 8 waves): 0.3..2.2 us faster than
+//                                                             (1) / (3) on every N = 512 shape of C2, replaces both there
 // (3- and 4-stage rings, 256x128 / 256x256 / 192x128 tiles, 64x64 tiles and a persistent tile loop were all measured slower
 //  on this path's shapes - M = 10k..16k, N = 512..1536, K = 512..1536 - and removed: the waves wait ~55 % of their
 //  cycles (SQ_WAIT_ANY) on LDS/barrier latency, which more resident waves hide better than deeper DMA rings)
@@ -235,7 +238,8 @@ int pick_nt_tile(int64_t M, int64_t N, int64_t K) {
   if (override_tile >= 0) return override_tile;
   const int64_t wg128 = ceil_div(M, 128) * ceil_div(N, 128);
   if (wg128 >= 512) return 2;
-  return (K >= 1024 && ceil_div(M, 96) * ceil_div(N, 128) <= 512) ? 3 : 1;
+  (void)K;
+  return ceil_div(M, 96) * ceil_div(N, 128) <= 512 ? 5 : 1;
 }
 
 }  // namespace
