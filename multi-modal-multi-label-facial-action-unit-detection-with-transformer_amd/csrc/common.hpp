@@ -205,15 +205,21 @@ __device__ __forceinline__ float fast_tanh(float z) {
   const float e = __builtin_amdgcn_exp2f(z * 2.885390081777927f);  // 2*log2(e)
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
 }
+// tanh-GELU through the logistic form: 0.5 u (1 + tanh z) = u * sigma(2 z), 2 z log2(e) = u (K1 + K2 u^2) - 13 VALU
+// slots per element instead of 18 (the transcendental pair exp2 / rcp is 8 of them); same value to fp32 rounding
+constexpr float GELU_K1 = 2.302208198f;    // 2 sqrt(2/pi) log2(e)
+constexpr float GELU_K2 = 0.1029432396f;   // K1 * 0.044715
 __device__ __forceinline__ float gelu_tanh_fast(float u) {
-  const float c = 0.7978845608028654f;
-  return 0.5f * u * (1.0f + fast_tanh(c * (u + 0.044715f * u * u * u)));
+  const float e = __builtin_amdgcn_exp2f(-u * fmaf(GELU_K2, u * u, GELU_K1));
+  return u * __builtin_amdgcn_rcpf(1.0f + e);
 }
+// d/du [u sigma(2z)] = s + u s (1 - s) d(2z)/du,  d(2z)/du = 2 sqrt(2/pi) (1 + 3 * 0.044715 u^2)
 __device__ __forceinline__ float dgelu_tanh_fast(float u) {
-  const float c = 0.7978845608028654f;
   const float u2 = u * u;
-  const float t = fast_tanh(c * (u + 0.044715f * u * u2));
-  return 0.5f * (1.0f + t) + 0.5f * u * (1.0f - t * t) * c * (1.0f + 3.0f * 0.044715f * u2);
+  const float e = __builtin_amdgcn_exp2f(-u * fmaf(GELU_K2, u2, GELU_K1));
+  const float s = __builtin_amdgcn_rcpf(1.0f + e);
+  const float q = fmaf(0.2140644488f, u2, 1.5957691216f);  // 6 c a, 2 c  (c = sqrt(2/pi), a = 0.044715)
+  return fmaf(u * s * (1.0f - s), q, s);
 }
 
 // ---------------------------------------------------------------------------------------------
