@@ -102,7 +102,7 @@ struct TileStager {
 // =============================================================================================
 template <int DH>
 __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
-                                                            float* __restrict__ lse2, int B, int N, int H, int qs) {
+                                                            float* __restrict__ lse2, int /*B*/, int N, int H, int qs) {
   constexpr int KS = DH / 32, DB = DH / 16;
   constexpr int KLD = DH * 2 + 32;  // K tile: row reads (ds_read_b128); +32 B keeps them conflict-free (PMC-checked)
   constexpr int VLD = DH * 2 + 32;  // V tile: transposed reads, 8 consecutive rows -> 8 distinct bank windows
@@ -937,7 +937,7 @@ template <int DH>
 __global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
                                                            const float* __restrict__ lse2,
                                                            const float* __restrict__ delta, bf16* __restrict__ dqkv,
-                                                           int B, int N, int H, int qs) {
+                                                           int /*B*/, int N, int H, int qs) {
   constexpr int KS = DH / 32, DB = DH / 16;
   constexpr int KLD = DH * 2 + 32;  // K tile: row reads AND transposed reads
   constexpr int VLD = DH * 2 + 32;  // V tile: row reads only (+32 B: conflict-free, PMC-checked)
@@ -1072,7 +1072,7 @@ template <int DH>
 __global__ __launch_bounds__(256, 2) void attn_dkv_bf16_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
                                                             const float* __restrict__ lse2,
                                                             const float* __restrict__ delta, bf16* __restrict__ dqkv,
-                                                            int B, int N, int H, int qs) {
+                                                            int /*B*/, int N, int H, int qs) {
   constexpr int KS = DH / 32, DB = DH / 16;
   constexpr int TLD = DH * 2 + 32;  // Q and dO tiles: row reads AND transposed reads
   constexpr int STAGE = 2 * 64 * TLD + 2 * 64 * 4;

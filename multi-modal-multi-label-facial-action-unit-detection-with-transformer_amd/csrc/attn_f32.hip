@@ -28,7 +28,7 @@ __device__ __forceinline__ void stage_rows(float* dst, const float* src, int64_t
 
 template <int DH>
 __global__ __launch_bounds__(64) void attn_fwd_f32_kernel(const float* __restrict__ qkv, float* __restrict__ o,
-                                                          float* __restrict__ lse2, int B, int N, int H) {
+                                                          float* __restrict__ lse2, int /*B*/, int N, int H) {
   __shared__ __attribute__((aligned(16))) float Ks[KT * DH];
   __shared__ __attribute__((aligned(16))) float Vs[KT * DH];
   const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64) void attn_fwd_f32_kernel(const float* __restric
 template <int DH>
 __global__ __launch_bounds__(64) void attn_dq_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
                                                          const float* __restrict__ lse2, const float* __restrict__ delta,
-                                                         float* __restrict__ dqkv, int B, int N, int H) {
+                                                         float* __restrict__ dqkv, int /*B*/, int N, int H) {
   __shared__ __attribute__((aligned(16))) float Ks[KT * DH];
   __shared__ __attribute__((aligned(16))) float Vs[KT * DH];
   const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
@@ -150,7 +150,7 @@ template <int DH, int PASS>
 __global__ __launch_bounds__(64) void attn_dkv_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
                                                           const float* __restrict__ lse2,
                                                           const float* __restrict__ delta, float* __restrict__ dqkv,
-                                                          int B, int N, int H) {
+                                                          int /*B*/, int N, int H) {
   __shared__ __attribute__((aligned(16))) float Qs[KT * DH];
   __shared__ __attribute__((aligned(16))) float Gs[KT * DH];
   __shared__ float Ls[KT], Ds[KT];
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(64) void attn_dkv_f32_kernel(const float* __restric
     stage_rows<DH>(Qs, base, ld, qt, nq);
     stage_rows<DH>(Gs, d_o + (int64_t)b * N * I + h * DH, I, qt, nq);
     if (threadIdx.x < KT) {
-      const bool ok = threadIdx.x < nq;
+      const bool ok = (int)threadIdx.x < nq;
       Ls[threadIdx.x] = ok ? lse2[(int64_t)bh * N + qt + threadIdx.x] : INFINITY;  // 2^(s - inf) = 0
       Ds[threadIdx.x] = ok ? delta[(int64_t)bh * N + qt + threadIdx.x] : 0.f;
     }

@@ -22,7 +22,6 @@ namespace {
 typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 
-constexpr float LOG2E_S = 1.4426950408889634f;
 
 struct SmallArgs {
   const float* x_in;
