@@ -12,6 +12,19 @@ namespace avf {
 
 namespace {
 
+// streaming accesses of the optimizer state (touched once per step): non-temporal, so they do not evict the bf16 weight
+// images and activations the next forward re-reads from L2 / Infinity Cache
+typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float* p) {
+  const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void nt_store4(float* p, float4 v) {
+  const f32x4_nt t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<f32x4_nt*>(p));
+}
+
+
 struct AdamDesc {
   float* p;
   const float* g;  // null: no update, the bf16 images are still refreshed
@@ -88,11 +101,11 @@ __global__ __launch_bounds__(256) void adam_layer_kernel(AdamBatch b) {
       const int64_t o = (int64_t)r * d.C + c;
       P[i] = G[i] = Mv[i] = Vv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (ok[i]) {
-        P[i] = *reinterpret_cast<const float4*>(d.p + o);
+        P[i] = nt_load4(d.p + o);
         if (upd) {
-          G[i] = *reinterpret_cast<const float4*>(d.g + o);
-          Mv[i] = *reinterpret_cast<const float4*>(d.m + o);
-          Vv[i] = *reinterpret_cast<const float4*>(d.v + o);
+          G[i] = nt_load4(d.g + o);
+          Mv[i] = nt_load4(d.m + o);
+          Vv[i] = nt_load4(d.v + o);
         }
       }
     }
@@ -107,9 +120,9 @@ __global__ __launch_bounds__(256) void adam_layer_kernel(AdamBatch b) {
           const float4 g = G[i];
           adam1(p.x, g.x, m.x, v.x, k); adam1(p.y, g.y, m.y, v.y, k);
           adam1(p.z, g.z, m.z, v.z, k); adam1(p.w, g.w, m.w, v.w, k);
-          *reinterpret_cast<float4*>(d.p + o) = p;
-          *reinterpret_cast<float4*>(d.m + o) = m;
-          *reinterpret_cast<float4*>(d.v + o) = v;
+          nt_store4(d.p + o, p);
+          nt_store4(d.m + o, m);
+          nt_store4(d.v + o, v);
         }
         if (d.lo) {
           const float sc = r < d.lo_scaled_rows ? d.lo_scale : 1.0f;
