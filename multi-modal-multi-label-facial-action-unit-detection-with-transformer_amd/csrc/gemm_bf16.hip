@@ -500,12 +500,10 @@ __global__ __launch_bounds__(256) void fold_group_kernel(TnGroup g, int nslab, F
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (; i < n4; i += stride) {
-    float4 a = reinterpret_cast<const float4*>(P.slabs)[i];
-    for (int s = 1; s < g.S; ++s) {
-      const float4 b = reinterpret_cast<const float4*>(P.slabs + (int64_t)s * slab)[i];
-      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-    }
-    reinterpret_cast<float4*>(P.C)[i] = a;
+    typedef float f32x4_nt __attribute__((ext_vector_type(4)));  // slabs are read exactly once: non-temporal
+    f32x4_nt a = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(P.slabs) + i);
+    for (int s = 1; s < g.S; ++s) a += __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(P.slabs + (int64_t)s * slab) + i);
+    reinterpret_cast<float4*>(P.C)[i] = make_float4(a[0], a[1], a[2], a[3]);
   }
 }
 

@@ -303,7 +303,9 @@ __global__ __launch_bounds__(256) void ln_bwd_reg_kernel(const DyT* __restrict__
       d[i] = xh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (act[i]) {
         d[i] = load4<DyT>(dy + row * D + c);
-        const float4 v = *reinterpret_cast<const float4*>(x + row * D + c);
+        typedef float f32x4_nt __attribute__((ext_vector_type(4)));  // last use of this x row in the step: non-temporal
+        const f32x4_nt xv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(x + row * D + c));
+        const float4 v = make_float4(xv[0], xv[1], xv[2], xv[3]);
         xh[i] = make_float4((v.x - mu) * rs, (v.y - mu) * rs, (v.z - mu) * rs, (v.w - mu) * rs);
       }
       const float g0 = d[i].x * g[i].x, g1 = d[i].y * g[i].y, g2 = d[i].z * g[i].z, g3 = d[i].w * g[i].w;
