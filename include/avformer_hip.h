@@ -175,6 +175,12 @@ int avf_token_mean_bwd(const float* g, float* dy, void* dy_bf16, float* colsum, 
  * (contiguous) = d loss / d logits.  All rows dropped => NaN (as the reference). */
 int avf_au_loss(const float* logits, int64_t ld_logits, const float* labels, int64_t ld_labels, const float* pos_weight,
                 float ignore, int rows, int ncls, float* loss, float* grad_unit, void* stream);
+/* The same as a (sum, count) pair for batch-sharded data parallelism - loss.py:85-102 is a RATIO, so ranks with different
+ * numbers of ignored rows must reduce numerator and denominator separately: sum_count[0] = sum over kept rows of the row's
+ * mean BCE, sum_count[1] = kept rows, grad_unit = d sum_count[0] / d logits.  All rows dropped => (0, 0), zero gradient. */
+int avf_au_loss_sum(const float* logits, int64_t ld_logits, const float* labels, int64_t ld_labels,
+                    const float* pos_weight, float ignore, int rows, int ncls, float* sum_count, float* grad_unit,
+                    void* stream);
 
 /* ---- one transformer layer (heads.py:246-255), forward and backward ------------------------ */
 size_t avf_layer_saved_bytes(const avf_layer_cfg* cfg);     /* activations kept for backward        */

@@ -71,7 +71,9 @@ class MelFrontEnd(nn.Module):
             pad[..., -mel.shape[-1]:] = mel
             mel = pad
         db = 10.0 * torch.log10(torch.clamp(mel, min=1e-10))
-        # top_db: relative to the maximum of each clip ([channel, mel, time] block)
-        peak = db.amax(dim=(-3, -2, -1), keepdim=True) if db.dim() >= 3 else db.amax()
+        # top_db: relative to the maximum of EACH clip, as the reference's per-clip AmplitudeToDB on [1, n_mels, T]
+        # (aff2compdataset.py:60-68): audio[samples] -> one clip; audio[B, samples] -> per row; audio[B, C, samples] ->
+        # per row over its channels.  Never across the batch (a quiet clip batched with a loud one keeps its own floor).
+        peak = db.amax(dim=(-3, -2, -1), keepdim=True) if db.dim() >= 4 else db.amax(dim=(-2, -1), keepdim=True)
         db = torch.maximum(db, peak - self.top_db)
         return (db - self.mean) / self.std

@@ -1259,14 +1259,23 @@ int res_waves(int N) {
 template <typename K, typename... Args>
 int res_launch(const TimingScope* ts, K kernel, const char* name, int blocks, int waves, size_t smem, hipStream_t s, Args... args) {
   // raise the dynamic-LDS limit once per kernel (nine instantiations share this function template per signature)
-  static const void* raised[16];
+  // (the table is append-only under a lock: the forward thread and autograd's device thread may both get here)
+  static struct { const void* fn; PerDeviceOnce once; } raised[32];
   static int nraised = 0;
-  bool seen = false;
-  for (int i = 0; i < nraised; ++i) seen = seen || raised[i] == (const void*)kernel;
-  if (!seen) {
+  static int lock = 0;
+  PerDeviceOnce* once = nullptr;
+  while (__atomic_exchange_n(&lock, 1, __ATOMIC_ACQUIRE)) {}
+  for (int i = 0; i < nraised; ++i)
+    if (raised[i].fn == (const void*)kernel) once = &raised[i].once;
+  if (!once && nraised < 32) {
+    raised[nraised].fn = (const void*)kernel;
+    once = &raised[nraised++].once;
+  }
+  __atomic_store_n(&lock, 0, __ATOMIC_RELEASE);
+  if (!once || once->need()) {
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     AVF_REQUIRE(e == hipSuccess, "%s: cannot raise dynamic LDS limit: %s", name, hipGetErrorString(e));
-    if (nraised < 16) raised[nraised++] = (const void*)kernel;
+    if (once) once->mark();
   }
   AVF_REQUIRE(smem <= 160 * 1024, "%s: %zu bytes of LDS", name, smem);
   launch_in_scope(ts, kernel, dim3(blocks), dim3(waves * 64), (uint32_t)smem, s, args...);

@@ -270,6 +270,23 @@ __device__ __forceinline__ float4 drop_factor4(const DropCfg& d, uint64_t key, u
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// "dynamic-LDS limit raised" bookkeeping, one bit per device (hipFuncSetAttribute is per device; a process that runs stacks
+// on a second GPU must raise it there too).  Racing threads (forward thread, autograd's device thread) may both call
+// hipFuncSetAttribute - idempotent - and the bit is set with an atomic OR.
+struct PerDeviceOnce {
+  uint64_t done = 0;
+  bool need() const {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return ((__atomic_load_n(&done, __ATOMIC_ACQUIRE) >> (dev & 63)) & 1u) == 0;
+  }
+  void mark() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    __atomic_fetch_or(&done, 1ull << (dev & 63), __ATOMIC_RELEASE);
+  }
+};
+
 // ---------------------------------------------------------------------------------------------
 // internal launchers shared between translation units (all return 0 / non-zero)
 // ---------------------------------------------------------------------------------------------

@@ -208,12 +208,12 @@ int launch_nt_glds(const NtParams& p, hipStream_t s, int* part_rows, TimingScope
   constexpr int BMT = 16 * MI * WM, BNT = 16 * NI * WN;
   constexpr int SMEM = NS * (BMT + BNT) * 128;
   static_assert(NS >= 2 && NS <= 4 && SMEM <= 160 * 1024, "stage count / LDS budget");
-  static bool raised = false;
-  if (!raised && SMEM > 64 * 1024) {
+  static PerDeviceOnce raised;
+  if (SMEM > 64 * 1024 && raised.need()) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_glds_kernel<EPI, CT, WM, WN, MI, NI, NS>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     AVF_REQUIRE(e == hipSuccess, "gemm_bf16_nt: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
-    raised = true;
+    raised.mark();
   }
   const int tiles_m = (p.M + BMT - 1) / BMT, tiles_n = (p.N + BNT - 1) / BNT;
   const int nwg = tiles_m * tiles_n;
@@ -485,8 +485,138 @@ __global__ __launch_bounds__(128 * WNW) void gemm_bf16_tn_group_kernel(TnGroup g
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// grouped TN kernel, 256 x 128 tile: ONE workgroup of 8 wavefronts (4 x 2, 64 x 64 each) per CU.
+// The 128 x 128 kernel above moves 32 KB from L2 into LDS per 2.1 MFLOP K-step (64 FLOP/B) and two co-resident
+// workgroups saturate the CU's L2 -> LDS path (~38 B/clk: 1690 cycles per pair of K-steps against 1024 of MFMA time);
+// this tile moves 48 KB per 4.2 MFLOP (85 FLOP/B).  A rows are 512 B in LDS (two rows per LDS-DMA instruction), B rows
+// 256 B (four per instruction); the same chunk XOR (row & 7) << 1 keeps ds_read_b64_tr_b16 conflict-free for both row
+// lengths (either is a multiple of the 256-byte bank row).  NS-stage ring (3: 144 KB), counted vmcnt, one raw
+// s_barrier per K-step - weight gradients reduce over thousands of token rows, so the ring runs at depth for the whole
+// launch and there is no short-K prologue / epilogue problem here.
+// ------------------------------------------------------------------------------------------
+constexpr int TBM = 256;  // big-tile M extent (columns of A)
+
+template <int ROWB>
+__device__ __forceinline__ bf16x8_t tr_frag_swz_rb(const lds_char* tile, int row_base, int col_base, int li, int lg) {
+  const int row = row_base + 4 * lg + (li >> 2);  // row & 7 is the same for the +16 read
+  const int chunk = (col_base >> 3) + ((li & 3) >> 1);
+  const int off = ((chunk ^ ((row & 7) << 1)) << 4) + ((li & 1) << 3);
+  const lds_char* p0 = tile + row * ROWB + off;
+  s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
+  s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0 + 16 * ROWB));
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  s16x8_t r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+
+template <int NS>
+__global__ __launch_bounds__(512) void gemm_bf16_tn_group_big_kernel(TnGroup g) {
+  constexpr int A_BYTES = TR * 512, B_BYTES = TR * 256, STAGE = A_BYTES + B_BYTES;  // 32 + 16 KiB
+  constexpr int A_INS = 4, B_INS = 2, INS = A_INS + B_INS;                          // per wave per stage
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 15, lg = lane >> 4;
+  const int tile = blockIdx.x / g.S, split = blockIdx.x - tile * g.S;
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (i < g.nprob && tile >= g.p[i].tile_start) pi = i;
+  const TnProblem& P = g.p[pi];
+  const int lt = tile - P.tile_start;
+  const int m0 = (lt / P.tiles_n) * TBM, n0 = (lt % P.tiles_n) * TB;
+  const int kbeg = split * g.kchunk;
+  const int kend = (kbeg + g.kchunk) < g.K ? (kbeg + g.kchunk) : g.K;
+
+  // LDS-DMA sources.  A: instruction q = 4 wave + j fills rows 2q, 2q+1 (lanes 0..31 / 32..63, 32 chunks of 16 B each);
+  // B: instruction q = 2 wave + j fills rows 4q .. 4q+3 (16 lanes, 16 chunks each).
+  const bf16* ga[A_INS];
+  const bf16* gb[B_INS];
+#pragma unroll
+  for (int j = 0; j < A_INS; ++j) {
+    const int row = (wave * A_INS + j) * 2 + (lane >> 5);
+    const int chunk = (lane & 31) ^ ((row & 7) << 1);
+    const int ca = (m0 + chunk * 8 < P.M) ? m0 + chunk * 8 : 0;  // columns past the edge: any valid address
+    ga[j] = P.A + (int64_t)(kbeg + row) * P.lda + ca;
+  }
+#pragma unroll
+  for (int j = 0; j < B_INS; ++j) {
+    const int row = (wave * B_INS + j) * 4 + (lane >> 4);
+    const int chunk = (lane & 15) ^ ((row & 7) << 1);
+    const int cb = (n0 + chunk * 8 < P.N) ? n0 + chunk * 8 : 0;
+    gb[j] = P.B + (int64_t)(kbeg + row) * P.ldb + cb;
+  }
+  const int64_t astep = (int64_t)TR * P.lda, bstep = (int64_t)TR * P.ldb;
+  auto stage = [&](int st, int t) {
+    char* sa = dsm + st * STAGE;
+    char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int j = 0; j < A_INS; ++j) glds16(ga[j] + t * astep, sa + (wave * A_INS + j) * 1024);
+#pragma unroll
+    for (int j = 0; j < B_INS; ++j) glds16(gb[j] + t * bstep, sb + (wave * B_INS + j) * 1024);
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nt = kend > kbeg ? (kend - kbeg) / TR : 0;
+#pragma unroll
+  for (int i = 0; i < NS - 1; ++i)
+    if (i < nt) stage(i, i);
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    const int ahead = (nt - 1 - t) < (NS - 2) ? (nt - 1 - t) : (NS - 2);  // tiles issued after tile t
+    if (ahead >= 2) wait_vmcnt<2 * INS>();
+    else if (ahead == 1) wait_vmcnt<INS>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (t + NS - 1 < nt) {
+      int slot = cur + NS - 1;
+      slot = slot >= NS ? slot - NS : slot;
+      stage(slot, t + NS - 1);
+    }
+    const lds_char* sa = (const lds_char*)(dsm + cur * STAGE);
+    const lds_char* sb = sa + A_BYTES;
+    bf16x8_t fa[2][4], fb[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[ks][i] = tr_frag_swz_rb<512>(sa, ks * 32, wm * 64 + i * 16, li, lg);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[ks][j] = tr_frag_swz_rb<256>(sb, ks * 32, wn * 64 + j * 16, li, lg);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
+    cur = (cur + 1 == NS) ? 0 : cur + 1;
+  }
+  float* out = g.S > 1 ? P.slabs + (int64_t)split * P.M * P.N : P.C;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + li;
+    if (m >= P.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + 4 * lg;
+      if (n >= P.N) continue;
+      *reinterpret_cast<float4*>(out + (int64_t)m * P.N + n) =
+          make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
+  }
+}
+
 // C_i = sum_s slabs_i[s]  for every problem of the group, plus the layer's deferred column folds (one launch):
 // blockIdx.y < nslab selects a weight-gradient problem, the remaining rows select a FoldJob.
+template <int SS>  // SS > 0: the split count, fully unrolled (all slab loads of an element in flight); 0: runtime g.S
 __global__ __launch_bounds__(256) void fold_group_kernel(TnGroup g, int nslab, FoldList fl) {
   if ((int)blockIdx.y >= nslab) {
     __shared__ float4 red[32][8];
@@ -501,13 +631,23 @@ __global__ __launch_bounds__(256) void fold_group_kernel(TnGroup g, int nslab, F
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (; i < n4; i += stride) {
     typedef float f32x4_nt __attribute__((ext_vector_type(4)));  // slabs are read exactly once: non-temporal
-    f32x4_nt a = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(P.slabs) + i);
-    for (int s = 1; s < g.S; ++s) a += __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(P.slabs + (int64_t)s * slab) + i);
+    f32x4_nt a;
+    if (SS > 0) {
+      f32x4_nt v[SS > 0 ? SS : 1];
+#pragma unroll
+      for (int s = 0; s < SS; ++s) v[s] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(P.slabs + (int64_t)s * slab) + i);
+      a = v[0];
+#pragma unroll
+      for (int s = 1; s < SS; ++s) a += v[s];  // same order as the runtime loop: bitwise the same sums
+    } else {
+      a = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(P.slabs) + i);
+      for (int s = 1; s < g.S; ++s) a += __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(P.slabs + (int64_t)s * slab) + i);
+    }
     reinterpret_cast<float4*>(P.C)[i] = make_float4(a[0], a[1], a[2], a[3]);
   }
 }
 
-int tn_group_splits(int total_tiles, int64_t K) {
+int tn_group_splits(int total_tiles, int64_t K, int slots = 512) {
   static const int forced = [] {
     const char* e = getenv("AVF_TN_SPLITS");  // tuning aid
     return e ? atoi(e) : 0;
@@ -522,7 +662,7 @@ int tn_group_splits(int total_tiles, int64_t K) {
   double best_score = -1.0;
   for (int s = 1; s <= 8 && s <= maxs; ++s) {
     const int64_t wgs = (int64_t)total_tiles * s;
-    const double eff = (double)wgs / (double)(ceil_div(wgs, 512) * 512);
+    const double eff = (double)wgs / (double)(ceil_div(wgs, slots) * slots);
     const double score = eff - 0.05 * (s - 1);
     if (score > best_score + 1e-9) { best_score = score; best = s; }
   }
@@ -584,6 +724,15 @@ int gemm_bf16_nt(const GemmArgs& a, hipStream_t s) {
   if (a.colsum) {
     AVF_REQUIRE(a.workspace, "gemm_bf16_nt: column-sum workspace missing");
     p.cs_partial = (float*)a.workspace;
+    // the partial rows the chosen tile will write must fit the workspace - checked BEFORE anything is enqueued
+    int planned = part_rows;
+    if (dma) {
+      const int t = pick_nt_tile(a.M, a.N, a.K);
+      const int bmt = (t == 0 || t == 2) ? 128 : (t == 1 ? 64 : 96);
+      planned = (int)ceil_div(a.M, bmt) * 2;  // every configuration has two wave rows per block tile
+    }
+    AVF_REQUIRE((size_t)planned * a.N * sizeof(float) <= gemm_nt_colsum_ws(a.M, a.N),
+                "gemm_bf16_nt: column-sum partials exceed their workspace (internal error)");
   }
 #define LAUNCH(E)                                                         \
   do {                                                                    \
@@ -611,8 +760,6 @@ int gemm_bf16_nt(const GemmArgs& a, hipStream_t s) {
   }
 #undef LAUNCH
   AVF_TRY(check_launch("gemm_bf16_nt_kernel"));
-  AVF_REQUIRE(!a.colsum || (size_t)part_rows * a.N * sizeof(float) <= gemm_nt_colsum_ws(a.M, a.N),
-              "gemm_bf16_nt: column-sum partials exceed their workspace (internal error)");
   if (a.colsum) {
     if (a.defer_fold) *a.defer_fold = FoldJob{p.cs_partial, part_rows, (int)a.N, (int)a.N, a.colsum, nullptr, nullptr};
     else AVF_TRY(fold_partials(p.cs_partial, part_rows, (int)a.N, a.colsum, s));
@@ -629,11 +776,11 @@ int gemm_bf16_tn(const GemmArgs& a, hipStream_t s) {
   AVF_REQUIRE(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.B & 15) == 0 && ((uintptr_t)a.C & 15) == 0,
               "gemm_bf16_tn: operands must be 16-byte aligned");
   AVF_REQUIRE(a.M < (1LL << 31) && a.N < (1LL << 31) && a.K < (1LL << 31), "gemm_bf16_tn: shape too large");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_set;
+  if (attr_set.need()) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_SMEM);
     AVF_REQUIRE(e == hipSuccess, "gemm_bf16_tn: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
-    attr_set = true;
+    attr_set.mark();
   }
   const int S = tn_splits(a.M, a.N, a.K);
   AVF_REQUIRE(S == 1 || a.workspace, "gemm_bf16_tn: split-K workspace missing");
@@ -668,14 +815,29 @@ bool gemm_bf16_tn_group_ok(const TnGroupArgs& a) {
   return true;
 }
 
-size_t gemm_bf16_tn_group_ws(const TnGroupArgs& a) {
+// 256 x 128 tiles (one 8-wave workgroup per CU) when the group has enough work to fill the chip with them
+static bool tn_group_big(const TnGroupArgs& a) {
+  static const int forced = [] {
+    const char* e = getenv("AVF_TN_BIG");  // tuning aid: 0 = always the 128 x 128 kernel, 1 = always the 256 x 128 one
+    return e ? atoi(e) : -1;
+  }();
+  if (forced >= 0) return forced != 0;
+  int64_t tiles = 0;
+  for (int i = 0; i < a.count; ++i) tiles += ceil_div(a.M[i], TBM) * ceil_div(a.N[i], TB);
+  return tiles >= 32 && a.K >= 2048;
+}
+static int tn_group_tiles(const TnGroupArgs& a, bool big) {
   int tiles = 0;
+  for (int i = 0; i < a.count; ++i) tiles += (int)(ceil_div(a.M[i], big ? TBM : TB) * ceil_div(a.N[i], TB));
+  return tiles;
+}
+
+size_t gemm_bf16_tn_group_ws(const TnGroupArgs& a) {
   size_t elems = 0;
-  for (int i = 0; i < a.count; ++i) {
-    tiles += (int)(ceil_div(a.M[i], TB) * ceil_div(a.N[i], TB));
-    elems += (size_t)a.M[i] * a.N[i];
-  }
-  const int S = tn_group_splits(tiles, a.K);
+  for (int i = 0; i < a.count; ++i) elems += (size_t)a.M[i] * a.N[i];
+  // the larger of the two kernels' needs (the choice can be overridden by the environment at run time)
+  const int S0 = tn_group_splits(tn_group_tiles(a, false), a.K, 512), S1 = tn_group_splits(tn_group_tiles(a, true), a.K, 256);
+  const int S = S0 > S1 ? S0 : S1;
   return S > 1 ? (size_t)S * elems * sizeof(float) : 0;
 }
 
@@ -687,18 +849,19 @@ int gemm_bf16_tn_group(const TnGroupArgs& a, hipStream_t s, const FoldList* extr
   g.K = (int)a.K;
   int tiles = 0;
   double flops = 0, bytes = 0;
+  const bool big = tn_group_big(a);
   for (int i = 0; i < a.count; ++i) {
     TnProblem& P = g.p[i];
     P.A = (const bf16*)a.A[i]; P.B = (const bf16*)a.B[i]; P.C = a.C[i];
     P.lda = (int)a.lda[i]; P.ldb = (int)a.ldb[i]; P.M = (int)a.M[i]; P.N = (int)a.N[i];
     P.tiles_n = (int)ceil_div(a.N[i], TB);
     P.tile_start = tiles;
-    tiles += (int)ceil_div(a.M[i], TB) * P.tiles_n;
+    tiles += (int)ceil_div(a.M[i], big ? TBM : TB) * P.tiles_n;
     flops += 2.0 * a.M[i] * a.N[i] * a.K;
     bytes += 2.0 * (a.M[i] + a.N[i]) * a.K + 4.0 * a.M[i] * a.N[i];
   }
   g.total_tiles = tiles;
-  g.S = tn_group_splits(tiles, a.K);
+  g.S = tn_group_splits(tiles, a.K, big ? 256 : 512);
   g.kchunk = (int)(ceil_div(ceil_div(a.K, g.S), TR) * TR);
   if (g.S > 1) {
     AVF_REQUIRE(a.workspace, "gemm_bf16_tn_group: split-K workspace missing");
@@ -713,7 +876,28 @@ int gemm_bf16_tn_group(const TnGroupArgs& a, hipStream_t s, const FoldList* extr
     const char* e = getenv("AVF_TN_WAVES");  // tuning aid
     return e ? atoi(e) : 4;  // 8 waves measured 5 % slower here (unlike the NT kernel)
   }();
-  if (tn_waves == 4) launch_in_scope(&ts, gemm_bf16_tn_group_kernel<2>, dim3(tiles * g.S), dim3(256), 0, s, g);
+  if (big) {
+    static const int stages = [] {
+      const char* e = getenv("AVF_TN_STAGES");  // tuning aid
+      return e ? atoi(e) : 3;
+    }();
+    static PerDeviceOnce raised2, raised3;
+    if (stages == 2) {
+      if (raised2.need()) {
+        AVF_REQUIRE(hipFuncSetAttribute((const void*)gemm_bf16_tn_group_big_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        2 * 48 * 1024) == hipSuccess, "gemm_bf16_tn_group: cannot raise dynamic LDS limit");
+        raised2.mark();
+      }
+      launch_in_scope(&ts, gemm_bf16_tn_group_big_kernel<2>, dim3(tiles * g.S), dim3(512), 2 * 48 * 1024, s, g);
+    } else {
+      if (raised3.need()) {
+        AVF_REQUIRE(hipFuncSetAttribute((const void*)gemm_bf16_tn_group_big_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        3 * 48 * 1024) == hipSuccess, "gemm_bf16_tn_group: cannot raise dynamic LDS limit");
+        raised3.mark();
+      }
+      launch_in_scope(&ts, gemm_bf16_tn_group_big_kernel<3>, dim3(tiles * g.S), dim3(512), 3 * 48 * 1024, s, g);
+    }
+  } else if (tn_waves == 4) launch_in_scope(&ts, gemm_bf16_tn_group_kernel<2>, dim3(tiles * g.S), dim3(256), 0, s, g);
   else launch_in_scope(&ts, gemm_bf16_tn_group_kernel<4>, dim3(tiles * g.S), dim3(512), 0, s, g);
   AVF_TRY(check_launch("gemm_bf16_tn_group_kernel"));
   FoldList fl;
@@ -722,7 +906,16 @@ int gemm_bf16_tn_group(const TnGroupArgs& a, hipStream_t s, const FoldList* extr
   const int nslab = g.S > 1 ? a.count : 0;
   if (nslab + fl.count > 0) {
     dim3 grid(256, nslab + fl.count);
-    launch_in_scope(&ts, fold_group_kernel, grid, dim3(256), 0, s, g, nslab, fl);
+    switch (nslab ? g.S : 0) {
+      case 2: launch_in_scope(&ts, fold_group_kernel<2>, grid, dim3(256), 0, s, g, nslab, fl); break;
+      case 3: launch_in_scope(&ts, fold_group_kernel<3>, grid, dim3(256), 0, s, g, nslab, fl); break;
+      case 4: launch_in_scope(&ts, fold_group_kernel<4>, grid, dim3(256), 0, s, g, nslab, fl); break;
+      case 5: launch_in_scope(&ts, fold_group_kernel<5>, grid, dim3(256), 0, s, g, nslab, fl); break;
+      case 6: launch_in_scope(&ts, fold_group_kernel<6>, grid, dim3(256), 0, s, g, nslab, fl); break;
+      case 7: launch_in_scope(&ts, fold_group_kernel<7>, grid, dim3(256), 0, s, g, nslab, fl); break;
+      case 8: launch_in_scope(&ts, fold_group_kernel<8>, grid, dim3(256), 0, s, g, nslab, fl); break;
+      default: launch_in_scope(&ts, fold_group_kernel<0>, grid, dim3(256), 0, s, g, nslab, fl); break;
+    }
     AVF_TRY(check_launch("fold_group_kernel"));
   }
   return 0;

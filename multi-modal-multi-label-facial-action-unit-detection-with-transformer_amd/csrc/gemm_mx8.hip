@@ -160,12 +160,12 @@ int launch_mx8(const Mx8Params& q, hipStream_t s, int* part_rows, TimingScope* t
   constexpr int BMT = 16 * MI * WM, BNT = 16 * NI * WN;
   constexpr int SMEM = 2 * ((BMT + BNT) * 128 + ((BMT + BNT + 63) / 64) * 256);
   static_assert(SMEM <= 160 * 1024, "LDS budget");
-  static bool raised = false;
-  if (!raised && SMEM > 64 * 1024) {
+  static PerDeviceOnce raised;
+  if (SMEM > 64 * 1024 && raised.need()) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_mx8_nt_kernel<EPI, CT, WM, WN, MI, NI>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     AVF_REQUIRE(e == hipSuccess, "gemm_mx8_nt: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
-    raised = true;
+    raised.mark();
   }
   const int tiles_m = (q.nt.M + BMT - 1) / BMT, tiles_n = (q.nt.N + BNT - 1) / BNT;
   const int nwg = tiles_m * tiles_n;

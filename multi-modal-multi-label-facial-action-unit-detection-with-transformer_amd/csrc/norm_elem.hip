@@ -425,8 +425,8 @@ int layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gam
     const size_t lds = (size_t)4 * 3 * dim * sizeof(float);
     const int nv = (dim + 255) / 256;
     if (lds > 64 * 1024) {  // only the NV=6 instantiations (D up to 1536) can exceed the default dynamic-LDS limit
-      static bool raised = false;
-      if (!raised) {
+      static PerDeviceOnce raised;
+      if (raised.need()) {
         hipError_t e1 = hipFuncSetAttribute((const void*)ln_bwd_reg_kernel<float, 6>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 3 * 1536 * 4);
         hipError_t e2 = hipFuncSetAttribute((const void*)ln_bwd_reg_kernel<bf16, 6>,
@@ -434,7 +434,7 @@ int layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gam
         hipError_t e3 = hipFuncSetAttribute((const void*)ln_bwd_reg_kernel<bf16, 6, bf16>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 3 * 1536 * 4);
         AVF_REQUIRE(e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess, "layernorm_bwd: cannot raise dynamic LDS limit");
-        raised = true;
+        raised.mark();
       }
     }
 #define LAUNCH_NV(T, NVV)                                                                                                   \
@@ -649,7 +649,7 @@ int prep_weight_bf16(const float* w, void* w_lo, void* w_t_lo, int rows, int col
 __global__ __launch_bounds__(256) void au_loss_kernel(const float* __restrict__ z, int64_t ldz,
                                                       const float* __restrict__ y, int64_t ldy,
                                                       const float* __restrict__ pw, float ignore, int rows, int ncls,
-                                                      float* __restrict__ loss, float* __restrict__ grad) {
+                                                      float* __restrict__ loss, float* __restrict__ grad, int sum_mode) {
   __shared__ float red[4];
   __shared__ int redc[4];
   float acc = 0.f;
@@ -673,8 +673,13 @@ __global__ __launch_bounds__(256) void au_loss_kernel(const float* __restrict__ 
   __syncthreads();
   const float total = (red[0] + red[1]) + (red[2] + red[3]);
   const int nk = redc[0] + redc[1] + redc[2] + redc[3];
-  const float denom = (float)nk * (float)ncls;
-  if (threadIdx.x == 0) loss[0] = total / denom;  // 0/0 -> NaN when every row is ignored (as the reference)
+  // sum_mode (data-parallel shards): loss[0] = sum over kept rows of the row mean, loss[1] = kept rows; the caller
+  // divides by the GLOBAL kept count after reducing both over the ranks (loss.py:85-102 is a ratio)
+  const float denom = (sum_mode ? 1.0f : (float)nk) * (float)ncls;
+  if (threadIdx.x == 0) {
+    loss[0] = total / denom;  // 0/0 -> NaN when every row is ignored (as the reference)
+    if (sum_mode) loss[1] = (float)nk;
+  }
   const float inv = 1.0f / denom;
   for (int i = threadIdx.x; i < rows * ncls; i += 256) {
     const int r = i / ncls, c = i - r * ncls;
@@ -834,6 +839,16 @@ extern "C" int avf_au_loss(const float* logits, int64_t ld_logits, const float* 
   using namespace avf;
   AVF_REQUIRE(rows > 0 && ncls > 0 && logits && labels && pos_weight && loss && grad_unit, "au_loss: bad arguments");
   au_loss_kernel<<<1, 256, 0, (hipStream_t)stream>>>(logits, ld_logits, labels, ld_labels, pos_weight, ignore, rows,
-                                                     ncls, loss, grad_unit);
+                                                     ncls, loss, grad_unit, 0);
+  return check_launch("au_loss_kernel");
+}
+
+extern "C" int avf_au_loss_sum(const float* logits, int64_t ld_logits, const float* labels, int64_t ld_labels,
+                               const float* pos_weight, float ignore, int rows, int ncls, float* sum_count,
+                               float* grad_unit, void* stream) {
+  using namespace avf;
+  AVF_REQUIRE(rows > 0 && ncls > 0 && logits && labels && pos_weight && sum_count && grad_unit, "au_loss_sum: bad arguments");
+  au_loss_kernel<<<1, 256, 0, (hipStream_t)stream>>>(logits, ld_logits, labels, ld_labels, pos_weight, ignore, rows,
+                                                     ncls, sum_count, grad_unit, 1);
   return check_launch("au_loss_kernel");
 }

@@ -22,6 +22,22 @@ import torch
 import torch.distributed as dist
 
 
+class _GlobalMeanFn(torch.autograd.Function):
+    """loss = (sum_r s_r) / (sum_r k_r) from each rank's (s_r, k_r).  The wrapper AVERAGES parameter gradients over the
+    ranks, so each rank back-propagates world / K times its own numerator: the average is then d loss / d theta."""
+
+    @staticmethod
+    def forward(ctx, s, k, world, group):
+        pack = torch.stack([s.detach().to(torch.float32), k.detach().to(torch.float32)])
+        dist.all_reduce(pack, op=dist.ReduceOp.SUM, group=group)
+        ctx.scale = float(world) / pack[1]  # a tensor: no host synchronisation (K = 0 on every rank -> NaN, as the reference)
+        return pack[0] / pack[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.scale, None, None, None
+
+
 class DataParallel:
     def __init__(self, model: torch.nn.Module, process_group=None, broadcast_parameters: bool = True,
                  bucket_layers: int = 2):
@@ -40,6 +56,10 @@ class DataParallel:
         self._cuda = any(p.is_cuda for p in model.parameters())
         self._pending: List = []
         self._held: List = []  # (layer, flat) handed over but not launched yet
+        # losses that are ratios over the kept rows (AULoss, loss.py:85-102) reduce numerator and denominator over the ranks
+        for m in model.modules():
+            if hasattr(m, "global_mean"):
+                m.global_mean = self.global_mean
         if broadcast_parameters:
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, src=0, group=process_group)
@@ -93,6 +113,14 @@ class DataParallel:
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending.append((work, flat))
         return work
+
+    def global_mean(self, local_sum: torch.Tensor, local_count: torch.Tensor) -> torch.Tensor:
+        """mean over the GLOBAL batch of a per-row quantity from each rank's (sum over its kept rows, number of kept rows):
+        equals the single-process loss on the concatenated batch for any split of the ignored rows over the ranks"""
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("DataParallel: the loss reduction (a blocking collective) cannot be captured into a hipGraph; "
+                               "capture forward/backward of the stack only, or run the data-parallel step eagerly")
+        return _GlobalMeanFn.apply(local_sum, local_count, self.world, self.group)
 
     # -- called once per step, after loss.backward() and before optimizer.step() -------------------
     def finish(self):

@@ -18,13 +18,18 @@ class GraphedTrainStep:
 
     ``loss_fn(model, batch) -> scalar loss`` must only use the tensors in ``batch`` (a dict); they are copied into
     static buffers before each replay.  The optimizer must be capturable (e.g. ``torch.optim.Adam(..., fused=True,
-    capturable=True)``).  Not for use together with the data-parallel wrapper in this version.
+    capturable=True)``).  Refuses (RuntimeError) a model that dp.DataParallel has wrapped.
     """
 
     def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer,
                  loss_fn: Callable[[torch.nn.Module, Dict[str, torch.Tensor]], torch.Tensor],
                  example_batch: Dict[str, torch.Tensor], warmup: int = 3):
         self.model, self.optimizer, self.loss_fn = model, optimizer, loss_fn
+        # the data-parallel wrapper launches process-group collectives from the backward hook and reduces the loss with a
+        # blocking one: neither is recorded by this capture, a replay would silently step on UNREDUCED gradients
+        if any(getattr(m, "_grad_hook", None) is not None or callable(getattr(m, "global_mean", None)) for m in model.modules()):
+            raise RuntimeError("GraphedTrainStep: the model is wrapped by dp.DataParallel (gradient hooks / loss reduction "
+                               "are installed); hipGraph replay of a data-parallel step is not supported - run it eagerly")
         self.static = {k: v.clone() for k, v in example_batch.items()}
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())

@@ -28,6 +28,27 @@ class _AULossFn(torch.autograd.Function):
         return grad * g, None, None, None
 
 
+class _AULossSumFn(torch.autograd.Function):
+    """(sum over kept rows of the row-mean BCE, kept rows): numerator and denominator of loss.py:85-102, kept apart so
+    that a data-parallel wrapper can reduce both over the ranks before dividing"""
+
+    @staticmethod
+    def forward(ctx, y_pred, y_true, pos_weight, ignore):
+        if y_pred.stride(-1) != 1:
+            y_pred = y_pred.contiguous()
+        if y_true.stride(-1) != 1 or y_true.dtype != torch.float32:
+            y_true = y_true.to(torch.float32).contiguous()
+        sc, grad = ops.au_loss_sum(y_pred.to(torch.float32), y_true, pos_weight, ignore)
+        ctx.save_for_backward(grad)
+        ctx.mark_non_differentiable(sc[1])
+        return sc[0], sc[1]
+
+    @staticmethod
+    def backward(ctx, g, _gk):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None
+
+
 class AULoss(nn.Module):
     """Rows whose FIRST label equals ``ignore`` are dropped (loss.py:85-88); the loss is the mean of
     ``BCEWithLogits(reduction='none', pos_weight=[1,1,1,1,1,1,1,3,3,3,1,2])`` over kept rows x 12.
@@ -39,9 +60,15 @@ class AULoss(nn.Module):
         super().__init__()
         self.ignore = ignore
         self.register_buffer("pos_weight", torch.tensor(AU_POS_WEIGHT, dtype=torch.float32), persistent=False)
+        # set by dp.DataParallel: callable (local_sum, local_kept) -> global mean whose backward, AVERAGED over the ranks,
+        # is the gradient of that global mean (ranks may hold different numbers of ignored rows)
+        self.global_mean = None
 
     def forward(self, y_pred, y_true):
         if not y_pred.is_cuda:
             raise RuntimeError("AULoss (HIP) needs its inputs on the MI355X; there is no CPU fallback")
         pw = self.pos_weight if self.pos_weight.device == y_pred.device else self.pos_weight.to(y_pred.device)
+        if self.global_mean is not None:
+            s, k = _AULossSumFn.apply(y_pred, y_true, pw, float(self.ignore))
+            return self.global_mean(s, k)
         return _AULossFn.apply(y_pred, y_true, pw, float(self.ignore))

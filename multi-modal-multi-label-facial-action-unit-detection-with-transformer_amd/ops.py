@@ -245,6 +245,21 @@ def au_loss(logits: torch.Tensor, labels: torch.Tensor, pos_weight: torch.Tensor
     return loss, grad
 
 
+def au_loss_sum(logits: torch.Tensor, labels: torch.Tensor, pos_weight: torch.Tensor, ignore: float = -1.0):
+    """-> ([sum over kept rows of the row-mean BCE, kept rows] as a 2-vector, d sum / d logits [rows, ncls]): the
+    numerator / denominator of loss.py:85-102, for ranks that hold different numbers of ignored rows."""
+    _need_cuda(logits, labels, pos_weight)
+    assert logits.dim() == 2 and labels.dim() == 2 and logits.shape == labels.shape
+    assert logits.stride(1) == 1 and labels.stride(1) == 1 and logits.dtype == torch.float32
+    labels = labels.to(torch.float32)
+    rows, ncls = logits.shape
+    sc = torch.empty(2, dtype=torch.float32, device=logits.device)
+    grad = torch.empty((rows, ncls), dtype=torch.float32, device=logits.device)
+    _lib.check(_lib.load().avf_au_loss_sum(_ptr(logits), logits.stride(0), _ptr(labels), labels.stride(0), _ptr(pos_weight),
+                                           float(ignore), rows, ncls, _ptr(sc), _ptr(grad), _stream()), "au_loss_sum")
+    return sc, grad
+
+
 def fuse_tokens(clip: torch.Tensor, audio: torch.Tensor, pos: Optional[torch.Tensor]) -> torch.Tensor:
     """[B,Tv,D] ++ [B,Ta,D] on the token axis, + pos[Tv+Ta, D] (nullable): one pass (avf_fuse_tokens)."""
     _need_cuda(clip, audio)

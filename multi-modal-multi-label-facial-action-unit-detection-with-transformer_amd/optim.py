@@ -56,12 +56,15 @@ class FusedAdam(torch.optim.Optimizer):
                 k = p.numel()
                 mv.append(m[off:off + k].view_as(p))
                 vv.append(v[off:off + k].view_as(p))
+                off += k
+                if id(p) not in self._owned:
+                    continue  # frozen tensor of a partly trainable layer: its slice is private scratch (the kernel skips
+                              # tensors without a gradient); it is in no param_group, so it must not appear in self.state
                 st = self.state[p]
                 if "exp_avg" in st:  # state loaded before the first step: adopt it
                     mv[-1].copy_(st["exp_avg"])
                     vv[-1].copy_(st["exp_avg_sq"])
                 st["exp_avg"], st["exp_avg_sq"] = mv[-1], vv[-1]
-                off += k
             self._flat[key] = (m, v, mv, vv)
         return self._flat[key]
 
@@ -95,6 +98,8 @@ class FusedAdam(torch.optim.Optimizer):
                 stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
                 for si, st in enumerate(self._stacks):
                     params = st.flat_parameters()
+                    if not any(id(p) in self._owned for p in params):
+                        continue  # fully frozen stack (pretrained branch): no state, no launch; its forward caches the images
                     cfg = st._cfg(1, 1)
                     bf16 = cfg.dtype == _lib.BF16
                     if bf16 and st._lowp_bufs is None:
@@ -115,7 +120,8 @@ class FusedAdam(torch.optim.Optimizer):
                             M_[l] = _lib.LayerPtrs(*[t.data_ptr() for t in mv])
                             V_[l] = _lib.LayerPtrs(*[t.data_ptr() for t in vv])
                             for p in lp:
-                                self.state[p]["step"] = self._step_dev  # shared device counter (as capturable Adam)
+                                if id(p) in self._owned:
+                                    self.state[p]["step"] = self._step_dev  # shared device counter (as capturable Adam)
                         lows = (C.c_void_p * L)(*[(b.data_ptr() if bf16 else None) for b in (st._lowp_bufs or [None] * L)]) \
                             if bf16 else None
                         hit = (pptr, P_, M_, V_, lows)
@@ -135,6 +141,7 @@ class FusedAdam(torch.optim.Optimizer):
                                                        float(b2), eps, wd, _ptr(self._step_dev), stream), "stack_adam_step")
                     if bf16:
                         st._lowp_ptrs = [p.data_ptr() for p in params]
+                        st._lowp_versions = [p._version for p in params]  # an in-place edit after this step voids the skip
                         st._lowp_ready = True  # the next forward may skip its weight-preparation pass
         if len(self.param_groups) > 1:
             grp = self.param_groups[1]

@@ -235,6 +235,7 @@ class _StackFn(torch.autograd.Function):
 
 class Transformer(nn.Module):
     """MI355X-native ``Transformer`` (reference models/heads.py:242-256)."""
+    _instances = 0
 
     def __init__(self, dim, depth, heads, dim_head, mlp_dim, dropout=0., compute_dtype="bf16"):
         super().__init__()
@@ -258,6 +259,9 @@ class Transformer(nn.Module):
         self._grad_hook: Optional[Callable] = None
         self._seed_dev = None
         self._last_seed_t = None
+        # per-module salt of the dropout seed: construction order (deterministic from run to run, unlike id(self))
+        Transformer._instances += 1
+        self._seed_salt = Transformer._instances
 
     # ---- parameter plumbing --------------------------------------------------------------------
     def layer_parameters(self, l: int) -> List[torch.Tensor]:
@@ -309,14 +313,14 @@ class Transformer(nn.Module):
                 and os.environ.get("AVF_GRAD_STREAM", "bf16") != "f32")
 
     def _advance_seed(self, dev) -> Optional[torch.Tensor]:
-        """Dropout seed of this forward, as a DEVICE tensor: the module's counter (initialised from torch.initial_seed(),
-        so runs are reproducible under torch.manual_seed) is advanced by an in-place add and snapshotted; the kernels read
+        """Dropout seed of this forward, as a DEVICE tensor: the module's counter (initialised from torch.initial_seed()
+        and the module's construction index, so runs are reproducible under torch.manual_seed) is advanced by an in-place add and snapshotted; the kernels read
         the snapshot at run time.  Both ops are capturable, so a hipGraph of a training step draws fresh masks on every
         replay.  (The masks come from a counter-based hash in the kernels, not from torch's generator.)"""
         if not (self.training and self.dropout > 0.0):
             return None
         if self._seed_dev is None or self._seed_dev.device != dev:
-            host = (torch.initial_seed() * 0x9E3779B97F4A7C15 + (id(self) % 65521) * 0xD1B54A32D192ED03) & 0x7FFFFFFFFFFFFFFF
+            host = (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._seed_salt * 0xD1B54A32D192ED03) & 0x7FFFFFFFFFFFFFFF
             self._seed_dev = torch.tensor([host], dtype=torch.int64, device=dev)
         self._seed_dev.add_(1)
         self._last_seed_t = self._seed_dev.clone()
@@ -357,15 +361,24 @@ class Transformer(nn.Module):
             self._lowp_bufs = [_alloc_bytes(need, dev) for _ in range(self.depth)]
             fresh = True
         ptrs = [p.data_ptr() for p in params]
-        ready = self._lowp_ready and not fresh and self._lowp_ptrs == ptrs
+        vers = [p._version for p in params]  # detached views share the masters' version counters
+        same = not fresh and self._lowp_ptrs == ptrs and self.__dict__.get("_lowp_versions") == vers
+        # (1) the optimizer (optim.FusedAdam) rewrote the images in its own pass - valid for ONE forward, and only while
+        #     nothing has modified a master in place since (EMA swap, clipping, a second optimizer: version counters);
+        # (2) cache_weights (inference), or a stack without a single trainable tensor (the reference's frozen pretrained
+        #     branches, avformer.py:76-85): reuse the images while pointers and version counters are unchanged.
+        #     Writes through ``p.data`` bypass the counters: call refresh_weights() after those.
+        ready = self._lowp_ready and same
         self._lowp_ready = False  # one forward per optimizer step; anything else re-prepares (weights may have changed)
+        frozen = not any(q.requires_grad for q in self.flat_parameters())
         changed = ready  # the optimizer rewrote the bf16 images
-        if not ready and (fresh or not self.cache_weights or self._lowp_ptrs != ptrs):
+        if not ready and not ((self.cache_weights or frozen) and same):
             for l in range(self.depth):
                 pp = self._param_struct(params, l)
                 _lib.check(lib.avf_layer_prepare_weights(C.byref(cfg), C.byref(pp), _ptr(self._lowp_bufs[l]), stream),
                            f"prepare_weights[{l}]")
             self._lowp_ptrs = ptrs
+            self._lowp_versions = vers
             changed = True
         if self.mx8 and changed:  # the e4m3 images follow the bf16 ones: one launch for the stack
             if fresh or self.__dict__.get("_mx_ptr_array") is None:
@@ -376,6 +389,7 @@ class Transformer(nn.Module):
 
     def refresh_weights(self):
         self._lowp_ptrs = None
+        self._lowp_versions = None
         self._lowp_ready = False
 
     # ---- forward -------------------------------------------------------------------------------

@@ -14,7 +14,10 @@ as fp32 ``.npz`` files.  The fixtures are data only; no reference source text is
 Fixture list: G1 attention, G2 feed-forward, G3 transformer at config C1,
 G4 transformer with inner != dim at N in {12, 17, 49}, G5 AU_former (eval), G6 tformer_AU_head
 (emb 64), G7 TFormer, G8 AULoss with/without ignored rows, G9 tiny pipeline TFormer -> AU_former
--> AULoss with gradients, G10 tanh-GELU on a grid, G11 the token section of ResFormer.forward.
+-> AULoss with gradients, G10 tanh-GELU on a grid, G11 the token section of ResFormer.forward, G12 the evaluation
+score of metrics/accf1.py (MultiLabelAccF1, the reference's own sklearn-backed implementation) on seeded batches.
+
+    python tests/golden/make_golden.py --only g12        (re)generates just that fixture
 """
 import importlib.util
 import os
@@ -212,5 +215,40 @@ def main():
     save("g10_gelu", u=u.detach(), y=yv.detach(), dy_du=u.grad)
 
 
+def metric_fixture():
+    """G12: the reference's MultiLabelAccF1 (metrics/accf1.py:47-77; numpy + sklearn only) fed as train.py:155-163 feeds
+    it - round(sigmoid(logits)) per batch, labels in {0, 1, -1} - over several seeded cases incl. an AU without a single
+    positive label and an all-negative / nothing-predicted case (sklearn's zero_division path)."""
+    import warnings
+    accf1 = _load_standalone("ref_accf1", os.path.join(REF, "metrics", "accf1.py"))
+    rng = np.random.default_rng(12)
+    out = {}
+    cases = {"mixed": (7, 37), "single_batch": (1, 64), "no_positive_au": (3, 20), "all_negative": (2, 8)}
+    for name, (nb, bs) in cases.items():
+        m = accf1.MultiLabelAccF1(ignore_index=-1)
+        logits = rng.normal(size=(nb, bs, 21)).astype(np.float32)
+        y = (rng.random((nb, bs, 12)) > 0.6).astype(np.float32)
+        y[rng.random((nb, bs, 12)) < 0.1] = -1
+        if name == "no_positive_au":
+            y[:, :, 5] = 0
+        if name == "all_negative":
+            y[:] = 0
+            logits[:] = -3.0
+        for b in range(nb):
+            pred = np.round(torch.sigmoid(torch.from_numpy(logits[b, :, :12])).numpy())  # train.py:155
+            m.update(pred, y[b])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            acc, f1 = m.get()
+        out[f"{name}.logits"], out[f"{name}.labels"] = logits, y
+        out[f"{name}.acc"], out[f"{name}.f1"] = np.float64(acc), np.float64(f1)
+    np.savez(os.path.join(OUT, "g12_metric.npz"), **out)
+    print("g12_metric", {k: float(v) for k, v in out.items() if k.endswith((".acc", ".f1"))})
+
+
 if __name__ == "__main__":
-    main()
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "g12":
+        metric_fixture()
+    else:
+        main()
+        metric_fixture()

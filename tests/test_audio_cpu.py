@@ -41,3 +41,16 @@ def test_batch_elements_are_clamped_independently():
     y = fe(torch.stack([a, b])[:, None])        # [2, 1, samples]
     assert np.abs(y[0, 0].numpy() - mel_features(a.numpy())).max() < 2e-3
     assert np.abs(y[1, 0].numpy() - mel_features(b.numpy())).max() < 2e-3
+
+
+def test_two_dimensional_batch_is_clamped_per_clip_too():
+    """audio[B, samples] (no channel axis) took the top_db peak over the whole batch - a quiet clip batched
+    with a loud one was clamped against the loud clip's peak, unlike the reference's per-clip AmplitudeToDB"""
+    fe = A.audio.MelFrontEnd()
+    a, b = _wave(2.0, 4), 1e-4 * _wave(2.0, 5)
+    y = fe(torch.stack([a, b]))                 # [2, samples] -> [2, 64, 1001]
+    assert y.shape == (2, 64, 1001)
+    assert np.abs(y[0].numpy() - mel_features(a.numpy())).max() < 2e-3
+    assert np.abs(y[1].numpy() - mel_features(b.numpy())).max() < 2e-3
+    assert torch.equal(y[1], fe(b[None])[0])    # the same clip alone
+    assert torch.equal(fe(a), y[0])             # and a bare [samples] clip

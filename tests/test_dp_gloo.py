@@ -112,6 +112,79 @@ def test_dp_two_ranks_match_single_process(bucket_layers):
         assert ncoll == (3 if bucket_layers == 1 else 2), ncoll
 
 
+class OracleAULoss(torch.nn.Module):
+    """CPU stand-in for loss.AULoss with the same data-parallel protocol: when the wrapper has set ``global_mean`` it hands
+    over (sum over kept rows of the row mean, kept rows) instead of dividing locally"""
+
+    def __init__(self):
+        super().__init__()
+        self.global_mean = None
+
+    def forward(self, z, y):
+        keep = y[:, 0] != -1
+        k = keep.sum()
+        s = oracle.au_loss(z[keep], y[keep]) * k if int(k) > 0 else z.sum() * 0.0
+        if self.global_mean is not None:
+            return self.global_mean(s, k.float())
+        return s / k
+
+
+class TinyModelWithLoss(TinyModel):
+    def __init__(self):
+        super().__init__()
+        self.loss_AU = OracleAULoss()
+
+
+def _worker_unequal(rank, world, port, out, ignored):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100)
+        model = TinyModelWithLoss()
+        dp = A.dp.DataParallel(model)
+        assert model.loss_AU.global_mean is not None  # the wrapper found the ratio loss
+        g = torch.Generator().manual_seed(9)
+        x = torch.randn(8, 6, D, generator=g)
+        y = (torch.rand(8, 12, generator=g) > 0.5).float()
+        y[ignored] = -1  # all of them in rank 0's half: the ranks keep different numbers of rows
+        ref = TinyModelWithLoss()
+        ref.load_state_dict(model.state_dict())
+        loss_ref = oracle.au_loss(ref(x), y)  # loss.py:85-102 on the global batch
+        loss_ref.backward()
+        sl = slice(rank * 4, rank * 4 + 4)
+        model.zero_grad(set_to_none=True)
+        loss = model.loss_AU(model(x[sl]), y[sl])
+        loss.backward()
+        model.stack.emulate_backward_hooks()
+        dp.finish()
+        worst = 0.0
+        for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+            worst = max(worst, (p.grad - q.grad).abs().max().item() / (q.grad.abs().max().item() + 1e-12))
+        # what plain mean-of-means would have given (the round-1 behaviour) - must differ, or the case proves nothing
+        out.put((rank, worst, abs(loss.item() - loss_ref.item()) / abs(loss_ref.item())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ignored", [[0, 2, 3], [0, 1, 2, 3]], ids=["3_of_4_ignored_on_rank0", "rank0_all_ignored"])
+def test_dp_global_mean_loss_with_unequal_ignored_rows(ignored):
+    """AULoss is a ratio (loss.py:85-102): with different numbers of ignored rows per rank the mean of the per-rank means is
+    not the global mean.  The wrapper reduces (sum, count): loss and averaged gradients equal the single-process ones."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_unequal, args=(r, 2, port, out, ignored)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, worst, loss_err in res:
+        assert worst < 1e-5, (rank, worst)
+        assert loss_err < 1e-6, (rank, loss_err)
+
+
 def test_dp_requires_process_group():
     with pytest.raises(RuntimeError, match="torch.distributed"):
         A.dp.DataParallel(torch.nn.Linear(2, 2))

@@ -34,9 +34,88 @@ def test_dp_single_rank_nccl_matches_plain_step():
                 m.get_au_loss(m(batch), labels).backward()
             dp.finish()
             torch.cuda.synchronize()
+            # the wrapped model takes the (sum, count) form of AULoss (one more fp32 rounding in d loss / d logits, which a
+            # bf16 cast further down may amplify to one bf16 ulp on single elements): equal to rounding, not bitwise
             for (n, p), (_, q) in zip(m_dp.named_parameters(), m_ref.named_parameters()):
-                assert p.grad is not None and torch.equal(p.grad, q.grad), n
+                assert p.grad is not None, n
+                err = ((p.grad - q.grad).norm() / (q.grad.norm() + 1e-30)).item()
+                assert err < 1e-3, (n, err)
         assert len(dp._pending) == 0
+        # a wrapped model must not be captured into a hipGraph (the collectives would not be replayed)
+        with pytest.raises(RuntimeError, match="DataParallel"):
+            A.graphs.GraphedTrainStep(m_dp, torch.optim.Adam(m_dp.parameters()), lambda m, b: m.get_au_loss(m(b), labels), batch)
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_au_loss_sum_count_form_matches_mean_form():
+    """avf_au_loss_sum (numerator, denominator of loss.py:85-102) against the fused mean kernel and the oracle, incl. a
+    shard whose rows are all ignored (sum 0, count 0, zero gradient - no NaN leaks into the other ranks' reduction)"""
+    import avformer_amd as A
+    import oracle
+    g = torch.Generator().manual_seed(12)
+    z = torch.randn(9, 12, generator=g)
+    y = (torch.rand(9, 12, generator=g) > 0.5).float()
+    y[[1, 4]] = -1
+    pw = torch.tensor(A.loss.AU_POS_WEIGHT)
+    sc, grad = A.ops.au_loss_sum(z.cuda(), y.cuda(), pw.cuda())
+    loss, grad_mean = A.ops.au_loss(z.cuda(), y.cuda(), pw.cuda())
+    assert sc[1].item() == 7.0
+    torch.testing.assert_close((sc[0] / sc[1]).cpu(), oracle.au_loss(z, y), rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(grad / sc[1], grad_mean, rtol=1e-6, atol=1e-9)
+    sc0, grad0 = A.ops.au_loss_sum(z.cuda(), -torch.ones(9, 12).cuda(), pw.cuda())
+    assert sc0.tolist() == [0.0, 0.0] and float(grad0.abs().sum()) == 0.0
+
+
+def _rccl_worker(rank, world, port, q):
+    import avformer_amd as A
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        torch.manual_seed(3 + rank)  # different init per rank: the wrapper broadcasts rank 0's
+        kw = dict(dim=128, depth=3, heads=8, dim_head=32, mlp_dim=256, t_video=20, t_audio=13, compute_dtype="f32")
+        m_dp = A.SyntheticAVFormer(**kw).cuda()
+        dp = A.dp.DataParallel(m_dp)
+        m_ref = A.SyntheticAVFormer(**kw).cuda()
+        m_ref.load_state_dict(m_dp.state_dict())
+        g = torch.Generator().manual_seed(4)
+        clip, aud = torch.randn(8, 20, 128, generator=g).cuda(), torch.randn(8, 13, 128, generator=g).cuda()
+        labels = (torch.rand(8, 12, generator=g) > 0.5).float()
+        labels[[0, 1, 2]] = -1  # all in rank 0's shard: unequal kept counts
+        labels = labels.cuda()
+        m_ref.get_au_loss(m_ref({"clip": clip, "audio_features": aud}), labels).backward()
+        sl = slice(rank * 4, rank * 4 + 4)
+        loss = m_dp.get_au_loss(m_dp({"clip": clip[sl], "audio_features": aud[sl]}), labels[sl])
+        loss.backward()
+        dp.finish()
+        torch.cuda.synchronize()
+        worst = max(((p.grad - r.grad).norm() / (r.grad.norm() + 1e-30)).item()
+                    for p, r in zip(m_dp.parameters(), m_ref.parameters()))
+        q.put((rank, worst))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the driver's 8-GPU node; a gpurun box has one)")
+def test_dp_two_ranks_rccl_match_single_process():
+    """two processes, one GPU each, RCCL: averaged gradients (with unequal ignored rows per rank) == the single-process
+    gradients on the concatenated batch, parity mode"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, worst in res:
+        assert worst < 1e-4, (rank, worst)

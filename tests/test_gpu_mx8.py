@@ -13,7 +13,7 @@ import pytest
 import torch
 
 import oracle
-from gpu_util import rel_fro
+from gpu_util import check_rel, rel_fro
 
 pytestmark = pytest.mark.gpu
 
@@ -86,11 +86,11 @@ def test_gemm_epilogues(ops, M, N, K):
     bq, bs = ops.quant_mx8(b.cuda())
     ref = (oracle.mx8_dequant(aq, as_).double() @ oracle.mx8_dequant(bq, bs).double().t()).float() + bias
     c, u = ops.gemm_mx8(aq, as_, bq, bs, out_dtype=torch.bfloat16, epilogue=A.ops.EPI_BIAS_GELU, bias=bias.cuda())
-    assert rel_fro(u, ref) < 5e-3          # bf16 storage of the saved pre-activation
-    assert rel_fro(c, oracle.gelu_tanh(ref)) < 6e-3
+    check_rel(f"mx8_epi[{M}x{N}x{K}]:u", u, ref, 5e-3)          # bf16 storage of the saved pre-activation
+    check_rel(f"mx8_epi[{M}x{N}x{K}]:gelu", c, oracle.gelu_tanh(ref), 6e-3)
     y = ops.gemm_mx8(aq, as_, bq, bs, out_dtype=torch.float32, epilogue=A.ops.EPI_BIAS_RES, bias=bias.cuda(),
                      residual=res.cuda())
-    assert rel_fro(y, ref + res) < 1e-3
+    check_rel(f"mx8_epi[{M}x{N}x{K}]:res", y, ref + res, 1e-3)
 
 
 @pytest.mark.parametrize("M,N,K", [(1296, 1536, 512), (1296, 512, 1024)])
@@ -102,7 +102,7 @@ def test_gemm_against_fp32_product(ops, M, N, K):
     aq, as_ = ops.quant_mx8(a.cuda())
     bq, bs = ops.quant_mx8(b.cuda())
     c = ops.gemm_mx8(aq, as_, bq, bs)
-    assert rel_fro(c, a @ b.t()) < 0.05
+    check_rel(f"mx8_vs_fp32[{M}x{N}x{K}]", c, a @ b.t(), 0.05)
 
 
 def test_rejects_bad_shapes(ops):
@@ -174,13 +174,14 @@ def test_stack_forward_backward_against_bf16_mode(cfg, B, N):
         (y.float() ** 2).mean().backward()
         outs.append((y.detach(), xi.grad, {k: p.grad.clone() for k, p in t.named_parameters()}))
     (y0, dx0, g0), (y1, dx1, g1) = outs
-    assert rel_fro(y1, y0) < 0.03
-    assert rel_fro(dx1, dx0) < 0.06
+    tag = f"mx8_stack[{cfg['dim']}x{cfg['depth']},{B}x{N}]"
+    check_rel(tag + ":y", y1, y0, 0.03)
+    check_rel(tag + ":dx", dx1, dx0, 0.06)
     for k in g0:
-        assert rel_fro(g1[k], g0[k]) < 0.10, k
+        check_rel(f"{tag}:g.{k}", g1[k], g0[k], 0.10)
     sd = {k: v.detach().cpu() for k, v in ref.state_dict().items()}
     y_cpu = oracle.transformer_forward(x.cpu(), sd, cfg["depth"], cfg["heads"])
-    assert rel_fro(y1, y_cpu) < 0.04
+    check_rel(tag + ":y_vs_oracle", y1, y_cpu, 0.04)
 
 
 def test_rejects_unsupported_widths():

@@ -10,7 +10,7 @@ import torch
 
 import oracle
 from conftest import load_golden
-from gpu_util import max_abs, rel_fro
+from gpu_util import check_abs, check_rel, max_abs, rel_fro
 
 pytestmark = pytest.mark.gpu
 
@@ -41,7 +41,7 @@ def test_layernorm_fwd(ops, rows, D, out_dtype):
     if out_dtype == torch.float32:
         _close(y, ref)
     else:
-        assert rel_fro(y, ref) < 4e-3
+        check_rel(f"ln_fwd[{rows}x{D}]", y, ref, 4e-3)
     _close(mean, x.mean(-1))
     _close(rstd, 1 / torch.sqrt(x.var(-1, unbiased=False) + 1e-5), atol=1e-5, rtol=1e-4)
 
@@ -65,7 +65,7 @@ def test_layernorm_bwd(ops, rows, D, dy_dtype):
     _close(dg, w.grad, atol=2e-4, rtol=2e-4)
     _close(db, b.grad, atol=2e-4, rtol=2e-4)
     _close(cs, ref_dx.sum(0), atol=5e-4, rtol=2e-4)
-    assert rel_fro(dx_lo, ref_dx) < 4e-3
+    check_rel(f"ln_bwd[{rows}x{D},{str(dy_dtype)[6:]}]:dx_lo", dx_lo, ref_dx, 4e-3)
 
 
 def test_colsum_and_cast(ops):
@@ -156,7 +156,7 @@ def test_gemm_bf16_nt(ops, M, N, K):
     # fp32 accumulation of exact bf16 products: only summation-order noise
     _close(c32, ref.float(), atol=2e-5 * K, rtol=1e-5)
     c16 = ops.gemm(a.cuda(), b.cuda())
-    assert rel_fro(c16, ref) < 4e-3
+    check_rel(f"gemm_nt[{M}x{N}x{K}]", c16, ref, 4e-3)
 
 
 @pytest.mark.parametrize("M,N,K", [(8, 8, 8), (64, 128, 64), (136, 96, 200), (1536, 512, 2048), (48, 40, 1000),
@@ -228,13 +228,13 @@ def test_attention_bf16(ops, B, N, H, dh, qs):
         qkv, ref_in = _prescale_q(qkv, H, dh)
     o_ref, lse_ref, dqkv_ref = _attn_ref(ref_in, B, N, H, dh, d_o.float())
     o, lse2 = ops.attn_fwd(qkv.cuda(), B, N, H, dh, q_prescaled=qs)
-    assert rel_fro(o, o_ref) < 1e-2, rel_fro(o, o_ref)
+    tag = f"attn[{B}x{N}x{H}x{dh},qs{int(qs)}]"
+    check_rel(tag + ":o", o, o_ref, 1e-2)
     _close(lse2, lse_ref.float(), atol=2e-2, rtol=1e-3)
     dqkv = ops.attn_bwd(qkv.cuda(), o, d_o.cuda(), lse2, B, N, H, dh, q_prescaled=qs)
     I = H * dh
     for name, sl in (("dq", slice(0, I)), ("dk", slice(I, 2 * I)), ("dv", slice(2 * I, 3 * I))):
-        e = rel_fro(dqkv[:, sl], dqkv_ref[:, sl])
-        assert e < 2e-2, (name, e)
+        check_rel(f"{tag}:{name}", dqkv[:, sl], dqkv_ref[:, sl], 2e-2)
 
 
 @pytest.mark.parametrize("N", [1, 15, 16, 31, 33, 63, 64, 65, 96, 127, 128, 200, 256, 320, 383, 384, 385, 448, 500, 512,
@@ -253,7 +253,8 @@ def test_attention_bf16_dh64_lengths(ops, N, qs):
     o_ref, lse_ref, dqkv_ref = _attn_ref(ref_in, B, N, H, dh, d_o.float())
     o, lse2 = ops.attn_fwd(qkv.cuda(), B, N, H, dh, q_prescaled=qs)
     assert torch.isfinite(o.float()).all() and torch.isfinite(lse2).all()
-    assert rel_fro(o, o_ref) < 1e-2, rel_fro(o, o_ref)
+    tag = f"attn_len[{N},qs{int(qs)}]"
+    check_rel(tag + ":o", o, o_ref, 1e-2)
     _close(lse2, lse_ref.float(), atol=2e-2, rtol=1e-3)
     dqkv = ops.attn_bwd(qkv.cuda(), o, d_o.cuda(), lse2, B, N, H, dh, q_prescaled=qs)
     assert torch.isfinite(dqkv.float()).all()
@@ -262,8 +263,7 @@ def test_attention_bf16_dh64_lengths(ops, N, qs):
         if N == 1 and name != "dv":  # a single key: p = 1, dS = 0 exactly -> dq = dk = 0 (no relative error to take)
             assert max_abs(dqkv[:, sl], dqkv_ref[:, sl]) < 1e-2
             continue
-        e = rel_fro(dqkv[:, sl], dqkv_ref[:, sl])
-        assert e < 2e-2, (name, e)
+        check_rel(f"{tag}:{name}", dqkv[:, sl], dqkv_ref[:, sl], 2e-2)
 
 
 @pytest.mark.parametrize("qs", [False, True], ids=["raw_q", "prescaled_q"])
@@ -302,11 +302,11 @@ def test_attention_bf16_rescale_paths(ops, mode, qs):
     o_ref, lse_ref, dqkv_ref = _attn_ref(ref_in, B, N, H, dh, d_o.float())
     o, lse2 = ops.attn_fwd(qkv.cuda(), B, N, H, dh, q_prescaled=qs)
     assert torch.isfinite(o.float()).all() and torch.isfinite(lse2).all()
-    assert rel_fro(o, o_ref) < 1e-2, rel_fro(o, o_ref)
+    check_rel(f"attn_rescale[{mode},qs{int(qs)}]:o", o, o_ref, 1e-2)
     _close(lse2, lse_ref.float(), atol=5e-2, rtol=2e-3)
     dqkv = ops.attn_bwd(qkv.cuda(), o, d_o.cuda(), lse2, B, N, H, dh, q_prescaled=qs)
     assert torch.isfinite(dqkv.float()).all()
-    assert rel_fro(dqkv, dqkv_ref) < 3e-2, rel_fro(dqkv, dqkv_ref)
+    check_rel(f"attn_rescale[{mode},qs{int(qs)}]:dqkv", dqkv, dqkv_ref, 3e-2)
 
 
 def test_attention_bf16_spiked_scores(ops):
@@ -318,8 +318,8 @@ def test_attention_bf16_spiked_scores(ops):
     qkv = qkv.to(torch.bfloat16)
     o_ref, lse_ref, _ = _attn_ref(qkv.float(), B, N, H, dh)
     o, lse2 = ops.attn_fwd(qkv.cuda(), B, N, H, dh)
-    assert rel_fro(o, o_ref) < 1e-2
-    assert max_abs(o, o_ref) < 5e-2
+    check_rel("attn_spiked:o", o, o_ref, 1e-2)
+    check_abs("attn_spiked:o_maxabs", o, o_ref, 5e-2)
     _close(lse2, lse_ref.float(), atol=5e-2, rtol=1e-3)
 
 

@@ -132,3 +132,73 @@ def test_training_trajectory_bf16_library_adam_tracks_f32_torch_adam():
     assert a[-1] < 0.6 * a[0] and b[-1] < 0.6 * b[0], (a[0], a[-1], b[0], b[-1])  # both fit the batch
     for i in (0, 5, 10, 20, 39):
         assert abs(a[i] - b[i]) < 0.05 * a[i] + 5e-3, (i, a[i], b[i])
+
+
+def test_frozen_stack_and_partly_frozen_layer_state_dict_roundtrip():
+    """the reference's default setup: pretrained branches frozen (avformer.py:76-85).  A fully frozen stack gets no
+    optimizer state and no launch; frozen tensors of a partly trainable stack stay out of ``state`` - so
+    ``state_dict()`` / ``load_state_dict()`` work (KeyError in torch's param_mappings before)."""
+    import avformer_amd as A
+    torch.manual_seed(0)
+    m = A.build_model("avformer", task="AU", compute_dtype="bf16").to(DEV).train()
+    for p in m.audio_model.parameters():     # whole branch (one stack) frozen
+        p.requires_grad = False
+    vt = m.video_model.au_head.corr_transformer
+    for p in vt.layer_parameters(0):         # first layer of the video stack frozen, second trainable
+        p.requires_grad = False
+    frozen_before = {n: p.detach().clone() for n, p in m.named_parameters() if not p.requires_grad}
+    opt = A.optim.FusedAdam(m, lr=1e-2, weight_decay=1e-2)
+    g = torch.Generator().manual_seed(1)
+    batch = {"clip": torch.randn(8, 512, generator=g).to(DEV), "audio_features": torch.randn(8, 512, generator=g).to(DEV)}
+    labels = (torch.rand(8, 12, generator=g) > 0.5).float().to(DEV)
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        m.get_au_loss(m(batch), labels).backward()
+        opt.step()
+    torch.cuda.synchronize()
+    for n, p in m.named_parameters():
+        if not p.requires_grad:
+            assert torch.equal(p, frozen_before[n]), f"frozen tensor {n} was updated"
+            assert p not in opt.state, f"optimizer state created for the frozen tensor {n}"
+    sd = opt.state_dict()                     # raised KeyError before the fix
+    # (the per-token logit weights of the two branch heads get no gradient: avformer.py:100 uses their tokens only)
+    assert len(sd["state"]) == sum(1 for p in m.parameters() if p.requires_grad and p.grad is not None)
+    opt2 = A.optim.FusedAdam(m, lr=1e-2, weight_decay=1e-2)
+    opt2.load_state_dict(sd)
+    opt2.zero_grad(set_to_none=True)
+    m.get_au_loss(m(batch), labels).backward()
+    opt2.step()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p).all() for p in m.parameters())
+    # the frozen audio stack caches its bf16 images across forwards (nothing retrains it); an in-place edit is noticed
+    at = m.audio_model.au_head.corr_transformer
+    kept = at._lowp_versions
+    with torch.no_grad():
+        m(batch)
+    assert at._lowp_versions is kept
+    with torch.no_grad():
+        at.layer_parameters(0)[2].mul_(1.5)   # version counter moves -> images are re-derived
+        before = m(batch)
+        at.layer_parameters(0)[2].div_(1.5)
+        after = m(batch)
+    assert not torch.equal(before, after)
+
+
+def test_inplace_weight_edit_after_fused_step_is_not_ignored():
+    """after FusedAdam.step() the next forward skips the weight preparation; an in-place edit of a master in
+    between (EMA swap, clipping) must void that skip"""
+    A, ma, _, (Tv, Ta, D) = _models("bf16")
+    opt = A.optim.FusedAdam(ma, lr=1e-3)
+    g = torch.Generator().manual_seed(4)
+    batch = {"clip": torch.randn(3, Tv, D, generator=g).to(DEV), "audio_features": torch.randn(3, Ta, D, generator=g).to(DEV)}
+    labels = (torch.rand(3, 12, generator=g) > 0.5).float().to(DEV)
+    ma.get_au_loss(ma(batch), labels).backward()
+    opt.step()
+    w = ma.transformer.layer_parameters(0)[7]   # net.0.weight
+    with torch.no_grad():
+        w.mul_(0.0)
+        y_zeroed = ma(batch)
+    ma.transformer.refresh_weights()
+    with torch.no_grad():
+        y_fresh = ma(batch)
+    assert torch.equal(y_zeroed, y_fresh)

@@ -42,3 +42,23 @@ def test_matches_sklearn_recipe_over_batches():
     m.clear()
     m.update(torch.zeros(4, 12), torch.zeros(4, 12))
     assert m.get() == (1.0, 0.0)   # all negatives, none predicted: accuracy 1, F1 defined as 0 (sklearn zero_division)
+
+
+G12_CASES = ["mixed", "single_batch", "no_positive_au", "all_negative"]
+
+
+def _run_g12(case, device):
+    from conftest import load_golden
+    g = load_golden("g12_metric")
+    m = A.metrics.MultiLabelAccF1(ignore_index=-1)
+    logits, labels = g[f"{case}.logits"], g[f"{case}.labels"]
+    for b in range(logits.shape[0]):
+        m.update_from_logits(logits[b].to(device), labels[b].to(device))
+    return m.get(), (g[f"{case}.acc"], g[f"{case}.f1"])
+
+
+def test_matches_the_reference_metric_fixture():
+    """G12: values produced by the reference's own metrics/accf1.py::MultiLabelAccF1 (tests/golden/make_golden.py)"""
+    for case in G12_CASES:
+        (acc, f1), (acc_ref, f1_ref) = _run_g12(case, "cpu")
+        assert abs(acc - acc_ref) < 1e-12 and abs(f1 - f1_ref) < 1e-12, (case, acc, acc_ref, f1, f1_ref)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 outputs into the small summaries committed under profiles/.
 
-  python tools/pmc_traffic.py <kernel_stats.csv> <fetch_counter_collection.csv> <write_counter_collection.csv> <tag>
+  python tools/pmc_traffic.py <kernel_stats.csv> <fetch_counter_collection.csv> <write_counter_collection.csv> <tag> [workload]
 
 Writes profiles/<tag>_kernel_stats.csv (verbatim copy of rocprofv3 --kernel-trace --stats), profiles/<tag>_pmc_summary.csv
 (per kernel: launches, mean FETCH_SIZE / WRITE_SIZE in KiB as reported, corrected HBM bytes per launch) and
@@ -46,6 +46,7 @@ def mean_counter(path, name):
 
 def main():
     stats, fetch, write, tag = sys.argv[1:5]
+    workload = sys.argv[5] if len(sys.argv) > 5 else "c2"
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
     shutil.copy(stats, os.path.join(out, f"{tag}_kernel_stats.csv"))
@@ -67,7 +68,14 @@ def main():
         for r in sorted(rows, key=lambda r: -r[4] * r[1]):
             wr.writerow([r[0], r[1], f"{r[2]:.1f}", f"{r[3]:.1f}", f"{r[4]:.0f}"])
     traffic = {c: v / n for c, (n, v) in per_class.items()}
-    json.dump({"unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)", "per_class": traffic},
+    sys.path.insert(0, ROOT)
+    import subprocess
+    from bench import kernel_source_hash
+    head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+    # the stamp bench.py checks: the traffic is quoted only while the kernel sources are the ones profiled
+    json.dump({"unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)", "workload": workload,
+               "kernel_sources_sha": kernel_source_hash(), "commit": head or "(not a git checkout: GPU box snapshot)",
+               "per_class": traffic},
               open(os.path.join(out, f"{tag}_traffic.json"), "w"), indent=1)
     for c, v in traffic.items():
         print(f"{c:14s} {v / 1e6:8.1f} MB/launch")
