@@ -153,115 +153,123 @@ def spawn_ranks(n):
     return rc
 
 
-def measure(A, torch, dist, name, dtype, args, dev, rank, world, use_dist, steps, warmup, events):
-    """K timed steps (after W warm-up steps) of one configuration on this rank; then, optionally, K more steps with a HIP
-    event pair attached to every hot-path dispatch for the per-class durations.  -> dict"""
-    c = dict(CONFIGS[name])
-    if args.batch and name == args.config:
-        c["batch"] = args.batch
-    B, Tv, Ta = c["batch"], c["t_video"], c["t_audio"]
-    torch.manual_seed(123)  # identical weights on every rank (reference default seed, opts.py:19)
-    model = A.SyntheticAVFormer(c["dim"], c["depth"], c["heads"], c["dim_head"], c["mlp_dim"], Tv, Ta, task="AU",
-                                compute_dtype=dtype).to(dev)
-    g = torch.Generator().manual_seed(123 + rank)  # rank-distinct synthetic clips
-    clip = torch.randn(B, Tv, c["dim"], generator=g).to(dev)
-    audio = torch.randn(B, Ta, c["dim"], generator=g).to(dev)
-    labels = (torch.rand(B, 12, generator=g) > 0.5).float()
-    labels[::16] = -1  # 1/16 of the clips carry the ignore label (SURVEY.md section 8d)
-    labels = labels.to(dev)
-    batch = {"clip": clip, "audio_features": audio}
-    opt = None
-    if not args.no_optimizer:
-        # Adam(lr, weight_decay) as the reference's loop (train.py:318-322)
-        if args.torch_adam:
-            try:
-                opt = torch.optim.Adam(model.parameters(), lr=5e-4, weight_decay=5e-5, fused=True)
-            except Exception:
-                opt = torch.optim.Adam(model.parameters(), lr=5e-4, weight_decay=5e-5)
-        else:
-            opt = A.optim.FusedAdam(model, lr=5e-4, weight_decay=5e-5)
-    dp = A.dp.DataParallel(model) if use_dist else None
+class Region:
+    """one configuration on this rank: model, resident synthetic batch, optimizer, the step closure"""
 
-    def step():
-        # optimizer.zero_grad() as the reference (train.py:206); Module.zero_grad walks the whole module tree (0.7 ms)
-        (opt if opt is not None else model).zero_grad(set_to_none=True)
-        out = model(batch)
-        loss = model.get_au_loss(out, labels)
-        loss.backward()
-        if dp is not None:
-            dp.finish()
-        if opt is not None:
-            opt.step()
-        return loss
+    def __init__(self, A, torch, dist, name, dtype, args, dev, rank, world, use_dist):
+        self.A, self.torch, self.dist, self.use_dist, self.world, self.dtype = A, torch, dist, use_dist, world, dtype
+        c = dict(CONFIGS[name])
+        if args.batch and name == args.config:
+            c["batch"] = args.batch
+        self.c, self.B = c, c["batch"]
+        B, Tv, Ta = c["batch"], c["t_video"], c["t_audio"]
+        torch.manual_seed(123)  # identical weights on every rank (reference default seed, opts.py:19)
+        model = A.SyntheticAVFormer(c["dim"], c["depth"], c["heads"], c["dim_head"], c["mlp_dim"], Tv, Ta, task="AU",
+                                    compute_dtype=dtype).to(dev)
+        g = torch.Generator().manual_seed(123 + rank)  # rank-distinct synthetic clips
+        clip = torch.randn(B, Tv, c["dim"], generator=g).to(dev)
+        audio = torch.randn(B, Ta, c["dim"], generator=g).to(dev)
+        labels = (torch.rand(B, 12, generator=g) > 0.5).float()
+        labels[::16] = -1  # 1/16 of the clips carry the ignore label (SURVEY.md section 8d)
+        labels = labels.to(dev)
+        batch = {"clip": clip, "audio_features": audio}
+        opt = None
+        if not args.no_optimizer:
+            # Adam(lr, weight_decay) as the reference's loop (train.py:318-322)
+            if args.torch_adam:
+                try:
+                    opt = torch.optim.Adam(model.parameters(), lr=5e-4, weight_decay=5e-5, fused=True)
+                except Exception:
+                    opt = torch.optim.Adam(model.parameters(), lr=5e-4, weight_decay=5e-5)
+            else:
+                opt = A.optim.FusedAdam(model, lr=5e-4, weight_decay=5e-5)
+        dp = A.dp.DataParallel(model) if use_dist else None
+        self.model, self.opt, self.dp, self.dev = model, opt, dp, dev
+        self.optimizer = None if opt is None else type(opt).__name__
 
-    def fence():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-            torch.cuda.synchronize()
+        def step():
+            # optimizer.zero_grad() as the reference (train.py:206); Module.zero_grad walks the whole module tree (0.7 ms)
+            (opt if opt is not None else model).zero_grad(set_to_none=True)
+            out = model(batch)
+            loss = model.get_au_loss(out, labels)
+            loss.backward()
+            if dp is not None:
+                dp.finish()
+            if opt is not None:
+                opt.step()
+            return loss
 
-    for _ in range(warmup):
-        step()
-    fence()
-    run = step
-    if args.graph and dp is None:
-        if opt is not None:
-            for gdict in opt.param_groups:
-                gdict["capturable"] = True
-            step()
-        gr = torch.cuda.CUDAGraph()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            step()
-        torch.cuda.current_stream().wait_stream(side)
-        with torch.cuda.graph(gr):
-            static_loss = step()
-        run = lambda: (gr.replay(), static_loss)[1]
-        for _ in range(3):
-            run()
-        fence()
-    # ---- timed region: exactly K steps between two fences, no instrumentation ------------------------------
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = run()
-    fence()
-    dt = time.perf_counter() - t0
-    # ---- the same K steps again with a HIP-event pair attached to every kernel launch of the hot path (on the launch
-    # stream): per-kernel-class durations for the roofline line.  Kept out of the region above because the ~220
-    # event records per step cost 15-20 % step time.
-    dt_events, tm = None, None
-    if events:
+        self.step = step
+
+    def fence(self):
+        self.torch.cuda.synchronize()
+        if self.use_dist:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def timed(self, steps, warmup, graph=False):
+        """W untimed steps, then exactly K steps between two fences, no instrumentation; MAX over ranks"""
+        torch = self.torch
+        for _ in range(warmup):
+            self.step()
+        self.fence()
+        run = self.step
+        if graph and self.dp is None:
+            if self.opt is not None:
+                for gdict in self.opt.param_groups:
+                    gdict["capturable"] = True
+                self.step()
+            gr = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.step()
+            torch.cuda.current_stream().wait_stream(side)
+            with torch.cuda.graph(gr):
+                static_loss = self.step()
+            run = lambda: (gr.replay(), static_loss)[1]
+            for _ in range(3):
+                run()
+            self.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = run()
+        self.fence()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+        if self.use_dist:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        dt = t.item()
+        self.steps = steps
+        self.ms = dt / steps * 1e3
+        self.clips_per_s = self.B * self.world * steps / dt
+        self.loss = float(loss.item())
+        self.tflops = 3.0 * stack_flops_fwd(self.c, self.B) / (self.ms * 1e-3) / 1e12
+        self.frac = self.tflops / MFMA_PEAK_TFLOPS[self.dtype]
+
+    def instrumented(self, steps):
+        """K more steps with a HIP-event pair ATTACHED to every hot-path dispatch (hipExtLaunchKernelGGL start/stop events =
+        the kernel's own begin / end timestamps, on the launch stream): per-kernel-class durations.  Run after ALL timed
+        regions: the ~220 event records per step cost 15-20 % of a step, and once a stream has carried such dispatches the
+        launches after them stay slow (a timed region placed behind an instrumented pass measured 3x its real time)."""
+        A = self.A
         A._lib.timing_enable(True)
         t1 = time.perf_counter()
         for _ in range(steps):
-            step()
-        fence()
-        dt_events = time.perf_counter() - t1
+            self.step()
+        self.fence()
+        self.ms_events = (time.perf_counter() - t1) / steps * 1e3
         tm = A._lib.timing_read()
         A._lib.timing_enable(False)
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = t.item()
-    ms = dt / steps * 1e3
-    flops_step = 3.0 * stack_flops_fwd(c, B)
-    peak = MFMA_PEAK_TFLOPS[dtype]
-    res = {"cfg": c, "B": B, "ms_per_step": ms, "clips_per_s": B * world * steps / dt, "loss": float(loss.item()),
-           "stack_tflops_per_gpu": flops_step / (ms * 1e-3) / 1e12, "optimizer": None if opt is None else type(opt).__name__,
-           "ms_events": None if dt_events is None else dt_events / steps * 1e3, "classes": None, "timing": tm}
-    res["stack_frac_of_mfma_peak"] = res["stack_tflops_per_gpu"] / peak
-    if tm is not None:
-        res["classes"] = {
+        peak = MFMA_PEAK_TFLOPS[self.dtype]
+        self.timing = tm
+        self.classes = {
             k: {"ms_per_step": round(v["ms"] / steps, 4), "launches_per_step": v["launches"] / steps,
                 "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 and v["flops"] > 0 else None,
                 "frac_of_mfma_peak": (round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / (MX8_PEAK_TFLOPS if k == "gemm_mx8_nt" else peak), 4)
                                       if v["ms"] > 0 and v["flops"] > 0 else None),
                 "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None}
             for k, v in tm.items() if v["launches"] > 0}
-    del model, opt, dp
-    torch.cuda.empty_cache()
-    return res
 
 
 def main():
@@ -314,35 +322,47 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     events = not args.no_kernel_events
-    main_r = measure(A, torch, dist, args.config, args.dtype, args, dev, rank, world, use_dist, args.steps, args.warmup, events)
-    c, B = main_r["cfg"], main_r["B"]
+    mk = lambda name, dtype, dist_on: Region(A, torch, dist, name, dtype, args, dev, rank, world, dist_on)
+    # ---- timed regions first, all un-instrumented: the contract's own, then (same process) the shape the north-star
+    # target is quoted on (C3: B=32/GPU, T=512, d=512 = BASELINE configs[2], which at N=8 is exactly its global batch of
+    # 256) and, at N=1, the fp32 parity mode on the main workload (the mode that meets north_star's logits rtol 1e-3).
+    main_r = mk(args.config, args.dtype, use_dist)
+    main_r.timed(args.steps, args.warmup, args.graph)
+    c, B = main_r.c, main_r.B
     Tv, Ta = c["t_video"], c["t_audio"]
     result = {
         "metric": "clips/sec (fwd+bwd) on synthetic (B,T,d) AV sequences",
-        "value": round(main_r["clips_per_s"], 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(main_r["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak",
+        "value": round(main_r.clips_per_s, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(main_r.ms, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"BASELINE.json configs[{'1' if args.config == 'c2' else args.config}]: avformer "
                                f"transformer stack d={c['dim']} L={c['depth']} H={c['heads']}x{c['dim_head']} "
                                f"mlp={c['mlp_dim']}, T_v={Tv}+T_a={Ta} tokens, B={B}/GPU",
                    "global_batch": B * world, "seq_len": Tv + Ta, "parallelism": f"dp{world}",
-                   "step": "zero_grad+fwd+AULoss+bwd" + ("+allreduce" if use_dist else "") + ("+adam" if main_r["optimizer"] else ""),
-                   "optimizer": main_r["optimizer"], "loss": main_r["loss"]},
+                   "step": "zero_grad+fwd+AULoss+bwd" + ("+allreduce" if use_dist else "") + ("+adam" if main_r.optimizer else ""),
+                   "optimizer": main_r.optimizer, "loss": main_r.loss},
     }
-    # ---- extra timed regions (same process, after the contract's own): the shape the north-star target is quoted on
-    # (C3: B=32/GPU, T=512, d=512 = BASELINE configs[2], which at N=8 is exactly its global batch of 256) and, at N=1, the fp32
-    # parity mode on the main workload (the mode that meets north_star's logits rtol 1e-3).  Every rank takes part.
     c3_r = f32_r = None
     if not args.no_extra and args.config == "c2" and args.dtype == "bf16":
-        c3_r = measure(A, torch, dist, "c3", "bf16", args, dev, rank, world, use_dist, args.steps, args.warmup, events)
+        c3_r = mk("c3", "bf16", use_dist)
+        c3_r.timed(args.steps, args.warmup)
         if world == 1:
-            f32_r = measure(A, torch, dist, args.config, "f32", args, dev, rank, world, False, max(2, args.steps // 6), 1, False)
+            f32_r = mk(args.config, "f32", False)
+            f32_r.timed(max(2, args.steps // 6), 1)
+            f32_steps = f32_r.steps
+            f32_r.model = f32_r.opt = f32_r.step = None  # free it before the instrumented passes
+    # ---- then the instrumented passes (per-kernel-class HIP events) of the regions that report classes
+    if events:
+        main_r.instrumented(args.steps)
+        if c3_r is not None:
+            c3_r.instrumented(args.steps)
     if rank == 0:
-        result["stack_tflops_per_gpu"] = round(main_r["stack_tflops_per_gpu"], 2)
-        result["stack_frac_of_mfma_peak"] = round(main_r["stack_frac_of_mfma_peak"], 4)
-        if main_r["ms_events"] is not None:
-            result["ms_per_step_with_kernel_events"] = round(main_r["ms_events"], 4)
-        tm = main_r["timing"]
+        result["stack_tflops_per_gpu"] = round(main_r.tflops, 2)
+        result["stack_frac_of_mfma_peak"] = round(main_r.frac, 4)
+        tm = None
+        if events:
+            result["ms_per_step_with_kernel_events"] = round(main_r.ms_events, 4)
+            tm = main_r.timing
         if tm is not None:
             mfma = {k: v for k, v in tm.items() if k.startswith("gemm") or k.startswith("attn")}
             dom = max(mfma, key=lambda k: mfma[k]["ms"])
@@ -362,21 +382,21 @@ def main():
                                 "(hipExtLaunchKernelGGL start/stop events: the dispatch's own begin/end timestamps), over "
                                 "K instrumented steps run right after the timed region (same process, same inputs)",
                 }
-            result["kernel_classes"] = main_r["classes"]
+            result["kernel_classes"] = main_r.classes
         if c3_r is not None:
-            cc = c3_r["cfg"]
+            cc = c3_r.c
             result["north_star_shape"] = {
                 "workload": f"BASELINE.json configs[2] per GPU: d={cc['dim']} L={cc['depth']} T={cc['t_video'] + cc['t_audio']} "
-                            f"B={c3_r['B']}/GPU (global {c3_r['B'] * world}), same step as `value`",
-                "clips_per_s": round(c3_r["clips_per_s"], 2), "ms_per_step": round(c3_r["ms_per_step"], 4),
+                            f"B={c3_r.B}/GPU (global {c3_r.B * world}), same step as `value`",
+                "clips_per_s": round(c3_r.clips_per_s, 2), "ms_per_step": round(c3_r.ms, 4),
                 "steps": args.steps, "warmup": args.warmup,
-                "stack_tflops_per_gpu": round(c3_r["stack_tflops_per_gpu"], 2),
-                "stack_frac_of_mfma_peak": round(c3_r["stack_frac_of_mfma_peak"], 4),
-                "target_frac": 0.30, "kernel_classes": c3_r["classes"]}
+                "stack_tflops_per_gpu": round(c3_r.tflops, 2),
+                "stack_frac_of_mfma_peak": round(c3_r.frac, 4),
+                "target_frac": 0.30, "kernel_classes": c3_r.classes if events else None}
         if f32_r is not None:
-            result["f32_parity_clips_per_s"] = round(f32_r["clips_per_s"], 2)
-            result["f32_parity"] = {"ms_per_step": round(f32_r["ms_per_step"], 3), "steps": max(2, args.steps // 6),
-                                    "stack_tflops_per_gpu": round(f32_r["stack_tflops_per_gpu"], 2),
+            result["f32_parity_clips_per_s"] = round(f32_r.clips_per_s, 2)
+            result["f32_parity"] = {"ms_per_step": round(f32_r.ms, 3), "steps": f32_steps,
+                                    "stack_tflops_per_gpu": round(f32_r.tflops, 2),
                                     "peak": MFMA_PEAK_TFLOPS["f32"],
                                     "note": "compute_dtype='f32' (fp32 MFMA + fp32 attention): the mode held to logits rtol 1e-3"}
         if world == 1 and not args.no_cpu_baseline:

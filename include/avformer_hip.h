@@ -62,6 +62,10 @@ typedef struct avf_layer_cfg {
   int32_t mx8_fwd;     /* 1 (AVF_BF16 only; dim, mlp_dim % 128 == 0): the forward GEMMs of to_qkv, net.0 and net.3 take MX-FP8
                           operands (BASELINE config 5).  The bf16 weight-image buffer then also holds their e4m3 images:
                           refresh them with avf_stack_quant_weights_mx8 whenever the bf16 images changed.          */
+  int32_t resid_bf16;  /* 1 (AVF_BF16 only; dim % 8 == 0, dim <= 1536): the FORWARD residual stream is stored in bf16 - x_in, x_out of
+                          avf_layer_fwd / avf_layer_bwd and the saved mid-layer stream are bf16 tensors (LayerNorm statistics,
+                          GEMM accumulation and the residual add itself stay fp32; one bf16 rounding per residual add).
+                          Cuts the HBM bytes of the two LayerNorms and the two residual GEMM epilogues of a layer by a third. */
 } avf_layer_cfg;
 
 /* fp32 master parameters of one layer, in state_dict order:
@@ -120,6 +124,14 @@ int avf_gemm(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K,
              const void* B, int64_t ldb, void* C, int64_t ldc, int c_dtype, int epilogue, const float* bias,
              const float* residual, int64_t ldres, void* aux, int64_t ldaux, void* workspace, void* stream);
 
+/* The weight gradients of one layer as ONE grouped launch (autograd of nn.Linear, heads.py:191,195,212,215): up to four
+ * C_i[M_i,N_i] (fp32, dense) = A_i[K,M_i]^T * B_i[K,N_i] (bf16, token-major, dense: lda = M_i, ldb = N_i) that share the
+ * reduction length K (the B*N token rows); K % 64 == 0, M_i % 8 == 0, N_i % 8 == 0.  Split-K partial slabs live in
+ * `workspace` (avf_gemm_tn_group_workspace_bytes) and are folded by a second launch. */
+size_t avf_gemm_tn_group_workspace_bytes(int count, int64_t K, const int64_t* M, const int64_t* N);
+int avf_gemm_tn_group(int count, int64_t K, const void* const* A, const void* const* B, float* const* C, const int64_t* M,
+                      const int64_t* N, void* workspace, void* stream);
+
 /* MX-FP8 operands (OCP microscaling: e4m3 elements, one E8M0 scale byte per 32 consecutive elements of a row) for the
  * forward nn.Linear GEMMs (heads.py:191,195,212) on v_mfma_scale_f32_16x16x128_f8f6f4 - BASELINE config 5.
  *   avf_quant_mx8:   x [rows,cols] (AVF_F32 | AVF_BF16, cols % 32 == 0) -> q [rows,cols] bytes, scales [rows,cols/32] bytes;
@@ -167,6 +179,11 @@ int avf_attn_bwd_qs(const void* qkv, const void* o, const void* d_o, const float
 int avf_fuse_tokens(const float* clip, const float* audio, const float* pos, float* out, int batch, int t_video,
                     int t_audio, int dim, void* stream);
 int avf_token_mean_fwd(const float* y, float* out, int batch, int tokens, int dim, void* stream);
+/* the two ends of a bf16 residual stream (cfg.resid_bf16; dim % 8 == 0): the fused token build writing bf16, the token mean
+ * reading bf16 (fp32 accumulation, fp32 result) */
+int avf_fuse_tokens_bf16(const float* clip, const float* audio, const float* pos, void* out_bf16, int batch, int t_video,
+                         int t_audio, int dim, void* stream);
+int avf_token_mean_fwd_bf16(const void* y_bf16, float* out, int batch, int tokens, int dim, void* stream);
 int avf_token_mean_bwd(const float* g, float* dy, void* dy_bf16, float* colsum, int batch, int tokens, int dim,
                        void* stream);
 
@@ -212,17 +229,18 @@ int avf_adam_step_tensors(int count, float* const* p, const float* const* g, flo
                           float* const* exp_avg_sq, const int64_t* numel, float lr, float beta1, float beta2, float eps,
                           float weight_decay, const float* step, void* stream);
 
-/* x_out = layer(x_in); x_in, x_out fp32 [B*N, D] (may not alias). */
-int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p, const void* lowp, const float* x_in,
-                  float* x_out, void* saved, void* workspace, void* stream);
+/* x_out = layer(x_in); x_in, x_out [B*N, D] (may not alias): fp32, or bf16 when cfg.resid_bf16 is set. */
+int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p, const void* lowp, const void* x_in,
+                  void* x_out, void* saved, void* workspace, void* stream);
 
 /* dx_in (fp32) and all parameter gradients from dx_out (fp32).  dx_out_lo: optional bf16 copy of dx_out
  * (null => made internally); dx_in_lo: optional bf16 copy of dx_in to hand to the previous layer (with dropout
  * active it already carries layer_index-1's site-2 mask, which is what that layer's MLP gradients consume).
  * dx_out_colsum: optional [D] column sums of dx_out (= this layer's b2 gradient) already computed by the
  * caller's previous call; dx_in_colsum: optional [D] output, column sums of dx_in for the next call.
- * dx_in may alias dx_out (dx_out_lo / dx_in_lo must then be distinct buffers). */
-int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p, const void* lowp, const float* x_in,
+ * dx_in may alias dx_out (dx_out_lo / dx_in_lo must then be distinct buffers).  x_in: the tensor avf_layer_fwd was given
+ * (bf16 when cfg.resid_bf16); the gradients dx_* are fp32 / bf16 images independently of it. */
+int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p, const void* lowp, const void* x_in,
                   const void* saved, const float* dx_out, const void* dx_out_lo, const float* dx_out_colsum,
                   float* dx_in, void* dx_in_lo, float* dx_in_colsum, const avf_layer_grads* g, void* workspace,
                   void* stream);

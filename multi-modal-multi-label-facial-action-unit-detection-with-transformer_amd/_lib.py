@@ -54,6 +54,8 @@ SIGNATURES = {
     "avf_gemm_workspace_bytes": (_sz, [_int, _int, _int, _i64, _i64, _i64]),
     "avf_gemm": (_int, [_int, _int, _int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _int, _int, _vp, _vp,
                         _i64, _vp, _i64, _vp, _vp]),
+    "avf_gemm_tn_group_workspace_bytes": (_sz, [_int, _i64, _vp, _vp]),
+    "avf_gemm_tn_group": (_int, [_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "avf_stack_quant_weights_mx8": (_int, [_vp, _int, _vp, _vp]),
     "avf_quant_mx8": (_int, [_int, _vp, _i64, _i64, _vp, _vp, _vp]),
     "avf_gemm_mx8_nt": (_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _i64, _vp, _i64,

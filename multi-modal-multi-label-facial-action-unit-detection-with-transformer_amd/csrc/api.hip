@@ -212,6 +212,33 @@ extern "C" int avf_gemm(int dtype, int transA, int transB, int64_t M, int64_t N,
   return gemm(a, (hipStream_t)stream);
 }
 
+static int fill_tn_group(TnGroupArgs* g, int count, int64_t K, const void* const* A, const void* const* B, float* const* C,
+                         const int64_t* M, const int64_t* N) {
+  AVF_REQUIRE(count >= 1 && count <= 4 && M && N, "gemm_tn_group: 1..4 problems");
+  memset(g, 0, sizeof(*g));
+  g->count = count;
+  g->K = K;
+  for (int i = 0; i < count; ++i) {
+    g->A[i] = A ? A[i] : nullptr; g->B[i] = B ? B[i] : nullptr; g->C[i] = C ? C[i] : nullptr;
+    g->M[i] = M[i]; g->N[i] = N[i]; g->lda[i] = M[i]; g->ldb[i] = N[i];
+  }
+  return 0;
+}
+extern "C" size_t avf_gemm_tn_group_workspace_bytes(int count, int64_t K, const int64_t* M, const int64_t* N) {
+  TnGroupArgs g;
+  if (fill_tn_group(&g, count, K, nullptr, nullptr, nullptr, M, N)) return 0;
+  return gemm_bf16_tn_group_ws(g);
+}
+extern "C" int avf_gemm_tn_group(int count, int64_t K, const void* const* A, const void* const* B, float* const* C,
+                                 const int64_t* M, const int64_t* N, void* workspace, void* stream) {
+  AVF_REQUIRE(A && B && C, "gemm_tn_group: null pointer");
+  TnGroupArgs g;
+  AVF_TRY(fill_tn_group(&g, count, K, A, B, C, M, N));
+  for (int i = 0; i < count; ++i) AVF_REQUIRE(A[i] && B[i] && C[i], "gemm_tn_group: null operand %d", i);
+  g.workspace = workspace;
+  return gemm_bf16_tn_group(g, (hipStream_t)stream, nullptr);
+}
+
 extern "C" int avf_layernorm_fwd_mx8(const float* x, const float* gamma, const float* beta, void* y_bf16, float* mean,
                                      float* rstd, void* y_q, void* y_scales, int64_t rows, int dim, float eps, void* stream) {
   AVF_REQUIRE(x && gamma && beta && y_bf16 && mean && rstd && y_q && y_scales, "layernorm_fwd_mx8: null pointer");

@@ -292,16 +292,19 @@ struct PerDeviceOnce {
 // ---------------------------------------------------------------------------------------------
 struct FoldJob;
 // mx_q / mx_s (optional, bf16 output only): also write the MX-FP8 image of y ([rows,dim] e4m3 + [rows,dim/32] E8M0)
-int layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype, float* mean,
-                  float* rstd, int64_t rows, int dim, float eps, hipStream_t s, void* mx_q = nullptr, void* mx_s = nullptr);
+// x_dtype AVF_BF16 (bf16 residual stream): x is read as bf16 (dim % 4 == 0, dim <= 1536)
+int layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, int y_dtype, float* mean,
+                  float* rstd, int64_t rows, int dim, float eps, hipStream_t s, void* mx_q = nullptr, void* mx_s = nullptr,
+                  int x_dtype = AVF_F32);
 size_t layernorm_bwd_ws(int64_t rows, int dim);
 // drop: mask applied to the bf16 copy dx_lo AND to the column sums (they feed the Linear behind a dropout site);
 // dx itself (the residual stream gradient) is never masked.
 // dres_dtype AVF_BF16 (bf16 gradient stream): dres is read as bf16, dx may be null (dx_lo is then the only output).
-int layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean,
+// x_dtype AVF_BF16 (bf16 residual stream): the saved LayerNorm input is bf16 (bf16 dy, dim % 4 == 0, dim <= 1536)
+int layernorm_bwd(const void* dy, int dy_dtype, const void* x, const float* gamma, const float* mean,
                   const float* rstd, const void* dres, float* dx, void* dx_lo, float* dgamma, float* dbeta,
                   float* dcolsum, void* ws, int64_t rows, int dim, hipStream_t s, const DropCfg& drop = kNoDrop,
-                  FoldJob* defer_fold = nullptr, int dres_dtype = AVF_F32);
+                  FoldJob* defer_fold = nullptr, int dres_dtype = AVF_F32, int x_dtype = AVF_F32);
 size_t colsum_ws(int64_t rows, int cols);
 int colsum(const void* in, int in_dtype, int64_t rows, int cols, int64_t ld, float* out, void* ws, hipStream_t s);
 int cast_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t s, const DropCfg& drop = kNoDrop);
@@ -380,7 +383,7 @@ struct GemmArgs {
   int c_dtype;
   int epilogue;
   const float* bias;
-  const float* residual;
+  const void* residual;  // BIAS_RES: fp32 when C is fp32; bf16 when C is bf16 (bf16 residual stream)
   int64_t ldres;
   void* aux;
   int64_t ldaux;

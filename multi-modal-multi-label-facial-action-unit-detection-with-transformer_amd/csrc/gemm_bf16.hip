@@ -510,8 +510,28 @@ __device__ __forceinline__ bf16x8_t tr_frag_swz_rb(const lds_char* tile, int row
   return __builtin_bit_cast(bf16x8_t, r);
 }
 
+// Fragment reads as INLINE ASM.  hipcc treats an LDS-DMA in flight as a pending LDS store that may alias any later
+// ds_read of the same array and puts s_waitcnt vmcnt(0) in front of the first read of every K-step - which drains the ring
+// to depth one whatever the counted waits in the source say.  The asm is opaque to that pass; ordering against the DMA is
+// the kernel's own counted vmcnt + s_barrier, and every use of the results sits behind an explicit s_waitcnt lgkmcnt(0)
+// followed by sched_barrier(0) (the compiler may otherwise hoist register-only MFMAs above the asm wait).
+template <int OFF>
+__device__ __forceinline__ s16x4_t lds_tr16_asm(uint32_t addr) {
+  s16x4_t v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+template <int OFF_LO, int OFF_HI>
+__device__ __forceinline__ bf16x8_t tr_frag_asm(uint32_t addr) {
+  const s16x4_t lo = lds_tr16_asm<OFF_LO>(addr), hi = lds_tr16_asm<OFF_HI>(addr);
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  const s16x8_t r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+
 template <int NS>
 __global__ __launch_bounds__(512) void gemm_bf16_tn_group_big_kernel(TnGroup g) {
+  static_assert(NS == 3, "the ping-pong schedule below is written for a 3-slot ring");
   constexpr int A_BYTES = TR * 512, B_BYTES = TR * 256, STAGE = A_BYTES + B_BYTES;  // 32 + 16 KiB
   constexpr int A_INS = 4, B_INS = 2, INS = A_INS + B_INS;                          // per wave per stage
   extern __shared__ __attribute__((aligned(16))) char dsm[];
@@ -564,32 +584,63 @@ __global__ __launch_bounds__(512) void gemm_bf16_tn_group_big_kernel(TnGroup g) 
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const int nt = kend > kbeg ? (kend - kbeg) / TR : 0;
+  // Ping-pong between the two halves of the workgroup (waves 0-3 / 4-7; a SIMD hosts one wave of each).  Every wave
+  // alternates a LOAD phase (fragment reads of tile t, LDS-DMA issue for tile t+2, waits) with a COMPUTE phase (its 32
+  // MFMAs), one s_barrier after each; the second half runs one phase behind (one extra barrier up front), so while one
+  // wave of a SIMD computes its partner loads.  With all eight waves in lock-step (same code, one barrier per K-step)
+  // this tile ran 20 % SLOWER than two independent 128 x 128 workgroups: both waves of a SIMD read, then both compute.
+  // Hazards (interval = time between two barriers; half 0 loads tile t in interval 2t+1, half 1 in 2t+2):
+  //   RAW  a wave waits for its own pieces of tile t+1 (vmcnt) at the end of its load phase t, i.e. by the end of interval
+  //        2t+2 for every wave; the first read of tile t+1 is in interval 2t+3.
+  //   WAR  tile t+2 lands in the slot of tile t-1, first written in interval 2t+1; its last reads ended (lgkmcnt(0) before
+  //        the barrier) in interval 2t.
+  // per-lane fragment offsets inside a stage (row = 4 lg + (li >> 2) (+16, +32, +48 by immediate), swizzled 16-byte chunk)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char*)dsm;
+  uint32_t aoff[4], boff[4];
+  {
+    const int row = 4 * lg + (li >> 2), sw = (row & 7) << 1;
 #pragma unroll
-  for (int i = 0; i < NS - 1; ++i)
-    if (i < nt) stage(i, i);
+    for (int i = 0; i < 4; ++i) {
+      const int ca = ((wm * 64 + i * 16) >> 3) + ((li & 3) >> 1), cb = ((wn * 64 + i * 16) >> 3) + ((li & 3) >> 1);
+      aoff[i] = (uint32_t)(row * 512 + ((ca ^ sw) << 4) + ((li & 1) << 3));
+      boff[i] = (uint32_t)(row * 256 + ((cb ^ sw) << 4) + ((li & 1) << 3));
+    }
+  }
+  const int nt = kend > kbeg ? (kend - kbeg) / TR : 0;
+  const int half = wave >> 2;
+  if (nt > 0) stage(0, 0);
+  if (nt > 1) stage(1, 1);
+  if (nt > 1) wait_vmcnt<INS>();
+  else wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  if (half == 1) __builtin_amdgcn_s_barrier();
   int cur = 0;
   for (int t = 0; t < nt; ++t) {
-    const int ahead = (nt - 1 - t) < (NS - 2) ? (nt - 1 - t) : (NS - 2);  // tiles issued after tile t
-    if (ahead >= 2) wait_vmcnt<2 * INS>();
-    else if (ahead == 1) wait_vmcnt<INS>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (t + NS - 1 < nt) {
-      int slot = cur + NS - 1;
-      slot = slot >= NS ? slot - NS : slot;
-      stage(slot, t + NS - 1);
-    }
-    const lds_char* sa = (const lds_char*)(dsm + cur * STAGE);
-    const lds_char* sb = sa + A_BYTES;
+    const uint32_t sbase = lds0 + (uint32_t)cur * STAGE;
     bf16x8_t fa[2][4], fb[2][4];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fa[ks][i] = tr_frag_swz_rb<512>(sa, ks * 32, wm * 64 + i * 16, li, lg);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fb[ks][j] = tr_frag_swz_rb<256>(sb, ks * 32, wn * 64 + j * 16, li, lg);
+    for (int i = 0; i < 4; ++i) {
+      fa[0][i] = tr_frag_asm<0, 16 * 512>(sbase + aoff[i]);
+      fa[1][i] = tr_frag_asm<32 * 512, 48 * 512>(sbase + aoff[i]);
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      fb[0][j] = tr_frag_asm<A_BYTES, A_BYTES + 16 * 256>(sbase + boff[j]);
+      fb[1][j] = tr_frag_asm<A_BYTES + 32 * 256, A_BYTES + 48 * 256>(sbase + boff[j]);
+    }
+    if (t + 2 < nt) {
+      int slot = cur + 2;
+      slot = slot >= 3 ? slot - 3 : slot;
+      stage(slot, t + 2);
+      wait_vmcnt<INS>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -597,8 +648,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_tn_group_big_kernel(TnGroup g) 
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
-    cur = (cur + 1 == NS) ? 0 : cur + 1;
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    cur = (cur + 1 == 3) ? 0 : cur + 1;
   }
+  if (half == 0) __builtin_amdgcn_s_barrier();
   float* out = g.S > 1 ? P.slabs + (int64_t)split * P.M * P.N : P.C;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -702,7 +758,7 @@ int gemm_bf16_nt(const GemmArgs& a, hipStream_t s) {
   // algorithmic bytes: both operands once, C once, plus what the fused epilogue reads / writes beside C (fp32 residual;
   // the saved pre-activation, in C's type)
   const double csz = a.c_dtype == AVF_F32 ? 4.0 : 2.0;
-  const double epi_bytes = a.epilogue == AVF_EPI_BIAS_RES ? 4.0 * a.M * a.N
+  const double epi_bytes = a.epilogue == AVF_EPI_BIAS_RES ? csz * a.M * a.N
                            : (a.epilogue == AVF_EPI_BIAS_GELU || a.epilogue == AVF_EPI_DGELU) ? csz * a.M * a.N : 0.0;
   TimingScope ts(KC_GEMM_BF16_NT, 2.0 * a.M * a.N * a.K, 2.0 * (a.M * a.K + a.N * a.K) + csz * a.M * a.N + epi_bytes, s,
                  /*per_kernel=*/true);
@@ -745,7 +801,7 @@ int gemm_bf16_nt(const GemmArgs& a, hipStream_t s) {
   switch (a.epilogue) {
     case AVF_EPI_NONE: LAUNCH(AVF_EPI_NONE); break;
     case AVF_EPI_BIAS_RES:
-      AVF_REQUIRE(a.residual && cf32 && a.ldres % 4 == 0, "gemm_bf16_nt: BIAS_RES needs fp32 C and residual");
+      AVF_REQUIRE(a.residual && a.ldres % 4 == 0, "gemm_bf16_nt: BIAS_RES needs a residual (in C's storage type)");
       LAUNCH(AVF_EPI_BIAS_RES);
       break;
     case AVF_EPI_BIAS_GELU:
@@ -877,26 +933,13 @@ int gemm_bf16_tn_group(const TnGroupArgs& a, hipStream_t s, const FoldList* extr
     return e ? atoi(e) : 4;  // 8 waves measured 5 % slower here (unlike the NT kernel)
   }();
   if (big) {
-    static const int stages = [] {
-      const char* e = getenv("AVF_TN_STAGES");  // tuning aid
-      return e ? atoi(e) : 3;
-    }();
-    static PerDeviceOnce raised2, raised3;
-    if (stages == 2) {
-      if (raised2.need()) {
-        AVF_REQUIRE(hipFuncSetAttribute((const void*)gemm_bf16_tn_group_big_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        2 * 48 * 1024) == hipSuccess, "gemm_bf16_tn_group: cannot raise dynamic LDS limit");
-        raised2.mark();
-      }
-      launch_in_scope(&ts, gemm_bf16_tn_group_big_kernel<2>, dim3(tiles * g.S), dim3(512), 2 * 48 * 1024, s, g);
-    } else {
-      if (raised3.need()) {
-        AVF_REQUIRE(hipFuncSetAttribute((const void*)gemm_bf16_tn_group_big_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        3 * 48 * 1024) == hipSuccess, "gemm_bf16_tn_group: cannot raise dynamic LDS limit");
-        raised3.mark();
-      }
-      launch_in_scope(&ts, gemm_bf16_tn_group_big_kernel<3>, dim3(tiles * g.S), dim3(512), 3 * 48 * 1024, s, g);
+    static PerDeviceOnce raised3;
+    if (raised3.need()) {
+      AVF_REQUIRE(hipFuncSetAttribute((const void*)gemm_bf16_tn_group_big_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      3 * 48 * 1024) == hipSuccess, "gemm_bf16_tn_group: cannot raise dynamic LDS limit");
+      raised3.mark();
     }
+    launch_in_scope(&ts, gemm_bf16_tn_group_big_kernel<3>, dim3(tiles * g.S), dim3(512), 3 * 48 * 1024, s, g);
   } else if (tn_waves == 4) launch_in_scope(&ts, gemm_bf16_tn_group_kernel<2>, dim3(tiles * g.S), dim3(256), 0, s, g);
   else launch_in_scope(&ts, gemm_bf16_tn_group_kernel<4>, dim3(tiles * g.S), dim3(512), 0, s, g);
   AVF_TRY(check_launch("gemm_bf16_tn_group_kernel"));

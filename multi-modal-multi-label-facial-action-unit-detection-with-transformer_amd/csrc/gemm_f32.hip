@@ -128,7 +128,7 @@ int gemm_f32(const GemmArgs& a, hipStream_t s) {
   p.C = (float*)a.C;
   p.ldc = a.ldc;
   p.bias = a.bias;
-  p.residual = a.residual;
+  p.residual = (const float*)a.residual;
   p.ldres = a.ldres;
   p.aux = (float*)a.aux;
   p.ldaux = a.ldaux;

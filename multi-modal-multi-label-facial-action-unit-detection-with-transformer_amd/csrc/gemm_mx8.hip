@@ -298,7 +298,7 @@ int gemm_mx8_nt(const GemmArgs& a, const void* a_scales, const void* b_scales, h
   Mx8Params q;
   NtParams& p = q.nt;
   const double csz = a.c_dtype == AVF_F32 ? 4.0 : 2.0;
-  const double epi_bytes = a.epilogue == AVF_EPI_BIAS_RES ? 4.0 * a.M * a.N : a.epilogue == AVF_EPI_BIAS_GELU ? csz * a.M * a.N : 0.0;
+  const double epi_bytes = a.epilogue == AVF_EPI_BIAS_RES ? csz * a.M * a.N : a.epilogue == AVF_EPI_BIAS_GELU ? csz * a.M * a.N : 0.0;
   TimingScope ts(KC_GEMM_MX8_NT, 2.0 * a.M * a.N * a.K,
                  1.0 * (a.M * a.K + a.N * a.K) * (1.0 + 1.0 / 32) + csz * a.M * a.N + epi_bytes + (mx_q ? a.M * a.N * (1.0 + 1.0 / 32) : 0.0),
                  s, /*per_kernel=*/true);
@@ -329,7 +329,7 @@ int gemm_mx8_nt(const GemmArgs& a, const void* a_scales, const void* b_scales, h
   switch (a.epilogue) {
     case AVF_EPI_NONE: LAUNCH(AVF_EPI_NONE); break;
     case AVF_EPI_BIAS_RES:
-      AVF_REQUIRE(a.residual && cf32 && a.ldres % 4 == 0, "gemm_mx8_nt: BIAS_RES needs fp32 C and residual");
+      AVF_REQUIRE(a.residual && a.ldres % 4 == 0, "gemm_mx8_nt: BIAS_RES needs a residual (in C's storage type)");
       LAUNCH(AVF_EPI_BIAS_RES);
       break;
     case AVF_EPI_BIAS_GELU:

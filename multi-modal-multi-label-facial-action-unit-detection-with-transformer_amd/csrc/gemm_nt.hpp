@@ -22,7 +22,7 @@ struct NtParams {
   void* C;
   int64_t ldc;
   const float* bias;
-  const float* residual;
+  const void* residual;  // fp32, or bf16 when C is bf16 (BIAS_RES on the bf16 residual stream)
   int64_t ldres;
   void* aux;          // saved pre-activation, stored in C's type (BIAS_GELU writes it, DGELU reads it)
   int64_t ldaux;
@@ -92,7 +92,10 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
       const int mc = mm[ii] < p.M ? mm[ii] : p.M - 1;
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
-        if (EPI == AVF_EPI_BIAS_RES) ex[ii][j] = *reinterpret_cast<const float4*>(p.residual + (int64_t)mc * p.ldres + nc[j]);
+        if (EPI == AVF_EPI_BIAS_RES) {
+          if (sizeof(CT) == 2) ex[ii][j] = load4<bf16>((const bf16*)p.residual + (int64_t)mc * p.ldres + nc[j]);
+          else ex[ii][j] = *reinterpret_cast<const float4*>((const float*)p.residual + (int64_t)mc * p.ldres + nc[j]);
+        }
         else if (EPI == AVF_EPI_DGELU) ex[ii][j] = load4<CT>((const CT*)p.aux + (int64_t)mc * p.ldaux + nc[j]);
       }
     }

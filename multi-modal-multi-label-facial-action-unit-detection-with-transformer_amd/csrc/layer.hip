@@ -29,6 +29,8 @@ struct Dims {
   int layer;
   bool gs16;  // backward keeps the residual gradient stream in bf16 (no fp32 dx between the LayerNorm backward kernels)
   bool mx;    // forward nn.Linear GEMMs fed by LayerNorm / GELU (qkv, mlp1, mlp2) take MX-FP8 operands (config 5)
+  bool rs16;  // the FORWARD residual stream (x_in, x_mid, x_out) is stored in bf16 (statistics / accumulation stay fp32)
+  int xdt;    // storage type of the residual stream
 };
 
 int make_dims(const avf_layer_cfg* c, Dims* d) {
@@ -56,6 +58,10 @@ int make_dims(const avf_layer_cfg* c, Dims* d) {
   AVF_REQUIRE(!d->mx || (c->dtype == AVF_BF16 && c->dim % 128 == 0 && c->mlp_dim % 128 == 0 && c->dim <= 1536),
               "layer: mx8_fwd needs the bf16 path with dim and mlp_dim multiples of 128 (dim=%d mlp_dim=%d)", c->dim,
               c->mlp_dim);
+  d->rs16 = c->resid_bf16 != 0;
+  d->xdt = d->rs16 ? AVF_BF16 : AVF_F32;
+  AVF_REQUIRE(!d->rs16 || (c->dtype == AVF_BF16 && c->dim % 8 == 0 && c->dim <= 1536),
+              "layer: resid_bf16 needs the bf16 path, dim %% 8 == 0 and dim <= 1536 (dim=%d)", c->dim);
   if (c->dtype == AVF_BF16) {
     AVF_REQUIRE(d->D % 8 == 0 && d->I % 8 == 0 && d->M % 8 == 0, "layer(bf16): dim, inner and mlp_dim must be multiples of 8");
     AVF_REQUIRE(d->dh == 32 || d->dh == 64, "layer(bf16): dim_head must be 32 or 64 (got %d)", d->dh);
@@ -77,8 +83,8 @@ struct Carver {
 };
 
 struct Saved {
-  void *h1, *qkv, *o, *h2, *u, *g;
-  float *mean1, *rstd1, *lse2, *x_mid, *mean2, *rstd2;
+  void *h1, *qkv, *o, *h2, *u, *g, *x_mid;  // x_mid: fp32, or bf16 on the bf16 residual stream
+  float *mean1, *rstd1, *lse2, *mean2, *rstd2;
 };
 size_t carve_saved(const Dims& d, void* base, Saved* s) {
   Carver c(base);
@@ -89,7 +95,7 @@ size_t carve_saved(const Dims& d, void* base, Saved* s) {
   t.qkv = c.take(d.R * 3 * d.I * d.es);
   t.o = c.take(d.R * d.I * d.es);
   t.lse2 = (float*)c.take((size_t)d.B * d.H * d.N * 4);
-  t.x_mid = (float*)c.take(d.R * d.D * 4);
+  t.x_mid = c.take(d.R * d.D * (d.rs16 ? 2 : 4));
   t.h2 = c.take(d.R * d.D * d.es);
   t.mean2 = (float*)c.take(d.R * 4);
   t.rstd2 = (float*)c.take(d.R * 4);
@@ -191,7 +197,7 @@ size_t carve_work(const Dims& d, void* base, Work* w) {
 
 // C[R, out] = A[R, in] * W[out, in]^T  (nn.Linear forward)
 int linear_fwd(const Dims& d, const void* A, int in, const void* W, int out, void* C, int c_dtype, int epi,
-               const float* bias, const float* res, void* aux, hipStream_t s, const DropCfg& drop = kNoDrop) {
+               const float* bias, const void* res, void* aux, hipStream_t s, const DropCfg& drop = kNoDrop) {
   GemmArgs a;
   a.dtype = d.dt; a.transA = 0; a.transB = 1;
   a.M = d.R; a.N = out; a.K = in;
@@ -204,7 +210,7 @@ int linear_fwd(const Dims& d, const void* A, int in, const void* W, int out, voi
 
 // the same from MX-FP8 images of A and W; mx_q / mx_s: also emit the image of C (BIAS_GELU)
 int linear_fwd_mx(const Dims& d, const void* Aq, const void* As, int in, const void* Wq, const void* Ws, int out, void* C,
-                  int c_dtype, int epi, const float* bias, const float* res, void* aux, hipStream_t s, const DropCfg& drop,
+                  int c_dtype, int epi, const float* bias, const void* res, void* aux, hipStream_t s, const DropCfg& drop,
                   void* mx_q = nullptr, void* mx_s = nullptr) {
   GemmArgs a;
   a.dtype = AVF_BF16; a.transA = 0; a.transB = 1;
@@ -318,8 +324,8 @@ extern "C" int avf_stack_quant_weights_mx8(const avf_layer_cfg* cfg, int layers,
   return quant_mx8_multi(jobs, 3 * layers, (hipStream_t)stream);
 }
 
-extern "C" int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p, const void* lowp, const float* x_in,
-                             float* x_out, void* saved, void* workspace, void* stream) {
+extern "C" int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p, const void* lowp, const void* x_in,
+                             void* x_out, void* saved, void* workspace, void* stream) {
   Dims d;
   AVF_TRY(make_dims(cfg, &d));
   AVF_REQUIRE(p && x_in && x_out && saved, "layer_fwd: null pointer");
@@ -344,39 +350,39 @@ extern "C" int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p
     carve_work(d, workspace, &w);
     const DropCfg dr0 = make_drop(d.p, d.seed, d.layer, 0, d.seed_dev), dr1 = make_drop(d.p, d.seed, d.layer, 1, d.seed_dev),
                   dr2 = make_drop(d.p, d.seed, d.layer, 2, d.seed_dev);
-    AVF_TRY(layernorm_fwd(x_in, p->ln1_w, p->ln1_b, sv.h1, d.dt, sv.mean1, sv.rstd1, d.R, d.D, cfg->ln_eps, s, w.hq, w.hs));
+    AVF_TRY(layernorm_fwd(x_in, p->ln1_w, p->ln1_b, sv.h1, d.dt, sv.mean1, sv.rstd1, d.R, d.D, cfg->ln_eps, s, w.hq, w.hs, d.xdt));
     AVF_TRY(linear_fwd_mx(d, w.hq, w.hs, d.D, l.wqkv_q, l.wqkv_s, 3 * d.I, sv.qkv, d.dt, AVF_EPI_NONE, nullptr, nullptr,
                           nullptr, s, kNoDrop));
     AVF_TRY(attn_fwd_bf16((const bf16*)sv.qkv, (bf16*)sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s, attn_q_prescale_on()));
-    AVF_TRY(linear_fwd(d, sv.o, d.I, wo, d.D, sv.x_mid, AVF_F32, AVF_EPI_BIAS_RES, p->b_out, x_in, nullptr, s, dr0));
-    AVF_TRY(layernorm_fwd(sv.x_mid, p->ln2_w, p->ln2_b, sv.h2, d.dt, sv.mean2, sv.rstd2, d.R, d.D, cfg->ln_eps, s, w.hq, w.hs));
+    AVF_TRY(linear_fwd(d, sv.o, d.I, wo, d.D, sv.x_mid, d.xdt, AVF_EPI_BIAS_RES, p->b_out, x_in, nullptr, s, dr0));
+    AVF_TRY(layernorm_fwd(sv.x_mid, p->ln2_w, p->ln2_b, sv.h2, d.dt, sv.mean2, sv.rstd2, d.R, d.D, cfg->ln_eps, s, w.hq, w.hs, d.xdt));
     AVF_TRY(linear_fwd_mx(d, w.hq, w.hs, d.D, l.w1_q, l.w1_s, d.M, sv.g, d.dt, AVF_EPI_BIAS_GELU, p->b1, nullptr, sv.u, s, dr1,
                           w.gq, w.gs));
-    AVF_TRY(linear_fwd_mx(d, w.gq, w.gs, d.M, l.w2_q, l.w2_s, d.D, x_out, AVF_F32, AVF_EPI_BIAS_RES, p->b2, sv.x_mid, nullptr,
+    AVF_TRY(linear_fwd_mx(d, w.gq, w.gs, d.M, l.w2_q, l.w2_s, d.D, x_out, d.xdt, AVF_EPI_BIAS_RES, p->b2, sv.x_mid, nullptr,
                           s, dr2));
     return 0;
   }
-  if (small_layer_ok(d.dt, d.N, d.D, d.H, d.dh, d.M)) {  // short sequences: the whole layer in one launch
+  if (!d.rs16 && small_layer_ok(d.dt, d.N, d.D, d.H, d.dh, d.M)) {  // short sequences: the whole layer in one launch
     const float sc = attn_q_prescale_on() ? 1.0f : 1.4426950408889634f / sqrtf((float)d.dh);
-    return layer_fwd_small(d.B, d.N, d.D, d.H, d.M, cfg->ln_eps, sc, p, wqkv, wo, w1, w2, x_in, x_out, sv.h1, sv.mean1,
-                           sv.rstd1, sv.qkv, sv.o, sv.lse2, sv.x_mid, sv.h2, sv.mean2, sv.rstd2, sv.u, sv.g,
+    return layer_fwd_small(d.B, d.N, d.D, d.H, d.M, cfg->ln_eps, sc, p, wqkv, wo, w1, w2, (const float*)x_in, (float*)x_out, sv.h1,
+                           sv.mean1, sv.rstd1, sv.qkv, sv.o, sv.lse2, (float*)sv.x_mid, sv.h2, sv.mean2, sv.rstd2, sv.u, sv.g,
                            make_drop(d.p, d.seed, d.layer, 0, d.seed_dev), make_drop(d.p, d.seed, d.layer, 1, d.seed_dev),
                            make_drop(d.p, d.seed, d.layer, 2, d.seed_dev), s);
   }
-  AVF_TRY(layernorm_fwd(x_in, p->ln1_w, p->ln1_b, sv.h1, d.dt, sv.mean1, sv.rstd1, d.R, d.D, cfg->ln_eps, s));
+  AVF_TRY(layernorm_fwd(x_in, p->ln1_w, p->ln1_b, sv.h1, d.dt, sv.mean1, sv.rstd1, d.R, d.D, cfg->ln_eps, s, nullptr, nullptr, d.xdt));
   AVF_TRY(linear_fwd(d, sv.h1, d.D, wqkv, 3 * d.I, sv.qkv, d.dt, AVF_EPI_NONE, nullptr, nullptr, nullptr, s));
   if (lo) AVF_TRY(attn_fwd_bf16((const bf16*)sv.qkv, (bf16*)sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s, attn_q_prescale_on()));
   else AVF_TRY(attn_fwd_f32((const float*)sv.qkv, (float*)sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s));
   const DropCfg dr0 = make_drop(d.p, d.seed, d.layer, 0, d.seed_dev), dr1 = make_drop(d.p, d.seed, d.layer, 1, d.seed_dev),
                 dr2 = make_drop(d.p, d.seed, d.layer, 2, d.seed_dev);
-  AVF_TRY(linear_fwd(d, sv.o, d.I, wo, d.D, sv.x_mid, AVF_F32, AVF_EPI_BIAS_RES, p->b_out, x_in, nullptr, s, dr0));
-  AVF_TRY(layernorm_fwd(sv.x_mid, p->ln2_w, p->ln2_b, sv.h2, d.dt, sv.mean2, sv.rstd2, d.R, d.D, cfg->ln_eps, s));
+  AVF_TRY(linear_fwd(d, sv.o, d.I, wo, d.D, sv.x_mid, d.xdt, AVF_EPI_BIAS_RES, p->b_out, x_in, nullptr, s, dr0));
+  AVF_TRY(layernorm_fwd(sv.x_mid, p->ln2_w, p->ln2_b, sv.h2, d.dt, sv.mean2, sv.rstd2, d.R, d.D, cfg->ln_eps, s, nullptr, nullptr, d.xdt));
   AVF_TRY(linear_fwd(d, sv.h2, d.D, w1, d.M, sv.g, d.dt, AVF_EPI_BIAS_GELU, p->b1, nullptr, sv.u, s, dr1));
-  AVF_TRY(linear_fwd(d, sv.g, d.M, w2, d.D, x_out, AVF_F32, AVF_EPI_BIAS_RES, p->b2, sv.x_mid, nullptr, s, dr2));
+  AVF_TRY(linear_fwd(d, sv.g, d.M, w2, d.D, x_out, d.xdt, AVF_EPI_BIAS_RES, p->b2, sv.x_mid, nullptr, s, dr2));
   return 0;
 }
 
-extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p, const void* lowp, const float* x_in,
+extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p, const void* lowp, const void* x_in,
                              const void* saved, const float* dx_out, const void* dx_out_lo,
                              const float* dx_out_colsum, float* dx_in, void* dx_in_lo, float* dx_in_colsum,
                              const avf_layer_grads* g, void* workspace, void* stream) {
@@ -450,11 +456,11 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   AVF_TRY(linear_dx(d, w.du, d.M, p->w1, l.w1_t, d.D, w.dh, AVF_EPI_NONE, nullptr, s));
   if (d.gs16)  // residual gradient in: the bf16 image the GEMMs read; out: the bf16 dx_mid only
     AVF_TRY(layernorm_bwd(w.dh, d.dt, sv.x_mid, p->ln2_w, sv.mean2, sv.rstd2, gy, nullptr, w.dx_mid_lo, g->ln2_w, g->ln2_b,
-                          g->b_out, w.ln_ws, d.R, d.D, s, dr0, grouped ? &folds.job[1] : nullptr, AVF_BF16));
+                          g->b_out, w.ln_ws, d.R, d.D, s, dr0, grouped ? &folds.job[1] : nullptr, AVF_BF16, d.xdt));
   else
     AVF_TRY(layernorm_bwd(w.dh, d.dt, sv.x_mid, p->ln2_w, sv.mean2, sv.rstd2, dx_out, w.dx_mid,
                           lo ? w.dx_mid_lo : nullptr, g->ln2_w, g->ln2_b, g->b_out, w.ln_ws, d.R, d.D, s, dr0,
-                          grouped ? &folds.job[1] : nullptr));
+                          grouped ? &folds.job[1] : nullptr, AVF_F32, d.xdt));
   // ---- attention half ----------------------------------------------------------------------
   if (!grouped) AVF_TRY(linear_dw(d, gm, d.D, sv.o, d.I, g->w_out, w.gemm_ws, s));
   AVF_TRY(linear_dx(d, gm, d.D, p->w_out, l.wo_t, d.I, w.d_o, AVF_EPI_NONE, nullptr, s));
@@ -469,11 +475,11 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   // dx_in may alias dx_out, which the grouped dW2 GEMM does not read (it uses the bf16 copy gy)
   if (d.gs16)
     AVF_TRY(layernorm_bwd(w.dh, d.dt, x_in, p->ln1_w, sv.mean1, sv.rstd1, w.dx_mid_lo, dx_in, dx_in_lo, g->ln1_w, g->ln1_b,
-                          dx_in_colsum, w.ln_ws1, d.R, d.D, s, dr_prev2, grouped ? &folds.job[2] : nullptr, AVF_BF16));
+                          dx_in_colsum, w.ln_ws1, d.R, d.D, s, dr_prev2, grouped ? &folds.job[2] : nullptr, AVF_BF16, d.xdt));
   else
     AVF_TRY(layernorm_bwd(w.dh, d.dt, x_in, p->ln1_w, sv.mean1, sv.rstd1, w.dx_mid, dx_in, lo ? dx_in_lo : nullptr,
                           g->ln1_w, g->ln1_b, dx_in_colsum, w.ln_ws1, d.R, d.D, s, dr_prev2,
-                          grouped ? &folds.job[2] : nullptr));
+                          grouped ? &folds.job[2] : nullptr, AVF_F32, d.xdt));
   // one launch folds the split-K slabs of the four weight gradients and the three deferred column folds
   // (db1; dgamma2/dbeta2/dbo; dgamma1/dbeta1/previous layer's db2)
   if (grouped) AVF_TRY(gemm_bf16_tn_group(grp, s, &folds));

@@ -71,8 +71,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // D % 4 == 0 and D <= 256*NV: the row lives in registers (one HBM read, no re-reads from cache)
 // MX: also emit the MX-FP8 image of the row (common.hpp mx8_encode4: D % 32 == 0, so the 8 lanes of a block are
 // live together) - the A operand of the following forward GEMM in the fp8 mode (layer.hip)
-template <typename OutT, int NV, bool MX = false>
-__global__ __launch_bounds__(256) void ln_fwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+template <typename OutT, int NV, bool MX = false, typename InT = float>
+__global__ __launch_bounds__(256) void ln_fwd_reg_kernel(const InT* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, OutT* __restrict__ y,
                                                          float* __restrict__ mean, float* __restrict__ rstd,
                                                          int64_t rows, int D, float eps, uint8_t* __restrict__ yq = nullptr,
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void ln_fwd_reg_kernel(const float* __restrict
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane * 4 + 256 * i;
-    v[i] = c < D ? *reinterpret_cast<const float4*>(x + row * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    v[i] = c < D ? load4<InT>(x + row * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   }
   const float mu = wave_sum(s) / (float)D;
@@ -123,13 +123,36 @@ __global__ __launch_bounds__(256) void ln_fwd_reg_kernel(const float* __restrict
   }
 }
 
-int layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype, float* mean,
-                  float* rstd, int64_t rows, int dim, float eps, hipStream_t s, void* mx_q, void* mx_s) {
+int layernorm_fwd(const void* xv, const float* gamma, const float* beta, void* y, int y_dtype, float* mean,
+                  float* rstd, int64_t rows, int dim, float eps, hipStream_t s, void* mx_q, void* mx_s, int x_dtype) {
   AVF_REQUIRE(rows > 0 && dim > 0, "layernorm_fwd: bad shape rows=%lld dim=%d", (long long)rows, dim);
   AVF_REQUIRE(y_dtype == AVF_F32 || y_dtype == AVF_BF16, "layernorm_fwd: bad dtype %d", y_dtype);
-  TimingScope ts(KC_LAYERNORM, 0.0, (double)rows * dim * (4.0 + (y_dtype == AVF_BF16 ? 2.0 : 4.0) + (mx_q ? 1.03125 : 0.0)), s,
-                 /*per_kernel=*/true);
+  AVF_REQUIRE(x_dtype == AVF_F32 || (x_dtype == AVF_BF16 && y_dtype == AVF_BF16 && dim % 4 == 0 && dim <= 1536),
+              "layernorm_fwd: a bf16 input needs a bf16 output, dim %% 4 == 0 and dim <= 1536 (dim=%d)", dim);
+  const float* x = (const float*)xv;
+  TimingScope ts(KC_LAYERNORM, 0.0, (double)rows * dim * ((x_dtype == AVF_BF16 ? 2.0 : 4.0) + (y_dtype == AVF_BF16 ? 2.0 : 4.0) +
+                                                         (mx_q ? 1.03125 : 0.0)), s, /*per_kernel=*/true);
   dim3 grid((unsigned)ceil_div(rows, 4)), block(256);
+  if (x_dtype == AVF_BF16) {  // bf16 residual stream: bf16 in, bf16 out (+ optional MX-FP8 image)
+    const bf16* xb = (const bf16*)xv;
+#define LAUNCH_LO(NVV)                                                                                                    \
+  do {                                                                                                                    \
+    if (mx_q) launch_in_scope(&ts, ln_fwd_reg_kernel<bf16, NVV, true, bf16>, grid, block, 0, s, xb, gamma, beta, (bf16*)y, mean, rstd, \
+                              rows, dim, eps, (uint8_t*)mx_q, (uint8_t*)mx_s);                                            \
+    else launch_in_scope(&ts, ln_fwd_reg_kernel<bf16, NVV, false, bf16>, grid, block, 0, s, xb, gamma, beta, (bf16*)y, mean, rstd, \
+                         rows, dim, eps, (uint8_t*)nullptr, (uint8_t*)nullptr);                                           \
+  } while (0)
+    AVF_REQUIRE(!mx_q || (mx_s && dim % 32 == 0), "layernorm_fwd: the MX-FP8 image needs dim %% 32 == 0");
+    switch ((dim + 255) / 256) {
+      case 1: LAUNCH_LO(1); break;
+      case 2: LAUNCH_LO(2); break;
+      case 3: LAUNCH_LO(3); break;
+      case 4: LAUNCH_LO(4); break;
+      default: LAUNCH_LO(6); break;
+    }
+#undef LAUNCH_LO
+    return check_launch("ln_fwd_reg_kernel(bf16 in)");
+  }
   if (mx_q) {
     AVF_REQUIRE(mx_s && y_dtype == AVF_BF16 && dim % 32 == 0 && dim <= 1536,
                 "layernorm_fwd: the MX-FP8 image needs bf16 output, dim %% 32 == 0 and dim <= 1536 (dim=%d)", dim);
@@ -270,8 +293,8 @@ constexpr int LNR_ROWS_PER_BLOCK = 16;
 
 // ResT: storage type of the incoming residual gradient dres (fp32, or bf16 when the gradient stream is kept in bf16:
 // then dx is null and dx_lo is the stream the next LayerNorm backward reads as ITS dres)
-template <typename DyT, int NV, typename ResT = float>
-__global__ __launch_bounds__(256) void ln_bwd_reg_kernel(const DyT* __restrict__ dy, const float* __restrict__ x,
+template <typename DyT, int NV, typename ResT = float, typename XT = float>
+__global__ __launch_bounds__(256) void ln_bwd_reg_kernel(const DyT* __restrict__ dy, const XT* __restrict__ x,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const ResT* __restrict__ dres, float* __restrict__ dx,
@@ -303,9 +326,17 @@ __global__ __launch_bounds__(256) void ln_bwd_reg_kernel(const DyT* __restrict__
       d[i] = xh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (act[i]) {
         d[i] = load4<DyT>(dy + row * D + c);
-        typedef float f32x4_nt __attribute__((ext_vector_type(4)));  // last use of this x row in the step: non-temporal
-        const f32x4_nt xv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(x + row * D + c));
-        const float4 v = make_float4(xv[0], xv[1], xv[2], xv[3]);
+        float4 v;
+        if (sizeof(XT) == 4) {
+          typedef float f32x4_nt __attribute__((ext_vector_type(4)));  // last use of this x row in the step: non-temporal
+          const f32x4_nt xv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(x + row * D + c));
+          v = make_float4(xv[0], xv[1], xv[2], xv[3]);
+        } else {
+          typedef uint32_t u32x2_nt __attribute__((ext_vector_type(2)));
+          const u32x2_nt xv = __builtin_nontemporal_load(reinterpret_cast<const u32x2_nt*>(x + row * D + c));
+          v = make_float4(__uint_as_float(xv[0] << 16), __uint_as_float(xv[0] & 0xffff0000u), __uint_as_float(xv[1] << 16),
+                          __uint_as_float(xv[1] & 0xffff0000u));
+        }
         xh[i] = make_float4((v.x - mu) * rs, (v.y - mu) * rs, (v.z - mu) * rs, (v.w - mu) * rs);
       }
       const float g0 = d[i].x * g[i].x, g1 = d[i].y * g[i].y, g2 = d[i].z * g[i].z, g3 = d[i].w * g[i].w;
@@ -402,11 +433,14 @@ size_t layernorm_bwd_ws(int64_t rows, int dim) {
   return (size_t)ceil_div(rows, LNR_ROWS_PER_BLOCK) * 3 * dim * sizeof(float);  // LNR < LNB: covers both paths
 }
 
-int layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean,
+int layernorm_bwd(const void* dy, int dy_dtype, const void* xv, const float* gamma, const float* mean,
                   const float* rstd, const void* dres, float* dx, void* dx_lo, float* dgamma, float* dbeta,
                   float* dcolsum, void* ws, int64_t rows, int dim, hipStream_t s, const DropCfg& drop,
-                  FoldJob* defer_fold, int dres_dtype) {
+                  FoldJob* defer_fold, int dres_dtype, int x_dtype) {
   AVF_REQUIRE(rows > 0 && dim > 0 && ws, "layernorm_bwd: bad arguments");
+  AVF_REQUIRE(x_dtype == AVF_F32 || (x_dtype == AVF_BF16 && dy_dtype == AVF_BF16 && dim % 4 == 0 && dim <= 1536),
+              "layernorm_bwd: a bf16 LayerNorm input needs bf16 dy, dim %% 4 == 0 and dim <= 1536");
+  const float* x = (const float*)xv;
   AVF_REQUIRE(dres_dtype == AVF_F32 || (dres_dtype == AVF_BF16 && dy_dtype == AVF_BF16 && dim % 4 == 0 && dim <= 1536 &&
                                          !drop.thresh16 && dx_lo),
               "layernorm_bwd: a bf16 residual gradient needs bf16 dy, a bf16 output, dim %% 4 == 0, dim <= 1536, no dropout");
@@ -414,7 +448,7 @@ int layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gam
   AVF_REQUIRE(!drop.thresh16 || (dim % 4 == 0 && dim <= 1536), "layernorm_bwd: dropout needs dim %% 4 == 0 and dim <= 1536");
   AVF_REQUIRE((size_t)3 * dim * sizeof(float) <= 64 * 1024, "layernorm_bwd: dim %d too large", dim);
   TimingScope ts(KC_LAYERNORM, 0.0,
-                 (double)rows * dim * ((dy_dtype == AVF_BF16 ? 2.0 : 4.0) + 4.0 + (dres ? (dres_dtype == AVF_BF16 ? 2.0 : 4.0) : 0.0) +
+                 (double)rows * dim * ((dy_dtype == AVF_BF16 ? 2.0 : 4.0) + (x_dtype == AVF_BF16 ? 2.0 : 4.0) + (dres ? (dres_dtype == AVF_BF16 ? 2.0 : 4.0) : 0.0) +
                                        (dx ? 4.0 : 0.0) + (dx_lo ? 2.0 : 0.0)), s, /*per_kernel=*/true);
   float* partial = (float*)ws;
   const int wc = dcolsum ? 1 : 0;
@@ -433,13 +467,24 @@ int layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gam
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 3 * 1536 * 4);
         hipError_t e3 = hipFuncSetAttribute((const void*)ln_bwd_reg_kernel<bf16, 6, bf16>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 3 * 1536 * 4);
-        AVF_REQUIRE(e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess, "layernorm_bwd: cannot raise dynamic LDS limit");
+        hipError_t e4 = hipFuncSetAttribute((const void*)ln_bwd_reg_kernel<bf16, 6, bf16, bf16>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 3 * 1536 * 4);
+        hipError_t e5 = hipFuncSetAttribute((const void*)ln_bwd_reg_kernel<bf16, 6, float, bf16>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 3 * 1536 * 4);
+        AVF_REQUIRE(e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess && e4 == hipSuccess && e5 == hipSuccess,
+                    "layernorm_bwd: cannot raise dynamic LDS limit");
         raised.mark();
       }
     }
 #define LAUNCH_NV(T, NVV)                                                                                                   \
   do {                                                                                                                      \
-    if (dres_dtype == AVF_BF16)                                                                                             \
+    if (x_dtype == AVF_BF16 && dres_dtype == AVF_BF16)                                                                      \
+      launch_in_scope(&ts, ln_bwd_reg_kernel<bf16, NVV, bf16, bf16>, dim3(nb), dim3(256), (uint32_t)lds, s, (const bf16*)dy,   \
+                      (const bf16*)xv, gamma, mean, rstd, (const bf16*)dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop); \
+    else if (x_dtype == AVF_BF16)                                                                                           \
+      launch_in_scope(&ts, ln_bwd_reg_kernel<bf16, NVV, float, bf16>, dim3(nb), dim3(256), (uint32_t)lds, s, (const bf16*)dy,  \
+                      (const bf16*)xv, gamma, mean, rstd, (const float*)dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop); \
+    else if (dres_dtype == AVF_BF16)                                                                                        \
       launch_in_scope(&ts, ln_bwd_reg_kernel<bf16, NVV, bf16>, dim3(nb), dim3(256), (uint32_t)lds, s, (const bf16*)dy, x, gamma, \
                       mean, rstd, (const bf16*)dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop);                       \
     else                                                                                                                    \

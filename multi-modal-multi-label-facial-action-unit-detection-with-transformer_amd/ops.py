@@ -147,6 +147,25 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool 
     return c
 
 
+def gemm_tn_group(pairs):
+    """[(A_i [K, M_i] bf16, B_i [K, N_i] bf16), ...] (up to 4, same K) -> [C_i [M_i, N_i] fp32 = A_i^T B_i]: the grouped
+    weight-gradient launch of a layer's backward (avf_gemm_tn_group)."""
+    lib = _lib.load()
+    n = len(pairs)
+    As = [a.contiguous() for a, _ in pairs]
+    Bs = [b.contiguous() for _, b in pairs]
+    _need_cuda(*As, *Bs)
+    K = As[0].shape[0]
+    assert all(a.shape[0] == K and b.shape[0] == K and a.dtype == b.dtype == torch.bfloat16 for a, b in zip(As, Bs))
+    Ms = (C.c_int64 * n)(*[a.shape[1] for a in As])
+    Ns = (C.c_int64 * n)(*[b.shape[1] for b in Bs])
+    Cs = [torch.empty((a.shape[1], b.shape[1]), dtype=torch.float32, device=a.device) for a, b in zip(As, Bs)]
+    arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    ws = _bytes(lib.avf_gemm_tn_group_workspace_bytes(n, K, Ms, Ns), As[0].device)
+    _lib.check(lib.avf_gemm_tn_group(n, K, arr(As), arr(Bs), arr(Cs), Ms, Ns, _ptr(ws), _stream()), "gemm_tn_group")
+    return Cs
+
+
 def quant_mx8(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """[rows, cols] f32|bf16 -> (e4m3 bytes [rows, cols] uint8, E8M0 scale bytes [rows, cols/32] uint8)."""
     _need_cuda(x)

@@ -375,3 +375,44 @@ def test_au_loss_strided_and_all_ignored(ops):
     got = crit(out.cuda()[:, :12], y.cuda())  # strided view, as get_au_loss passes it (avformer.py:116)
     _close(got, ref, atol=1e-6, rtol=1e-5)
     assert torch.isnan(crit(out.cuda()[:, :12], -torch.ones(9, 12).cuda()))
+
+
+@pytest.mark.parametrize("K,shapes", [
+    (128, [(64, 64)]),                                               # one 128 x 128 tile, two K-steps
+    (4096, [(1536, 512), (1024, 512), (512, 1024), (512, 512)]),     # a d=512 layer: the 256 x 128 kernel (64 tiles)
+    (2112, [(2304, 768), (1536, 768), (768, 1536), (768, 768)]),     # d=768 (C4): ragged split-K chunks
+    (2048, [(1000, 136), (264, 520), (8, 8)]),                       # ragged tiles in both extents
+])
+def test_gemm_tn_group(ops, K, shapes):
+    """the grouped weight-gradient launch (avf_gemm_tn_group) against fp64 products, through both tile configurations
+    (the host picks 256 x 128 for big groups; AVF_TN_BIG forces one or the other in the A/B tools)"""
+    g = torch.Generator().manual_seed(K + len(shapes))
+    pairs = [(torch.randn(K, m, generator=g).bfloat16(), torch.randn(K, n, generator=g).bfloat16()) for m, n in shapes]
+    outs = ops.gemm_tn_group([(a.cuda(), b.cuda()) for a, b in pairs])
+    for (a, b), c in zip(pairs, outs):
+        ref = a.double().t() @ b.double()
+        _close(c, ref.float(), atol=2e-5 * K, rtol=1e-5)
+
+
+def test_gemm_tn_group_big_tile_on_ragged_shapes():
+    """the 256 x 128 kernel forced (AVF_TN_BIG=1, read once per process) onto shapes whose edges are ragged in both tile
+    extents and whose K splits unevenly - a child process, as the choice is cached at first use"""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+import avformer_amd as A
+for K, shapes in [(2048, [(1000, 136), (264, 520), (8, 8)]), (192, [(256, 128)]), (4160, [(520, 1032), (1544, 72)]), (64, [(24, 40)])]:
+    g = torch.Generator().manual_seed(K)
+    pairs = [(torch.randn(K, m, generator=g).bfloat16(), torch.randn(K, n, generator=g).bfloat16()) for m, n in shapes]
+    outs = A.ops.gemm_tn_group([(a.cuda(), b.cuda()) for a, b in pairs])
+    for (a, b), c in zip(pairs, outs):
+        ref = (a.double().t() @ b.double()).float()
+        torch.testing.assert_close(c.cpu(), ref, atol=2e-5 * K, rtol=1e-5)
+print("TN_BIG_OK")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, AVF_TN_BIG="1"),
+                       timeout=600)
+    assert r.returncode == 0 and "TN_BIG_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

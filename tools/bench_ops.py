@@ -55,6 +55,16 @@ def gemm_tn(R):
         print(f"gemm_tn {name:12s} M={m} N={n} K={R}: {t * 1e6:8.1f} us  {2.0 * m * n * R / t / 1e12:7.1f} TF/s")
 
 
+def gemm_tn_group(R):
+    """the layer's four weight gradients as the grouped launch the backward uses"""
+    D, I, M = 512, 512, 1024
+    shapes = [(3 * I, D), (M, D), (D, M), (D, I)]
+    pairs = [(torch.randn(R, m, device="cuda").bfloat16(), torch.randn(R, n, device="cuda").bfloat16()) for m, n in shapes]
+    t = timeit(lambda: ops.gemm_tn_group(pairs))
+    fl = sum(2.0 * m * n * R for m, n in shapes)
+    print(f"gemm_tn_group (4 dW of a d=512 layer) K={R}: {t * 1e6:8.1f} us (GEMM + fold)  {fl / t / 1e12:7.1f} TF/s")
+
+
 def attn(B, N):
     H, dh = 8, 64
     qkv = torch.randn(B * N, 3 * H * dh, device="cuda").bfloat16()
@@ -91,6 +101,8 @@ if __name__ == "__main__":
         gemm_nt(R)
     if a.what in ("gemm_tn", "all"):
         gemm_tn(R)
+    if a.what in ("gemm_tn_group", "all"):
+        gemm_tn_group(R)
     if a.what in ("attn", "all"):
         attn(a.batch, a.tokens)
     if a.what in ("ln", "all"):
