@@ -164,8 +164,9 @@ class Region:
         self.c, self.B = c, c["batch"]
         B, Tv, Ta = c["batch"], c["t_video"], c["t_audio"]
         torch.manual_seed(123)  # identical weights on every rank (reference default seed, opts.py:19)
+        self.residual = args.residual if dtype != "f32" else "f32"
         model = A.SyntheticAVFormer(c["dim"], c["depth"], c["heads"], c["dim_head"], c["mlp_dim"], Tv, Ta, task="AU",
-                                    compute_dtype=dtype).to(dev)
+                                    compute_dtype=dtype, residual_dtype=self.residual).to(dev)
         g = torch.Generator().manual_seed(123 + rank)  # rank-distinct synthetic clips
         clip = torch.randn(B, Tv, c["dim"], generator=g).to(dev)
         audio = torch.randn(B, Ta, c["dim"], generator=g).to(dev)
@@ -280,6 +281,8 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "mx8"],
                     help="mx8: bf16 path with MX-FP8 operands on the forward qkv / mlp GEMMs (BASELINE config 5)")
+    ap.add_argument("--residual", default="f32", choices=["f32", "bf16"],
+                    help="storage type of the forward residual stream in the bf16 / mx8 modes (Transformer(residual_dtype=...))")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
@@ -340,7 +343,7 @@ def main():
                                f"mlp={c['mlp_dim']}, T_v={Tv}+T_a={Ta} tokens, B={B}/GPU",
                    "global_batch": B * world, "seq_len": Tv + Ta, "parallelism": f"dp{world}",
                    "step": "zero_grad+fwd+AULoss+bwd" + ("+allreduce" if use_dist else "") + ("+adam" if main_r.optimizer else ""),
-                   "optimizer": main_r.optimizer, "loss": main_r.loss},
+                   "optimizer": main_r.optimizer, "residual_stream": main_r.residual, "loss": main_r.loss},
     }
     c3_r = f32_r = None
     if not args.no_extra and args.config == "c2" and args.dtype == "bf16":

@@ -26,7 +26,8 @@ class LayerCfg(C.Structure):
     _fields_ = [("batch", C.c_int32), ("tokens", C.c_int32), ("dim", C.c_int32), ("heads", C.c_int32),
                 ("dim_head", C.c_int32), ("mlp_dim", C.c_int32), ("dtype", C.c_int32), ("project_out", C.c_int32),
                 ("ln_eps", C.c_float), ("dropout_p", C.c_float), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32),
-                ("layer_index", C.c_int32), ("seed_dev", C.c_void_p), ("grad_stream_bf16", C.c_int32), ("mx8_fwd", C.c_int32)]
+                ("layer_index", C.c_int32), ("seed_dev", C.c_void_p), ("grad_stream_bf16", C.c_int32), ("mx8_fwd", C.c_int32),
+                ("resid_bf16", C.c_int32)]
 
 
 PARAM_FIELDS = ("ln1_w", "ln1_b", "w_qkv", "w_out", "b_out", "ln2_w", "ln2_b", "w1", "b1", "w2", "b2")
@@ -68,6 +69,8 @@ SIGNATURES = {
     "avf_attn_bwd_qs": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     "avf_fuse_tokens": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     "avf_token_mean_fwd": (_int, [_vp, _vp, _int, _int, _int, _vp]),
+    "avf_token_mean_fwd_bf16": (_int, [_vp, _vp, _int, _int, _int, _vp]),
+    "avf_fuse_tokens_bf16": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     "avf_token_mean_bwd": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _vp]),
     "avf_au_loss": (_int, [_vp, _i64, _vp, _i64, _vp, _f, _int, _int, _vp, _vp, _vp]),
     "avf_au_loss_sum": (_int, [_vp, _i64, _vp, _i64, _vp, _f, _int, _int, _vp, _vp, _vp]),

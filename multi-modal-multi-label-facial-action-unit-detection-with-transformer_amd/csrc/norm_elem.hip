@@ -747,8 +747,9 @@ __global__ __launch_bounds__(256) void au_loss_kernel(const float* __restrict__ 
 constexpr int TOK_ROWS_PER_BLOCK = 4;
 
 // one workgroup per TOK_ROWS_PER_BLOCK token rows (row = b * T + t): no per-element index division
+template <typename OutT>  // float: float4 stores; bf16: the bf16 residual stream, 8-byte stores
 __global__ __launch_bounds__(256) void fuse_tokens_kernel(const float4* __restrict__ clip, const float4* __restrict__ audio,
-                                                         const float4* __restrict__ pos, float4* __restrict__ out, int Tv,
+                                                         const float4* __restrict__ pos, OutT* __restrict__ out, int Tv,
                                                          int Ta, int D4, int64_t rows) {
   const int T = Tv + Ta;
 #pragma unroll
@@ -759,20 +760,21 @@ __global__ __launch_bounds__(256) void fuse_tokens_kernel(const float4* __restri
     const int t = (int)(row - b * T);
     const float4* src = t < Tv ? clip + (b * Tv + t) * D4 : audio + (b * Ta + (t - Tv)) * D4;
     const float4* pr = pos ? pos + (int64_t)t * D4 : nullptr;
-    float4* dst = out + row * D4;
+    OutT* dst = out + row * D4 * 4;
     for (int c = threadIdx.x; c < D4; c += 256) {
       float4 v = src[c];
       if (pr) {
         const float4 p = pr[c];
         v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
       }
-      dst[c] = v;
+      store4<OutT>(dst + 4 * c, v);
     }
   }
 }
 
 // grid (ceil(D4/16), B); 256 threads = 16 float4 column groups x 16 token lanes
-__global__ __launch_bounds__(256) void token_mean_fwd_kernel(const float4* __restrict__ y, float4* __restrict__ out, int T,
+template <typename InT>
+__global__ __launch_bounds__(256) void token_mean_fwd_kernel(const InT* __restrict__ y, float4* __restrict__ out, int T,
                                                             int D4) {
   __shared__ float4 red[16][16];
   const int cg = threadIdx.x & 15, tl = threadIdx.x >> 4;
@@ -780,16 +782,17 @@ __global__ __launch_bounds__(256) void token_mean_fwd_kernel(const float4* __res
   const int64_t b = blockIdx.y;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < D4) {
-    const float4* base = y + b * T * D4 + c;
+    const InT* base = y + (b * T * D4 + c) * 4;
+    const int64_t ld = (int64_t)D4 * 4;
     int t = tl;
     for (; t + 48 < T; t += 64) {  // four independent loads in flight
-      const float4 v0 = base[(int64_t)t * D4], v1 = base[(int64_t)(t + 16) * D4], v2 = base[(int64_t)(t + 32) * D4],
-                   v3 = base[(int64_t)(t + 48) * D4];
+      const float4 v0 = load4<InT>(base + t * ld), v1 = load4<InT>(base + (t + 16) * ld), v2 = load4<InT>(base + (t + 32) * ld),
+                   v3 = load4<InT>(base + (t + 48) * ld);
       acc.x += (v0.x + v1.x) + (v2.x + v3.x); acc.y += (v0.y + v1.y) + (v2.y + v3.y);
       acc.z += (v0.z + v1.z) + (v2.z + v3.z); acc.w += (v0.w + v1.w) + (v2.w + v3.w);
     }
     for (; t < T; t += 16) {
-      const float4 v = base[(int64_t)t * D4];
+      const float4 v = load4<InT>(base + t * ld);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
   }
@@ -845,8 +848,23 @@ extern "C" int avf_fuse_tokens(const float* clip, const float* audio, const floa
               "fuse_tokens: pointers must be 16-byte aligned");
   const int64_t rows = (int64_t)batch * (t_video + t_audio);
   AVF_REQUIRE(ceil_div(rows, TOK_ROWS_PER_BLOCK) < (1LL << 31), "fuse_tokens: too many rows");
-  fuse_tokens_kernel<<<(unsigned)ceil_div(rows, TOK_ROWS_PER_BLOCK), 256, 0, (hipStream_t)stream>>>(
-      (const float4*)clip, (const float4*)audio, (const float4*)pos, (float4*)out, t_video, t_audio, dim / 4, rows);
+  fuse_tokens_kernel<float><<<(unsigned)ceil_div(rows, TOK_ROWS_PER_BLOCK), 256, 0, (hipStream_t)stream>>>(
+      (const float4*)clip, (const float4*)audio, (const float4*)pos, out, t_video, t_audio, dim / 4, rows);
+  return check_launch("fuse_tokens_kernel");
+}
+
+extern "C" int avf_fuse_tokens_bf16(const float* clip, const float* audio, const float* pos, void* out_bf16, int batch,
+                                    int t_video, int t_audio, int dim, void* stream) {
+  using namespace avf;
+  AVF_REQUIRE(out_bf16 && batch > 0 && t_video >= 0 && t_audio >= 0 && t_video + t_audio > 0 && (clip || t_video == 0) &&
+                  (audio || t_audio == 0) && dim > 0 && dim % 4 == 0,
+              "fuse_tokens_bf16: bad arguments (dim must be a multiple of 4)");
+  AVF_REQUIRE((((uintptr_t)clip | (uintptr_t)audio | (uintptr_t)pos) & 15) == 0 && ((uintptr_t)out_bf16 & 7) == 0,
+              "fuse_tokens_bf16: misaligned pointers");
+  const int64_t rows = (int64_t)batch * (t_video + t_audio);
+  AVF_REQUIRE(ceil_div(rows, TOK_ROWS_PER_BLOCK) < (1LL << 31), "fuse_tokens_bf16: too many rows");
+  fuse_tokens_kernel<bf16><<<(unsigned)ceil_div(rows, TOK_ROWS_PER_BLOCK), 256, 0, (hipStream_t)stream>>>(
+      (const float4*)clip, (const float4*)audio, (const float4*)pos, (bf16*)out_bf16, t_video, t_audio, dim / 4, rows);
   return check_launch("fuse_tokens_kernel");
 }
 
@@ -856,8 +874,18 @@ extern "C" int avf_token_mean_fwd(const float* y, float* out, int batch, int tok
               "token_mean_fwd: bad arguments (dim must be a multiple of 4)");
   AVF_REQUIRE((((uintptr_t)y | (uintptr_t)out) & 15) == 0, "token_mean_fwd: pointers must be 16-byte aligned");
   const int D4 = dim / 4;
-  token_mean_fwd_kernel<<<dim3((D4 + 15) / 16, batch), 256, 0, (hipStream_t)stream>>>((const float4*)y, (float4*)out, tokens,
-                                                                                       D4);
+  token_mean_fwd_kernel<float><<<dim3((D4 + 15) / 16, batch), 256, 0, (hipStream_t)stream>>>(y, (float4*)out, tokens, D4);
+  return check_launch("token_mean_fwd_kernel");
+}
+
+extern "C" int avf_token_mean_fwd_bf16(const void* y_bf16, float* out, int batch, int tokens, int dim, void* stream) {
+  using namespace avf;
+  AVF_REQUIRE(y_bf16 && out && batch > 0 && batch <= 65535 && tokens > 0 && dim > 0 && dim % 4 == 0,
+              "token_mean_fwd_bf16: bad arguments (dim must be a multiple of 4)");
+  AVF_REQUIRE(((uintptr_t)y_bf16 & 7) == 0 && ((uintptr_t)out & 15) == 0, "token_mean_fwd_bf16: misaligned pointers");
+  const int D4 = dim / 4;
+  token_mean_fwd_kernel<bf16><<<dim3((D4 + 15) / 16, batch), 256, 0, (hipStream_t)stream>>>((const bf16*)y_bf16, (float4*)out,
+                                                                                             tokens, D4);
   return check_launch("token_mean_fwd_kernel");
 }
 

@@ -124,44 +124,19 @@ class TwoStreamAuralVisualFormer(nn.Module, _TaskLossMixin):
         return out
 
 
-class _FuseTokens(torch.autograd.Function):
-    """tokens[b] = cat(clip[b], audio[b]) on the token axis + pos  (avf_fuse_tokens); d_pos = sum over the batch."""
-
-    @staticmethod
-    def forward(ctx, clip, audio, pos):
-        T = clip.shape[1] + audio.shape[1]
-        if pos.shape[-2] < T or pos.shape[-1] != clip.shape[-1]:
-            raise ValueError(f"pos_embedding {tuple(pos.shape)} does not cover {T} tokens of width {clip.shape[-1]}")
-        ctx.tv, ctx.shape_pos = clip.shape[1], pos.shape
-        p = pos.detach().reshape(pos.shape[-2], pos.shape[-1])[:T]
-        return ops.fuse_tokens(clip.detach().float(), audio.detach().float(), p)
-
-    @staticmethod
-    def backward(ctx, dy):
-        d_clip = dy[:, :ctx.tv] if ctx.needs_input_grad[0] else None
-        d_audio = dy[:, ctx.tv:] if ctx.needs_input_grad[1] else None
-        d_pos = None
-        if ctx.needs_input_grad[2]:
-            B, T, D = dy.shape
-            d_pos = ops.colsum(dy.contiguous().view(B, T * D)).view(T, D)
-            if ctx.shape_pos[-2] > T:  # embedding table longer than the sequence: the unused rows get zero gradient
-                d_pos = F.pad(d_pos, (0, 0, 0, ctx.shape_pos[-2] - T))
-            d_pos = d_pos.view(ctx.shape_pos)
-        return d_clip, d_audio, d_pos
-
-
 class SyntheticAVFormer(nn.Module, _TaskLossMixin):
     """BASELINE.json configs C2-C5: one Transformer(dim, depth, heads, dim_head, mlp_dim) over the fused
     [B, T_v + T_a, dim] token sequence, mean pooling, 12 AU logits in the reference's [B,21] layout."""
 
     def __init__(self, dim=512, depth=6, heads=8, dim_head=64, mlp_dim=1024, t_video=196, t_audio=128, task='AU',
-                 compute_dtype="bf16"):
+                 compute_dtype="bf16", residual_dtype="f32"):
         super().__init__()
         self.task = task
         self.modes = ['clip', 'audio_features']
         self.t_video, self.t_audio = t_video, t_audio
         self.pos_embedding = nn.Parameter(torch.randn(1, t_video + t_audio, dim) * 0.02)
-        self.transformer = Transformer(dim, depth, heads, dim_head, mlp_dim, 0.0, compute_dtype=compute_dtype)
+        self.transformer = Transformer(dim, depth, heads, dim_head, mlp_dim, 0.0, compute_dtype=compute_dtype,
+                                       residual_dtype=residual_dtype)
         self.au_fc = nn.Linear(dim, 12)
         self.loss_AU = AULoss()
 
@@ -169,8 +144,9 @@ class SyntheticAVFormer(nn.Module, _TaskLossMixin):
         # fusion on the SEQUENCE axis + positional embedding: cat([clip, audio], 1) + pos_embedding, then the stack and
         # y.mean(dim=1).  Widths that are a multiple of 4 take the one-pass library kernels for both ends.
         if x['clip'].shape[-1] % 4 == 0:
-            tokens = _FuseTokens.apply(x['clip'], x['audio_features'], self.pos_embedding)
-            pooled = self.transformer(tokens, pool='mean')
+            # (one library pass builds the sequence in the residual stream's storage type; its backward returns d clip,
+            # d audio and d pos_embedding from the fp32 gradient of the sequence)
+            pooled = self.transformer(x['clip'], pool='mean', fuse=(x['audio_features'], self.pos_embedding))
         else:
             tokens = torch.cat([x['clip'], x['audio_features']], dim=1)
             pooled = self.transformer(tokens + self.pos_embedding[:, :tokens.shape[1]]).mean(dim=1)

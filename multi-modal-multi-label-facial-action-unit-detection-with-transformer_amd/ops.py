@@ -279,8 +279,9 @@ def au_loss_sum(logits: torch.Tensor, labels: torch.Tensor, pos_weight: torch.Te
     return sc, grad
 
 
-def fuse_tokens(clip: torch.Tensor, audio: torch.Tensor, pos: Optional[torch.Tensor]) -> torch.Tensor:
-    """[B,Tv,D] ++ [B,Ta,D] on the token axis, + pos[Tv+Ta, D] (nullable): one pass (avf_fuse_tokens)."""
+def fuse_tokens(clip: torch.Tensor, audio: torch.Tensor, pos: Optional[torch.Tensor], out_bf16: bool = False) -> torch.Tensor:
+    """[B,Tv,D] ++ [B,Ta,D] on the token axis, + pos[Tv+Ta, D] (nullable): one pass (avf_fuse_tokens); out_bf16: the
+    result is written in bf16 (the storage type of a bf16 residual stream, avf_fuse_tokens_bf16)."""
     _need_cuda(clip, audio)
     clip, audio = clip.contiguous(), audio.contiguous()
     B, Tv, D = clip.shape
@@ -289,19 +290,20 @@ def fuse_tokens(clip: torch.Tensor, audio: torch.Tensor, pos: Optional[torch.Ten
     if pos is not None:
         pos = pos.contiguous()
         assert pos.numel() == (Tv + Ta) * D and pos.dtype == torch.float32
-    out = torch.empty((B, Tv + Ta, D), dtype=torch.float32, device=clip.device)
-    _lib.check(_lib.load().avf_fuse_tokens(_ptr(clip), _ptr(audio), _ptr(pos), _ptr(out), B, Tv, Ta, D, _stream()),
-               "fuse_tokens")
+    out = torch.empty((B, Tv + Ta, D), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=clip.device)
+    fn = _lib.load().avf_fuse_tokens_bf16 if out_bf16 else _lib.load().avf_fuse_tokens
+    _lib.check(fn(_ptr(clip), _ptr(audio), _ptr(pos), _ptr(out), B, Tv, Ta, D, _stream()), "fuse_tokens")
     return out
 
 
 def token_mean_fwd(y: torch.Tensor) -> torch.Tensor:
-    """[B,T,D] fp32 -> [B,D] mean over tokens."""
+    """[B,T,D] fp32 (or bf16: the bf16 residual stream) -> [B,D] fp32 mean over tokens."""
     _need_cuda(y)
     y = y.contiguous()
     B, T, D = y.shape
     out = torch.empty((B, D), dtype=torch.float32, device=y.device)
-    _lib.check(_lib.load().avf_token_mean_fwd(_ptr(y), _ptr(out), B, T, D, _stream()), "token_mean_fwd")
+    fn = _lib.load().avf_token_mean_fwd_bf16 if y.dtype == torch.bfloat16 else _lib.load().avf_token_mean_fwd
+    _lib.check(fn(_ptr(y), _ptr(out), B, T, D, _stream()), "token_mean_fwd")
     return out
 
 

@@ -22,7 +22,7 @@ from typing import Callable, List, Optional
 import torch
 from torch import nn
 
-from . import _lib
+from . import _lib, ops
 from .ops import avf_dtype
 
 PARAMS_PER_LAYER = 11
@@ -98,8 +98,19 @@ class _StackFn(torch.autograd.Function):
     """x -> L layers.  Saved activations live in per-layer byte buffers carved by the library."""
 
     @staticmethod
-    def forward(ctx, x, mod, pool, *params):
+    def forward(ctx, x, audio, pos, mod, pool, *params):
+        """audio / pos not None: x is the video token tensor and the stack's input is the fused sequence
+        cat([x, audio], 1) + pos (avformer.py:95-103 on the sequence axis), built by the library in the residual stream's
+        storage type; backward then hands d clip / d audio / d pos back from the fp32 gradient of that sequence."""
         lib = _lib.load()
+        ctx.fused = audio is not None
+        if ctx.fused:
+            T = x.shape[1] + audio.shape[1]
+            if pos.shape[-2] < T or pos.shape[-1] != x.shape[-1]:
+                raise ValueError(f"pos_embedding {tuple(pos.shape)} does not cover {T} tokens of width {x.shape[-1]}")
+            ctx.tv, ctx.shape_pos = x.shape[1], pos.shape
+            x = ops.fuse_tokens(x.detach().float(), audio.detach().float(),
+                                pos.detach().reshape(pos.shape[-2], pos.shape[-1])[:T], out_bf16=mod.resid_bf16)
         B, N, D = x.shape
         dev = x.device
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -109,12 +120,19 @@ class _StackFn(torch.autograd.Function):
         cfg = cfgs[0]
         params = [p.detach() for p in params]
         need_grad = any(ctx.needs_input_grad)  # (grad mode is off inside Function.forward)
+        ctx.grad_in = ctx.needs_input_grad[:3]
         saved_bytes = lib.avf_layer_saved_bytes(C.byref(cfg))
         if saved_bytes == 0:
             _lib.check(1, "layer configuration")
         ws = mod._workspace(lib, cfg, dev)
         lowps = mod._lowp(lib, cfg, params, dev, stream)
-        xs = [x.detach().contiguous().view(B * N, D)]
+        rs16 = bool(cfg.resid_bf16)
+        x0 = x.detach().contiguous().view(B * N, D)
+        if rs16 and x0.dtype != torch.bfloat16:  # the stream enters in bf16 (a caller may hand it over in bf16 already)
+            xb = torch.empty((B * N, D), dtype=torch.bfloat16, device=dev)
+            _lib.check(lib.avf_cast_f32_to_bf16(_ptr(x0), _ptr(xb), B * N * D, stream), "cast")
+            x0 = xb
+        xs = [x0]
         saved = []
         shared = None
         for l in range(L):
@@ -124,7 +142,7 @@ class _StackFn(torch.autograd.Function):
             else:
                 shared = shared if shared is not None else _alloc_bytes(saved_bytes, dev)
                 sv = shared
-            x_out = torch.empty((B * N, D), dtype=torch.float32, device=dev)
+            x_out = torch.empty((B * N, D), dtype=torch.bfloat16 if rs16 else torch.float32, device=dev)
             _lib.check(lib.avf_layer_fwd(C.byref(cfgs[l]), C.byref(pp), _ptr(lowps[l]), _ptr(xs[-1]), _ptr(x_out), _ptr(sv),
                                          _ptr(ws), stream), f"layer_fwd[{l}]")
             saved.append(sv)
@@ -141,9 +159,11 @@ class _StackFn(torch.autograd.Function):
         _check_canaries()
         if pool:  # token-mean pooling of the last layer's output, fused on the library side (heads that pool)
             pooled = torch.empty((B, D), dtype=torch.float32, device=dev)
-            _lib.check(lib.avf_token_mean_fwd(_ptr(xs[-1]), _ptr(pooled), B, N, D, stream), "token_mean_fwd")
+            fn = lib.avf_token_mean_fwd_bf16 if rs16 else lib.avf_token_mean_fwd
+            _lib.check(fn(_ptr(xs[-1]), _ptr(pooled), B, N, D, stream), "token_mean_fwd")
             return pooled
-        return xs[-1].view(B, N, D)
+        out = xs[-1].view(B, N, D)
+        return out.float() if rs16 else out  # the caller's interface stays fp32
 
     @staticmethod
     def backward(ctx, dy):
@@ -230,14 +250,26 @@ class _StackFn(torch.autograd.Function):
         _check_canaries()
         ctx.saved_bufs = None
         ctx.xs = None
-        return (dx.view(B, N, D), None, None, *([None] * (L * PARAMS_PER_LAYER)))
+        tail = (None, None, *([None] * (L * PARAMS_PER_LAYER)))
+        dx = dx.view(B, N, D)
+        if not ctx.fused:
+            return (dx, None, None) + tail
+        d_clip = dx[:, :ctx.tv] if ctx.grad_in[0] else None
+        d_audio = dx[:, ctx.tv:] if ctx.grad_in[1] else None
+        d_pos = None
+        if ctx.grad_in[2]:  # d pos = sum over the clips (fp32 column sums of the [B, T*D] view)
+            d_pos = ops.colsum(dx.view(B, N * D)).view(N, D)
+            if ctx.shape_pos[-2] > N:  # embedding table longer than the sequence: the unused rows get zero gradient
+                d_pos = torch.nn.functional.pad(d_pos, (0, 0, 0, ctx.shape_pos[-2] - N))
+            d_pos = d_pos.view(ctx.shape_pos)
+        return (d_clip, d_audio, d_pos) + tail
 
 
 class Transformer(nn.Module):
     """MI355X-native ``Transformer`` (reference models/heads.py:242-256)."""
     _instances = 0
 
-    def __init__(self, dim, depth, heads, dim_head, mlp_dim, dropout=0., compute_dtype="bf16"):
+    def __init__(self, dim, depth, heads, dim_head, mlp_dim, dropout=0., compute_dtype="bf16", residual_dtype="f32"):
         super().__init__()
         self.dim, self.depth, self.heads, self.dim_head, self.mlp_dim = dim, depth, heads, dim_head, mlp_dim
         self.dropout = float(dropout)
@@ -247,6 +279,16 @@ class Transformer(nn.Module):
             raise ValueError(f"compute_dtype='mx8' needs dim and mlp_dim to be multiples of 128 and dim <= 1536 "
                              f"(dim={dim}, mlp_dim={mlp_dim})")
         self.compute_dtype = _lib.BF16 if self.mx8 else avf_dtype(compute_dtype)
+        # residual_dtype="bf16" (throughput modes only): the forward residual stream x -> x + attn(..) -> x + mlp(..) is
+        # STORED in bf16 between the kernels (LayerNorm statistics, GEMM accumulation and the add itself stay fp32): a third
+        # fewer HBM bytes in the two LayerNorms and the two residual GEMM epilogues of a layer, for one bf16 rounding per
+        # residual add (tolerance in tests/test_gpu_resid16.py).  "f32" keeps the fp32 stream.
+        rd = str(residual_dtype).lower()
+        if rd not in ("f32", "fp32", "float32", "bf16", "bfloat16"):
+            raise ValueError(f"residual_dtype must be 'f32' or 'bf16', got {residual_dtype!r}")
+        self.resid_bf16 = rd in ("bf16", "bfloat16")
+        if self.resid_bf16 and (self.compute_dtype != _lib.BF16 or dim % 8 or dim > 1536):
+            raise ValueError("residual_dtype='bf16' needs compute_dtype 'bf16' / 'mx8', dim % 8 == 0 and dim <= 1536")
         self.project_out = not (heads == 1 and dim_head == dim)
         self.layers = nn.ModuleList([_make_layer(dim, heads, dim_head, mlp_dim, dropout) for _ in range(depth)])
         self._ws = None
@@ -303,7 +345,7 @@ class Transformer(nn.Module):
         return _lib.LayerCfg(B, N, self.dim, self.heads, self.dim_head, self.mlp_dim, self.compute_dtype,
                              int(self.project_out), 1e-5, float(p), 0, 0, layer,
                              seed_t.data_ptr() if (seed_t is not None and p != 0.0) else None,
-                             int(self._grad_stream_bf16(p)), int(self.mx8))
+                             int(self._grad_stream_bf16(p)), int(self.mx8), int(self.resid_bf16))
 
     def _grad_stream_bf16(self, p: float) -> bool:
         """backward keeps the residual gradient between the LayerNorm backward kernels in bf16 (the GEMMs read that image
@@ -393,10 +435,11 @@ class Transformer(nn.Module):
         self._lowp_ready = False
 
     # ---- forward -------------------------------------------------------------------------------
-    def forward(self, x, mask=None, pool=None):
+    def forward(self, x, mask=None, pool=None, fuse=None):
         """``pool='mean'`` (an addition to the reference signature) returns the token mean [B, dim] of the stack's output
         instead of [B, N, dim]: the pooling and its backward run inside the library (heads that pool, e.g.
-        SyntheticAVFormer)."""
+        SyntheticAVFormer).  ``fuse=(audio_tokens, pos_embedding)``: ``x`` holds the video tokens and the stack runs on
+        ``cat([x, audio], 1) + pos`` built by one library pass (dim % 4 == 0)."""
         if pool not in (None, 'mean'):
             raise ValueError(f"pool must be None or 'mean', got {pool!r}")
         if pool == 'mean' and self.dim % 4 != 0:
@@ -409,6 +452,13 @@ class Transformer(nn.Module):
                                "use oracle/ only as a test checker")
         if x.dim() != 3 or x.shape[-1] != self.dim:
             raise ValueError(f"expected [B, N, {self.dim}], got {tuple(x.shape)}")
+        audio = pos = None
+        if fuse is not None:
+            audio, pos = fuse
+            if self.dim % 4 != 0 or audio.dim() != 3 or audio.shape[0] != x.shape[0] or audio.shape[-1] != self.dim:
+                raise ValueError("fuse=(audio, pos) needs dim % 4 == 0 and audio tokens [B, T_a, dim]")
+            if x.shape[0] == 0 or x.shape[1] + audio.shape[1] == 0:
+                x, audio, pos = torch.cat([x, audio], 1) + pos[..., :x.shape[1] + audio.shape[1], :], None, None
         if x.shape[0] == 0 or x.shape[1] == 0:
             # empty batch / empty sequence: nothing to launch.  As in the reference (every op is per token), the result is
             # the empty tensor of the right shape; parameters receive zero gradients through the zero-weight sum
@@ -419,4 +469,4 @@ class Transformer(nn.Module):
             if p.dtype != torch.float32 or not p.is_cuda:
                 raise RuntimeError("Transformer (HIP): parameters must be fp32 tensors on the GPU (model.to('cuda'))")
         with torch.cuda.device(x.device):  # launches go to the input's device and its current stream
-            return _StackFn.apply(x.to(torch.float32), self, pool == 'mean', *params)
+            return _StackFn.apply(x.to(torch.float32), audio, pos, self, pool == 'mean', *params)
