@@ -187,6 +187,37 @@ int avf_token_mean_fwd_bf16(const void* y_bf16, float* out, int batch, int token
 int avf_token_mean_bwd(const float* g, float* dy, void* dy_bf16, float* colsum, int batch, int tokens, int dim,
                        void* stream);
 
+/* ---- token producers / consumers either side of the stack; fp32, one launch each ------------------
+ * avf_bn1d_fwd / _bwd: nn.BatchNorm1d of AU_former (heads.py:263,293) on x [batch, features].  training != 0: batch
+ *   statistics (and, when non-null, running_mean / running_var <- (1-momentum) r + momentum stat, unbiased variance, and
+ *   *num_batches_tracked += 1); training == 0: the running statistics.  y = (x - mean) * invstd * gamma + beta; mean /
+ *   invstd [features] are kept for backward.  Backward: dx (nullable), dgamma, dbeta (nullable) from dy.
+ * avf_token_dots_fwd / _bwd: the per-token bias-free Linear(emb, 1) heads (heads.py:325-337, tformer.py:389-401):
+ *   out[b, t] = tokens[b, t, :] . w[t, :] (w rows ldw apart); out rows are ldo apart and columns tokens_per_clip .. pad_to-1
+ *   are zeroed (the [B,21] layout of train.py:136-138).  Backward: dtokens (nullable), dw [tokens_per_clip, emb] rows lddw apart
+ *   (nullable).
+ * avf_assemble_tokens: out[b, t, :] = (t < n_lead ? lead[t, :] : x[b, t - n_lead, :]) + pos[t, :] (pos nullable) - TFormer's
+ *   cls token + positional table (vformer.py:279-287; n_lead = 1), or a bare positional add (n_lead = 0).
+ * avf_cat_features: out[b, t, :] = concat(a[b, t, :emb_a], v[b, t, :emb_v]) + pos[t, :] - avformer.py:100 + tformer.py:383-386.
+ * avf_transpose_add: in [batch, rows, cols] -> out [batch, cols, rows] (+ pos [cols, rows], nullable): the feature-map <-> token
+ *   permutes of ResFormer.forward (sformer.py:316-318, 326-327).
+ * avf_zero_cols: out[r, c0..c1) = 0. */
+int avf_bn1d_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                 int64_t* num_batches_tracked, float* y, float* mean, float* invstd, int batch, int features, float eps,
+                 float momentum, int training, void* stream);
+int avf_bn1d_bwd(const float* x, const float* dy, const float* gamma, const float* mean, const float* invstd, float* dx,
+                 float* dgamma, float* dbeta, int batch, int features, int training, void* stream);
+int avf_token_dots_fwd(const float* tokens, const float* w, int64_t ldw, float* out, int64_t ldo, int pad_to, int batch,
+                       int tokens_per_clip, int emb, void* stream);
+int avf_token_dots_bwd(const float* dout, int64_t ldo, const float* tokens, const float* w, int64_t ldw, float* dtokens,
+                       float* dw, int64_t lddw, int batch, int tokens_per_clip, int emb, void* stream);
+int avf_assemble_tokens(const float* x, const float* lead, const float* pos, float* out, int batch, int patches, int n_lead,
+                        int dim, void* stream);
+int avf_cat_features(const float* a, const float* v, const float* pos, float* out, int batch, int tokens_per_clip, int emb_a,
+                     int emb_v, void* stream);
+int avf_transpose_add(const float* in, const float* pos, float* out, int batch, int rows, int cols, void* stream);
+int avf_zero_cols(float* out, int64_t ld, int rows, int c0, int c1, void* stream);
+
 /* AULoss - loss.py:63-103.  logits/labels fp32 [rows, 12] (ld given); rows whose FIRST label == ignore
  * are dropped; loss[0] = mean over kept rows x 12 of BCE-with-logits(pos_weight); grad_unit [rows,12]
  * (contiguous) = d loss / d logits.  All rows dropped => NaN (as the reference). */

@@ -72,6 +72,14 @@ SIGNATURES = {
     "avf_token_mean_fwd_bf16": (_int, [_vp, _vp, _int, _int, _int, _vp]),
     "avf_fuse_tokens_bf16": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     "avf_token_mean_bwd": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _vp]),
+    "avf_bn1d_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _f, _f, _int, _vp]),
+    "avf_bn1d_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _vp]),
+    "avf_token_dots_fwd": (_int, [_vp, _vp, _i64, _vp, _i64, _int, _int, _int, _int, _vp]),
+    "avf_token_dots_bwd": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _int, _int, _int, _vp]),
+    "avf_assemble_tokens": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
+    "avf_cat_features": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
+    "avf_transpose_add": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp]),
+    "avf_zero_cols": (_int, [_vp, _i64, _int, _int, _int, _vp]),
     "avf_au_loss": (_int, [_vp, _i64, _vp, _i64, _vp, _f, _int, _int, _vp, _vp, _vp]),
     "avf_au_loss_sum": (_int, [_vp, _i64, _vp, _i64, _vp, _f, _int, _int, _vp, _vp, _vp]),
     "avf_layer_saved_bytes": (_sz, [C.POINTER(LayerCfg)]),

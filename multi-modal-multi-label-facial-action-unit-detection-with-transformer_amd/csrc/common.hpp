@@ -395,6 +395,7 @@ struct GemmArgs {
 size_t gemm_ws(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K);
 int gemm(const GemmArgs& a, hipStream_t s);
 int gemm_f32(const GemmArgs& a, hipStream_t s);
+size_t gemm_f32_ws(int64_t M, int64_t N, int64_t K);  // split-K slabs of skinny shapes (0: no split)
 int gemm_bf16_nt(const GemmArgs& a, hipStream_t s);
 int gemm_bf16_tn(const GemmArgs& a, hipStream_t s);
 // MX-FP8 NT GEMM (gemm_mx8.hip): A, B are e4m3 byte images (lda, ldb in bytes), scales [rows][K/32] E8M0 bytes

@@ -183,6 +183,12 @@ size_t carve_work(const Dims& d, void* base, Work* w) {
     TnGroupArgs ga = dw_group(d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     const size_t gg = gemm_bf16_tn_group_ws(ga);
     g = g > gg ? g : gg;
+  } else {  // parity mode: the weight-gradient GEMMs of narrow layers split their long token reduction (gemm_f32_ws)
+    const size_t a = gemm_f32_ws(3 * d.I, d.D, d.R), b = gemm_f32_ws(d.D, d.I, d.R);
+    const size_t e = gemm_f32_ws(d.M, d.D, d.R), f = gemm_f32_ws(d.D, d.M, d.R);
+    g = a > b ? a : b;
+    g = g > e ? g : e;
+    g = g > f ? g : f;
   }
   t.gemm_ws = c.take(g);
   if (d.mx) {
@@ -255,6 +261,7 @@ int linear_dw(const Dims& d, const void* dY, int out, const void* X, int in, flo
 
 size_t gemm_ws(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K) {
   if (dtype == AVF_BF16 && transA == 1 && transB == 0) return gemm_bf16_tn_ws(M, N, K);
+  if (dtype == AVF_F32) return gemm_f32_ws(M, N, K);
   return 0;
 }
 

@@ -9,27 +9,203 @@ HIP ``Transformer``:
 * ``ResFormerTokens``  - the token section of ``ResFormer.forward``, reference models/sformer.py:313-327
                          (= vformer.py:245-259, tformer.py:246-260); the conv stages around it are out of scope
 
-The glue outside the block (BatchNorm1d, the 12 small projections, the 12 per-token dots, cls/pos
-assembly) is plain PyTorch on the GPU in this version ("next"); the 24
-``nn.Linear`` holders keep the reference's parameter names so its checkpoints load.
+Everything outside the block runs in the library too (csrc/heads.hip + the parity GEMM), fp32:
+BatchNorm1d (batch statistics / running statistics and their update), the 12 projections as ONE GEMM on the concatenated
+weights with bias and positional table in its epilogue, the 12 per-token dots, cls / positional assembly, the
+feature-axis fusion of avformer.py:100, the feature-map <-> token permutes.  The 24 ``nn.Linear`` holders keep the
+reference's parameter names so its checkpoints load; ``_FlatGroup`` keeps their storage adjacent so that no
+concatenation runs per step.
 """
 from __future__ import annotations
+
+from typing import List, Optional
 
 import torch
 from torch import nn
 
+from . import ops
 from .transformer import Transformer
+
+
+def _need_gpu(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what} (HIP) needs its input on the MI355X; there is no CPU fallback - "
+                           "use oracle/ only as a test checker")
+
+
+class _FlatGroup:
+    """Keeps the ``.data`` of same-shaped Parameters as consecutive slices of ONE buffer, so that a group of small
+    ``nn.Linear`` layers is one GEMM operand without a per-step concatenation.  The Parameters stay the objects the
+    optimizer and ``state_dict`` know; only their storage is re-pointed (``p.data = flat[i]``).  ``Module.to`` /
+    ``.cuda()`` give every Parameter fresh storage: the next ``get()`` notices (addresses are no longer adjacent) and
+    re-packs once."""
+
+    def __init__(self, params: List[nn.Parameter]):
+        self.params = params
+        self.flat: Optional[torch.Tensor] = None
+
+    def get(self) -> torch.Tensor:
+        ps = self.params
+        p0 = ps[0]
+        step = p0.numel() * p0.element_size()
+        f = self.flat
+        if (f is None or f.device != p0.device or f.dtype != p0.dtype
+                or any(p.data_ptr() != f.data_ptr() + i * step for i, p in enumerate(ps))):
+            f = torch.empty((len(ps),) + tuple(p0.shape), dtype=p0.dtype, device=p0.device)
+            with torch.no_grad():
+                for i, p in enumerate(ps):
+                    f[i].copy_(p.data)
+                    p.data = f[i]
+            self.flat = f
+        return f
+
+
+class _FrontFn(torch.autograd.Function):
+    """AU_former's front (heads.py:291-323): BatchNorm1d -> 12 x Linear(in, E) -> [B, 12, E] + pos_embedding"""
+
+    @staticmethod
+    def forward(ctx, x, mod, bn_w, bn_b, pos, *wb):
+        bn = mod.AU_BN1
+        training = bool(bn.training or bn.running_mean is None)
+        x = x.detach().float().contiguous()
+        B = x.shape[0]
+        E = pos.shape[-1]
+        y, mean, invstd = ops.bn1d_fwd(x, bn_w.detach(), bn_b.detach(), bn.running_mean, bn.running_var,
+                                       bn.num_batches_tracked if bn.training else None, bn.eps,
+                                       0.1 if bn.momentum is None else bn.momentum, training)
+        W = mod._proj_w.get().view(12 * E, -1)   # [12 E, in]: token i = rows i*E .. (i+1)*E (cat on dim 1, heads.py:318-319)
+        bias = mod._proj_b.get().view(12 * E)
+        tokens = ops.gemm(y, W, epilogue=ops.EPI_BIAS_RES, bias=bias, residual=pos.detach().reshape(12 * E), residual_ld=0)
+        ctx.save_for_backward(x, y, mean, invstd, bn_w.detach(), W)
+        ctx.training, ctx.E = training, E
+        return tokens.view(B, 12, E)
+
+    @staticmethod
+    def backward(ctx, dtok):
+        x, y, mean, invstd, bn_w, W = ctx.saved_tensors
+        E = ctx.E
+        B = x.shape[0]
+        dt = dtok.contiguous().view(B, 12 * E)
+        dbias = ops.colsum(dt)                                   # [12 E]: the 12 bias gradients, concatenated
+        dpos = ops.colsum(dt).view(1, 12, E) if ctx.needs_input_grad[4] else None  # same sums, own storage (no aliased .grad)
+        dW = ops.gemm(dt, y, trans_a=True, trans_b=False)        # [12 E, in]
+        dy = ops.gemm(dt, W, trans_b=False)                      # [B, in]
+        dx, dg, db = ops.bn1d_bwd(x, dy, bn_w, mean, invstd, ctx.training, need_dx=ctx.needs_input_grad[0])
+        gw = [dW[i * E:(i + 1) * E] for i in range(12)]
+        gb = [dbias[i * E:(i + 1) * E] for i in range(12)]
+        return (dx, None, dg, db, dpos, *gw, *gb)
+
+
+class _DotsFn(torch.autograd.Function):
+    """the 12 per-token bias-free Linear(E, 1) heads (heads.py:325-337): logits[b, i] = tokens[b, i, :] . w_i, written into
+    a [B, pad_to] row (columns 12.. zero: the [B,21] layout)"""
+
+    @staticmethod
+    def forward(ctx, tokens, mod, pad_to, *w):
+        tokens = tokens.detach().float().contiguous()
+        W = mod._last_w.get().view(12, -1)
+        ctx.save_for_backward(tokens, W)
+        return ops.token_dots_fwd(tokens, W, pad_to)
+
+    @staticmethod
+    def backward(ctx, dout):
+        tokens, W = ctx.saved_tensors
+        dtok, dw = ops.token_dots_bwd(dout, tokens, W, need_dtokens=ctx.needs_input_grad[0])
+        return (dtok, None, None, *[dw[i:i + 1] for i in range(12)])
+
+
+class _AssembleFn(torch.autograd.Function):
+    """out[b] = cat(lead, x[b]) + pos  (TFormer: lead = cls_token, vformer.py:279-287; lead None: a bare positional add)"""
+
+    @staticmethod
+    def forward(ctx, x, lead, pos):
+        ctx.n_lead = 0 if lead is None else lead.numel() // x.shape[-1]
+        ctx.shapes = (None if lead is None else lead.shape, pos.shape)
+        T = x.shape[1] + ctx.n_lead
+        return ops.assemble_tokens(x.detach().float(), None if lead is None else lead.detach(),
+                                   pos.detach().reshape(pos.shape[-2], pos.shape[-1])[:T])
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, T, D = dout.shape
+        dout = dout.contiguous()
+        lead_shape, pos_shape = ctx.shapes
+        dx = dout[:, ctx.n_lead:] if ctx.needs_input_grad[0] else None
+        dlead = None
+        if ctx.n_lead and ctx.needs_input_grad[1]:
+            dlead = ops.colsum(dout.view(B, T * D)[:, :ctx.n_lead * D]).view(lead_shape)
+        dpos = None
+        if ctx.needs_input_grad[2]:
+            dpos = ops.colsum(dout.view(B, T * D)).view(T, D)
+            if pos_shape[-2] > T:
+                dpos = torch.nn.functional.pad(dpos, (0, 0, 0, pos_shape[-2] - T))
+            dpos = dpos.view(pos_shape)
+        return dx, dlead, dpos
+
+
+class _CatFeaturesFn(torch.autograd.Function):
+    """features = cat([a, v], dim=2) + pos  (avformer.py:100 then tformer.py:383-386)"""
+
+    @staticmethod
+    def forward(ctx, a, v, pos):
+        ctx.ea = a.shape[2]
+        ctx.pos_shape = pos.shape
+        return ops.cat_features(a.detach().float(), v.detach().float(), pos.detach().reshape(pos.shape[-2], pos.shape[-1]))
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, T, E = dout.shape
+        dout = dout.contiguous()
+        da = dout[..., :ctx.ea] if ctx.needs_input_grad[0] else None
+        dv = dout[..., ctx.ea:] if ctx.needs_input_grad[1] else None
+        dpos = ops.colsum(dout.view(B, T * E)).view(ctx.pos_shape) if ctx.needs_input_grad[2] else None
+        return da, dv, dpos
+
+
+class _MapToTokensFn(torch.autograd.Function):
+    """[B, C, h*w] -> [B, h*w, C] + pos  (sformer.py:316-318)"""
+
+    @staticmethod
+    def forward(ctx, x, pos):
+        ctx.pos_shape = pos.shape
+        S = x.shape[2]
+        return ops.transpose_add(x.detach().float(), pos.detach().reshape(pos.shape[-2], pos.shape[-1])[:S])
+
+    @staticmethod
+    def backward(ctx, dt):
+        B, S, Cn = dt.shape
+        dt = dt.contiguous()
+        dx = ops.transpose_add(dt, None) if ctx.needs_input_grad[0] else None
+        dpos = None
+        if ctx.needs_input_grad[1]:
+            dpos = ops.colsum(dt.view(B, S * Cn)).view(S, Cn)
+            if ctx.pos_shape[-2] > S:
+                dpos = torch.nn.functional.pad(dpos, (0, 0, 0, ctx.pos_shape[-2] - S))
+            dpos = dpos.view(ctx.pos_shape)
+        return dx, dpos
+
+
+class _TokensToMapFn(torch.autograd.Function):
+    """[B, S, C] -> [B, C, S]  (sformer.py:326-327)"""
+
+    @staticmethod
+    def forward(ctx, t):
+        return ops.transpose_add(t.detach().float(), None)
+
+    @staticmethod
+    def backward(ctx, dx):
+        return ops.transpose_add(dx.contiguous(), None)
 
 
 class _AUHeadBase(nn.Module):
     def _make_last(self, emb_dim):
         for i in range(1, 13):
             setattr(self, f"AU_linear_last{i}", nn.Linear(emb_dim, 1, bias=False))
+        self._last_w = _FlatGroup([getattr(self, f"AU_linear_last{i}").weight for i in range(1, 13)])
 
-    def _last_logits(self, tokens):
+    def _last_logits(self, tokens, pad_to=None):
         # token i -> bias-free Linear(emb,1) number i+1  == batched row-dot [B,12,E] . [12,E]
-        w = torch.cat([getattr(self, f"AU_linear_last{i}").weight for i in range(1, 13)], dim=0)  # [12, E]
-        return (tokens * w.unsqueeze(0)).sum(dim=-1)
+        return _DotsFn.apply(tokens, self, pad_to, *self._last_w.params)
 
 
 class AU_former(_AUHeadBase):
@@ -43,15 +219,18 @@ class AU_former(_AUHeadBase):
         self.corr_transformer = Transformer(emb_dim, depth=2, heads=8, mlp_dim=256, dim_head=32, dropout=dropout,
                                             compute_dtype=compute_dtype)
         self._make_last(emb_dim)
+        self._proj_w = _FlatGroup([getattr(self, f"AU_linear_p{i}").weight for i in range(1, 13)])
+        self._proj_b = _FlatGroup([getattr(self, f"AU_linear_p{i}").bias for i in range(1, 13)])
+
+    def tokens(self, emb):
+        """the AU tokens [B, 12, E] after the correlation transformer (what avformer.py:96-99 keeps of this head)"""
+        _need_gpu(emb, "AU_former")
+        bn = self.AU_BN1
+        tokens = _FrontFn.apply(emb, self, bn.weight, bn.bias, self.pos_embedding, *self._proj_w.params, *self._proj_b.params)
+        return self.corr_transformer(tokens)
 
     def forward(self, emb):
-        bs = emb.shape[0]
-        emb = self.AU_BN1(emb)
-        w = torch.cat([getattr(self, f"AU_linear_p{i}").weight for i in range(1, 13)], dim=0)  # [12*E, in]
-        b = torch.cat([getattr(self, f"AU_linear_p{i}").bias for i in range(1, 13)], dim=0)
-        tokens = torch.nn.functional.linear(emb, w, b).view(bs, 12, -1)  # heads.py:318-319
-        tokens = tokens + self.pos_embedding[:, :12]
-        out = self.corr_transformer(tokens)
+        out = self.tokens(emb)
         return self._last_logits(out), out
 
 
@@ -63,12 +242,18 @@ class tformer_AU_head(_AUHeadBase):
                                             compute_dtype=compute_dtype)
         self._make_last(emb_dim)
 
-    def forward(self, input):
+    def forward(self, input, pad_to=None):
+        _need_gpu(input, "tformer_AU_head")
         bs = input.shape[0]
-        tokens = input.reshape(bs, 12, -1)
-        tokens = tokens + self.pos_embedding[:, :12]
-        out = self.corr_transformer(tokens)
-        return self._last_logits(out)
+        tokens = _AssembleFn.apply(input.reshape(bs, 12, -1), None, self.pos_embedding)
+        return self._last_logits(self.corr_transformer(tokens), pad_to)
+
+    def forward_fused(self, a_tokens, v_tokens, pad_to=None):
+        """``forward(cat([a_tokens, v_tokens], dim=2))`` with the concatenation and the positional add in one pass, and the
+        logits written into a zero-padded [B, pad_to] row (avformer.py:100-105)"""
+        _need_gpu(a_tokens, "tformer_AU_head")
+        tokens = _CatFeaturesFn.apply(a_tokens, v_tokens, self.pos_embedding)
+        return self._last_logits(self.corr_transformer(tokens), pad_to)
 
 
 class former_AU_head(tformer_AU_head):
@@ -89,10 +274,9 @@ class TFormer(nn.Module):
                                                compute_dtype=compute_dtype)
 
     def forward(self, x):
+        _need_gpu(x, "TFormer")
         x = x.contiguous().view(-1, self.num_patches, self.dim)
-        b, n, _ = x.shape
-        x = torch.cat((self.cls_token.expand(b, -1, -1), x), dim=1)
-        x = x + self.pos_embedding[:, :(n + 1)]
+        x = _AssembleFn.apply(x, self.cls_token, self.pos_embedding)   # cat(cls, x) + pos[:, :n+1], vformer.py:282-284
         x = self.spatial_transformer(x)
         return x[:, 0]
 
@@ -112,8 +296,8 @@ class ResFormerTokens(nn.Module):
                                                compute_dtype=compute_dtype)
 
     def forward(self, x):
+        _need_gpu(x, "ResFormerTokens")
         b_l, c, h, w = x.shape
-        t = x.reshape((b_l, c, h * w)).permute(0, 2, 1)
-        t = t + self.pos_embedding[:, :t.shape[1]]
+        t = _MapToTokensFn.apply(x.reshape(b_l, c, h * w), self.pos_embedding)   # permute(0,2,1) + pos, sformer.py:316-318
         t = self.spatial_transformer(t)
-        return t.permute(0, 2, 1).reshape((b_l, c, h, w))
+        return _TokensToMapFn.apply(t).reshape(b_l, c, h, w)                      # sformer.py:326-327

@@ -43,8 +43,7 @@ class AudioFormer(nn.Module):
         self.au_head = AU_former(dropout=0.2, compute_dtype=compute_dtype)
 
     def forward(self, x):
-        _, tokens = self.au_head(self.audio_model(x))
-        return tokens
+        return self.au_head.tokens(self.audio_model(x))  # avformer.py:96: only the tokens of this head are used
 
 
 class VisualFormer(nn.Module):
@@ -57,8 +56,7 @@ class VisualFormer(nn.Module):
         self.au_head = AU_former(input_dim=in_features, compute_dtype=compute_dtype)
 
     def forward(self, x):
-        _, tokens = self.au_head(self.video_model(x))
-        return tokens
+        return self.au_head.tokens(self.video_model(x))  # avformer.py:99
 
 
 class _TaskLossMixin:
@@ -117,11 +115,35 @@ class TwoStreamAuralVisualFormer(nn.Module, _TaskLossMixin):
         else:
             audio_tok = self.audio_model(a_in)
             video_tok = self.video_model(v_in)
-        features = torch.cat([audio_tok, video_tok], dim=2)  # fusion on the FEATURE axis, avformer.py:100
-        out = torch.zeros(features.shape[0], 21, device=features.device, dtype=features.dtype)
         if self.task == 'AU':
-            out[:, :12] = self.au_head(features)
+            # fusion on the FEATURE axis (avformer.py:100) + the head's positional add in one pass; the 12 logits land in
+            # a zero-padded [B, 21] row (avformer.py:101-105)
+            return self.au_head.forward_fused(audio_tok, video_tok, pad_to=21)
+        return torch.zeros(audio_tok.shape[0], 21, device=audio_tok.device, dtype=torch.float32)
+
+
+class _LinearPadFn(torch.autograd.Function):
+    """out[:, :O] = x W^T + b, out[:, O:width] = 0 - the AU logits Linear written straight into the reference's [B,21] row"""
+
+    @staticmethod
+    def forward(ctx, x, w, b, width):
+        x = x.detach().float().contiguous()
+        out = torch.empty((x.shape[0], width), dtype=torch.float32, device=x.device)
+        O = w.shape[0]
+        ops.gemm(x, w.detach(), bias=b.detach(), out=out[:, :O])  # the fp32 kernel adds a non-null bias in every epilogue
+        ops.zero_cols(out, O, width)
+        ctx.save_for_backward(x, w.detach())
+        ctx.O = O
         return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w = ctx.saved_tensors
+        dl = dout[:, :ctx.O]                                        # row stride `width`: read in place
+        dw = ops.gemm(dl, x, trans_a=True, trans_b=False) if ctx.needs_input_grad[1] else None
+        db = ops.colsum(dl) if ctx.needs_input_grad[2] else None
+        dx = ops.gemm(dl, w, trans_b=False) if ctx.needs_input_grad[0] else None
+        return dx, dw, db, None
 
 
 class SyntheticAVFormer(nn.Module, _TaskLossMixin):
@@ -150,8 +172,8 @@ class SyntheticAVFormer(nn.Module, _TaskLossMixin):
         else:
             tokens = torch.cat([x['clip'], x['audio_features']], dim=1)
             pooled = self.transformer(tokens + self.pos_embedding[:, :tokens.shape[1]]).mean(dim=1)
-        logits = self.au_fc(pooled)
-        return F.pad(logits, (0, 21 - logits.shape[1]))  # the reference's [B,21] layout: AU logits in slots 0..11
+        # the reference's [B,21] layout: AU logits in slots 0..11, the rest zero
+        return _LinearPadFn.apply(pooled, self.au_fc.weight, self.au_fc.bias, 21)
 
 
 # name -> class, as the if/elif chain in the reference's train.py:292-315 does for --model_name

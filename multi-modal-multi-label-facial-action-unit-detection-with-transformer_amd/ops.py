@@ -89,14 +89,18 @@ def layernorm_bwd(dy, x, weight, mean, rstd, dres=None, want_lo=False, want_cols
 
 
 def colsum(t: torch.Tensor) -> torch.Tensor:
+    """column sums over all leading axes; a 2-D view whose rows are a constant stride apart (unit column stride) is read
+    in place"""
     _need_cuda(t)
     lib = _lib.load()
-    t = t.contiguous()
+    if not (t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]):
+        t = t.contiguous()
     cols = t.shape[-1]
     rows = t.numel() // cols
+    ld = t.stride(0) if t.dim() == 2 else cols
     out = torch.empty(cols, dtype=torch.float32, device=t.device)
     ws = _bytes(lib.avf_colsum_workspace_bytes(rows, cols), t.device)
-    _lib.check(lib.avf_colsum(_ptr(t), avf_dtype(t.dtype), rows, cols, cols, _ptr(out), _ptr(ws), _stream()), "colsum")
+    _lib.check(lib.avf_colsum(_ptr(t), avf_dtype(t.dtype), rows, cols, ld, _ptr(out), _ptr(ws), _stream()), "colsum")
     return out
 
 
@@ -118,14 +122,23 @@ def prep_weight_bf16(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     return lo, lo_t
 
 
+def _rows2d(t: torch.Tensor) -> torch.Tensor:
+    """a 2-D operand as the library takes it: unit column stride, rows a constant stride (>= width) apart; else a copy"""
+    if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]:
+        return t
+    return t.contiguous()
+
+
 def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = True, out_dtype=None,
          epilogue: int = EPI_NONE, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-         aux: Optional[torch.Tensor] = None):
-    """C = op(A) op(B) with a fused epilogue.  Returns C (and aux for EPI_BIAS_GELU)."""
+         aux: Optional[torch.Tensor] = None, residual_ld: Optional[int] = None, out: Optional[torch.Tensor] = None):
+    """C = op(A) op(B) with a fused epilogue.  Returns C (and aux for EPI_BIAS_GELU).  A / B may be row-strided 2-D views
+    (leading dimension = their row stride); residual_ld = 0 broadcasts one residual row over all rows (a positional
+    table); out: a preallocated, possibly row-strided [M, >= N] fp32 / bf16 view to write into."""
     _need_cuda(a, b, bias, residual, aux)
     lib = _lib.load()
-    a = a.contiguous()
-    b = b.contiguous()
+    a = _rows2d(a)
+    b = _rows2d(b)
     assert a.dtype == b.dtype
     dt = avf_dtype(a.dtype)
     M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
@@ -133,15 +146,20 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool 
     Kb = b.shape[1] if trans_b else b.shape[0]
     assert K == Kb, (a.shape, b.shape, trans_a, trans_b)
     cdt = torch_dtype(out_dtype) if out_dtype is not None else a.dtype
-    c = torch.empty((M, N), dtype=cdt, device=a.device)
+    if out is not None:
+        assert out.dim() == 2 and out.shape[0] == M and out.shape[1] >= N and out.stride(1) == 1 and out.dtype == cdt
+        c = out
+    else:
+        c = torch.empty((M, N), dtype=cdt, device=a.device)
     made_aux = None
     if epilogue == EPI_BIAS_GELU and aux is None:
         made_aux = aux = torch.empty((M, N), dtype=cdt, device=a.device)
     ws = _bytes(lib.avf_gemm_workspace_bytes(dt, int(trans_a), int(trans_b), M, N, K), a.device)
-    _lib.check(lib.avf_gemm(dt, int(trans_a), int(trans_b), M, N, K, _ptr(a), a.shape[1], _ptr(b), b.shape[1],
-                            _ptr(c), N, avf_dtype(cdt), epilogue, _ptr(bias),
-                            _ptr(residual.contiguous() if residual is not None else None), N,
-                            _ptr(aux), N, _ptr(ws), _stream()), "gemm")
+    if residual is not None and residual_ld is None:
+        residual = residual.contiguous()
+    _lib.check(lib.avf_gemm(dt, int(trans_a), int(trans_b), M, N, K, _ptr(a), a.stride(0), _ptr(b), b.stride(0),
+                            _ptr(c), c.stride(0), avf_dtype(cdt), epilogue, _ptr(bias), _ptr(residual),
+                            N if residual_ld is None else int(residual_ld), _ptr(aux), N, _ptr(ws), _stream()), "gemm")
     if made_aux is not None:
         return c, made_aux
     return c
@@ -248,6 +266,102 @@ def attn_bwd(qkv, o, d_o, lse2, batch: int, tokens: int, heads: int, dim_head: i
         _lib.check(lib.avf_attn_bwd(avf_dtype(qkv.dtype), _ptr(qkv), _ptr(o), _ptr(d_o), _ptr(lse2), _ptr(dqkv), _ptr(ws),
                                     batch, tokens, heads, dim_head, _stream()), "attn_bwd")
     return dqkv
+
+
+# ---- token producers / consumers either side of the stack (csrc/heads.hip) ---------------------------------------
+def bn1d_fwd(x, gamma, beta, running_mean, running_var, num_batches_tracked, eps: float, momentum: float, training: bool):
+    """nn.BatchNorm1d on [B, C] -> (y, mean, invstd); training updates the running statistics in place"""
+    _need_cuda(x, gamma, beta, running_mean, running_var)
+    x = x.contiguous()
+    B, Cn = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(Cn, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(Cn, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().avf_bn1d_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                        _ptr(num_batches_tracked), _ptr(y), _ptr(mean), _ptr(invstd), B, Cn, float(eps),
+                                        float(momentum), int(training), _stream()), "bn1d_fwd")
+    return y, mean, invstd
+
+
+def bn1d_bwd(x, dy, gamma, mean, invstd, training: bool, need_dx: bool = True):
+    """-> (dx or None, dgamma, dbeta)"""
+    _need_cuda(x, dy, gamma, mean, invstd)
+    x, dy = x.contiguous(), dy.contiguous()
+    B, Cn = x.shape
+    dx = torch.empty_like(x) if need_dx else None
+    dg = torch.empty(Cn, dtype=torch.float32, device=x.device)
+    db = torch.empty(Cn, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().avf_bn1d_bwd(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(mean), _ptr(invstd), _ptr(dx), _ptr(dg), _ptr(db),
+                                        B, Cn, int(training), _stream()), "bn1d_bwd")
+    return dx, dg, db
+
+
+def token_dots_fwd(tokens: torch.Tensor, w: torch.Tensor, pad_to: Optional[int] = None) -> torch.Tensor:
+    """tokens [B,T,E] . w [T,E] (row-strided ok) -> [B, pad_to or T], columns T.. zero"""
+    _need_cuda(tokens, w)
+    tokens = tokens.contiguous()
+    B, T, E = tokens.shape
+    w = _rows2d(w)
+    width = pad_to or T
+    out = torch.empty((B, width), dtype=torch.float32, device=tokens.device)
+    _lib.check(_lib.load().avf_token_dots_fwd(_ptr(tokens), _ptr(w), w.stride(0), _ptr(out), width, width, B, T, E, _stream()),
+               "token_dots_fwd")
+    return out
+
+
+def token_dots_bwd(dout: torch.Tensor, tokens: torch.Tensor, w: torch.Tensor, need_dtokens=True, need_dw=True):
+    _need_cuda(dout, tokens, w)
+    tokens = tokens.contiguous()
+    dout = _rows2d(dout)
+    B, T, E = tokens.shape
+    w = _rows2d(w)
+    dtok = torch.empty_like(tokens) if need_dtokens else None
+    dw = torch.empty((T, E), dtype=torch.float32, device=tokens.device) if need_dw else None
+    _lib.check(_lib.load().avf_token_dots_bwd(_ptr(dout), dout.stride(0), _ptr(tokens), _ptr(w), w.stride(0), _ptr(dtok), _ptr(dw),
+                                              E, B, T, E, _stream()), "token_dots_bwd")
+    return dtok, dw
+
+
+def assemble_tokens(x: torch.Tensor, lead: Optional[torch.Tensor], pos: Optional[torch.Tensor]) -> torch.Tensor:
+    """[B,P,D] (+ lead rows [n_lead,D] in front) + pos[n_lead+P, D] -> [B, n_lead+P, D]"""
+    _need_cuda(x, lead, pos)
+    x = x.contiguous()
+    B, P, D = x.shape
+    n_lead = 0 if lead is None else lead.numel() // D
+    out = torch.empty((B, P + n_lead, D), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().avf_assemble_tokens(_ptr(x), _ptr(lead.contiguous() if lead is not None else None),
+                                               _ptr(pos.contiguous() if pos is not None else None), _ptr(out), B, P, n_lead, D,
+                                               _stream()), "assemble_tokens")
+    return out
+
+
+def cat_features(a: torch.Tensor, v: torch.Tensor, pos: Optional[torch.Tensor]) -> torch.Tensor:
+    """[B,T,Ea] ++ [B,T,Ev] on the feature axis + pos[T, Ea+Ev]"""
+    _need_cuda(a, v, pos)
+    a, v = a.contiguous(), v.contiguous()
+    B, T, Ea = a.shape
+    Ev = v.shape[2]
+    out = torch.empty((B, T, Ea + Ev), dtype=torch.float32, device=a.device)
+    _lib.check(_lib.load().avf_cat_features(_ptr(a), _ptr(v), _ptr(pos.contiguous() if pos is not None else None), _ptr(out), B, T,
+                                            Ea, Ev, _stream()), "cat_features")
+    return out
+
+
+def transpose_add(x: torch.Tensor, pos: Optional[torch.Tensor]) -> torch.Tensor:
+    """[B, R, C] -> [B, C, R] (+ pos [C, R])"""
+    _need_cuda(x, pos)
+    x = x.contiguous()
+    B, R, Cn = x.shape
+    out = torch.empty((B, Cn, R), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().avf_transpose_add(_ptr(x), _ptr(pos.contiguous() if pos is not None else None), _ptr(out), B, R, Cn,
+                                             _stream()), "transpose_add")
+    return out
+
+
+def zero_cols(t: torch.Tensor, c0: int, c1: int):
+    _need_cuda(t)
+    assert t.dim() == 2 and t.stride(1) == 1 and t.dtype == torch.float32
+    _lib.check(_lib.load().avf_zero_cols(_ptr(t), t.stride(0), t.shape[0], c0, c1, _stream()), "zero_cols")
 
 
 def au_loss(logits: torch.Tensor, labels: torch.Tensor, pos_weight: torch.Tensor, ignore: float = -1.0):

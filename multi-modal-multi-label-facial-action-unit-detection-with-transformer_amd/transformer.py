@@ -305,6 +305,20 @@ class Transformer(nn.Module):
         Transformer._instances += 1
         self._seed_salt = Transformer._instances
 
+    # per-process caches (ctypes structs, device scratch, bf16 weight images): never copied or pickled with the module
+    _CACHES = {"_ws": None, "_lowp_bufs": None, "_lowp_ptrs": None, "_lowp_versions": None, "_lowp_ready": False,
+               "_seed_dev": None, "_last_seed_t": None}
+    _LAZY_CACHES = ("_pstruct_cache", "_mx_ptr_array", "_flat_cache")  # created on first use
+
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        for k, v in self._CACHES.items():
+            if k in d:
+                d[k] = v
+        for k in self._LAZY_CACHES:
+            d.pop(k, None)
+        return d
+
     # ---- parameter plumbing --------------------------------------------------------------------
     def layer_parameters(self, l: int) -> List[torch.Tensor]:
         """The 11 tensors of layer ``l`` in state_dict order."""
