@@ -301,6 +301,12 @@ def main():
         # plain `python bench.py --gpus N`: become the launcher.  Nothing above imported torch or touched the GPU.
         sys.exit(spawn_ranks(args.gpus))
     os.dup2(2, 1)  # worker: everything but the result line (written to the saved descriptor) goes to stderr
+    if os.environ.get("AVF_BENCH_DRYRUN") == "1":
+        # launcher rehearsal without GPUs (tests/test_bench_cpu.py): report the rendezvous this rank was handed, touch nothing
+        if int(os.environ.get("RANK", "0")) == 0:
+            os.write(_REAL_STDOUT, (json.dumps({"dryrun": True, "world": int(os.environ.get("WORLD_SIZE", "1")),
+                                                "master": os.environ.get("MASTER_ADDR"), "n_gpus": args.gpus}) + "\n").encode())
+        return
 
     import torch
     import torch.distributed as dist

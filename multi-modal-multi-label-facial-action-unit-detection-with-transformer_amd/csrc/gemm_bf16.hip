@@ -382,6 +382,7 @@ struct TnProblem {
 struct TnGroup {
   TnProblem p[4];
   int nprob, K, kchunk, S, total_tiles;
+  int xcd_groups;  // 256 x 128 kernel: > 0 = XCD-aware block order (see gemm_bf16_tn_group_big_kernel), 0 = tile-major ids
 };
 
 __device__ __forceinline__ bf16x8_t tr_frag_swz(const lds_char* tile, int row_base, int col_base, int li, int lg) {
@@ -539,7 +540,24 @@ __global__ __launch_bounds__(512) void gemm_bf16_tn_group_big_kernel(TnGroup g) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 15, lg = lane >> 4;
-  const int tile = blockIdx.x / g.S, split = blockIdx.x - tile * g.S;
+  // Block -> (tile, split).  Workgroups are dealt to the 8 XCDs round-robin (ids congruent mod 8 share an L2 - a speed
+  // assumption only).  With S splits dividing 8, XCD x takes K-range x % S of the tiles of group x / S, the tile list being
+  // cut into 8 / S contiguous groups: an XCD then streams ONE K-range of operand panels that no other group needs (the
+  // list is ordered so that the cut falls between problems: dWqkv + dWo | dW1 + dW2), and every operand byte crosses the
+  // fabric once.  The tile-major order (tile = id / S) spread the tiles of one panel over two XCD groups: 235 MB per launch
+  // at C2 against 161 MB of operands + slabs.
+  int tile, split;
+  if (g.xcd_groups > 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    split = xcd % g.S;
+    const int grp = xcd / g.S;
+    const int lo = (int)((int64_t)g.total_tiles * grp / g.xcd_groups), hi = (int)((int64_t)g.total_tiles * (grp + 1) / g.xcd_groups);
+    tile = lo + j;
+    if (tile >= hi) return;  // (whole workgroup: uniform)
+  } else {
+    tile = blockIdx.x / g.S;
+    split = blockIdx.x - tile * g.S;
+  }
   int pi = 0;
 #pragma unroll
   for (int i = 1; i < 4; ++i)
@@ -939,7 +957,22 @@ int gemm_bf16_tn_group(const TnGroupArgs& a, hipStream_t s, const FoldList* extr
                                       3 * 48 * 1024) == hipSuccess, "gemm_bf16_tn_group: cannot raise dynamic LDS limit");
       raised3.mark();
     }
-    launch_in_scope(&ts, gemm_bf16_tn_group_big_kernel<3>, dim3(tiles * g.S), dim3(512), 3 * 48 * 1024, s, g);
+    static const int xcd_order = [] {
+      const char* e = getenv("AVF_TN_XCD");  // tuning aid: 0 = tile-major block ids
+      return e ? atoi(e) : 1;
+    }();
+    int nblocks = tiles * g.S;
+    g.xcd_groups = 0;
+    if (xcd_order && (g.S == 1 || g.S == 2 || g.S == 4 || g.S == 8)) {
+      g.xcd_groups = 8 / g.S;
+      int per = 0;  // tiles of the largest group
+      for (int grp = 0; grp < g.xcd_groups; ++grp) {
+        const int n = (int)((int64_t)tiles * (grp + 1) / g.xcd_groups - (int64_t)tiles * grp / g.xcd_groups);
+        per = n > per ? n : per;
+      }
+      nblocks = 8 * per;
+    }
+    launch_in_scope(&ts, gemm_bf16_tn_group_big_kernel<3>, dim3(nblocks), dim3(512), 3 * 48 * 1024, s, g);
   } else if (tn_waves == 4) launch_in_scope(&ts, gemm_bf16_tn_group_kernel<2>, dim3(tiles * g.S), dim3(256), 0, s, g);
   else launch_in_scope(&ts, gemm_bf16_tn_group_kernel<4>, dim3(tiles * g.S), dim3(512), 0, s, g);
   AVF_TRY(check_launch("gemm_bf16_tn_group_kernel"));

@@ -143,10 +143,12 @@ TnGroupArgs dw_group(const Dims& d, const void* gy, const void* g_act, const voi
   memset(&a, 0, sizeof(a));
   a.count = 4;
   a.K = d.R;
+  // order: attention half, then MLP half - the XCD-aware block order of the 256 x 128 kernel cuts the tile list in the
+  // middle, and the two halves then share no operand panel (3 I D + D I tiles | 2 M D tiles: equal when I = D, M = 2 D)
   a.A[0] = dqkv; a.B[0] = h1; a.C[0] = g ? g->w_qkv : nullptr; a.M[0] = 3 * d.I; a.N[0] = d.D;
-  a.A[1] = du;   a.B[1] = h2; a.C[1] = g ? g->w1 : nullptr;    a.M[1] = d.M;     a.N[1] = d.D;
-  a.A[2] = gy;   a.B[2] = g_act; a.C[2] = g ? g->w2 : nullptr; a.M[2] = d.D;     a.N[2] = d.M;
-  a.A[3] = gm;   a.B[3] = o;  a.C[3] = g ? g->w_out : nullptr; a.M[3] = d.D;     a.N[3] = d.I;
+  a.A[1] = gm;   a.B[1] = o;  a.C[1] = g ? g->w_out : nullptr; a.M[1] = d.D;     a.N[1] = d.I;
+  a.A[2] = du;   a.B[2] = h2; a.C[2] = g ? g->w1 : nullptr;    a.M[2] = d.M;     a.N[2] = d.D;
+  a.A[3] = gy;   a.B[3] = g_act; a.C[3] = g ? g->w2 : nullptr; a.M[3] = d.D;     a.N[3] = d.M;
   for (int i = 0; i < 4; ++i) { a.lda[i] = a.M[i]; a.ldb[i] = a.N[i]; }
   return a;
 }

@@ -1,29 +1,38 @@
 #!/bin/bash
 # Runs the rocprofv3 passes profiles/README.md lists (on the GPU box) and condenses them into profiles/<tag>_*.
-#   bash tools/collect_profiles.sh r01        (from the repo root; raw output under gpurun_out/final)
+#   bash tools/collect_profiles.sh r02        (from the repo root; raw output under gpurun_out/final)
 # Each pass is its own rocprofv3 process with the program directly after "--" (no wrappers); counters are collected
-# without any trace domain beside the kernel trace.
+# without any trace domain beside the kernel trace.  C2 (the bench's `value` workload): kernel stats, FETCH / WRITE traffic,
+# two SQ counter passes.  C3 (the north-star shape): kernel stats and traffic.  The reference's real head shapes: kernel stats.
 set -e -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$PWD
 O=$R/gpurun_out/final
 mkdir -p $O
 cd /tmp
 export TMPDIR=/tmp
-B="python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-events"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/stats.json 2> $O/stats.err
-echo "stats done"
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- $B > /dev/null 2> $O/fetch.err
-echo "fetch done"
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o w -- $B > /dev/null 2> $O/write.err
-echo "write done"
+for CFG in c2 c3; do
+  B="python $R/bench.py --config $CFG --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-events --no-extra"
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$CFG -o s -- python $R/bench.py --config $CFG --steps 10 --warmup 3 --no-cpu-baseline --no-extra > $O/stats_$CFG.json 2> $O/stats_$CFG.err
+  echo "$CFG stats done"
+  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_$CFG -o f -- $B > /dev/null 2> $O/fetch_$CFG.err
+  echo "$CFG fetch done"
+  timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_$CFG -o w -- $B > /dev/null 2> $O/write_$CFG.err
+  echo "$CFG write done"
+done
+B="python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-events --no-extra"
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/sq1 -o q -- $B > /dev/null 2> $O/sq1.err
 echo "sq1 done"
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT --output-format csv -d $O/sq2 -o q -- $B > /dev/null 2> $O/sq2.err
 echo "sq2 done"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_real -o s -- python $R/tools/bench_real_model.py 64 > $O/stats_real.log 2> $O/stats_real.err
+echo "real-model stats done"
 cd $R
-mkdir -p $O/profiles
-python tools/pmc_traffic.py $O/stats/s_kernel_stats.csv $O/fetch/f_counter_collection.csv $O/write/w_counter_collection.csv $TAG
+python tools/pmc_traffic.py $O/stats_c2/s_kernel_stats.csv $O/fetch_c2/f_counter_collection.csv $O/write_c2/w_counter_collection.csv $TAG c2
+python tools/pmc_traffic.py $O/stats_c3/s_kernel_stats.csv $O/fetch_c3/f_counter_collection.csv $O/write_c3/w_counter_collection.csv ${TAG}_c3 c3
 python tools/sq_summary.py $O/sq1/q_counter_collection.csv $O/sq2/q_counter_collection.csv $TAG
-cp profiles/${TAG}_kernel_stats.csv profiles/${TAG}_pmc_summary.csv profiles/${TAG}_traffic.json profiles/${TAG}_sq_counters.csv $O/profiles/
+cp $O/stats_real/s_kernel_stats.csv profiles/${TAG}_real_heads_kernel_stats.csv
+mkdir -p $O/profiles
+cp profiles/${TAG}_* $O/profiles/
+grep "real avformer" $O/stats_real.log || true
 echo "condensed"

@@ -268,6 +268,184 @@ __global__ __launch_bounds__(512) void k(const uint16_t* A, const uint16_t* B, u
 }
 }  // namespace k1
 
+
+// ------------------------------------------------------------------------------------------------ K2 (full-row tile + LayerNorm)
+// x_new = A W^T + bias + x_res ; h = LayerNorm(x_new) in ONE kernel: a workgroup owns 64 full rows (N = 512 = 8 waves x 64
+// columns), so the row statistics are complete inside it.  Ping-pong halves, 2-slot ring; A (8 KB / K-tile) is shared and
+// issued by the first half, every wave streams its OWN 64 weight rows (B is private per wave: no cross-wave hazard on it).
+namespace k2 {
+constexpr int TK = 64, BMT = 64, BNT = 512;
+constexpr int A_BYTES = BMT * 128, B_BYTES = BNT * 128, STAGE = A_BYTES + B_BYTES;  // 8 + 64 KiB
+constexpr int NSLOT = 2;
+
+template <bool RES16>
+__global__ __launch_bounds__(512) void k(const uint16_t* A, const uint16_t* B, const float* bias, const void* res,
+                                         const float* gamma, const float* beta, void* X, uint16_t* H, float* mean,
+                                         float* rstd, int M, int K, float eps) {
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int half = wave >> 2;
+  const int m0 = blockIdx.x * BMT, n0 = wave * 64;
+
+  const int lrow = lane >> 3, lchunk = (lane & 7) ^ (lane >> 3);
+  const uint16_t* ga[2];
+  const uint16_t* gb[8];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { int r = m0 + ((wave & 3) * 2 + j) * 8 + lrow; r = r < M ? r : M - 1; ga[j] = A + (int64_t)r * K + lchunk * 8; }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) gb[j] = B + (int64_t)(n0 + j * 8 + lrow) * K + lchunk * 8;
+  auto stage = [&](int st, int k0) {
+    char* sa = dsm + st * STAGE; char* sb = sa + A_BYTES;
+    if (half == 0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) glds16(ga[j] + k0, sa + ((wave & 3) * 2 + j) * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) glds16(gb[j] + k0, sb + (wave * 8 + j) * 1024);
+  };
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char*)dsm;
+  const int c0 = lg ^ (li & 7), c1 = c0 ^ 4;
+  const uint32_t a_ks0 = (uint32_t)(li * 128 + (c0 << 4)), a_ks1 = (uint32_t)(li * 128 + (c1 << 4));
+  const uint32_t b_ks0 = (uint32_t)(A_BYTES + (n0 + li) * 128 + (c0 << 4)), b_ks1 = (uint32_t)(A_BYTES + (n0 + li) * 128 + (c1 << 4));
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0, 0, 0, 0};
+
+  const int nt = K / TK;
+  stage(0, 0);
+  // residual tile of this wave (rows 16 i + li, columns n0 + 16 j + 4 lg ..): loaded now, consumed in the epilogue
+  f32x4_t rres[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = m0 + 16 * i + li; m = m < M ? m : M - 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + 16 * j + 4 * lg;
+      if (RES16) {
+        const uint2 r = *reinterpret_cast<const uint2*>((const uint16_t*)res + (int64_t)m * BNT + n);
+        rres[i][j] = f32x4_t{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                             __uint_as_float(r.y & 0xffff0000u)};
+      } else {
+        rres[i][j] = *reinterpret_cast<const f32x4_t*>((const float*)res + (int64_t)m * BNT + n);
+      }
+    }
+  }
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  if (half == 1) __builtin_amdgcn_s_barrier();
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    const uint32_t sb_ = lds0 + (uint32_t)cur * STAGE;
+    bf16x8_t fa[2][4], fb[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const uint32_t aa = sb_ + (ks ? a_ks1 : a_ks0), bb = sb_ + (ks ? b_ks1 : b_ks0);
+      fa[ks][0] = lds_b128<0>(aa); fa[ks][1] = lds_b128<2048>(aa); fa[ks][2] = lds_b128<4096>(aa); fa[ks][3] = lds_b128<6144>(aa);
+      fb[ks][0] = lds_b128<0>(bb); fb[ks][1] = lds_b128<2048>(bb); fb[ks][2] = lds_b128<4096>(bb); fb[ks][3] = lds_b128<6144>(bb);
+    }
+    if (t + 1 < nt) stage(cur ^ 1, (t + 1) * TK);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    wait_vmcnt<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    cur ^= 1;
+  }
+  if (half == 0) __builtin_amdgcn_s_barrier();
+  // ---- epilogue: x = acc + bias + residual; row statistics over the 8 waves through LDS; h = LN(x) ----------------------
+  float* red = reinterpret_cast<float*>(dsm);  // [8 waves][64 rows] (the ring is idle now: every wave passed the last barrier)
+  float4 bj[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bj[j] = *reinterpret_cast<const float4*>(bias + n0 + 16 * j + 4 * lg);
+  float rs_[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[i][j][0] += bj[j].x + rres[i][j][0]; acc[i][j][1] += bj[j].y + rres[i][j][1];
+      acc[i][j][2] += bj[j].z + rres[i][j][2]; acc[i][j][3] += bj[j].w + rres[i][j][3];
+      s += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+    }
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    rs_[i] = s;
+  }
+  if (lg == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[wave * 64 + 16 * i + li] = rs_[i];
+  }
+  __syncthreads();
+  float mu[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) s += red[w * 64 + 16 * i + li];
+    mu[i] = s * (1.0f / BNT);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float d = acc[i][j][r] - mu[i]; q += d * d; }
+    q += __shfl_xor(q, 16, 64);
+    q += __shfl_xor(q, 32, 64);
+    rs_[i] = q;
+  }
+  if (lg == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[wave * 64 + 16 * i + li] = rs_[i];
+  }
+  __syncthreads();
+  float4 gj[4], btj[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    gj[j] = *reinterpret_cast<const float4*>(gamma + n0 + 16 * j + 4 * lg);
+    btj[j] = *reinterpret_cast<const float4*>(beta + n0 + 16 * j + 4 * lg);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float q = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) q += red[w * 64 + 16 * i + li];
+    const float rstdv = 1.0f / sqrtf(q * (1.0f / BNT) + eps);
+    const int m = m0 + 16 * i + li;
+    if (m >= M) continue;
+    if (wave == 0 && lg == 0) { mean[m] = mu[i]; rstd[m] = rstdv; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + 16 * j + 4 * lg;
+      if (RES16) store_bf16x4((uint16_t*)X + (int64_t)m * BNT + n, acc[i][j]);
+      else *reinterpret_cast<f32x4_t*>((float*)X + (int64_t)m * BNT + n) = acc[i][j];
+      f32x4_t h;
+      h[0] = (acc[i][j][0] - mu[i]) * rstdv * gj[j].x + btj[j].x; h[1] = (acc[i][j][1] - mu[i]) * rstdv * gj[j].y + btj[j].y;
+      h[2] = (acc[i][j][2] - mu[i]) * rstdv * gj[j].z + btj[j].z; h[3] = (acc[i][j][3] - mu[i]) * rstdv * gj[j].w + btj[j].w;
+      store_bf16x4(H + (int64_t)m * BNT + n, h);
+    }
+  }
+}
+}  // namespace k2
+
 static float ref_elem(const std::vector<uint16_t>& a, const std::vector<uint16_t>& b, int K, int m, int n) {
   double s = 0;
   for (int k = 0; k < K; ++k) {
@@ -293,7 +471,44 @@ int main(int argc, char** argv) {
   hipMemcpy(A, ha.data(), na * 2, hipMemcpyHostToDevice); hipMemcpy(B, hb.data(), nb * 2, hipMemcpyHostToDevice);
   hipMemset(C, 0, nc * 2);
   int nwg, tiles_n;
+  // K2 operands (N must be 512)
+  float *biasd = nullptr, *gammad = nullptr, *betad = nullptr, *meand = nullptr, *rstdd = nullptr;
+  void *resd = nullptr, *Xd = nullptr;
+  uint16_t* Hd = nullptr;
+  std::vector<float> hbias(N), hres;
+  if (variant >= 3) {
+    if (N != 512) { printf("variant %d needs N = 512\n", variant); return 1; }
+    for (auto& v : hbias) v = (float)rand() / RAND_MAX - 0.5f;
+    std::vector<float> ones(N, 1.f), zeros(N, 0.f);
+    hipMalloc(&biasd, N * 4); hipMalloc(&gammad, N * 4); hipMalloc(&betad, N * 4); hipMalloc(&meand, M * 4); hipMalloc(&rstdd, M * 4);
+    hipMemcpy(biasd, hbias.data(), N * 4, hipMemcpyHostToDevice);
+    hipMemcpy(gammad, ones.data(), N * 4, hipMemcpyHostToDevice); hipMemcpy(betad, zeros.data(), N * 4, hipMemcpyHostToDevice);
+    hres.resize(nc);
+    for (auto& v : hres) v = (float)rand() / RAND_MAX * 2.f - 1.f;
+    if (variant == 4) {
+      std::vector<uint16_t> r16(nc);
+      for (size_t i = 0; i < nc; ++i) { uint32_t u; memcpy(&u, &hres[i], 4); r16[i] = (uint16_t)(u >> 16); u &= 0xffff0000u; memcpy(&hres[i], &u, 4); }
+      hipMalloc(&resd, nc * 2); hipMemcpy(resd, r16.data(), nc * 2, hipMemcpyHostToDevice);
+      hipMalloc(&Xd, nc * 2);
+    } else {
+      hipMalloc(&resd, nc * 4); hipMemcpy(resd, hres.data(), nc * 4, hipMemcpyHostToDevice);
+      hipMalloc(&Xd, nc * 4);
+    }
+    hipMalloc(&Hd, nc * 2);
+  }
   auto launch = [&](bool stamps) {
+    if (variant >= 3) {
+      nwg = (M + 63) / 64; tiles_n = 1;
+      const int smem = k2::NSLOT * k2::STAGE;
+      if (variant == 4) {
+        hipFuncSetAttribute((const void*)k2::k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        k2::k<true><<<nwg, 512, smem>>>(A, B, biasd, resd, gammad, betad, Xd, Hd, meand, rstdd, M, K, 1e-5f);
+      } else {
+        hipFuncSetAttribute((const void*)k2::k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        k2::k<false><<<nwg, 512, smem>>>(A, B, biasd, resd, gammad, betad, Xd, Hd, meand, rstdd, M, K, 1e-5f);
+      }
+      return;
+    }
     if (variant == 0) {
       tiles_n = (N + 127) / 128; nwg = ((M + 127) / 128) * tiles_n;
       hipFuncSetAttribute((const void*)k0::k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * k0::STAGE);
@@ -321,6 +536,24 @@ int main(int argc, char** argv) {
     float ref = ref_elem(ha, hb, K, m, n);
     maxerr = std::max(maxerr, (double)fabsf(got - ref) / (fabs(ref) + 1.0));
   }
+  if (variant >= 3) {
+    hipMemcpy(hc.data(), Hd, nc * 2, hipMemcpyDeviceToHost);
+    maxerr = 0;
+    for (int s2 = 0; s2 < 6; ++s2) {
+      const int m = s2 == 0 ? 0 : (s2 == 1 ? M - 1 : rand() % M);
+      std::vector<double> xr(N);
+      double mu = 0;
+      for (int n = 0; n < N; ++n) { xr[n] = (double)ref_elem(ha, hb, K, m, n) + hbias[n] + hres[(size_t)m * N + n]; mu += xr[n]; }
+      mu /= N;
+      double var = 0;
+      for (int n = 0; n < N; ++n) var += (xr[n] - mu) * (xr[n] - mu);
+      const double rs = 1.0 / sqrt(var / N + 1e-5);
+      for (int n = 0; n < N; ++n) {
+        uint32_t u = (uint32_t)hc[(size_t)m * N + n] << 16; float got; memcpy(&got, &u, 4);
+        maxerr = std::max(maxerr, fabs(got - (xr[n] - mu) * rs));
+      }
+    }
+  }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 5; ++i) launch(false);
   hipEventRecord(e0);
@@ -331,6 +564,7 @@ int main(int argc, char** argv) {
   const double us = ms * 1e3 / iters;
   printf("variant %d  M=%d N=%d K=%d  wgs=%d  %.2f us  %.1f TF/s  max rel err %.2e %s\n", variant, M, N, K, nwg, us,
          2.0 * M * N * K / us * 1e-6, maxerr, maxerr < 2e-2 ? "OK" : "WRONG");
+  if (variant >= 3) return 0;
   if (want_stamps && variant >= 1) {
     hipMalloc(&S, (size_t)nwg * 2 * 16 * 8);
     hipMemset(S, 0, (size_t)nwg * 2 * 16 * 8);
