@@ -499,6 +499,17 @@ __global__ __launch_bounds__(MAXW * 64) void attn_fwd_res_kernel(const bf16* __r
         if (FEED) loader.issue_one();
       }
       AVF_PHASE_MARK(2);
+      // 8-wave builds (two waves per SIMD, registers to spare): the V fragments of the first k-step are requested BEFORE
+      // the softmax and those of the second one before the first k-step's MFMAs, so the transposed LDS reads land under
+      // VALU / MFMA work instead of in front of the PV MFMAs (stamps: the PV section was 1100 cycles per tile for 20 MFMAs)
+      constexpr bool VPF = MAXW == 8;
+      bf16x8_t fvp[2][DB];
+      if constexpr (VPF) {
+        if (!TAIL || nkb > 0) {
+#pragma unroll
+          for (int d = 0; d < DB; ++d) fvp[0][d] = lds_tr_frag(vt + off.tr[d]);
+        }
+      }
       if constexpr (QS) {
         // st = log2-domain score - m.  Re-centre when a row maximum exceeds m by more than RES_TAU (and always on the
         // first tile, which fixes m): only then are the accumulators and this tile's scores shifted.
@@ -582,12 +593,20 @@ __global__ __launch_bounds__(MAXW * 64) void attn_fwd_res_kernel(const bf16* __r
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         if (TAIL && 2 * s2 >= nkb) continue;
-        __builtin_amdgcn_sched_barrier(0);  // keep the V fragments of this k-step from being hoisted over the softmax
+        if constexpr (!VPF) __builtin_amdgcn_sched_barrier(0);  // keep the V fragments of this k-step from being hoisted over the softmax
         const bf16x8_t p0 = pack_pair(st[2 * s2][0], st[2 * s2 + 1][0]);
         const bf16x8_t p1 = pack_pair(st[2 * s2][1], st[2 * s2 + 1][1]);
+        if constexpr (VPF) {
+          if (s2 == 0 && (!TAIL || nkb > 2)) {
+#pragma unroll
+            for (int d = 0; d < DB; ++d) fvp[1][d] = lds_tr_frag(vt + 4096 + off.tr[d]);
+          }
+        }
 #pragma unroll
         for (int d = 0; d < DB; ++d) {
-          const bf16x8_t fv = lds_tr_frag(vt + s2 * 4096 + off.tr[d]);
+          bf16x8_t fv;
+          if constexpr (VPF) fv = fvp[s2][d];
+          else fv = lds_tr_frag(vt + s2 * 4096 + off.tr[d]);
           ot[d][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, p0, ot[d][0], 0, 0, 0);
           ot[d][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, p1, ot[d][1], 0, 0, 0);
         }
