@@ -311,6 +311,8 @@ int cast_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t s, const
 int dropout_factors(const DropCfg& drop, float* out, int64_t n, hipStream_t s);  // test aid: keep*scale per element
 // out[c] = sum_b partial[b][c]
 int fold_partials(const float* partial, int nb, int width, float* out, hipStream_t s);
+struct FoldJob;
+int fold_job(const FoldJob& job, hipStream_t s);  // one FoldJob (up to three output segments) as its own launch
 
 // A deferred column fold: out_k[c] = sum_b partial[b][k*seg + c] for the (up to 3) segments of width/seg.
 // Kernels that produce per-block partial sums can hand the fold back to the caller, which runs all folds of a layer
@@ -438,6 +440,19 @@ int layer_fwd_small(int B, int N, int D, int H, int M, float eps, float score_sc
                     void* h1, float* mean1, float* rstd1, void* qkv, void* o, float* lse2, float* x_mid, void* h2,
                     float* mean2, float* rstd2, void* u, void* g, const DropCfg& dr0, const DropCfg& dr1,
                     const DropCfg& dr2, hipStream_t s);
+// the fused backward pieces of the short-sequence layer (layer_small.hip): host-side argument blocks
+struct SmallBwdAHost {
+  const float* dx_out; const void* dx_out_lo; void* gy_store; const float* x_mid; const void* u;
+  const float *ln2_w, *mean2, *rstd2; const void *w2_t, *w1_t, *wo_t; void* du; float* dx_mid; void* dx_mid_lo; void* d_o;
+  float *pb1, *pln2; int gs16; DropCfg dr0, dr1, dr2;
+};
+struct SmallBwdBHost {
+  const void *dqkv, *wqkv_t; const float* x_in; const float *ln1_w, *mean1, *rstd1; const float* dx_mid; const void* dx_mid_lo;
+  float* dx_in; void* dx_in_lo; float* pln1; int gs16; DropCfg dr_prev2;
+};
+size_t small_bwd_partial_floats(int B, int D, int M);
+int layer_bwd_small_a(int B, int N, int D, int I, int M, const SmallBwdAHost& h, hipStream_t s);
+int layer_bwd_small_b(int B, int N, int D, int I, const SmallBwdBHost& h, hipStream_t s);
 float attn_q_prescale(int dh);
 bool attn_q_prescale_on();
 int attn_fwd_bf16(const bf16* qkv, bf16* o, float* lse2, int B, int N, int H, int dh, hipStream_t s,

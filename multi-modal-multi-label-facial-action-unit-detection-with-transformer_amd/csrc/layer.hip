@@ -157,6 +157,7 @@ struct Work {
   void *du, *dh, *d_o, *dqkv, *dx_mid_lo, *dx_out_lo, *ln_ws, *ln_ws1, *cs_ws, *gemm_ws;
   float *dx_mid, *delta;
   void *hq, *hs, *gq, *gs;  // mx8_fwd only: MX-FP8 images of the LayerNorm output and of gelu(u), forward scratch
+  float* small_part;        // short-sequence backward: per-clip partial rows (pb1 [B][M] | pln2 [B][3D] | pln1 [B][3D])
 };
 size_t carve_work(const Dims& d, void* base, Work* w) {
   Carver c(base);
@@ -193,6 +194,7 @@ size_t carve_work(const Dims& d, void* base, Work* w) {
     g = g > f ? g : f;
   }
   t.gemm_ws = c.take(g);
+  t.small_part = (float*)c.take(small_layer_ok(d.dt, d.N, d.D, d.H, d.dh, d.M) ? small_bwd_partial_floats(d.B, d.D, d.M) * 4 : 0);
   if (d.mx) {
     t.hq = c.take(d.R * d.D); t.hs = c.take(d.R * d.D / 32);
     t.gq = c.take(d.R * d.M); t.gs = c.take(d.R * d.M / 32);
@@ -417,10 +419,18 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   const DropCfg dr0 = make_drop(d.p, d.seed, d.layer, 0, d.seed_dev), dr1 = make_drop(d.p, d.seed, d.layer, 1, d.seed_dev),
                 dr2 = make_drop(d.p, d.seed, d.layer, 2, d.seed_dev);
   const DropCfg dr_prev2 = d.layer > 0 ? make_drop(d.p, d.seed, d.layer - 1, 2, d.seed_dev) : kNoDrop;
+  // short sequences (the reference's 12-token stacks): the six dependent launches around the attention backward run as two
+  // fused kernels (layer_small.hip), which also make the bf16 image of the incoming gradient when the caller gave none
+  static const int small_bwd_on = [] {
+    const char* e = getenv("AVF_LAYER_SMALL_BWD");  // tuning / A-B aid
+    return e ? atoi(e) : 1;
+  }();
+  const bool small_bwd = lo && !d.rs16 && !d.mx && small_bwd_on && small_layer_ok(d.dt, d.N, d.D, d.H, d.dh, d.M);
   const void* gy = dx_out;
   bool own_copy = false;
   if (lo) {
     if (dx_out_lo) gy = dx_out_lo;  // the caller's previous call already applied this layer's site-2 mask
+    else if (small_bwd) gy = w.dx_out_lo;  // written by the fused kernel below
     else {
       AVF_TRY(cast_f32_to_bf16(dx_out, w.dx_out_lo, d.R * d.D, s, dr2));
       gy = w.dx_out_lo;
@@ -436,6 +446,45 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   FoldList folds;
   memset(&folds, 0, sizeof(folds));
   folds.count = 3;
+
+  // the grouped dW launch and its fold are shared with the general path
+  if (small_bwd) {
+    float* pb1 = w.small_part;
+    float* pln2 = pb1 + (size_t)d.B * d.M;
+    float* pln1 = pln2 + (size_t)d.B * 3 * d.D;
+    SmallBwdAHost ha;
+    ha.dx_out = dx_out; ha.dx_out_lo = dx_out_lo; ha.gy_store = dx_out_lo ? nullptr : w.dx_out_lo; ha.x_mid = (const float*)sv.x_mid;
+    ha.u = sv.u; ha.ln2_w = p->ln2_w; ha.mean2 = sv.mean2; ha.rstd2 = sv.rstd2;
+    ha.w2_t = l.w2_t; ha.w1_t = l.w1_t; ha.wo_t = l.wo_t; ha.du = w.du; ha.dx_mid = d.gs16 ? nullptr : w.dx_mid;
+    ha.dx_mid_lo = w.dx_mid_lo; ha.d_o = w.d_o; ha.pb1 = pb1; ha.pln2 = pln2; ha.gs16 = d.gs16 ? 1 : 0;
+    ha.dr0 = dr0; ha.dr1 = dr1; ha.dr2 = dr2;
+    AVF_TRY(layer_bwd_small_a(d.B, d.N, d.D, d.I, d.M, ha, s));
+    // db2 (as below): handed over, or the column sums of the (masked) gradient image kernel A has just written / read
+    if (dx_out_colsum && dx_out_colsum != g->b2)
+      AVF_REQUIRE(hipMemcpyAsync(g->b2, dx_out_colsum, (size_t)d.D * 4, hipMemcpyDeviceToDevice, s) == hipSuccess,
+                  "layer_bwd: memcpy failed");
+    else if (!dx_out_colsum) {
+      if (d.p > 0.f || !dx_out) AVF_TRY(colsum(gy, AVF_BF16, d.R, d.D, d.D, g->b2, w.cs_ws, s));
+      else AVF_TRY(colsum(dx_out, AVF_F32, d.R, d.D, d.D, g->b2, w.cs_ws, s));
+    }
+    AVF_TRY(attn_bwd_bf16((const bf16*)sv.qkv, (const bf16*)sv.o, (const bf16*)w.d_o, sv.lse2, (bf16*)w.dqkv, w.delta,
+                          d.B, d.N, d.H, d.dh, s, attn_q_prescale_on(), w.delta + (size_t)d.B * d.H * d.N));
+    SmallBwdBHost hb;
+    hb.dqkv = w.dqkv; hb.wqkv_t = l.wqkv_t; hb.x_in = (const float*)x_in; hb.ln1_w = p->ln1_w; hb.mean1 = sv.mean1; hb.rstd1 = sv.rstd1;
+    hb.dx_mid = d.gs16 ? nullptr : w.dx_mid; hb.dx_mid_lo = w.dx_mid_lo; hb.dx_in = dx_in; hb.dx_in_lo = dx_in_lo; hb.pln1 = pln1;
+    hb.gs16 = d.gs16 ? 1 : 0; hb.dr_prev2 = dr_prev2;
+    AVF_TRY(layer_bwd_small_b(d.B, d.N, d.D, d.I, hb, s));
+    folds.job[0] = FoldJob{pb1, d.B, d.M, d.M, g->b1, nullptr, nullptr};
+    folds.job[1] = FoldJob{pln2, d.B, 3 * d.D, d.D, g->ln2_w, g->ln2_b, g->b_out};
+    folds.job[2] = FoldJob{pln1, d.B, 3 * d.D, d.D, g->ln1_w, g->ln1_b, dx_in_colsum};
+    if (grouped) return gemm_bf16_tn_group(grp, s, &folds);
+    AVF_TRY(linear_dw(d, gy, d.D, sv.g, d.M, g->w2, w.gemm_ws, s));
+    AVF_TRY(linear_dw(d, w.du, d.M, sv.h2, d.D, g->w1, w.gemm_ws, s));
+    AVF_TRY(linear_dw(d, gm, d.D, sv.o, d.I, g->w_out, w.gemm_ws, s));
+    AVF_TRY(linear_dw(d, w.dqkv, 3 * d.I, sv.h1, d.D, g->w_qkv, w.gemm_ws, s));
+    for (int j = 0; j < 3; ++j) AVF_TRY(fold_job(folds.job[j], s));
+    return 0;
+  }
 
   // ---- feed-forward half -------------------------------------------------------------------
   // db2 = column sums of dx_out: handed over by the caller (the next layer's LN1 backward produced them) or summed here

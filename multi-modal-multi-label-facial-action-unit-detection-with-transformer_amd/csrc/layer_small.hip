@@ -323,6 +323,260 @@ __global__ __launch_bounds__(NW * 64) void layer_fwd_small_kernel(SmallArgs a) {
   }
 }
 
+
+// =============================================================================================
+// BACKWARD of the short-sequence layer in THREE pieces instead of six dependent launches around the attention backward:
+//   kernel A (MLP half + LayerNorm 2 + out-projection):  du = (gy W2) o gelu'(u) -> dh2 = du W1 -> dx_mid = dres + LN2'(dh2)
+//                                                        -> d_o = gm Wo            (replaces 4 launches)
+//   [attention backward: the per-operator kernels]
+//   kernel B (QKV projection + LayerNorm 1):             dh1 = dqkv Wqkv -> dx_in = dx_mid + LN1'(dh1)   (replaces 2 launches)
+// One workgroup of 16 wavefronts per clip, the clip's gradients stay in LDS between the phases (dh2 / dh1 never leave the
+// chip, and stay fp32 where the per-operator path rounds them to bf16); the GEMM operands the grouped weight-gradient launch
+// needs (gy, du, gm, dqkv) are stored as the per-operator path stores them, and the bias / LayerNorm parameter gradients
+// leave as one partial row per clip that the layer's fold launch sums.  Same dropout sites and element indices as layer.hip.
+// =============================================================================================
+struct SmallBwdA {
+  const float* dx_out;     // fp32 incoming gradient (null on the bf16 gradient stream)
+  const bf16* dx_out_lo;   // its bf16 image, already carrying this layer's site-2 mask (null: made here from dx_out)
+  bf16* gy_store;          // where a locally made image is stored for the dW2 GEMM (null when dx_out_lo is given)
+  const float* x_mid;      // saved LayerNorm-2 input
+  const bf16* u;           // saved pre-activation
+  const float *ln2_w, *mean2, *rstd2;
+  const bf16 *w2_t, *w1_t, *wo_t;  // transposed bf16 weight images [in, out]
+  bf16* du;                // [R, M] for the dW1 GEMM
+  float* dx_mid;           // fp32 (null on the bf16 gradient stream)
+  bf16* dx_mid_lo;         // bf16 image (site-0 mask applied): operand of dWo and of the d_o GEMM
+  bf16* d_o;               // [R, I] for the attention backward
+  float* pb1;              // [B][M]   per-clip column sums of du            -> db1
+  float* pln2;             // [B][3 D] per-clip dgamma2 | dbeta2 | colsum(gm) -> dbo
+  int N;
+  int gs16;                // residual gradient arrives / leaves as bf16 only
+  DropCfg dr0, dr1, dr2;
+};
+
+template <int D32, int I32, int M32, int NW>
+__global__ __launch_bounds__(NW * 64) void layer_bwd_small_a_kernel(SmallBwdA a) {
+  constexpr int D = D32 * 32, I = I32 * 32, M = M32 * 32, R = 16;
+  constexpr int LDA = D + 8, LDG = M + 8, LDX = D + 4;
+  __shared__ __attribute__((aligned(16))) bf16 abuf[R * LDA];   // gy, then gm
+  __shared__ __attribute__((aligned(16))) bf16 gbuf[R * LDG];   // du
+  __shared__ __attribute__((aligned(16))) float xbuf[R * LDX];  // dh2 (fp32)
+  __shared__ __attribute__((aligned(16))) float mbuf[R * LDX];  // masked dx_mid (fp32), for its column sums
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int N = a.N;
+  const int64_t b = blockIdx.x, row0 = b * N;
+
+  // ---- phase 0: gy -> abuf (rows past N zero)
+  {
+    const uint64_t key2 = a.dr2.thresh16 ? drop_key(a.dr2) : 0;
+    for (int e = tid; e < R * (D / 4); e += NW * 64) {
+      const int r = e / (D / 4), c = (e - r * (D / 4)) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < N) {
+        if (a.dx_out_lo) {
+          v = load4<bf16>(a.dx_out_lo + (row0 + r) * D + c);
+        } else {
+          v = *reinterpret_cast<const float4*>(a.dx_out + (row0 + r) * D + c);
+          if (a.dr2.thresh16) {
+            const float4 f = drop_factor4(a.dr2, key2, (uint64_t)(row0 + r) * D + c);
+            v.x *= f.x; v.y *= f.y; v.z *= f.z; v.w *= f.w;
+          }
+          if (a.gy_store) store4<bf16>(a.gy_store + (row0 + r) * D + c, v);
+        }
+      }
+      store4<bf16>(abuf + r * LDA + c, v);
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 1: du = (gy W2) o mask1 o gelu'(u) -> gbuf, global du; per-clip column sums -> pb1
+  {
+    const uint64_t key1 = a.dr1.thresh16 ? drop_key(a.dr1) : 0;
+    small_gemm<1, D32, NW>(abuf, LDA, a.w2_t, M, wave, li, lg, [&](int cb, f32x4_t(&acc)[1]) {
+      const int n = cb * 16 + 4 * lg, r = li;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < N) {
+        const int64_t row = row0 + r;
+        const float4 uu = load4<bf16>(a.u + row * M + n);
+        float4 df = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (a.dr1.thresh16) df = drop_factor4(a.dr1, key1, (uint64_t)row * M + n);
+        v = make_float4(acc[0][0] * df.x * dgelu_tanh_fast(uu.x), acc[0][1] * df.y * dgelu_tanh_fast(uu.y),
+                        acc[0][2] * df.z * dgelu_tanh_fast(uu.z), acc[0][3] * df.w * dgelu_tanh_fast(uu.w));
+        store4<bf16>(a.du + row * M + n, v);
+      }
+      store4<bf16>(gbuf + r * LDG + n, v);
+      float cs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float t = cs[q];
+        t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+        cs[q] = t;
+      }
+      if (li == 0) *reinterpret_cast<float4*>(a.pb1 + b * M + n) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+    });
+  }
+  __syncthreads();
+
+  // ---- phase 2: dh2 = du W1 -> xbuf (fp32)
+  small_gemm<1, M32, NW>(gbuf, LDG, a.w1_t, D, wave, li, lg, [&](int cb, f32x4_t(&acc)[1]) {
+    *reinterpret_cast<float4*>(xbuf + li * LDX + cb * 16 + 4 * lg) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+  });
+  __syncthreads();
+
+  // ---- phase 3: LayerNorm-2 backward, one wave per row: dx_mid = dres + rstd (g - mean(g) - xhat mean(g xhat)), g = dh2 gamma
+  {
+    const uint64_t key0 = a.dr0.thresh16 ? drop_key(a.dr0) : 0;
+    const int c = lane * 4;
+    const bool act = c < D;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (act) g = *reinterpret_cast<const float4*>(a.ln2_w + c);
+    for (int r = wave; r < R; r += NW) {
+      if (r >= N) {
+        if (act) {
+          store4<bf16>(abuf + r * LDA + c, make_float4(0.f, 0.f, 0.f, 0.f));
+          *reinterpret_cast<float4*>(mbuf + r * LDX + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        continue;
+      }
+      const int64_t row = row0 + r;
+      const float mu = a.mean2[row], rs = a.rstd2[row];
+      float4 d = make_float4(0.f, 0.f, 0.f, 0.f), xh = d, res = d;
+      if (act) {
+        d = *reinterpret_cast<const float4*>(xbuf + r * LDX + c);
+        const float4 x = *reinterpret_cast<const float4*>(a.x_mid + row * D + c);
+        xh = make_float4((x.x - mu) * rs, (x.y - mu) * rs, (x.z - mu) * rs, (x.w - mu) * rs);
+        // bf16 gradient stream: the residual is the bf16 image (the caller's, or the one phase 0 made) - still in abuf
+        res = a.gs16 ? load4<bf16>(abuf + r * LDA + c) : *reinterpret_cast<const float4*>(a.dx_out + row * D + c);
+      }
+      const float g0 = d.x * g.x, g1 = d.y * g.y, g2 = d.z * g.z, g3 = d.w * g.w;
+      const float s1 = wave_sum((g0 + g1) + (g2 + g3)) / (float)D;
+      const float s2 = wave_sum((g0 * xh.x + g1 * xh.y) + (g2 * xh.z + g3 * xh.w)) / (float)D;
+      if (act) {
+        float4 o = make_float4(rs * (g0 - s1 - xh.x * s2) + res.x, rs * (g1 - s1 - xh.y * s2) + res.y,
+                               rs * (g2 - s1 - xh.z * s2) + res.z, rs * (g3 - s1 - xh.w * s2) + res.w);
+        if (a.dx_mid) *reinterpret_cast<float4*>(a.dx_mid + row * D + c) = o;
+        if (a.dr0.thresh16) {  // what the out-projection Linear sees: masked, rescaled
+          const float4 f = drop_factor4(a.dr0, key0, (uint64_t)row * D + c);
+          o.x *= f.x; o.y *= f.y; o.z *= f.z; o.w *= f.w;
+        }
+        store4<bf16>(abuf + r * LDA + c, o);
+        store4<bf16>(a.dx_mid_lo + row * D + c, o);
+        *reinterpret_cast<float4*>(mbuf + r * LDX + c) = o;
+      }
+    }
+  }
+  __syncthreads();
+  // column sums over the clip's rows: dgamma2 = sum dh2 xhat, dbeta2 = sum dh2, colsum(gm) (-> dbo)
+  for (int c = tid; c < D; c += NW * 64) {
+    float dg = 0.f, db = 0.f, cs = 0.f;
+    for (int r = 0; r < N; ++r) {
+      const int64_t row = row0 + r;
+      const float dy = xbuf[r * LDX + c];
+      dg += dy * (a.x_mid[row * D + c] - a.mean2[row]) * a.rstd2[row];
+      db += dy;
+      cs += mbuf[r * LDX + c];
+    }
+    float* o = a.pln2 + b * 3 * D;
+    o[c] = dg; o[D + c] = db; o[2 * D + c] = cs;
+  }
+
+  // ---- phase 4: d_o = gm Wo -> global (operand of the attention backward)
+  small_gemm<1, D32, NW>(abuf, LDA, a.wo_t, I, wave, li, lg, [&](int cb, f32x4_t(&acc)[1]) {
+    if (li < N) store4<bf16>(a.d_o + (row0 + li) * I + cb * 16 + 4 * lg, make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]));
+  });
+}
+
+struct SmallBwdB {
+  const bf16* dqkv;        // [R, 3 I]
+  const bf16* wqkv_t;      // [D, 3 I]
+  const float* x_in;       // saved LayerNorm-1 input
+  const float *ln1_w, *mean1, *rstd1;
+  const float* dx_mid;     // fp32 residual gradient (null on the bf16 gradient stream)
+  const bf16* dx_mid_lo;   // its bf16 image
+  float* dx_in;            // fp32 out (nullable)
+  bf16* dx_in_lo;          // bf16 out (mask of the PREVIOUS layer's site 2 applied)
+  float* pln1;             // [B][3 D] per-clip dgamma1 | dbeta1 | colsum(dx_in_lo) -> previous layer's db2
+  int N;
+  int gs16;
+  DropCfg dr_prev2;
+};
+
+template <int D32, int I32, int NW>
+__global__ __launch_bounds__(NW * 64) void layer_bwd_small_b_kernel(SmallBwdB a) {
+  constexpr int D = D32 * 32, I = I32 * 32, R = 16, K3 = 3 * I32;
+  constexpr int LDQ = 3 * I + 8, LDX = D + 4;
+  __shared__ __attribute__((aligned(16))) bf16 qbuf[R * LDQ];
+  __shared__ __attribute__((aligned(16))) float xbuf[R * LDX];
+  __shared__ __attribute__((aligned(16))) float mbuf[R * LDX];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int N = a.N;
+  const int64_t b = blockIdx.x, row0 = b * N;
+  for (int e = tid; e < R * (3 * I / 8); e += NW * 64) {
+    const int r = e / (3 * I / 8), c = (e - r * (3 * I / 8)) * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r < N) v = *reinterpret_cast<const uint4*>(a.dqkv + (row0 + r) * (3 * I) + c);
+    *reinterpret_cast<uint4*>(qbuf + r * LDQ + c) = v;
+  }
+  __syncthreads();
+  small_gemm<1, K3, NW>(qbuf, LDQ, a.wqkv_t, D, wave, li, lg, [&](int cb, f32x4_t(&acc)[1]) {
+    *reinterpret_cast<float4*>(xbuf + li * LDX + cb * 16 + 4 * lg) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+  });
+  __syncthreads();
+  {
+    const uint64_t keyp = a.dr_prev2.thresh16 ? drop_key(a.dr_prev2) : 0;
+    const int c = lane * 4;
+    const bool act = c < D;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (act) g = *reinterpret_cast<const float4*>(a.ln1_w + c);
+    for (int r = wave; r < R; r += NW) {
+      if (r >= N) {
+        if (act) *reinterpret_cast<float4*>(mbuf + r * LDX + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        continue;
+      }
+      const int64_t row = row0 + r;
+      const float mu = a.mean1[row], rs = a.rstd1[row];
+      float4 d = make_float4(0.f, 0.f, 0.f, 0.f), xh = d, res = d;
+      if (act) {
+        d = *reinterpret_cast<const float4*>(xbuf + r * LDX + c);
+        const float4 x = *reinterpret_cast<const float4*>(a.x_in + row * D + c);
+        xh = make_float4((x.x - mu) * rs, (x.y - mu) * rs, (x.z - mu) * rs, (x.w - mu) * rs);
+        res = a.gs16 ? load4<bf16>(a.dx_mid_lo + row * D + c) : *reinterpret_cast<const float4*>(a.dx_mid + row * D + c);
+      }
+      const float g0 = d.x * g.x, g1 = d.y * g.y, g2 = d.z * g.z, g3 = d.w * g.w;
+      const float s1 = wave_sum((g0 + g1) + (g2 + g3)) / (float)D;
+      const float s2 = wave_sum((g0 * xh.x + g1 * xh.y) + (g2 * xh.z + g3 * xh.w)) / (float)D;
+      if (act) {
+        float4 o = make_float4(rs * (g0 - s1 - xh.x * s2) + res.x, rs * (g1 - s1 - xh.y * s2) + res.y,
+                               rs * (g2 - s1 - xh.z * s2) + res.z, rs * (g3 - s1 - xh.w * s2) + res.w);
+        if (a.dx_in) *reinterpret_cast<float4*>(a.dx_in + row * D + c) = o;
+        if (a.dr_prev2.thresh16) {
+          const float4 f = drop_factor4(a.dr_prev2, keyp, (uint64_t)row * D + c);
+          o.x *= f.x; o.y *= f.y; o.z *= f.z; o.w *= f.w;
+        }
+        if (a.dx_in_lo) store4<bf16>(a.dx_in_lo + row * D + c, o);
+        *reinterpret_cast<float4*>(mbuf + r * LDX + c) = o;
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < D; c += NW * 64) {
+    float dg = 0.f, db = 0.f, cs = 0.f;
+    for (int r = 0; r < N; ++r) {
+      const int64_t row = row0 + r;
+      const float dy = xbuf[r * LDX + c];
+      dg += dy * (a.x_in[row * D + c] - a.mean1[row]) * a.rstd1[row];
+      db += dy;
+      cs += mbuf[r * LDX + c];
+    }
+    float* o = a.pln1 + b * 3 * D;
+    o[c] = dg; o[D + c] = db; o[2 * D + c] = cs;
+  }
+}
+
 template <int D32, int I32, int M32>
 int launch_small(const SmallArgs& a, int B, hipStream_t s) {
   // one 16-row block, 16 wavefronts.  (The kernel is written for up to four row blocks, but measured on B=4 x 64 tokens
@@ -367,6 +621,46 @@ int layer_fwd_small(int B, int N, int D, int H, int M, float eps, float score_sc
   AVF_SMALL(8, 4, 4); AVF_SMALL(8, 4, 8); AVF_SMALL(8, 8, 4); AVF_SMALL(8, 8, 8);
 #undef AVF_SMALL
   AVF_REQUIRE(false, "layer_fwd_small: unsupported shape D=%d I=%d M=%d", D, I, M);
+}
+
+// bytes of the per-clip partial rows of the two backward kernels: pb1 [B][M], pln2 [B][3D], pln1 [B][3D]
+size_t small_bwd_partial_floats(int B, int D, int M) { return (size_t)B * (M + 6 * (size_t)D); }
+
+int layer_bwd_small_a(int B, int N, int D, int I, int M, const SmallBwdAHost& h, hipStream_t s) {
+  SmallBwdA a;
+  a.dx_out = h.dx_out; a.dx_out_lo = (const bf16*)h.dx_out_lo; a.gy_store = (bf16*)h.gy_store; a.x_mid = h.x_mid;
+  a.u = (const bf16*)h.u; a.ln2_w = h.ln2_w; a.mean2 = h.mean2; a.rstd2 = h.rstd2;
+  a.w2_t = (const bf16*)h.w2_t; a.w1_t = (const bf16*)h.w1_t; a.wo_t = (const bf16*)h.wo_t;
+  a.du = (bf16*)h.du; a.dx_mid = h.dx_mid; a.dx_mid_lo = (bf16*)h.dx_mid_lo; a.d_o = (bf16*)h.d_o;
+  a.pb1 = h.pb1; a.pln2 = h.pln2; a.N = N; a.gs16 = h.gs16; a.dr0 = h.dr0; a.dr1 = h.dr1; a.dr2 = h.dr2;
+  AVF_REQUIRE(N >= 1 && N <= 16 && (a.dx_out || a.dx_out_lo) && (h.gs16 || a.dx_out) && (a.dx_out_lo || a.gy_store),
+              "layer_bwd_small_a: bad arguments");
+#define AVF_SMALL_A(DD, II, MM)                                                    \
+  if (D == DD * 32 && I == II * 32 && M == MM * 32) {                              \
+    layer_bwd_small_a_kernel<DD, II, MM, 16><<<B, 1024, 0, s>>>(a);                \
+    return check_launch("layer_bwd_small_a_kernel");                               \
+  }
+  AVF_SMALL_A(4, 4, 4) AVF_SMALL_A(4, 4, 8) AVF_SMALL_A(4, 8, 4) AVF_SMALL_A(4, 8, 8)
+  AVF_SMALL_A(8, 4, 4) AVF_SMALL_A(8, 4, 8) AVF_SMALL_A(8, 8, 4) AVF_SMALL_A(8, 8, 8)
+#undef AVF_SMALL_A
+  AVF_REQUIRE(false, "layer_bwd_small_a: unsupported shape D=%d I=%d M=%d", D, I, M);
+}
+
+int layer_bwd_small_b(int B, int N, int D, int I, const SmallBwdBHost& h, hipStream_t s) {
+  SmallBwdB a;
+  a.dqkv = (const bf16*)h.dqkv; a.wqkv_t = (const bf16*)h.wqkv_t; a.x_in = h.x_in; a.ln1_w = h.ln1_w; a.mean1 = h.mean1;
+  a.rstd1 = h.rstd1; a.dx_mid = h.dx_mid; a.dx_mid_lo = (const bf16*)h.dx_mid_lo; a.dx_in = h.dx_in; a.dx_in_lo = (bf16*)h.dx_in_lo;
+  a.pln1 = h.pln1; a.N = N; a.gs16 = h.gs16; a.dr_prev2 = h.dr_prev2;
+  AVF_REQUIRE(N >= 1 && N <= 16 && (a.dx_in || a.dx_in_lo) && (h.gs16 ? a.dx_mid_lo != nullptr : a.dx_mid != nullptr),
+              "layer_bwd_small_b: bad arguments");
+#define AVF_SMALL_B(DD, II)                                                 \
+  if (D == DD * 32 && I == II * 32) {                                       \
+    layer_bwd_small_b_kernel<DD, II, 16><<<B, 1024, 0, s>>>(a);             \
+    return check_launch("layer_bwd_small_b_kernel");                        \
+  }
+  AVF_SMALL_B(4, 4) AVF_SMALL_B(4, 8) AVF_SMALL_B(8, 4) AVF_SMALL_B(8, 8)
+#undef AVF_SMALL_B
+  AVF_REQUIRE(false, "layer_bwd_small_b: unsupported shape D=%d I=%d", D, I);
 }
 
 }  // namespace avf

@@ -429,6 +429,8 @@ int fold_partials(const float* partial, int nb, int width, float* out, hipStream
   return launch_fold(partial, nb, width, out, nullptr, nullptr, width, s);
 }
 
+int fold_job(const FoldJob& j, hipStream_t s) { return launch_fold(j.partial, j.nb, j.width, j.o0, j.o1, j.o2, j.seg, s); }
+
 size_t layernorm_bwd_ws(int64_t rows, int dim) {
   return (size_t)ceil_div(rows, LNR_ROWS_PER_BLOCK) * 3 * dim * sizeof(float);  // LNR < LNB: covers both paths
 }
