@@ -447,7 +447,9 @@ struct SmallBwdAHost {
   float *pb1, *pln2; int gs16; DropCfg dr0, dr1, dr2;
 };
 struct SmallBwdBHost {
-  const void *dqkv, *wqkv_t; const float* x_in; const float *ln1_w, *mean1, *rstd1; const float* dx_mid; const void* dx_mid_lo;
+  int attention;  // 1: the clip's attention backward runs inside the kernel (qkv / o / d_o / lse2 in, dqkv out)
+  const void *qkv, *o, *d_o; const float* lse2; float score_scale, dq_scale, dk_scale; int H;
+  void* dqkv; const void* wqkv_t; const float* x_in; const float *ln1_w, *mean1, *rstd1; const float* dx_mid; const void* dx_mid_lo;
   float* dx_in; void* dx_in_lo; float* pln1; int gs16; DropCfg dr_prev2;
 };
 size_t small_bwd_partial_floats(int B, int D, int M);

@@ -467,9 +467,23 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
       if (d.p > 0.f || !dx_out) AVF_TRY(colsum(gy, AVF_BF16, d.R, d.D, d.D, g->b2, w.cs_ws, s));
       else AVF_TRY(colsum(dx_out, AVF_F32, d.R, d.D, d.D, g->b2, w.cs_ws, s));
     }
-    AVF_TRY(attn_bwd_bf16((const bf16*)sv.qkv, (const bf16*)sv.o, (const bf16*)w.d_o, sv.lse2, (bf16*)w.dqkv, w.delta,
-                          d.B, d.N, d.H, d.dh, s, attn_q_prescale_on(), w.delta + (size_t)d.B * d.H * d.N));
+    static const int small_att_on = [] {
+      const char* e = getenv("AVF_LAYER_SMALL_ATT");  // tuning / A-B aid: 0 = per-operator attention backward
+      return e ? atoi(e) : 1;
+    }();
+    const bool fuse_att = small_att_on && d.H <= 16;
+    if (!fuse_att)
+      AVF_TRY(attn_bwd_bf16((const bf16*)sv.qkv, (const bf16*)sv.o, (const bf16*)w.d_o, sv.lse2, (bf16*)w.dqkv, w.delta,
+                            d.B, d.N, d.H, d.dh, s, attn_q_prescale_on(), w.delta + (size_t)d.B * d.H * d.N));
     SmallBwdBHost hb;
+    hb.attention = fuse_att ? 1 : 0;
+    hb.qkv = sv.qkv; hb.o = sv.o; hb.d_o = w.d_o; hb.lse2 = sv.lse2; hb.H = d.H;
+    {  // P = exp2(s c - lse2); dq = scale dS k; dk = scale dS^T q = dS^T q' / log2(e) when q' = q log2(e) scale (attn_bf16.hip)
+      const float scale = 1.0f / sqrtf((float)d.dh), log2e = 1.4426950408889634f;
+      hb.score_scale = attn_q_prescale_on() ? 1.0f : log2e * scale;
+      hb.dq_scale = scale;
+      hb.dk_scale = attn_q_prescale_on() ? 1.0f / log2e : scale;
+    }
     hb.dqkv = w.dqkv; hb.wqkv_t = l.wqkv_t; hb.x_in = (const float*)x_in; hb.ln1_w = p->ln1_w; hb.mean1 = sv.mean1; hb.rstd1 = sv.rstd1;
     hb.dx_mid = d.gs16 ? nullptr : w.dx_mid; hb.dx_mid_lo = w.dx_mid_lo; hb.dx_in = dx_in; hb.dx_in_lo = dx_in_lo; hb.pln1 = pln1;
     hb.gs16 = d.gs16 ? 1 : 0; hb.dr_prev2 = dr_prev2;

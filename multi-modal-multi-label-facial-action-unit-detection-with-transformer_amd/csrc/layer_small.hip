@@ -489,7 +489,15 @@ __global__ __launch_bounds__(NW * 64) void layer_bwd_small_a_kernel(SmallBwdA a)
 }
 
 struct SmallBwdB {
-  const bf16* dqkv;        // [R, 3 I]
+  // fused attention backward (ATT builds): the saved projection / output / statistics and the incoming d_o; dqkv is then
+  // an OUTPUT (the dWqkv GEMM reads it), otherwise the input the per-operator attention backward produced
+  const bf16* qkv;         // saved [R, 3 I]
+  const bf16* o;           // saved [R, I]
+  const bf16* d_o;         // [R, I]
+  const float* lse2;       // saved [B, H, N]
+  float score_scale, dq_scale, dk_scale;
+  int H;
+  bf16* dqkv;              // [R, 3 I]
   const bf16* wqkv_t;      // [D, 3 I]
   const float* x_in;       // saved LayerNorm-1 input
   const float *ln1_w, *mean1, *rstd1;
@@ -503,25 +511,138 @@ struct SmallBwdB {
   DropCfg dr_prev2;
 };
 
-template <int D32, int I32, int NW>
+// ATT: the attention backward of the clip (<= 16 tokens, dim_head 32, one wavefront per head) runs in front of the projection:
+//   S^T = K Q^T, P = exp2(S c - lse2), dP^T = V dO^T, delta = rowsum(dO o O), dS = P o (dP - delta)       [2 MFMAs per head]
+//   dV^T = dO^T P, dK^T = Q^T dS, dQ^T = K^T dS^T    (the 16 x 16 tiles P / dS pass through LDS to change orientation)
+// so that one launch takes d_o to dx_in.  Lane maps as layer_fwd_small_kernel (S^T: lane = query column, rows = keys).
+template <int D32, int I32, int NW, bool ATT>
 __global__ __launch_bounds__(NW * 64) void layer_bwd_small_b_kernel(SmallBwdB a) {
   constexpr int D = D32 * 32, I = I32 * 32, R = 16, K3 = 3 * I32;
   constexpr int LDQ = 3 * I + 8, LDX = D + 4;
-  __shared__ __attribute__((aligned(16))) bf16 qbuf[R * LDQ];
-  __shared__ __attribute__((aligned(16))) float xbuf[R * LDX];
-  __shared__ __attribute__((aligned(16))) float mbuf[R * LDX];
+  constexpr int LDS_ = 3 * I + 16;  // saved-projection tile (row stride as the forward's: conflict-free transposed reads)
+  constexpr int LDO = I + 8;
+  extern __shared__ __attribute__((aligned(16))) char bsm[];
+  // layout: [saved qkv tile 32 x LDS_ (ATT) | aliased afterwards by xbuf + mbuf] [dqkv tile] [d_o tile 32 x LDO (ATT)] [head scratch]
+  constexpr int SAVED_BYTES = ATT ? 32 * LDS_ * 2 : 0;
+  constexpr int X_BYTES = 2 * R * LDX * 4;
+  constexpr int FIRST_BYTES = SAVED_BYTES > X_BYTES ? SAVED_BYTES : X_BYTES;
+  bf16* sbuf = reinterpret_cast<bf16*>(bsm);
+  float* xbuf = reinterpret_cast<float*>(bsm);
+  float* mbuf = xbuf + R * LDX;
+  bf16* qbuf = reinterpret_cast<bf16*>(bsm + FIRST_BYTES);
+  bf16* dobuf = qbuf + R * LDQ;
+  bf16* hscr = dobuf + (ATT ? 32 * LDO : 0);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lg = lane >> 4;
   const int N = a.N;
   const int64_t b = blockIdx.x, row0 = b * N;
-  for (int e = tid; e < R * (3 * I / 8); e += NW * 64) {
-    const int r = e / (3 * I / 8), c = (e - r * (3 * I / 8)) * 8;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (r < N) v = *reinterpret_cast<const uint4*>(a.dqkv + (row0 + r) * (3 * I) + c);
-    *reinterpret_cast<uint4*>(qbuf + r * LDQ + c) = v;
+  if constexpr (ATT) {
+    const int H = a.H;
+    // saved projection rows (32-row image, rows past N zero) and the d_o rows (likewise)
+    for (int e = tid; e < 32 * (3 * I / 8); e += NW * 64) {
+      const int r = e / (3 * I / 8), c = (e - r * (3 * I / 8)) * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (r < N) v = *reinterpret_cast<const uint4*>(a.qkv + (row0 + r) * (3 * I) + c);
+      *reinterpret_cast<uint4*>(sbuf + r * LDS_ + c) = v;
+    }
+    for (int e = tid; e < 32 * (I / 8); e += NW * 64) {
+      const int r = e / (I / 8), c = (e - r * (I / 8)) * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (r < N) v = *reinterpret_cast<const uint4*>(a.d_o + (row0 + r) * I + c);
+      *reinterpret_cast<uint4*>(dobuf + r * LDO + c) = v;
+    }
+    for (int e = tid; e < (R - N) * (3 * I / 8); e += NW * 64) {  // rows N..15 of the dqkv tile: operands of the projection
+      const int r = N + e / (3 * I / 8), c = (e % (3 * I / 8)) * 8;
+      *reinterpret_cast<uint4*>(qbuf + r * LDQ + c) = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    bf16* pt = hscr + wave * 3 * 256;  // per-wave tiles: P^T [key][q], dS^T [key][q], dS [q][key] (16 x 16 bf16 each)
+    bf16* dst = pt + 256;
+    bf16* dsq = pt + 512;
+    const bool head = wave < H;
+    if (head) {
+      const int h = wave;
+      const bf16* qh = sbuf + h * 32;
+      const bf16x8_t fq = *reinterpret_cast<const bf16x8_t*>(qh + li * LDS_ + 8 * lg);
+      const bf16x8_t fk = *reinterpret_cast<const bf16x8_t*>(qh + li * LDS_ + I + 8 * lg);
+      const bf16x8_t fv = *reinterpret_cast<const bf16x8_t*>(qh + li * LDS_ + 2 * I + 8 * lg);
+      const bf16x8_t fdo = *reinterpret_cast<const bf16x8_t*>(dobuf + li * LDO + h * 32 + 8 * lg);
+      const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+      const f32x4_t st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq, z, 0, 0, 0);   // S^T[key 4lg+r][query li]
+      const f32x4_t dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, fdo, z, 0, 0, 0);  // dP^T[key][query]
+      // delta[query li] = sum_d dO[q][d] O[q][d]
+      float dl = 0.f;
+      if (li < N) {
+        const bf16x8_t fo = ldg_frag(a.o + (row0 + li) * I + h * 32 + 8 * lg);
+        typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+        const u32x4_t x = __builtin_bit_cast(u32x4_t, fdo), y = __builtin_bit_cast(u32x4_t, fo);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          dl = fmaf(__uint_as_float(x[i] << 16), __uint_as_float(y[i] << 16), dl);
+          dl = fmaf(__uint_as_float(x[i] & 0xffff0000u), __uint_as_float(y[i] & 0xffff0000u), dl);
+        }
+      }
+      dl = quad_sum(dl);
+      const float lse = li < N ? a.lse2[(b * H + h) * N + li] : 0.f;
+      float pv[4], dsv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool live = (4 * lg + r < N) && (li < N);
+        pv[r] = live ? __builtin_amdgcn_exp2f(st[r] * a.score_scale - lse) : 0.f;
+        dsv[r] = pv[r] * (dp[r] - dl);
+        pt[(4 * lg + r) * 16 + li] = from_f32<bf16>(pv[r]);
+        dst[(4 * lg + r) * 16 + li] = from_f32<bf16>(dsv[r]);
+      }
+      store4<bf16>(dsq + li * 16 + 4 * lg, make_float4(dsv[0], dsv[1], dsv[2], dsv[3]));
+    }
+    __syncthreads();
+    if (head) {
+      const int h = wave;
+      const bf16* qh = sbuf + h * 32;
+      typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+      // B operands with the k-slot order of the transposed A fragments: slots 0..3 = k 4 lg + 0..3, slots 4..7 = k 16 + ... = 0
+      auto bfrag = [&](const bf16* tile) {
+        const uint2 v = *reinterpret_cast<const uint2*>(tile + li * 16 + 4 * lg);
+        const u32x4_t r = {v.x, v.y, 0u, 0u};
+        return __builtin_bit_cast(bf16x8_t, r);
+      };
+      const bf16x8_t bp = bfrag(pt), bds_t = bfrag(dst), bds_q = bfrag(dsq);
+      const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        // transposed A fragments: rows = d (16 d + ...), k = token (32-row images, rows past N zero)
+        const bf16x8_t a_do = tr_frag_s<LDO * 2>((const lds_char*)(dobuf + h * 32), 0, 16 * d, li, lg);
+        const bf16x8_t a_q = tr_frag_s<LDS_ * 2>((const lds_char*)qh, 0, 16 * d, li, lg);
+        const bf16x8_t a_k = tr_frag_s<LDS_ * 2>((const lds_char*)(qh + I), 0, 16 * d, li, lg);
+        const f32x4_t dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_do, bp, z, 0, 0, 0);     // dV^T[d][key li]
+        const f32x4_t dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_q, bds_t, z, 0, 0, 0);   // dK^T[d][key li]
+        const f32x4_t dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_k, bds_q, z, 0, 0, 0);   // dQ^T[d][query li]
+        const int col = h * 32 + 16 * d + 4 * lg;
+        const float4 vq = make_float4(dq[0] * a.dq_scale, dq[1] * a.dq_scale, dq[2] * a.dq_scale, dq[3] * a.dq_scale);
+        const float4 vk = make_float4(dk[0] * a.dk_scale, dk[1] * a.dk_scale, dk[2] * a.dk_scale, dk[3] * a.dk_scale);
+        const float4 vv = make_float4(dv[0], dv[1], dv[2], dv[3]);
+        if (li < N) {
+          store4<bf16>(qbuf + li * LDQ + col, vq);
+          store4<bf16>(qbuf + li * LDQ + I + col, vk);
+          store4<bf16>(qbuf + li * LDQ + 2 * I + col, vv);
+          bf16* g = a.dqkv + (row0 + li) * (3 * I);
+          store4<bf16>(g + col, vq);
+          store4<bf16>(g + I + col, vk);
+          store4<bf16>(g + 2 * I + col, vv);
+        }
+      }
+    }
+    __syncthreads();  // dqkv tile complete; the saved-projection tile is dead (xbuf / mbuf take its place)
+  } else {
+    for (int e = tid; e < R * (3 * I / 8); e += NW * 64) {
+      const int r = e / (3 * I / 8), c = (e - r * (3 * I / 8)) * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (r < N) v = *reinterpret_cast<const uint4*>(a.dqkv + (row0 + r) * (3 * I) + c);
+      *reinterpret_cast<uint4*>(qbuf + r * LDQ + c) = v;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   small_gemm<1, K3, NW>(qbuf, LDQ, a.wqkv_t, D, wave, li, lg, [&](int cb, f32x4_t(&acc)[1]) {
     *reinterpret_cast<float4*>(xbuf + li * LDX + cb * 16 + 4 * lg) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
   });
@@ -646,18 +767,37 @@ int layer_bwd_small_a(int B, int N, int D, int I, int M, const SmallBwdAHost& h,
   AVF_REQUIRE(false, "layer_bwd_small_a: unsupported shape D=%d I=%d M=%d", D, I, M);
 }
 
+template <int D32, int I32, bool ATT>
+static int launch_small_b(const SmallBwdB& a, int B, hipStream_t s) {
+  constexpr int D = D32 * 32, I = I32 * 32;
+  constexpr int saved = ATT ? 32 * (3 * I + 16) * 2 : 0, xb = 2 * 16 * (D + 4) * 4;
+  constexpr int smem = (saved > xb ? saved : xb) + 16 * (3 * I + 8) * 2 + (ATT ? 32 * (I + 8) * 2 + 16 * 3 * 256 * 2 : 0);
+  static_assert(smem <= 160 * 1024, "LDS budget");
+  static PerDeviceOnce raised;
+  if (smem > 64 * 1024 && raised.need()) {
+    AVF_REQUIRE(hipFuncSetAttribute((const void*)layer_bwd_small_b_kernel<D32, I32, 16, ATT>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, smem) == hipSuccess,
+                "layer_bwd_small_b: cannot raise dynamic LDS limit");
+    raised.mark();
+  }
+  layer_bwd_small_b_kernel<D32, I32, 16, ATT><<<B, 1024, smem, s>>>(a);
+  return check_launch("layer_bwd_small_b_kernel");
+}
+
 int layer_bwd_small_b(int B, int N, int D, int I, const SmallBwdBHost& h, hipStream_t s) {
   SmallBwdB a;
-  a.dqkv = (const bf16*)h.dqkv; a.wqkv_t = (const bf16*)h.wqkv_t; a.x_in = h.x_in; a.ln1_w = h.ln1_w; a.mean1 = h.mean1;
+  a.qkv = (const bf16*)h.qkv; a.o = (const bf16*)h.o; a.d_o = (const bf16*)h.d_o; a.lse2 = h.lse2;
+  a.score_scale = h.score_scale; a.dq_scale = h.dq_scale; a.dk_scale = h.dk_scale; a.H = h.H;
+  a.dqkv = (bf16*)h.dqkv; a.wqkv_t = (const bf16*)h.wqkv_t; a.x_in = h.x_in; a.ln1_w = h.ln1_w; a.mean1 = h.mean1;
   a.rstd1 = h.rstd1; a.dx_mid = h.dx_mid; a.dx_mid_lo = (const bf16*)h.dx_mid_lo; a.dx_in = h.dx_in; a.dx_in_lo = (bf16*)h.dx_in_lo;
   a.pln1 = h.pln1; a.N = N; a.gs16 = h.gs16; a.dr_prev2 = h.dr_prev2;
-  AVF_REQUIRE(N >= 1 && N <= 16 && (a.dx_in || a.dx_in_lo) && (h.gs16 ? a.dx_mid_lo != nullptr : a.dx_mid != nullptr),
+  AVF_REQUIRE(N >= 1 && N <= 16 && a.dqkv && (a.dx_in || a.dx_in_lo) && (h.gs16 ? a.dx_mid_lo != nullptr : a.dx_mid != nullptr),
               "layer_bwd_small_b: bad arguments");
-#define AVF_SMALL_B(DD, II)                                                 \
-  if (D == DD * 32 && I == II * 32) {                                       \
-    layer_bwd_small_b_kernel<DD, II, 16><<<B, 1024, 0, s>>>(a);             \
-    return check_launch("layer_bwd_small_b_kernel");                        \
-  }
+  AVF_REQUIRE(!h.attention || (a.qkv && a.o && a.d_o && a.lse2 && h.H >= 1 && h.H <= 16 && h.H * 32 == I),
+              "layer_bwd_small_b: the fused attention backward needs the saved projection / output / lse2 and dim_head 32");
+#define AVF_SMALL_B(DD, II)                                                                   \
+  if (D == DD * 32 && I == II * 32)                                                           \
+    return h.attention ? launch_small_b<DD, II, true>(a, B, s) : launch_small_b<DD, II, false>(a, B, s);
   AVF_SMALL_B(4, 4) AVF_SMALL_B(4, 8) AVF_SMALL_B(8, 4) AVF_SMALL_B(8, 8)
 #undef AVF_SMALL_B
   AVF_REQUIRE(false, "layer_bwd_small_b: unsupported shape D=%d I=%d", D, I);
