@@ -154,6 +154,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(NtParam
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+  // LDS byte addresses of this lane's fragment rows in stage 0: row blocks i / j are 16 rows = 2048 bytes apart, and the
+  // swizzle term of nt_off() depends on (row & 7) = (li & 7) only, so one base per k-half serves all of them
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char*)dsm;
+  uint32_t abase[2], bbase[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    abase[ks] = lds0 + nt_off(wm * WTM + li, ks * 4 + lg);
+    bbase[ks] = lds0 + A_BYTES + nt_off(wn * WTN + li, ks * 4 + lg);
+  }
+
   // NS-stage ring: tiles t .. t+NS-2 are in flight while tile t is consumed.  Each wave counts its own DMA
   // instructions (INS per tile) with s_waitcnt vmcnt(N) - never draining to 0 inside the loop - and one raw
   // s_barrier per K-step makes every wave's landed tile visible and frees the slot of tile t-1 for tile t+NS-1.
@@ -174,28 +184,30 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(NtParam
       slot = slot >= NS ? slot - NS : slot;
       stage(slot, (t + NS - 1) * TK);
     }
-    const char* sa = dsm + cur * STAGE;
-    const char* sb = sa + A_BYTES;
-    // all fragment reads of the K-step are issued before its first MFMA (the compiler then waits with counted
-    // lgkmcnt, so the second half's reads overlap the first half's MFMAs instead of serialising behind them)
+    // all fragment reads of the K-step are issued (inline asm: gemm_nt.hpp) before its first MFMA; the first k-half's
+    // MFMAs start when its MI + NI reads have returned, the second half's reads overlap them
+    const uint32_t so = (uint32_t)cur * STAGE;
     bf16x8_t fa[2][MI], fb[2][NI];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-        fa[ks][i] = *reinterpret_cast<const bf16x8_t*>(sa + nt_off(wm * WTM + i * 16 + li, ks * 4 + lg));
-#pragma unroll
-      for (int j = 0; j < NI; ++j)
-        fb[ks][j] = *reinterpret_cast<const bf16x8_t*>(sb + nt_off(wn * WTN + j * 16 + li, ks * 4 + lg));
+      lds_read_frags<bf16x8_t, 2048>(fa[ks], abase[ks] + so, std::make_integer_sequence<int, MI>{});
+      lds_read_frags<bf16x8_t, 2048>(fb[ks], bbase[ks] + so, std::make_integer_sequence<int, NI>{});
     }
+    wait_lgkmcnt<MI + NI>();
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+      for (int j = 0; j < NI; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0][j], fa[0][i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    wait_lgkmcnt<0>();
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[1][j], fa[1][i], acc[i][j], 0, 0, 0);
     cur = (cur + 1 == NS) ? 0 : cur + 1;
   }
 

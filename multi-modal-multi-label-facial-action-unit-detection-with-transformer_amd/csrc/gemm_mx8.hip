@@ -111,6 +111,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mx8_nt_kernel(Mx8Params q, 
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+  // LDS byte addresses of this lane's fragment rows / scale dwords in stage 0 (row blocks are 2048 / 64 bytes apart)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char*)dsm;
+  uint32_t abase[2], bbase[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    abase[h] = lds0 + nt_off(wm * WTM + li, h * 4 + lg);
+    bbase[h] = lds0 + A_BYTES + nt_off(wn * WTN + li, h * 4 + lg);
+  }
+  const uint32_t sabase = lds0 + A_BYTES + B_BYTES + (wm * WTM + li) * 4;
+  const uint32_t sbbase = lds0 + A_BYTES + B_BYTES + (BMT + wn * WTN + li) * 4;
+
   const int nt = p.K / KS;
   stage(0, 0);
   int cur = 0;
@@ -118,27 +129,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mx8_nt_kernel(Mx8Params q, 
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (t + 1 < nt) stage(cur ^ 1, t + 1);
-    const char* sa = dsm + cur * STAGE;
-    const char* sb = sa + A_BYTES;
-    const char* ss = sb + B_BYTES;
+    // fragment and scale reads as inline asm (gemm_nt.hpp): the DMA of tile t+1 stays in flight under them
+    const uint32_t so = (uint32_t)cur * STAGE;
     i32x4_t fa[2][MI], fb[2][NI];
     uint32_t sca[MI], scb[NI];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-        fa[h][i] = *reinterpret_cast<const i32x4_t*>(sa + nt_off(wm * WTM + i * 16 + li, h * 4 + lg));
-#pragma unroll
-      for (int j = 0; j < NI; ++j)
-        fb[h][j] = *reinterpret_cast<const i32x4_t*>(sb + nt_off(wn * WTN + j * 16 + li, h * 4 + lg));
+      lds_read_frags<i32x4_t, 2048>(fa[h], abase[h] + so, std::make_integer_sequence<int, MI>{});
+      lds_read_frags<i32x4_t, 2048>(fb[h], bbase[h] + so, std::make_integer_sequence<int, NI>{});
     }
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-      sca[i] = (*reinterpret_cast<const uint32_t*>(ss + (wm * WTM + i * 16 + li) * 4) >> (8 * lg)) & 255u;
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-      scb[j] = (*reinterpret_cast<const uint32_t*>(ss + (BMT + wn * WTN + j * 16 + li) * 4) >> (8 * lg)) & 255u;
+    lds_read_words<64>(sca, sabase + so, std::make_integer_sequence<int, MI>{});
+    lds_read_words<64>(scb, sbbase + so, std::make_integer_sequence<int, NI>{});
+    wait_lgkmcnt<0>();
     __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) sca[i] = (sca[i] >> (8 * lg)) & 255u;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) scb[j] = (scb[j] >> (8 * lg)) & 255u;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const v8i_t va = {fa[0][i][0], fa[0][i][1], fa[0][i][2], fa[0][i][3], fa[1][i][0], fa[1][i][1], fa[1][i][2], fa[1][i][3]};

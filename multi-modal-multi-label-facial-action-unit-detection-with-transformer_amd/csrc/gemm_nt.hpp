@@ -3,6 +3,8 @@
 #pragma once
 #include <stdlib.h>
 
+#include <utility>
+
 #include "common.hpp"
 
 namespace avf {
@@ -210,6 +212,37 @@ __device__ __forceinline__ int xcd_remap(int id, int nwg) {
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkmcnt() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Fragment reads as inline asm.  With an LDS-DMA in flight hipcc (ROCm 7.2) drains vmcnt to 0 in front of the first
+// compiler-visible ds_read of a K-step (its wait-count pass takes the DMA for an LDS store that may alias the read), which
+// serialises the next tile's DMA with this tile's reads and MFMAs.  These reads are opaque to that pass: the kernel's own
+// vmcnt + s_barrier order them against the DMA, and the caller waits with wait_lgkmcnt<N>() + sched_barrier(0) before the
+// first use of the destination registers (the hardware does not interlock LDS returns).  DESIGN.md section 12(a).
+template <typename V, int OFF>
+__device__ __forceinline__ V lds_read_b128(uint32_t addr) {
+  V v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+template <int OFF>
+__device__ __forceinline__ uint32_t lds_read_b32(uint32_t addr) {
+  uint32_t v;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+// dst[i] = the 16 bytes at addr + i * STRIDE, i = 0 .. sizeof...(Is) - 1 (immediate offsets)
+template <typename V, int STRIDE, int... Is>
+__device__ __forceinline__ void lds_read_frags(V* dst, uint32_t addr, std::integer_sequence<int, Is...>) {
+  ((dst[Is] = lds_read_b128<V, Is * STRIDE>(addr)), ...);
+}
+template <int STRIDE, int... Is>
+__device__ __forceinline__ void lds_read_words(uint32_t* dst, uint32_t addr, std::integer_sequence<int, Is...>) {
+  ((dst[Is] = lds_read_b32<Is * STRIDE>(addr)), ...);
 }
 
 // tile configurations (block tile, wavefronts, LDS stages, resident blocks per CU):

@@ -1,6 +1,7 @@
 // Development harness (not part of the product): candidate structures for the bf16 NT GEMM C[M,N] = A[M,K] B[N,K]^T with a
 // plain bf16 epilogue, timed back to back and checked against a host reference on sampled elements.
 //   K0  the shipped structure: 128 x 128 tile, 8 waves of 64 x 32, 2 LDS stages, one barrier per K-step, 2 workgroups / CU
+//   K0A K0 with inline-asm fragment reads (variant 5: one wait, 6: split wait) - what the product kernel now does
 //   K1  256 x 128 tile, 8 waves of 64 x 64 in two groups that alternate LOAD and COMPUTE phases (ping-pong), 3-slot
 //       LDS-DMA ring, fragment reads by inline asm (no compiler-inserted vmcnt(0)), 1 workgroup / CU
 // Build here (cross-compile), run on the GPU box:
@@ -110,6 +111,83 @@ __global__ __launch_bounds__(512) void k(const uint16_t* A, const uint16_t* B, u
   }
 }
 }  // namespace k0
+
+// ------------------------------------------------------------------------------------------------ K0A (K0, asm fragment reads)
+// the shipped structure with the fragment reads issued as inline asm: the compiler no longer drains vmcnt before the first
+// ds_read of a K-step, so the DMA of tile t+1 really overlaps the reads and MFMAs of tile t inside one workgroup
+namespace k0a {
+using namespace k0;
+template <int SPLIT>
+__global__ __launch_bounds__(512) void k(const uint16_t* A, const uint16_t* B, uint16_t* C, int M, int N, int K, int tiles_n,
+                                         int nwg) {
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN, li = lane & 15, lg = lane >> 4;
+  const int wg = xcd_remap(blockIdx.x, nwg);
+  const int m0 = (wg / tiles_n) * BMT, n0 = (wg % tiles_n) * BNT;
+  const int lrow = lane >> 3, lchunk = (lane & 7) ^ (lane >> 3);
+  const uint16_t* ga[A_INS];
+  const uint16_t* gb[B_INS];
+  for (int j = 0; j < A_INS; ++j) { int r = m0 + (wave * A_INS + j) * 8 + lrow; r = r < M ? r : M - 1; ga[j] = A + (int64_t)r * K + lchunk * 8; }
+  for (int j = 0; j < B_INS; ++j) { int r = n0 + (wave * B_INS + j) * 8 + lrow; r = r < N ? r : N - 1; gb[j] = B + (int64_t)r * K + lchunk * 8; }
+  auto stage = [&](int st, int k0) {
+    char* sa = dsm + st * STAGE; char* sb = sa + A_BYTES;
+    for (int j = 0; j < A_INS; ++j) glds16(ga[j] + k0, sa + (wave * A_INS + j) * 1024);
+    for (int j = 0; j < B_INS; ++j) glds16(gb[j] + k0, sb + (wave * B_INS + j) * 1024);
+  };
+  f32x4_t acc[MI][NI];
+  for (int i = 0; i < MI; ++i) for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0, 0, 0, 0};
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char*)dsm;
+  uint32_t abase[2], bbase[2];
+  for (int ks = 0; ks < 2; ++ks) {
+    abase[ks] = lds0 + nt_off(wm * 64 + li, ks * 4 + lg);
+    bbase[ks] = lds0 + A_BYTES + nt_off(wn * 32 + li, ks * 4 + lg);
+  }
+  const int nt = K / TK;
+  stage(0, 0);
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 1 < nt) stage(cur ^ 1, (t + 1) * TK);
+    const uint32_t so = cur * STAGE;
+    bf16x8_t fa[2][MI], fb[2][NI];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      fa[ks][0] = lds_b128<0>(abase[ks] + so); fa[ks][1] = lds_b128<2048>(abase[ks] + so);
+      fa[ks][2] = lds_b128<4096>(abase[ks] + so); fa[ks][3] = lds_b128<6144>(abase[ks] + so);
+      fb[ks][0] = lds_b128<0>(bbase[ks] + so); fb[ks][1] = lds_b128<2048>(bbase[ks] + so);
+    }
+    if (SPLIT) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0][j], fa[0][i], acc[i][j], 0, 0, 0);
+    if (SPLIT) {
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[1][j], fa[1][i], acc[i][j], 0, 0, 0);
+    cur ^= 1;
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + li;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = n0 + wn * 32 + j * 16 + 4 * lg;
+      if (m < M && n < N) store_bf16x4(C + (int64_t)m * N + n, acc[i][j]);
+    }
+  }
+}
+}  // namespace k0a
 
 // ------------------------------------------------------------------------------------------------ K1 (ping-pong, 256 x 128)
 // PH = compute phases per K-tile per wave (1: 32 MFMAs per phase, 2: 16 per phase)
@@ -476,7 +554,7 @@ int main(int argc, char** argv) {
   void *resd = nullptr, *Xd = nullptr;
   uint16_t* Hd = nullptr;
   std::vector<float> hbias(N), hres;
-  if (variant >= 3) {
+  if ((variant == 3 || variant == 4)) {
     if (N != 512) { printf("variant %d needs N = 512\n", variant); return 1; }
     for (auto& v : hbias) v = (float)rand() / RAND_MAX - 0.5f;
     std::vector<float> ones(N, 1.f), zeros(N, 0.f);
@@ -497,7 +575,7 @@ int main(int argc, char** argv) {
     hipMalloc(&Hd, nc * 2);
   }
   auto launch = [&](bool stamps) {
-    if (variant >= 3) {
+    if ((variant == 3 || variant == 4)) {
       nwg = (M + 63) / 64; tiles_n = 1;
       const int smem = k2::NSLOT * k2::STAGE;
       if (variant == 4) {
@@ -509,7 +587,16 @@ int main(int argc, char** argv) {
       }
       return;
     }
-    if (variant == 0) {
+    if (variant == 5 || variant == 6) {
+      tiles_n = (N + 127) / 128; nwg = ((M + 127) / 128) * tiles_n;
+      if (variant == 5) {
+        hipFuncSetAttribute((const void*)k0a::k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * k0::STAGE);
+        k0a::k<0><<<nwg, 512, 2 * k0::STAGE>>>(A, B, C, M, N, K, tiles_n, nwg);
+      } else {
+        hipFuncSetAttribute((const void*)k0a::k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * k0::STAGE);
+        k0a::k<1><<<nwg, 512, 2 * k0::STAGE>>>(A, B, C, M, N, K, tiles_n, nwg);
+      }
+    } else if (variant == 0) {
       tiles_n = (N + 127) / 128; nwg = ((M + 127) / 128) * tiles_n;
       hipFuncSetAttribute((const void*)k0::k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * k0::STAGE);
       k0::k<<<nwg, 512, 2 * k0::STAGE>>>(A, B, C, M, N, K, tiles_n, nwg);
@@ -536,7 +623,7 @@ int main(int argc, char** argv) {
     float ref = ref_elem(ha, hb, K, m, n);
     maxerr = std::max(maxerr, (double)fabsf(got - ref) / (fabs(ref) + 1.0));
   }
-  if (variant >= 3) {
+  if ((variant == 3 || variant == 4)) {
     hipMemcpy(hc.data(), Hd, nc * 2, hipMemcpyDeviceToHost);
     maxerr = 0;
     for (int s2 = 0; s2 < 6; ++s2) {
@@ -564,7 +651,7 @@ int main(int argc, char** argv) {
   const double us = ms * 1e3 / iters;
   printf("variant %d  M=%d N=%d K=%d  wgs=%d  %.2f us  %.1f TF/s  max rel err %.2e %s\n", variant, M, N, K, nwg, us,
          2.0 * M * N * K / us * 1e-6, maxerr, maxerr < 2e-2 ? "OK" : "WRONG");
-  if (variant >= 3) return 0;
+  if ((variant == 3 || variant == 4)) return 0;
   if (want_stamps && variant >= 1) {
     hipMalloc(&S, (size_t)nwg * 2 * 16 * 8);
     hipMemset(S, 0, (size_t)nwg * 2 * 16 * 8);
