@@ -40,8 +40,8 @@ CONFIGS = {
     "c5": dict(dim=512, depth=6, heads=8, dim_head=64, mlp_dim=1024, t_video=384, t_audio=128, batch=64),  # with --dtype mx8
 }
 PKG_DIR = "multi-modal-multi-label-facial-action-unit-detection-with-transformer_amd"
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "mx8": 2500.0}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
-MX8_PEAK_TFLOPS = 5000.0  # the MX-scaled fp8 MFMA (kernel class gemm_mx8_nt only; mx8 mode keeps backward on bf16)
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "mx8": 2500.0, "mx8-fwd": 2500.0}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+MX8_PEAK_TFLOPS = 5000.0  # the MX-scaled fp8 MFMA (kernel class gemm_mx8_nt only; attention, dW and dqkv -> dh1 stay bf16)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -279,8 +279,9 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "mx8"],
-                    help="mx8: bf16 path with MX-FP8 operands on the forward qkv / mlp GEMMs (BASELINE config 5)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "mx8", "mx8-fwd"],
+                    help="mx8: bf16 path with MX-FP8 operands on the forward qkv / out / mlp GEMMs and the backward dX GEMMs of "
+                         "the mlp and out-projection (BASELINE config 5); mx8-fwd: forward operands only (A/B aid)")
     ap.add_argument("--residual", default="f32", choices=["f32", "bf16"],
                     help="storage type of the forward residual stream in the bf16 / mx8 modes (Transformer(residual_dtype=...))")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")

@@ -66,6 +66,13 @@ typedef struct avf_layer_cfg {
                           avf_layer_fwd / avf_layer_bwd and the saved mid-layer stream are bf16 tensors (LayerNorm statistics,
                           GEMM accumulation and the residual add itself stay fp32; one bf16 rounding per residual add).
                           Cuts the HBM bytes of the two LayerNorms and the two residual GEMM epilogues of a layer by a third. */
+  int32_t mx8_bwd;     /* 1 (needs mx8_fwd): the backward GEMMs dX = dY W of net.3, net.0 and to_out take MX-FP8 operands too: the
+                          LayerNorm backward kernels and the dGELU epilogue write the e4m3 image of their output beside the bf16
+                          one, avf_stack_quant_weights_mx8 also makes the images of the transposed weights.  The bf16
+                          gradient-stream buffers dx_out_lo / dx_in_lo of avf_layer_bwd are then avf_layer_grad_stream_bytes()
+                          long: [R, D] bf16 | [R, D] e4m3 | [R, D/32] E8M0 (each part 256-byte aligned).               */
+  int32_t dx_out_mx8;  /* mx8_bwd: 1 = dx_out_lo already carries that image (it was written as the dx_in_lo of the layer
+                          above by avf_layer_bwd with mx8_bwd set); 0 = the layer quantises dx_out_lo itself (top layer) */
 } avf_layer_cfg;
 
 /* fp32 master parameters of one layer, in state_dict order:
@@ -137,9 +144,10 @@ int avf_gemm_tn_group(int count, int64_t K, const void* const* A, const void* co
  *   avf_quant_mx8:   x [rows,cols] (AVF_F32 | AVF_BF16, cols % 32 == 0) -> q [rows,cols] bytes, scales [rows,cols/32] bytes;
  *                    scale = floor(log2(block amax)) - 8 (+127), q = rne_e4m3(clamp(x * 2^-(scale-127), +-448)).
  *   avf_gemm_mx8_nt: C[M,N] = A[M,K] * B[N,K]^T from two such images (K % 128 == 0), fp32 accumulate, epilogues
- *                    AVF_EPI_NONE / BIAS_RES / BIAS_GELU as avf_gemm; c_q / c_scales (optional, BIAS_GELU, N % 32 == 0):
+ *                    AVF_EPI_NONE / BIAS_RES / BIAS_GELU / DGELU as avf_gemm; c_q / c_scales (optional, BIAS_GELU / DGELU, N % 32 == 0):
  *                    also the MX-FP8 image of the stored C, ready to be the next GEMM's A operand. */
-/* e4m3 images of Wqkv, W1, W2 of every layer of a stack from their bf16 images, one launch (cfg.mx8_fwd = 1);
+/* e4m3 images of Wqkv, W1, W2, Wo (and, cfg.mx8_bwd, of the transposed W2, W1, Wo) of every layer of a stack from their
+ * bf16 images, one launch (cfg.mx8_fwd = 1);
  * lowp[i] = the avf_layer_lowp_bytes buffer of layer i, after avf_layer_prepare_weights / the library Adam wrote it */
 int avf_stack_quant_weights_mx8(const avf_layer_cfg* cfg, int layers, void* const* lowp, void* stream);
 int avf_quant_mx8(int dtype, const void* x, int64_t rows, int64_t cols, void* q, void* scales, void* stream);
@@ -150,6 +158,16 @@ int avf_gemm_mx8_nt(int64_t M, int64_t N, int64_t K, const void* a_q, const void
 /* nn.LayerNorm forward (heads.py:178-185) writing the bf16 output AND its MX-FP8 image (dim % 32 == 0, dim <= 1536) */
 int avf_layernorm_fwd_mx8(const float* x, const float* gamma, const float* beta, void* y_bf16, float* mean, float* rstd,
                           void* y_q, void* y_scales, int64_t rows, int dim, float eps, void* stream);
+
+/* nn.LayerNorm backward (avf_layernorm_bwd with bf16 dy) writing the bf16 image dx_lo of dx = dres + dLN AND its MX-FP8
+ * image (dim % 32 == 0, dim <= 1536): the A operand of the dX GEMM below the LayerNorm in the fp8 mode; dx (fp32) optional */
+int avf_layernorm_bwd_mx8(const void* dy_bf16, const float* x, const float* gamma, const float* mean, const float* rstd,
+                          const float* dres, float* dx, void* dx_lo, void* dx_q, void* dx_scales, float* dgamma, float* dbeta,
+                          void* workspace, int64_t rows, int dim, void* stream);
+/* bf16 attention forward (avf_attn_fwd) also writing the MX-FP8 image of o [B*N, I] - the A operand of to_out (heads.py:215)
+ * in the fp8 mode.  Head-resident kernel only: dim_head 64, tokens <= 576 (error otherwise). */
+int avf_attn_fwd_mx8(const void* qkv, void* o, float* lse2, void* o_q, void* o_scales, int batch, int tokens, int heads,
+                     int dim_head, void* stream);
 
 /* Multi-head self-attention core - heads.py:222-237.  qkv [B*N, 3I] (q|k|v, head-major columns),
  * o [B*N, I], lse2 fp32 [B,H,N] = log2-domain log-sum-exp of the scaled scores (saved for backward). */
@@ -234,6 +252,8 @@ int avf_au_loss_sum(const float* logits, int64_t ld_logits, const float* labels,
 size_t avf_layer_saved_bytes(const avf_layer_cfg* cfg);     /* activations kept for backward        */
 size_t avf_layer_lowp_bytes(const avf_layer_cfg* cfg);      /* bf16 weight copies (+transposes)     */
 size_t avf_layer_workspace_bytes(const avf_layer_cfg* cfg); /* scratch, reusable across layers      */
+size_t avf_layer_grad_stream_bytes(const avf_layer_cfg* cfg); /* bytes of one dx_out_lo / dx_in_lo buffer of avf_layer_bwd:
+                                                                 R*D bf16, plus the MX-FP8 image behind it when cfg.mx8_bwd */
 
 /* refresh the bf16 weight copies from the fp32 masters (no-op in AVF_F32 mode) */
 int avf_layer_prepare_weights(const avf_layer_cfg* cfg, const avf_layer_params* p, void* lowp, void* stream);

@@ -244,6 +244,23 @@ extern "C" int avf_layernorm_fwd_mx8(const float* x, const float* gamma, const f
   AVF_REQUIRE(x && gamma && beta && y_bf16 && mean && rstd && y_q && y_scales, "layernorm_fwd_mx8: null pointer");
   return layernorm_fwd(x, gamma, beta, y_bf16, AVF_BF16, mean, rstd, rows, dim, eps, (hipStream_t)stream, y_q, y_scales);
 }
+extern "C" int avf_layernorm_bwd_mx8(const void* dy_bf16, const float* x, const float* gamma, const float* mean,
+                                     const float* rstd, const float* dres, float* dx, void* dx_lo, void* dx_q, void* dx_scales,
+                                     float* dgamma, float* dbeta, void* workspace, int64_t rows, int dim, void* stream) {
+  AVF_REQUIRE(dy_bf16 && x && gamma && mean && rstd && dx_lo && dx_q && dx_scales && dgamma && dbeta && workspace,
+              "layernorm_bwd_mx8: null pointer");
+  return layernorm_bwd(dy_bf16, AVF_BF16, x, gamma, mean, rstd, dres, dx, dx_lo, dgamma, dbeta, nullptr, workspace, rows, dim,
+                       (hipStream_t)stream, kNoDrop, nullptr, AVF_F32, AVF_F32, dx_q, dx_scales);
+}
+extern "C" int avf_attn_fwd_mx8(const void* qkv, void* o, float* lse2, void* o_q, void* o_scales, int batch, int tokens,
+                                int heads, int dim_head, void* stream) {
+  AVF_REQUIRE(qkv && o && lse2 && o_q && o_scales, "attn_fwd_mx8: null pointer");
+  AVF_REQUIRE(attn_fwd_emits_mx8(tokens, dim_head),
+              "attn_fwd_mx8: only the head-resident kernel (dim_head 64, tokens <= 576) writes the image (tokens=%d dim_head=%d)",
+              tokens, dim_head);
+  return attn_fwd_bf16((const bf16*)qkv, (bf16*)o, lse2, batch, tokens, heads, dim_head, (hipStream_t)stream, false, o_q,
+                       o_scales);
+}
 extern "C" int avf_quant_mx8(int dtype, const void* x, int64_t rows, int64_t cols, void* q, void* scales, void* stream) {
   AVF_REQUIRE(x && q && scales, "quant_mx8: null pointer");
   return quant_mx8(x, dtype, cols, rows, cols, q, cols, scales, (hipStream_t)stream);

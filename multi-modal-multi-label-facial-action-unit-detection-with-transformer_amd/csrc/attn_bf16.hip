@@ -424,12 +424,26 @@ __device__ __forceinline__ void res_sweep(int N, bool first, TileFn&& tile, Sync
   if (nfull < nt && t0 <= nfull) tile(nfull, std::true_type{}, std::false_type{});
 }
 
+// 4 x 4 transpose of one dword between the register index and the lane group (lanes l, l + 16, l + 32, l + 48):
+// in: a[d] of lane group g = X[d][g]; out: a[k] of lane group g = X[g][k]
+__device__ __forceinline__ void tr4x4(uint32_t (&a)[4]) {
+  // lane groups g <-> g ^ 1: even groups keep X[d0][g] and take X[d0][g + 1], odd groups take X[d1][g - 1] and keep X[d1][g]
+  const auto p01 = __builtin_amdgcn_permlane16_swap(a[0], a[1], false, false);
+  const auto p23 = __builtin_amdgcn_permlane16_swap(a[2], a[3], false, false);
+  // lane groups g <-> g ^ 2 on the first / second words of the two pairs
+  const auto x = __builtin_amdgcn_permlane32_swap(p01[0], p23[0], false, false);
+  const auto y = __builtin_amdgcn_permlane32_swap(p01[1], p23[1], false, false);
+  a[0] = x[0]; a[1] = y[0]; a[2] = x[1]; a[3] = y[1];
+}
+
 // MULTI: more 32-row groups than waves (each wave loops over its groups); otherwise exactly one group per wave.
 // QS: the q columns already carry log2(e)/sqrt(dh) (layer path) - the scores leave the MFMA in the log2 domain, and the
 // subtraction of the running maximum (forward) / of lse2 (backward) rides in the MFMA's C operand: no per-score FMA.
 template <int MAXW, bool MULTI, bool QS>
 __global__ __launch_bounds__(MAXW * 64) void attn_fwd_res_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
-                                                                float* __restrict__ lse2, int N, int H) {
+                                                                float* __restrict__ lse2, int N, int H,
+                                                                uint8_t* __restrict__ oq = nullptr,
+                                                                uint8_t* __restrict__ osc = nullptr) {
   constexpr int DH = 64, KS = 2, DB = 4;
   extern __shared__ __attribute__((aligned(16))) char res_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -627,15 +641,46 @@ __global__ __launch_bounds__(MAXW * 64) void attn_fwd_res_kernel(const bf16* __r
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       const int q = q0 + qb * 16 + li;
+      const float l = ls[qb][0];
+      const float inv = 1.0f / l;
       if (q < N) {
-        const float l = ls[qb][0];
-        const float inv = 1.0f / l;
         bf16* orow = o + ((int64_t)b * N + q) * I + h * DH;
 #pragma unroll
         for (int d = 0; d < DB; ++d)
           store4<bf16>(orow + d * 16 + 4 * lg,
                        make_float4(ot[d][qb][0] * inv, ot[d][qb][1] * inv, ot[d][qb][2] * inv, ot[d][qb][3] * inv));
         if (lg == 0) lse2[(int64_t)bh * N + q] = m[qb] + log2f(l);
+      }
+      if (oq) {  // wave-uniform: MX-FP8 image of the output rows (A operand of the out-projection in the fp8 mode); a
+                 // 32-block of the head's 64 columns is two 16-column blocks x the 4 lane groups x 4 registers
+        // A lane holds columns 16 d + 4 lg .. + 3 of its row for d = 0..3: one dword of the image each, 16 bytes apart.  A
+        // 4 x 4 transpose between the register index d and the lane group lg (tr4x4) leaves lane group lg with the 16
+        // contiguous bytes of column block d = lg: one 16-byte store (64-byte row segments per instruction; 67.6 -> 65.7 us
+        // at B = 64, N = 512 against per-dword stores.  The same transpose on the bf16 output itself measured +2 %: not used)
+        const int64_t row = (int64_t)b * N + (q < N ? q : N - 1);
+        uint32_t qw[DB], sb[2];
+        float vb[DB][4];
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vb[d][r] = to_f32<bf16>(from_f32<bf16>(ot[d][qb][r] * inv));  // image of the STORED values
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+          float am = 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) am = fmaxf(am, fmaxf(fabsf(vb[2 * blk][r]), fabsf(vb[2 * blk + 1][r])));
+          am = fmaxf(am, __shfl_xor(am, 16, 64));
+          am = fmaxf(am, __shfl_xor(am, 32, 64));
+          float sinv;
+          sb[blk] = mx8_scale_byte(am, &sinv);
+          qw[2 * blk] = mx8_pack4(vb[2 * blk], sinv);
+          qw[2 * blk + 1] = mx8_pack4(vb[2 * blk + 1], sinv);
+        }
+        tr4x4(qw);  // lane group lg: bytes 16 lg .. 16 lg + 15 of the head's 64
+        if (q < N) {
+          *reinterpret_cast<uint4*>(oq + row * I + h * DH + lg * 16) = make_uint4(qw[0], qw[1], qw[2], qw[3]);
+          if (lg == 0) *reinterpret_cast<uint16_t*>(osc + row * (I >> 5) + h * 2) = (uint16_t)(sb[0] | (sb[1] << 8));
+        }
       }
     }
     AVF_PHASE_MARK(7);
@@ -1313,7 +1358,13 @@ bool attn_q_prescale_on() {
 }
 float attn_q_prescale(int dh) { return attn_q_prescale_on() ? LOG2E / sqrtf((float)dh) : 1.0f; }
 
-int attn_fwd_bf16(const bf16* qkv, bf16* o, float* lse2, int B, int N, int H, int dh, hipStream_t s, bool q_prescaled) {
+// the head-resident forward kernel can also write the MX-FP8 image of its output
+bool attn_fwd_emits_mx8(int N, int dh) { return use_resident(N, dh); }
+
+int attn_fwd_bf16(const bf16* qkv, bf16* o, float* lse2, int B, int N, int H, int dh, hipStream_t s, bool q_prescaled,
+                  void* mx_q, void* mx_s) {
+  AVF_REQUIRE(!mx_q || (mx_s && attn_fwd_emits_mx8(N, dh) && ((uintptr_t)mx_q & 3) == 0),
+              "attn_fwd_bf16: the MX-FP8 output image exists on the head-resident kernel only (N=%d dh=%d)", N, dh);
   AVF_REQUIRE(B > 0 && N > 0 && H > 0, "attn_fwd_bf16: bad shape");
   AVF_REQUIRE(ceil_div(N, 128) * B * H < (1LL << 31), "attn_fwd_bf16: grid too large");
   AVF_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)o & 7) == 0, "attn_fwd_bf16: misaligned pointers");
@@ -1321,7 +1372,8 @@ int attn_fwd_bf16(const bf16* qkv, bf16* o, float* lse2, int B, int N, int H, in
   if (use_resident(N, dh)) {
     const int W = res_waves(N);
     const size_t smem = (size_t)((N + 31) & ~31) * 128 * 2;
-#define AVF_FWD_RES(MW, MU, Q, NAME) res_launch(&ts, attn_fwd_res_kernel<MW, MU, Q>, NAME, B * H, W, smem, s, qkv, o, lse2, N, H)
+#define AVF_FWD_RES(MW, MU, Q, NAME) res_launch(&ts, attn_fwd_res_kernel<MW, MU, Q>, NAME, B * H, W, smem, s, qkv, o, lse2, N, H, \
+                                                (uint8_t*)mx_q, (uint8_t*)mx_s)
     if (q_prescaled) {
       if (res_multi(N)) return AVF_FWD_RES(8, true, true, "attn_fwd_res<8,multi,qs>");
       if (W <= 8) return AVF_FWD_RES(8, false, true, "attn_fwd_res<8,qs>");

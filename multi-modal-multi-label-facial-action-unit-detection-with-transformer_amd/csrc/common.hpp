@@ -304,7 +304,8 @@ size_t layernorm_bwd_ws(int64_t rows, int dim);
 int layernorm_bwd(const void* dy, int dy_dtype, const void* x, const float* gamma, const float* mean,
                   const float* rstd, const void* dres, float* dx, void* dx_lo, float* dgamma, float* dbeta,
                   float* dcolsum, void* ws, int64_t rows, int dim, hipStream_t s, const DropCfg& drop = kNoDrop,
-                  FoldJob* defer_fold = nullptr, int dres_dtype = AVF_F32, int x_dtype = AVF_F32);
+                  FoldJob* defer_fold = nullptr, int dres_dtype = AVF_F32, int x_dtype = AVF_F32, void* mx_q = nullptr,
+                  void* mx_s = nullptr);  // mx_q / mx_s: also the MX-FP8 image of the values written to dx_lo
 size_t colsum_ws(int64_t rows, int cols);
 int colsum(const void* in, int in_dtype, int64_t rows, int cols, int64_t ld, float* out, void* ws, hipStream_t s);
 int cast_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t s, const DropCfg& drop = kNoDrop);
@@ -458,7 +459,8 @@ int layer_bwd_small_b(int B, int N, int D, int I, const SmallBwdBHost& h, hipStr
 float attn_q_prescale(int dh);
 bool attn_q_prescale_on();
 int attn_fwd_bf16(const bf16* qkv, bf16* o, float* lse2, int B, int N, int H, int dh, hipStream_t s,
-                  bool q_prescaled = false);
+                  bool q_prescaled = false, void* mx_q = nullptr, void* mx_s = nullptr);
+bool attn_fwd_emits_mx8(int N, int dh);  // mx_q / mx_s: MX-FP8 image of o, written by the head-resident kernel only
 int attn_bwd_bf16(const bf16* qkv, const bf16* o, const bf16* d_o, const float* lse2, bf16* dqkv, float* delta,
                   int B, int N, int H, int dh, hipStream_t s, bool q_prescaled = false, float* nlse = nullptr);
 int attn_delta(int dtype, const void* o, const void* d_o, float* delta, int B, int N, int H, int dh, hipStream_t s);

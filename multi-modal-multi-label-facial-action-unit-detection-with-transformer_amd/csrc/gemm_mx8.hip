@@ -305,7 +305,7 @@ int gemm_mx8_nt(const GemmArgs& a, const void* a_scales, const void* b_scales, h
   Mx8Params q;
   NtParams& p = q.nt;
   const double csz = a.c_dtype == AVF_F32 ? 4.0 : 2.0;
-  const double epi_bytes = a.epilogue == AVF_EPI_BIAS_RES ? csz * a.M * a.N : a.epilogue == AVF_EPI_BIAS_GELU ? csz * a.M * a.N : 0.0;
+  const double epi_bytes = a.epilogue == AVF_EPI_NONE ? 0.0 : csz * a.M * a.N;  // residual / saved pre-activation
   TimingScope ts(KC_GEMM_MX8_NT, 2.0 * a.M * a.N * a.K,
                  1.0 * (a.M * a.K + a.N * a.K) * (1.0 + 1.0 / 32) + csz * a.M * a.N + epi_bytes + (mx_q ? a.M * a.N * (1.0 + 1.0 / 32) : 0.0),
                  s, /*per_kernel=*/true);
@@ -315,8 +315,9 @@ int gemm_mx8_nt(const GemmArgs& a, const void* a_scales, const void* b_scales, h
   p.drop = a.drop;
   p.mxq = (uint8_t*)mx_q; p.mxs = (uint8_t*)mx_s;
   p.wide = nt_wide_stores();
-  AVF_REQUIRE(!mx_q || (mx_s && a.epilogue == AVF_EPI_BIAS_GELU && a.N % 32 == 0 && ((uintptr_t)mx_q & 3) == 0),
-              "gemm_mx8_nt: the MX-FP8 output image needs the BIAS_GELU epilogue and N %% 32 == 0");
+  AVF_REQUIRE(!mx_q || (mx_s && (a.epilogue == AVF_EPI_BIAS_GELU || a.epilogue == AVF_EPI_DGELU) && a.N % 32 == 0 &&
+                        ((uintptr_t)mx_q & 7) == 0),
+              "gemm_mx8_nt: the MX-FP8 output image needs the BIAS_GELU / DGELU epilogue and N %% 32 == 0");
   AVF_REQUIRE(!a.drop.thresh16 || a.epilogue != AVF_EPI_NONE, "gemm_mx8_nt: dropout needs a fused epilogue");
   p.M = (int)a.M; p.N = (int)a.N; p.K = (int)a.K;
   q.As = (const uint8_t*)a_scales; q.Bs = (const uint8_t*)b_scales;
@@ -326,6 +327,8 @@ int gemm_mx8_nt(const GemmArgs& a, const void* a_scales, const void* b_scales, h
   p.cs_partial = nullptr;
   if (a.colsum) {
     AVF_REQUIRE(a.workspace, "gemm_mx8_nt: column-sum workspace missing");
+    AVF_REQUIRE((size_t)ceil_div(a.M, 32) * a.N * sizeof(float) <= gemm_nt_colsum_ws(a.M, a.N),
+                "gemm_mx8_nt: column-sum partials exceed their workspace (internal error)");
     p.cs_partial = (float*)a.workspace;
   }
 #define LAUNCH(E)                                                     \
@@ -343,13 +346,20 @@ int gemm_mx8_nt(const GemmArgs& a, const void* a_scales, const void* b_scales, h
       AVF_REQUIRE(a.aux && a.ldaux % 4 == 0, "gemm_mx8_nt: aux missing");
       LAUNCH(AVF_EPI_BIAS_GELU);
       break;
+    case AVF_EPI_DGELU:
+      AVF_REQUIRE(a.aux && a.ldaux % 4 == 0, "gemm_mx8_nt: DGELU needs the saved pre-activation (in C's type)");
+      LAUNCH(AVF_EPI_DGELU);
+      break;
     default: AVF_REQUIRE(false, "gemm_mx8_nt: bad epilogue %d", a.epilogue);
   }
 #undef LAUNCH
   AVF_TRY(check_launch("gemm_mx8_nt_kernel"));
   AVF_REQUIRE(!a.colsum || (size_t)part_rows * a.N * sizeof(float) <= gemm_nt_colsum_ws(a.M, a.N),
               "gemm_mx8_nt: column-sum partials exceed their workspace (internal error)");
-  if (a.colsum) AVF_TRY(fold_partials(p.cs_partial, part_rows, (int)a.N, a.colsum, s));
+  if (a.colsum) {
+    if (a.defer_fold) *a.defer_fold = FoldJob{p.cs_partial, part_rows, (int)a.N, (int)a.N, a.colsum, nullptr, nullptr};
+    else AVF_TRY(fold_partials(p.cs_partial, part_rows, (int)a.N, a.colsum, s));
+  }
   return 0;
 }
 

@@ -31,8 +31,8 @@ struct NtParams {
   float* cs_partial;  // optional [tiles_m * WM][N] column-sum partials of the stored C values (bias gradients)
   DropCfg drop;       // dropout site fused in the epilogue (thresh16 == 0: none); element index = m * N + n
   int wide;           // 1: 2-byte outputs are stored 16 bytes per lane after a lane-pair exchange (store_pair16)
-  uint8_t* mxq;       // optional (BIAS_GELU, N % 32 == 0): MX-FP8 image of the stored C, [M][N] e4m3 bytes ...
-  uint8_t* mxs;       // ... and [M][N/32] E8M0 scale bytes - the A operand of the next forward GEMM in the fp8 mode
+  uint8_t* mxq;       // optional (BIAS_GELU / DGELU, N % 32 == 0): MX-FP8 image of the stored C, [M][N] e4m3 bytes ...
+  uint8_t* mxs;       // ... and [M][N/32] E8M0 scale bytes - the A operand of the next GEMM in the fp8 mode
   int M, N, K;
 };
 
@@ -138,7 +138,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
 #pragma unroll
           for (int r = 0; r < 4; ++r) cs[j][r] += v[r];
         }
-        if (EPI == AVF_EPI_BIAS_GELU && (NI & 1) == 0) {
+        if ((EPI == AVF_EPI_BIAS_GELU || EPI == AVF_EPI_DGELU) && (NI & 1) == 0) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) mxv[j][r] = v[r];
         }
@@ -158,7 +158,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
         }
       }
       // MX-FP8 image of the row segment: a 32-block is the column blocks (j, j+1) x the 4 lane groups x 4 registers
-      if (EPI == AVF_EPI_BIAS_GELU && (NI & 1) == 0 && p.mxq) {  // wave-uniform
+      if ((EPI == AVF_EPI_BIAS_GELU || EPI == AVF_EPI_DGELU) && (NI & 1) == 0 && p.mxq) {  // wave-uniform
 #pragma unroll
         for (int j = 0; j < NI; j += 2) {
           float am = 0.f;

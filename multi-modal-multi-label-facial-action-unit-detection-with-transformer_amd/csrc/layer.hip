@@ -31,7 +31,16 @@ struct Dims {
   bool mx;    // forward nn.Linear GEMMs fed by LayerNorm / GELU (qkv, mlp1, mlp2) take MX-FP8 operands (config 5)
   bool rs16;  // the FORWARD residual stream (x_in, x_mid, x_out) is stored in bf16 (statistics / accumulation stay fp32)
   int xdt;    // storage type of the residual stream
+  bool mxb;   // backward dX GEMMs fed by LayerNorm backward / the dGELU epilogue take MX-FP8 operands too (config 5)
+  bool gy_mx; // the caller's dx_out_lo buffer already carries the MX-FP8 image behind the bf16 one
 };
+
+// bf16 gradient-stream buffers in the mx8_bwd mode: [R, D] bf16 | [R, D] e4m3 | [R, D / 32] E8M0, each part 256-aligned
+inline size_t grad_q_off(int64_t R, int D) { return align_up((size_t)R * D * 2, 256); }
+inline size_t grad_s_off(int64_t R, int D) { return grad_q_off(R, D) + align_up((size_t)R * D, 256); }
+inline size_t grad_stream_bytes(int64_t R, int D, bool mxb) {
+  return mxb ? grad_s_off(R, D) + align_up((size_t)R * D / 32, 256) : (size_t)R * D * 2;
+}
 
 int make_dims(const avf_layer_cfg* c, Dims* d) {
   AVF_REQUIRE(c, "layer: null cfg");
@@ -58,6 +67,9 @@ int make_dims(const avf_layer_cfg* c, Dims* d) {
   AVF_REQUIRE(!d->mx || (c->dtype == AVF_BF16 && c->dim % 128 == 0 && c->mlp_dim % 128 == 0 && c->dim <= 1536),
               "layer: mx8_fwd needs the bf16 path with dim and mlp_dim multiples of 128 (dim=%d mlp_dim=%d)", c->dim,
               c->mlp_dim);
+  d->mxb = c->mx8_bwd != 0;
+  d->gy_mx = c->dx_out_mx8 != 0;
+  AVF_REQUIRE(!d->mxb || d->mx, "layer: mx8_bwd needs mx8_fwd");
   d->rs16 = c->resid_bf16 != 0;
   d->xdt = d->rs16 ? AVF_BF16 : AVF_F32;
   AVF_REQUIRE(!d->rs16 || (c->dtype == AVF_BF16 && c->dim % 8 == 0 && c->dim <= 1536),
@@ -108,6 +120,8 @@ size_t carve_saved(const Dims& d, void* base, Saved* s) {
 struct LowP {
   void *wqkv, *wqkv_t, *wo, *wo_t, *w1, *w1_t, *w2, *w2_t;
   void *wqkv_q, *wqkv_s, *w1_q, *w1_s, *w2_q, *w2_s;  // mx8_fwd only
+  void *wo_q, *wo_s;                                  // mx8_fwd: out-projection (used when the attention kernel emits the image of o)
+  void *w2t_q, *w2t_s, *w1t_q, *w1t_s, *wot_q, *wot_s;  // mx8_bwd: images of the transposed weights (K = out features)
 };
 size_t carve_lowp(const Dims& d, void* base, LowP* l) {
   if (d.dt != AVF_BF16) {
@@ -128,8 +142,13 @@ size_t carve_lowp(const Dims& d, void* base, LowP* l) {
     t.wqkv_q = c.take((size_t)3 * d.I * d.D); t.wqkv_s = c.take((size_t)3 * d.I * d.D / 32);
     t.w1_q = c.take((size_t)d.M * d.D);       t.w1_s = c.take((size_t)d.M * d.D / 32);
     t.w2_q = c.take((size_t)d.D * d.M);       t.w2_s = c.take((size_t)d.D * d.M / 32);
+    t.wo_q = c.take((size_t)d.D * d.I);       t.wo_s = c.take((size_t)d.D * d.I / 32);
+    t.w2t_q = c.take((size_t)d.D * d.M);      t.w2t_s = c.take((size_t)d.D * d.M / 32);
+    t.w1t_q = c.take((size_t)d.D * d.M);      t.w1t_s = c.take((size_t)d.D * d.M / 32);
+    t.wot_q = c.take((size_t)d.D * d.I);      t.wot_s = c.take((size_t)d.D * d.I / 32);
   } else {
     t.wqkv_q = t.wqkv_s = t.w1_q = t.w1_s = t.w2_q = t.w2_s = nullptr;
+    t.wo_q = t.wo_s = t.w2t_q = t.w2t_s = t.w1t_q = t.w1t_s = t.wot_q = t.wot_s = nullptr;
   }
   if (l) *l = t;
   return c.off;
@@ -157,6 +176,8 @@ struct Work {
   void *du, *dh, *d_o, *dqkv, *dx_mid_lo, *dx_out_lo, *ln_ws, *ln_ws1, *cs_ws, *gemm_ws;
   float *dx_mid, *delta;
   void *hq, *hs, *gq, *gs;  // mx8_fwd only: MX-FP8 images of the LayerNorm output and of gelu(u), forward scratch
+  void *oq, *os;            // mx8_fwd: image of the attention output (forward scratch)
+  void *duq, *dus, *mq, *ms, *gyq, *gys;  // mx8_bwd: images of du, of dx_mid, and of dx_out when the caller brought none
   float* small_part;        // short-sequence backward: per-clip partial rows (pb1 [B][M] | pln2 [B][3D] | pln1 [B][3D])
 };
 size_t carve_work(const Dims& d, void* base, Work* w) {
@@ -198,8 +219,16 @@ size_t carve_work(const Dims& d, void* base, Work* w) {
   if (d.mx) {
     t.hq = c.take(d.R * d.D); t.hs = c.take(d.R * d.D / 32);
     t.gq = c.take(d.R * d.M); t.gs = c.take(d.R * d.M / 32);
+    t.oq = c.take(d.R * d.I); t.os = c.take(d.R * d.I / 32);
   } else {
-    t.hq = t.hs = t.gq = t.gs = nullptr;
+    t.hq = t.hs = t.gq = t.gs = t.oq = t.os = nullptr;
+  }
+  if (d.mxb) {
+    t.duq = c.take(d.R * d.M); t.dus = c.take(d.R * d.M / 32);
+    t.mq = c.take(d.R * d.D);  t.ms = c.take(d.R * d.D / 32);
+    t.gyq = c.take(d.R * d.D); t.gys = c.take(d.R * d.D / 32);
+  } else {
+    t.duq = t.dus = t.mq = t.ms = t.gyq = t.gys = nullptr;
   }
   if (w) *w = t;
   return c.off;
@@ -249,6 +278,21 @@ int linear_dx(const Dims& d, const void* dY, int out, const void* W_f32, const v
   return gemm(a, s);
 }
 
+// the same from MX-FP8 images of dY [R, out] and of Wt [in, out] (blocks along out, the reduction); mx_q / mx_s: also emit
+// the image of dX (DGELU)
+int linear_dx_mx(const Dims& d, const void* dYq, const void* dYs, int out, const void* Wtq, const void* Wts, int in, void* dX,
+                 int epi, void* aux, hipStream_t s, float* colsum_out, void* ws, const DropCfg& drop, FoldJob* defer,
+                 void* mx_q = nullptr, void* mx_s = nullptr) {
+  GemmArgs a;
+  a.dtype = AVF_BF16; a.transA = 0; a.transB = 1;
+  a.M = d.R; a.N = in; a.K = out;
+  a.A = dYq; a.lda = out; a.B = Wtq; a.ldb = out;
+  a.C = dX; a.ldc = in; a.c_dtype = AVF_BF16; a.epilogue = epi;
+  a.bias = nullptr; a.residual = nullptr; a.ldres = 0; a.aux = aux; a.ldaux = in; a.workspace = ws; a.colsum = colsum_out;
+  a.drop = drop; a.defer_fold = defer;
+  return gemm_mx8_nt(a, dYs, Wts, s, mx_q, mx_s);
+}
+
 // dW[out, in] = dY[R, out]^T * X[R, in]   (fp32 result)
 int linear_dw(const Dims& d, const void* dY, int out, const void* X, int in, float* dW, void* ws, hipStream_t s) {
   GemmArgs a;
@@ -293,6 +337,11 @@ extern "C" size_t avf_layer_lowp_bytes(const avf_layer_cfg* cfg) {
   if (make_dims(cfg, &d)) return 0;
   return carve_lowp(d, nullptr, nullptr);
 }
+extern "C" size_t avf_layer_grad_stream_bytes(const avf_layer_cfg* cfg) {
+  Dims d;
+  if (make_dims(cfg, &d)) return 0;
+  return grad_stream_bytes(d.R, d.D, d.mxb);
+}
 extern "C" size_t avf_layer_workspace_bytes(const avf_layer_cfg* cfg) {
   Dims d;
   if (make_dims(cfg, &d)) return 0;
@@ -323,16 +372,23 @@ extern "C" int avf_stack_quant_weights_mx8(const avf_layer_cfg* cfg, int layers,
   AVF_TRY(make_dims(cfg, &d));
   AVF_REQUIRE(d.mx, "stack_quant_weights_mx8: cfg.mx8_fwd is not set");
   AVF_REQUIRE(layers > 0 && layers <= 64 && lowp, "stack_quant_weights_mx8: bad arguments");
-  MxQuantJob jobs[64 * 3];
+  MxQuantJob jobs[64 * 7];
+  int n = 0;
   for (int i = 0; i < layers; ++i) {
     AVF_REQUIRE(lowp[i], "stack_quant_weights_mx8: null image buffer (layer %d)", i);
     LowP l;
     carve_lowp(d, lowp[i], &l);
-    jobs[3 * i + 0] = MxQuantJob{l.wqkv, l.wqkv_q, l.wqkv_s, 3 * d.I, d.D};
-    jobs[3 * i + 1] = MxQuantJob{l.w1, l.w1_q, l.w1_s, d.M, d.D};
-    jobs[3 * i + 2] = MxQuantJob{l.w2, l.w2_q, l.w2_s, d.D, d.M};
+    jobs[n++] = MxQuantJob{l.wqkv, l.wqkv_q, l.wqkv_s, 3 * d.I, d.D};
+    jobs[n++] = MxQuantJob{l.w1, l.w1_q, l.w1_s, d.M, d.D};
+    jobs[n++] = MxQuantJob{l.w2, l.w2_q, l.w2_s, d.D, d.M};
+    if (d.I % 128 == 0) jobs[n++] = MxQuantJob{l.wo, l.wo_q, l.wo_s, d.D, d.I};
+    if (d.mxb) {  // transposed images: Wt[in, out], blocks along out
+      jobs[n++] = MxQuantJob{l.w2_t, l.w2t_q, l.w2t_s, d.M, d.D};
+      jobs[n++] = MxQuantJob{l.w1_t, l.w1t_q, l.w1t_s, d.D, d.M};
+      jobs[n++] = MxQuantJob{l.wo_t, l.wot_q, l.wot_s, d.I, d.D};
+    }
   }
-  return quant_mx8_multi(jobs, 3 * layers, (hipStream_t)stream);
+  return quant_mx8_multi(jobs, n, (hipStream_t)stream);
 }
 
 extern "C" int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p, const void* lowp, const void* x_in,
@@ -355,7 +411,7 @@ extern "C" int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   if (d.mx) {
     // config 5: the three GEMMs whose A operand leaves a row-wise producer (LayerNorm, GELU epilogue) run on the MX-FP8
     // matrix path; the producers emit the e4m3 image beside the bf16 tensor backward needs, the weights' images come
-    // from avf_stack_quant_weights_mx8.  out-proj (A = attention output) and all of backward stay bf16.
+    // from avf_stack_quant_weights_mx8.  (mx8_bwd: the dX GEMMs fed by LayerNorm backward / dGELU likewise, avf_layer_bwd.)
     AVF_REQUIRE(workspace, "layer_fwd(mx8): workspace missing");
     Work w;
     carve_work(d, workspace, &w);
@@ -364,8 +420,19 @@ extern "C" int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p
     AVF_TRY(layernorm_fwd(x_in, p->ln1_w, p->ln1_b, sv.h1, d.dt, sv.mean1, sv.rstd1, d.R, d.D, cfg->ln_eps, s, w.hq, w.hs, d.xdt));
     AVF_TRY(linear_fwd_mx(d, w.hq, w.hs, d.D, l.wqkv_q, l.wqkv_s, 3 * d.I, sv.qkv, d.dt, AVF_EPI_NONE, nullptr, nullptr,
                           nullptr, s, kNoDrop));
-    AVF_TRY(attn_fwd_bf16((const bf16*)sv.qkv, (bf16*)sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s, attn_q_prescale_on()));
-    AVF_TRY(linear_fwd(d, sv.o, d.I, wo, d.D, sv.x_mid, d.xdt, AVF_EPI_BIAS_RES, p->b_out, x_in, nullptr, s, dr0));
+    // out-proj: its A operand is produced per head; the head-resident attention kernel writes the image from its epilogue
+    static const int o_mx_on = [] {
+      const char* e = getenv("AVF_MX8_OUTPROJ");  // tuning / A-B aid: 0 = out-projection on bf16 operands
+      return e ? atoi(e) : 1;
+    }();
+    const bool o_mx = o_mx_on && attn_fwd_emits_mx8(d.N, d.dh) && d.I % 128 == 0;
+    AVF_TRY(attn_fwd_bf16((const bf16*)sv.qkv, (bf16*)sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s, attn_q_prescale_on(),
+                          o_mx ? w.oq : nullptr, o_mx ? w.os : nullptr));
+    if (o_mx)
+      AVF_TRY(linear_fwd_mx(d, w.oq, w.os, d.I, l.wo_q, l.wo_s, d.D, sv.x_mid, d.xdt, AVF_EPI_BIAS_RES, p->b_out, x_in, nullptr,
+                            s, dr0));
+    else
+      AVF_TRY(linear_fwd(d, sv.o, d.I, wo, d.D, sv.x_mid, d.xdt, AVF_EPI_BIAS_RES, p->b_out, x_in, nullptr, s, dr0));
     AVF_TRY(layernorm_fwd(sv.x_mid, p->ln2_w, p->ln2_b, sv.h2, d.dt, sv.mean2, sv.rstd2, d.R, d.D, cfg->ln_eps, s, w.hq, w.hs, d.xdt));
     AVF_TRY(linear_fwd_mx(d, w.hq, w.hs, d.D, l.w1_q, l.w1_s, d.M, sv.g, d.dt, AVF_EPI_BIAS_GELU, p->b1, nullptr, sv.u, s, dr1,
                           w.gq, w.gs));
@@ -517,7 +584,28 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
     }
   }
   if (!grouped) AVF_TRY(linear_dw(d, gy, d.D, sv.g, d.M, g->w2, w.gemm_ws, s));
-  if (lo) {  // db1 = colsum(du) fused into the dGELU GEMM epilogue
+  // config 5, backward half: the three dX GEMMs whose A operand leaves a row-wise producer (LayerNorm backward of this /
+  // the next layer, the dGELU epilogue) read MX-FP8 images written by that producer; dqkv -> dh1 (A produced per head by the
+  // attention backward) and the four weight-gradient GEMMs (reduction over tokens, not features) stay bf16
+  const void *gyq = nullptr, *gys = nullptr;
+  void *inq = nullptr, *ins = nullptr;  // image of dx_in, behind the bf16 one in the caller's buffer
+  if (d.mxb) {
+    if (d.gy_mx && dx_out_lo) {
+      gyq = (const char*)dx_out_lo + grad_q_off(d.R, d.D);
+      gys = (const char*)dx_out_lo + grad_s_off(d.R, d.D);
+    } else {  // top of the stack (or a caller without the image): one quantiser pass over the bf16 gradient
+      AVF_TRY(quant_mx8(gy, AVF_BF16, d.D, d.R, d.D, w.gyq, d.D, w.gys, s));
+      gyq = w.gyq; gys = w.gys;
+    }
+    if (dx_in_lo) {
+      inq = (char*)dx_in_lo + grad_q_off(d.R, d.D);
+      ins = (char*)dx_in_lo + grad_s_off(d.R, d.D);
+    }
+  }
+  if (d.mxb) {
+    AVF_TRY(linear_dx_mx(d, gyq, gys, d.D, l.w2t_q, l.w2t_s, d.M, w.du, AVF_EPI_DGELU, sv.u, s, g->b1, w.cs_ws, dr1,
+                         grouped ? &folds.job[0] : nullptr, w.duq, w.dus));
+  } else if (lo) {  // db1 = colsum(du) fused into the dGELU GEMM epilogue
     AVF_TRY(linear_dx(d, gy, d.D, p->w2, l.w2_t, d.M, w.du, AVF_EPI_DGELU, sv.u, s, g->b1, w.cs_ws, dr1,
                       grouped ? &folds.job[0] : nullptr));
   } else {
@@ -525,17 +613,25 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
     AVF_TRY(colsum(w.du, d.dt, d.R, d.M, d.M, g->b1, w.cs_ws, s));
   }
   if (!grouped) AVF_TRY(linear_dw(d, w.du, d.M, sv.h2, d.D, g->w1, w.gemm_ws, s));
-  AVF_TRY(linear_dx(d, w.du, d.M, p->w1, l.w1_t, d.D, w.dh, AVF_EPI_NONE, nullptr, s));
+  if (d.mxb)
+    AVF_TRY(linear_dx_mx(d, w.duq, w.dus, d.M, l.w1t_q, l.w1t_s, d.D, w.dh, AVF_EPI_NONE, nullptr, s, nullptr, nullptr, kNoDrop,
+                         nullptr));
+  else
+    AVF_TRY(linear_dx(d, w.du, d.M, p->w1, l.w1_t, d.D, w.dh, AVF_EPI_NONE, nullptr, s));
   if (d.gs16)  // residual gradient in: the bf16 image the GEMMs read; out: the bf16 dx_mid only
     AVF_TRY(layernorm_bwd(w.dh, d.dt, sv.x_mid, p->ln2_w, sv.mean2, sv.rstd2, gy, nullptr, w.dx_mid_lo, g->ln2_w, g->ln2_b,
-                          g->b_out, w.ln_ws, d.R, d.D, s, dr0, grouped ? &folds.job[1] : nullptr, AVF_BF16, d.xdt));
+                          g->b_out, w.ln_ws, d.R, d.D, s, dr0, grouped ? &folds.job[1] : nullptr, AVF_BF16, d.xdt, w.mq, w.ms));
   else
     AVF_TRY(layernorm_bwd(w.dh, d.dt, sv.x_mid, p->ln2_w, sv.mean2, sv.rstd2, dx_out, w.dx_mid,
                           lo ? w.dx_mid_lo : nullptr, g->ln2_w, g->ln2_b, g->b_out, w.ln_ws, d.R, d.D, s, dr0,
-                          grouped ? &folds.job[1] : nullptr, AVF_F32, d.xdt));
+                          grouped ? &folds.job[1] : nullptr, AVF_F32, d.xdt, w.mq, w.ms));
   // ---- attention half ----------------------------------------------------------------------
   if (!grouped) AVF_TRY(linear_dw(d, gm, d.D, sv.o, d.I, g->w_out, w.gemm_ws, s));
-  AVF_TRY(linear_dx(d, gm, d.D, p->w_out, l.wo_t, d.I, w.d_o, AVF_EPI_NONE, nullptr, s));
+  if (d.mxb)
+    AVF_TRY(linear_dx_mx(d, w.mq, w.ms, d.D, l.wot_q, l.wot_s, d.I, w.d_o, AVF_EPI_NONE, nullptr, s, nullptr, nullptr, kNoDrop,
+                         nullptr));
+  else
+    AVF_TRY(linear_dx(d, gm, d.D, p->w_out, l.wo_t, d.I, w.d_o, AVF_EPI_NONE, nullptr, s));
   if (lo)
     AVF_TRY(attn_bwd_bf16((const bf16*)sv.qkv, (const bf16*)sv.o, (const bf16*)w.d_o, sv.lse2, (bf16*)w.dqkv, w.delta,
                           d.B, d.N, d.H, d.dh, s, attn_q_prescale_on(), w.delta + (size_t)d.B * d.H * d.N));
@@ -547,11 +643,12 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   // dx_in may alias dx_out, which the grouped dW2 GEMM does not read (it uses the bf16 copy gy)
   if (d.gs16)
     AVF_TRY(layernorm_bwd(w.dh, d.dt, x_in, p->ln1_w, sv.mean1, sv.rstd1, w.dx_mid_lo, dx_in, dx_in_lo, g->ln1_w, g->ln1_b,
-                          dx_in_colsum, w.ln_ws1, d.R, d.D, s, dr_prev2, grouped ? &folds.job[2] : nullptr, AVF_BF16, d.xdt));
+                          dx_in_colsum, w.ln_ws1, d.R, d.D, s, dr_prev2, grouped ? &folds.job[2] : nullptr, AVF_BF16, d.xdt,
+                          inq, ins));
   else
     AVF_TRY(layernorm_bwd(w.dh, d.dt, x_in, p->ln1_w, sv.mean1, sv.rstd1, w.dx_mid, dx_in, lo ? dx_in_lo : nullptr,
                           g->ln1_w, g->ln1_b, dx_in_colsum, w.ln_ws1, d.R, d.D, s, dr_prev2,
-                          grouped ? &folds.job[2] : nullptr, AVF_F32, d.xdt));
+                          grouped ? &folds.job[2] : nullptr, AVF_F32, d.xdt, inq, ins));
   // one launch folds the split-K slabs of the four weight gradients and the three deferred column folds
   // (db1; dgamma2/dbeta2/dbo; dgamma1/dbeta1/previous layer's db2)
   if (grouped) AVF_TRY(gemm_bf16_tn_group(grp, s, &folds));

@@ -299,7 +299,9 @@ __global__ __launch_bounds__(256) void ln_bwd_reg_kernel(const DyT* __restrict__
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const ResT* __restrict__ dres, float* __restrict__ dx,
                                                          bf16* __restrict__ dx_lo, float* __restrict__ partial,
-                                                         int64_t rows, int D, int want_colsum, DropCfg drop) {
+                                                         int64_t rows, int D, int want_colsum, DropCfg drop,
+                                                         uint8_t* __restrict__ dxq = nullptr,
+                                                         uint8_t* __restrict__ dxs = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [4 waves][3][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t row0 = (int64_t)blockIdx.x * LNR_ROWS_PER_BLOCK;
@@ -362,6 +364,13 @@ __global__ __launch_bounds__(256) void ln_bwd_reg_kernel(const DyT* __restrict__
         o.x *= f.x; o.y *= f.y; o.z *= f.z; o.w *= f.w;
       }
       if (dx_lo) store4<bf16>(dx_lo + row * D + c, o);
+      if (dxq) {  // wave-uniform: MX-FP8 image of the same values (D % 32 == 0: the 8 lanes of a block are live together)
+        const float ov[4] = {o.x, o.y, o.z, o.w};
+        uint32_t sb;
+        const uint32_t qw = mx8_encode4(ov, &sb);
+        *reinterpret_cast<uint32_t*>(dxq + row * D + c) = qw;
+        if ((lane & 7) == 0) dxs[row * (D >> 5) + (c >> 5)] = (uint8_t)sb;
+      }
       adg[i].x += d[i].x * xh[i].x; adg[i].y += d[i].y * xh[i].y; adg[i].z += d[i].z * xh[i].z; adg[i].w += d[i].w * xh[i].w;
       adb[i].x += d[i].x; adb[i].y += d[i].y; adb[i].z += d[i].z; adb[i].w += d[i].w;
       acs[i].x += o.x; acs[i].y += o.y; acs[i].z += o.z; acs[i].w += o.w;
@@ -438,8 +447,10 @@ size_t layernorm_bwd_ws(int64_t rows, int dim) {
 int layernorm_bwd(const void* dy, int dy_dtype, const void* xv, const float* gamma, const float* mean,
                   const float* rstd, const void* dres, float* dx, void* dx_lo, float* dgamma, float* dbeta,
                   float* dcolsum, void* ws, int64_t rows, int dim, hipStream_t s, const DropCfg& drop,
-                  FoldJob* defer_fold, int dres_dtype, int x_dtype) {
+                  FoldJob* defer_fold, int dres_dtype, int x_dtype, void* mx_q, void* mx_s) {
   AVF_REQUIRE(rows > 0 && dim > 0 && ws, "layernorm_bwd: bad arguments");
+  AVF_REQUIRE(!mx_q || (mx_s && dy_dtype == AVF_BF16 && dim % 32 == 0 && dim <= 1536 && ((uintptr_t)mx_q & 3) == 0),
+              "layernorm_bwd: the MX-FP8 image of dx needs bf16 dy, dim %% 32 == 0 and dim <= 1536 (dim=%d)", dim);
   AVF_REQUIRE(x_dtype == AVF_F32 || (x_dtype == AVF_BF16 && dy_dtype == AVF_BF16 && dim % 4 == 0 && dim <= 1536),
               "layernorm_bwd: a bf16 LayerNorm input needs bf16 dy, dim %% 4 == 0 and dim <= 1536");
   const float* x = (const float*)xv;
@@ -482,16 +493,18 @@ int layernorm_bwd(const void* dy, int dy_dtype, const void* xv, const float* gam
   do {                                                                                                                      \
     if (x_dtype == AVF_BF16 && dres_dtype == AVF_BF16)                                                                      \
       launch_in_scope(&ts, ln_bwd_reg_kernel<bf16, NVV, bf16, bf16>, dim3(nb), dim3(256), (uint32_t)lds, s, (const bf16*)dy,   \
-                      (const bf16*)xv, gamma, mean, rstd, (const bf16*)dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop); \
+                      (const bf16*)xv, gamma, mean, rstd, (const bf16*)dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop, (uint8_t*)mx_q, (uint8_t*)mx_s); \
     else if (x_dtype == AVF_BF16)                                                                                           \
       launch_in_scope(&ts, ln_bwd_reg_kernel<bf16, NVV, float, bf16>, dim3(nb), dim3(256), (uint32_t)lds, s, (const bf16*)dy,  \
-                      (const bf16*)xv, gamma, mean, rstd, (const float*)dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop); \
+                      (const bf16*)xv, gamma, mean, rstd, (const float*)dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop, (uint8_t*)mx_q, (uint8_t*)mx_s); \
     else if (dres_dtype == AVF_BF16)                                                                                        \
       launch_in_scope(&ts, ln_bwd_reg_kernel<bf16, NVV, bf16>, dim3(nb), dim3(256), (uint32_t)lds, s, (const bf16*)dy, x, gamma, \
-                      mean, rstd, (const bf16*)dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop);                       \
+                      mean, rstd, (const bf16*)dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop, (uint8_t*)mx_q,         \
+                      (uint8_t*)mx_s);                                                                                      \
     else                                                                                                                    \
       launch_in_scope(&ts, ln_bwd_reg_kernel<T, NVV, float>, dim3(nb), dim3(256), (uint32_t)lds, s, (const T*)dy, x, gamma, mean, \
-                      rstd, (const float*)dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop);                            \
+                      rstd, (const float*)dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop, (uint8_t*)mx_q,              \
+                      (uint8_t*)mx_s);                                                                                      \
   } while (0)
 #define LAUNCH_T(T)                                   \
   switch (nv) {                                       \

@@ -210,23 +210,68 @@ def layernorm_fwd_mx8(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor,
     return y, mean, rstd, q, s
 
 
+def layernorm_bwd_mx8(dy: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor,
+                      dres: Optional[torch.Tensor] = None):
+    """LayerNorm backward from a bf16 dy -> (dx fp32, dx bf16, e4m3 image of dx, its scale bytes, dgamma, dbeta)."""
+    _need_cuda(dy, x, weight, mean, rstd, dres)
+    assert dy.dtype == torch.bfloat16 and x.dtype == torch.float32
+    dy, x = dy.contiguous(), x.contiguous()
+    rows, dim = x.shape
+    lib = _lib.load()
+    dev = x.device
+    dx = torch.empty((rows, dim), dtype=torch.float32, device=dev)
+    dx_lo = torch.empty((rows, dim), dtype=torch.bfloat16, device=dev)
+    q = torch.empty((rows, dim), dtype=torch.uint8, device=dev)
+    s = torch.empty((rows, dim // 32), dtype=torch.uint8, device=dev)
+    dg = torch.empty(dim, dtype=torch.float32, device=dev)
+    db = torch.empty(dim, dtype=torch.float32, device=dev)
+    ws = torch.empty(max(1, lib.avf_layernorm_bwd_workspace_bytes(rows, dim)), dtype=torch.uint8, device=dev)
+    _lib.check(lib.avf_layernorm_bwd_mx8(_ptr(dy), _ptr(x), _ptr(weight), _ptr(mean), _ptr(rstd),
+                                         _ptr(dres.contiguous() if dres is not None else None), _ptr(dx), _ptr(dx_lo), _ptr(q),
+                                         _ptr(s), _ptr(dg), _ptr(db), _ptr(ws), rows, dim, _stream()), "layernorm_bwd_mx8")
+    return dx, dx_lo, q, s, dg, db
+
+
+def attn_fwd_mx8(qkv: torch.Tensor, batch: int, tokens: int, heads: int, dim_head: int):
+    """bf16 attention forward -> (o bf16 [B*N, I], lse2, e4m3 image of o, its scale bytes); dim_head 64, tokens <= 576."""
+    _need_cuda(qkv)
+    assert qkv.dtype == torch.bfloat16
+    qkv = qkv.contiguous()
+    inner = heads * dim_head
+    dev = qkv.device
+    o = torch.empty((batch * tokens, inner), dtype=torch.bfloat16, device=dev)
+    lse2 = torch.empty((batch, heads, tokens), dtype=torch.float32, device=dev)
+    q = torch.empty((batch * tokens, inner), dtype=torch.uint8, device=dev)
+    s = torch.empty((batch * tokens, inner // 32), dtype=torch.uint8, device=dev)
+    _lib.check(_lib.load().avf_attn_fwd_mx8(_ptr(qkv), _ptr(o), _ptr(lse2), _ptr(q), _ptr(s), batch, tokens, heads, dim_head,
+                                            _stream()), "attn_fwd_mx8")
+    return o, lse2, q, s
+
+
 def gemm_mx8(a_q: torch.Tensor, a_s: torch.Tensor, b_q: torch.Tensor, b_s: torch.Tensor, out_dtype=torch.float32,
              epilogue: int = EPI_NONE, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-             want_image: bool = False):
+             want_image: bool = False, aux: Optional[torch.Tensor] = None):
     """C[M,N] = A[M,K] B[N,K]^T from MX-FP8 images (quant_mx8).  Returns C (and the saved pre-activation for
-    EPI_BIAS_GELU; and with want_image the MX-FP8 image (q, scales) of C)."""
-    _need_cuda(a_q, a_s, b_q, b_s, bias, residual)
+    EPI_BIAS_GELU; and with want_image the MX-FP8 image (q, scales) of C).  EPI_DGELU reads ``aux`` (the saved
+    pre-activation, in C's type)."""
+    _need_cuda(a_q, a_s, b_q, b_s, bias, residual, aux)
     M, K = a_q.shape
     N = b_q.shape[0]
     assert b_q.shape[1] == K and a_s.shape == (M, K // 32) and b_s.shape == (N, K // 32)
     c = torch.empty((M, N), dtype=out_dtype, device=a_q.device)
-    aux = torch.empty((M, N), dtype=out_dtype, device=a_q.device) if epilogue == EPI_BIAS_GELU else None
+    if epilogue == EPI_DGELU:
+        assert aux is not None and aux.shape == (M, N) and aux.dtype == out_dtype
+        aux_in, aux = aux.contiguous(), None
+    else:
+        aux_in = None
+        aux = torch.empty((M, N), dtype=out_dtype, device=a_q.device) if epilogue == EPI_BIAS_GELU else None
     cq = torch.empty((M, N), dtype=torch.uint8, device=a_q.device) if want_image else None
     cs = torch.empty((M, N // 32), dtype=torch.uint8, device=a_q.device) if want_image else None
     _lib.check(_lib.load().avf_gemm_mx8_nt(M, N, K, _ptr(a_q.contiguous()), _ptr(a_s.contiguous()), _ptr(b_q.contiguous()),
                                            _ptr(b_s.contiguous()), _ptr(c), N, avf_dtype(out_dtype), epilogue, _ptr(bias),
                                            _ptr(residual.contiguous() if residual is not None else None), N,
-                                           _ptr(aux), N, _ptr(cq), _ptr(cs), _stream()), "gemm_mx8_nt")
+                                           _ptr(aux if aux is not None else aux_in), N, _ptr(cq), _ptr(cs), _stream()),
+               "gemm_mx8_nt")
     out = (c, aux) if aux is not None else (c,)
     if want_image:
         out = out + (cq, cs)

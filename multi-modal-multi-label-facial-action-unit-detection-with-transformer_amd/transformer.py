@@ -8,8 +8,8 @@ dual_sformer.py/vggformer.py): same constructor, same ``forward(x[B,N,dim], mask
 the reference would get).  The holders only own parameters: all math runs in
 ``libavformer_hip.so`` through one forward and one backward C call per layer.
 
-Extra keyword ``compute_dtype``: ``"mx8"`` (the bf16 mode with MX-FP8 operands on the forward GEMMs of to_qkv, net.0 and
-net.3 - BASELINE config 5; tolerance against the bf16 mode stated in tests/test_gpu_mx8.py), ``"bf16"`` (throughput mode: bf16 MFMA, fp32 accumulate / LayerNorm /
+Extra keyword ``compute_dtype``: ``"mx8"`` (the bf16 mode with MX-FP8 operands on the forward GEMMs of to_qkv, to_out, net.0
+and net.3 and the backward dX GEMMs of net.3, net.0 and to_out - BASELINE config 5; tolerance against the bf16 mode stated in tests/test_gpu_mx8.py), ``"bf16"`` (throughput mode: bf16 MFMA, fp32 accumulate / LayerNorm /
 softmax statistics / residual stream) or ``"f32"`` (parity mode: fp32 MFMA + fp32 attention; matches the
 fp32 CPU reference to ~1e-5).
 """
@@ -182,8 +182,10 @@ class _StackFn(torch.autograd.Function):
         L = mod.depth
         ws = mod._workspace(lib, cfg, dev)
         bf16 = cfg.dtype == _lib.BF16
-        lo_a = torch.empty((B * N, D), dtype=torch.bfloat16, device=dev) if bf16 else None
-        lo_b = torch.empty((B * N, D), dtype=torch.bfloat16, device=dev) if bf16 else None
+        # bf16 images of the gradient stream handed from layer to layer (mx8 backward: with the MX-FP8 image behind)
+        lo_bytes = lib.avf_layer_grad_stream_bytes(C.byref(cfg)) if bf16 else 0
+        lo_a = torch.empty(lo_bytes, dtype=torch.uint8, device=dev) if bf16 else None
+        lo_b = torch.empty(lo_bytes, dtype=torch.uint8, device=dev) if bf16 else None
         have_lo = False
         top_colsum = False
         if ctx.pool:
@@ -274,7 +276,10 @@ class Transformer(nn.Module):
         self.dim, self.depth, self.heads, self.dim_head, self.mlp_dim = dim, depth, heads, dim_head, mlp_dim
         self.dropout = float(dropout)
         # "mx8": the bf16 path with MX-FP8 operands for the forward GEMMs of to_qkv, net.0 and net.3 (BASELINE config 5)
-        self.mx8 = isinstance(compute_dtype, str) and compute_dtype.lower() in ("mx8", "fp8", "mxfp8")
+        # ("mx8-fwd": forward GEMMs only, the round-1 form of the mode - kept addressable for A/B runs and its tests)
+        cd = compute_dtype.lower().replace("_", "-") if isinstance(compute_dtype, str) else ""
+        self.mx8 = cd in ("mx8", "fp8", "mxfp8", "mx8-fwd")
+        self.mx8_bwd = self.mx8 and cd != "mx8-fwd"
         if self.mx8 and (dim % 128 or mlp_dim % 128 or dim > 1536):
             raise ValueError(f"compute_dtype='mx8' needs dim and mlp_dim to be multiples of 128 and dim <= 1536 "
                              f"(dim={dim}, mlp_dim={mlp_dim})")
@@ -359,7 +364,8 @@ class Transformer(nn.Module):
         return _lib.LayerCfg(B, N, self.dim, self.heads, self.dim_head, self.mlp_dim, self.compute_dtype,
                              int(self.project_out), 1e-5, float(p), 0, 0, layer,
                              seed_t.data_ptr() if (seed_t is not None and p != 0.0) else None,
-                             int(self._grad_stream_bf16(p)), int(self.mx8), int(self.resid_bf16))
+                             int(self._grad_stream_bf16(p)), int(self.mx8), int(self.resid_bf16), int(self.mx8_bwd),
+                             int(self.mx8_bwd and layer < self.depth - 1))
 
     def _grad_stream_bf16(self, p: float) -> bool:
         """backward keeps the residual gradient between the LayerNorm backward kernels in bf16 (the GEMMs read that image

@@ -163,8 +163,9 @@ def _pair(cfg, dropout=0.0):
                                      (dict(dim=128, depth=2, heads=8, dim_head=32, mlp_dim=256), 4, 12)])
 def test_stack_forward_backward_against_bf16_mode(cfg, B, N):
     """Config-5 tolerance for the stack: output within 3 %, input gradient within 6 %, every parameter gradient within
-    10 % (relative Frobenius; observed <= 7.3 %, largest on to_out.weight, whose operand is the attention output of the
-    fp8-fed q/k/v) of the bf16 mode on the same weights; the fp32 oracle output is within 4 %."""
+    10 % (relative Frobenius; observed <= 9.0 % since the backward dX GEMMs take e4m3 operands too - largest on the
+    LayerNorm / net.0 gradients below them; <= 7.3 % with forward operands only) of the bf16 mode on the same weights; the
+    fp32 oracle output is within 4 %."""
     ref, mx = _pair(cfg)
     x = torch.randn(B, N, cfg["dim"], generator=torch.Generator().manual_seed(1)).cuda()
     outs = []
@@ -238,3 +239,91 @@ def test_dropout_masks_replay_in_backward():
     assert torch.equal(y1, y2) and torch.equal(g1, xj.grad)
     mx.eval()
     assert rel_fro(mx(x), y1) > 0.05  # the masks were live
+
+
+# ---------------------------------------------------------------------------------------------- backward producers (round 2)
+@pytest.mark.parametrize("rows,D", [(5, 128), (324, 512), (77, 1536), (40, 256)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_layernorm_backward_emits_the_image_of_its_output(ops, rows, D, with_res):
+    g = torch.Generator().manual_seed(rows + D)
+    x = (torch.randn(rows, D, generator=g) * 2 + 0.5).cuda()
+    w = torch.randn(D, generator=g).cuda()
+    b = torch.randn(D, generator=g).cuda()
+    dy = torch.randn(rows, D, generator=g).bfloat16().cuda()
+    dres = torch.randn(rows, D, generator=g).cuda() if with_res else None
+    _, mean, rstd = ops.layernorm_fwd(x, w, b, 1e-5, torch.float32)
+    dx, dx_lo, q, s, dg, db = ops.layernorm_bwd_mx8(dy, x, w, mean, rstd, dres)
+    dx_ref, _, dg_ref, db_ref, _ = ops.layernorm_bwd(dy, x, w, mean, rstd, dres)  # the plain entry point: same arithmetic
+    assert torch.equal(dx, dx_ref) and torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
+    assert torch.equal(dx_lo.float(), dx.bfloat16().float())
+    q_ref, s_ref = oracle.mx8_quant(dx.cpu())
+    assert torch.equal(s.cpu(), s_ref)
+    assert torch.equal(q.cpu(), q_ref)
+
+
+@pytest.mark.parametrize("M,N,K", [(648, 1024, 512), (100, 256, 128), (1296, 128, 256)])
+def test_dgelu_epilogue_emits_the_image_of_its_output(ops, M, N, K):
+    import avformer_amd as A
+    g = torch.Generator().manual_seed(M + N + 1)
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(N, K, generator=g) * 0.1
+    u = torch.randn(M, N, generator=g)
+    aq, as_ = ops.quant_mx8(a.cuda())
+    bq, bs = ops.quant_mx8(b.cuda())
+    c, cq, cs = ops.gemm_mx8(aq, as_, bq, bs, out_dtype=torch.float32, epilogue=A.ops.EPI_DGELU, aux=u.cuda(), want_image=True)
+    acc = (oracle.mx8_dequant(aq, as_).double() @ oracle.mx8_dequant(bq, bs).double().t()).float()
+    uu = u.clone().requires_grad_(True)
+    oracle.gelu_tanh(uu).backward(acc)
+    check_rel(f"mx8_dgelu[{M}x{N}x{K}]", c, uu.grad, 2e-3)
+    q_ref, s_ref = oracle.mx8_quant(c.cpu())  # the image of exactly the values the kernel stored
+    assert torch.equal(cs.cpu(), s_ref)
+    assert torch.equal(cq.cpu(), q_ref)
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 324, 8), (1, 512, 4), (3, 37, 2), (2, 576, 2)])
+def test_attention_emits_the_image_of_its_output(ops, B, N, H):
+    g = torch.Generator().manual_seed(B + N + H)
+    qkv = torch.randn(B * N, 3 * H * 64, generator=g).bfloat16().cuda()
+    o, lse2, q, s = ops.attn_fwd_mx8(qkv, B, N, H, 64)
+    o_ref, lse_ref = ops.attn_fwd(qkv, B, N, H, 64)[:2]
+    assert torch.equal(o, o_ref) and torch.equal(lse2, lse_ref)
+    q_ref, s_ref = oracle.mx8_quant(o.float().cpu())  # the image of the stored bf16 tensor
+    assert torch.equal(s.cpu(), s_ref)
+    assert torch.equal(q.cpu(), q_ref)
+
+
+def test_attention_image_needs_the_head_resident_kernel(ops):
+    qkv = torch.zeros(640, 3 * 64, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(RuntimeError, match="head-resident"):
+        ops.attn_fwd_mx8(qkv, 1, 640, 1, 64)
+
+
+@pytest.mark.parametrize("cfg,B,N", [(dict(dim=512, depth=3, heads=8, dim_head=64, mlp_dim=1024), 2, 324),
+                                     (CFG, 3, 40)])
+def test_backward_images_chain_between_layers(cfg, B, N):
+    """mx8 (forward + backward operands) against mx8-fwd (round 1: backward in bf16) on the same weights: the forward differs
+    only by the out-projection's operand format, the gradients by the e4m3 rounding of three operands per layer."""
+    import avformer_amd as A
+    torch.manual_seed(5)
+    a = A.Transformer(cfg["dim"], cfg["depth"], cfg["heads"], cfg["dim_head"], cfg["mlp_dim"], compute_dtype="mx8-fwd").cuda()
+    b = A.Transformer(cfg["dim"], cfg["depth"], cfg["heads"], cfg["dim_head"], cfg["mlp_dim"], compute_dtype="mx8").cuda()
+    b.load_state_dict(a.state_dict())
+    assert b.mx8_bwd and not a.mx8_bwd
+    x = torch.randn(B, N, cfg["dim"], generator=torch.Generator().manual_seed(2)).cuda()
+    outs = []
+    for t in (a, b):
+        xi = x.clone().requires_grad_(True)
+        y = t(xi)
+        (y.float() ** 2).mean().backward()
+        outs.append((y.detach(), xi.grad, {k: p.grad.clone() for k, p in t.named_parameters()}))
+    (y0, dx0, g0), (y1, dx1, g1) = outs
+    tag = f"mx8_bwd[{cfg['dim']}x{cfg['depth']},{B}x{N}]"
+    check_rel(tag + ":y", y1, y0, 0.03)
+    check_rel(tag + ":dx", dx1, dx0, 0.08)
+    for k in g0:
+        check_rel(f"{tag}:g.{k}", g1[k], g0[k], 0.12)
+    # bitwise repeatable
+    xi = x.clone().requires_grad_(True)
+    y2 = b(xi)
+    (y2.float() ** 2).mean().backward()
+    assert torch.equal(y2, y1) and torch.equal(xi.grad, dx1)

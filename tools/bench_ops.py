@@ -73,6 +73,9 @@ def attn(B, N):
     t = timeit(lambda: ops.attn_fwd(qkv, B, N, H, dh))
     fl = 4.0 * B * H * N * N * dh
     print(f"attn_fwd B={B} N={N}: {t * 1e6:8.1f} us  {fl / t / 1e12:7.1f} TF/s")
+    if N <= 576:
+        t = timeit(lambda: ops.attn_fwd_mx8(qkv, B, N, H, dh))
+        print(f"attn_fwd+mx8 image B={B} N={N}: {t * 1e6:8.1f} us")
     t = timeit(lambda: ops.attn_bwd(qkv, o, d_o, lse, B, N, H, dh))
     print(f"attn_bwd B={B} N={N}: {t * 1e6:8.1f} us  {2.5 * fl / t / 1e12:7.1f} TF/s (nominal 2.5x fwd flops)")
 
