@@ -294,6 +294,29 @@ __device__ __forceinline__ void glds16(const void* g, char* l) {
   __builtin_amdgcn_global_load_lds((gptr_t*)g, (lptr_t*)l, 16, 0, 0);
 }
 
+// The same LDS-DMA issued as inline asm.  hipcc (ROCm 7.2) drains vmcnt to 0 in front of every compiler-visible LDS read
+// that follows a compiler-visible LDS-DMA (its wait-count pass takes the DMA for a store that may alias the read): the
+// pieces fed from hooks inside the first tile's compute then cost a full memory round trip each.  An asm DMA is opaque to
+// that pass; the kernels' own wait_all_loads() + s_barrier order the LDS reads of a tile after its arrival, and vmcnt is
+// in-order, so the compiler's own counted waits for its global loads only become more conservative.  AVF_ATTN_DMA_ASM=0
+// at build time (-DAVF_ATTN_DMA_ASM=0) restores the builtin.
+#ifndef AVF_ATTN_DMA_ASM
+#define AVF_ATTN_DMA_ASM 1
+#endif
+__device__ __forceinline__ void glds16_res(const void* g, char* l) {
+#if AVF_ATTN_DMA_ASM
+  typedef __attribute__((address_space(3))) char lds_c;
+  const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_c*)l);
+  uint32_t keep;  // m0 is a reserved register: saved and restored, so whatever the compiler keeps in it survives
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "s"(la), "v"(g)
+               : "memory");
+#else
+  glds16(g, l);
+#endif
+}
+
 __device__ __forceinline__ void glds4(const void* g, char* l) {
   typedef __attribute__((address_space(1))) const void gptr_t;
   typedef __attribute__((address_space(3))) void lptr_t;
@@ -376,8 +399,8 @@ struct ResLoader {
       const int i = cur >> 1;
       int row = i * 8 + lrow;
       row = row < N ? row : N - 1;
-      if (cur & 1) glds16(b + (int64_t)row * ldb + chunk * 8, lb + i * 1024);
-      else glds16(a + (int64_t)row * lda + chunk * 8, la + i * 1024);
+      if (cur & 1) glds16_res(b + (int64_t)row * ldb + chunk * 8, lb + i * 1024);
+      else glds16_res(a + (int64_t)row * lda + chunk * 8, la + i * 1024);
       cur += W;
     }
   }
