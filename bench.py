@@ -213,6 +213,16 @@ class Region:
         torch = self.torch
         for _ in range(warmup):
             self.step()
+        # the caching allocator may still be growing after W steps of a large configuration (C4: 59 device allocations over
+        # the first ~10 steps, each a multi-millisecond hipMalloc that would land inside the timed region): keep stepping,
+        # untimed, until two consecutive steps allocate nothing new (at most 12 more)
+        quiet, extra = 0, 0
+        while quiet < 2 and extra < 12:
+            before = torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0)
+            self.step()
+            extra += 1
+            quiet = quiet + 1 if torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0) == before else 0
+        self.extra_warmup = extra
         self.fence()
         run = self.step
         if graph and self.dp is None:
@@ -351,6 +361,7 @@ def main():
                    "global_batch": B * world, "seq_len": Tv + Ta, "parallelism": f"dp{world}",
                    "step": "zero_grad+fwd+AULoss+bwd" + ("+allreduce" if use_dist else "") + ("+adam" if main_r.optimizer else ""),
                    "optimizer": main_r.optimizer, "residual_stream": main_r.residual, "loss": main_r.loss},
+        "untimed_steps_beyond_warmup": main_r.extra_warmup,  # until the caching allocator stopped growing (Region.timed)
     }
     c3_r = f32_r = None
     if not args.no_extra and args.config == "c2" and args.dtype == "bf16":
