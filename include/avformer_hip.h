@@ -73,6 +73,11 @@ typedef struct avf_layer_cfg {
                           long: [R, D] bf16 | [R, D] e4m3 | [R, D/32] E8M0 (each part 256-byte aligned).               */
   int32_t dx_out_mx8;  /* mx8_bwd: 1 = dx_out_lo already carries that image (it was written as the dx_in_lo of the layer
                           above by avf_layer_bwd with mx8_bwd set); 0 = the layer quantises dx_out_lo itself (top layer) */
+  const void* key_mask; /* optional token mask of Transformer.forward(x, mask) (heads.py:225-232; no reference caller passes one):
+                          device bytes [batch, tokens], 1 = token kept - the reference's mask padded with a leading True.  A pair
+                          (i, j) with either token dropped scores -FLT_MAX: a dropped query attends uniformly to all keys, a kept
+                          query gives dropped keys zero weight; no gradient flows through a filled score.  With a mask the
+                          attention core runs on the fp32-arithmetic kernels in every mode (correct, not tuned).            */
 } avf_layer_cfg;
 
 /* fp32 master parameters of one layer, in state_dict order:
@@ -164,6 +169,12 @@ int avf_layernorm_fwd_mx8(const float* x, const float* gamma, const float* beta,
 int avf_layernorm_bwd_mx8(const void* dy_bf16, const float* x, const float* gamma, const float* mean, const float* rstd,
                           const float* dres, float* dx, void* dx_lo, void* dx_q, void* dx_scales, float* dgamma, float* dbeta,
                           void* workspace, int64_t rows, int dim, void* stream);
+/* avf_attn_fwd / avf_attn_bwd with the token mask of heads.py:225-232 (keep: device bytes [batch, tokens], 1 = kept; see
+ * avf_layer_cfg.key_mask); fp32 arithmetic on fp32 or bf16 storage; workspace as avf_attn_bwd */
+int avf_attn_fwd_masked(int dtype, const void* qkv, void* o, float* lse2, const void* keep, int batch, int tokens, int heads,
+                        int dim_head, void* stream);
+int avf_attn_bwd_masked(int dtype, const void* qkv, const void* o, const void* d_o, const float* lse2, void* dqkv,
+                        void* workspace, const void* keep, int batch, int tokens, int heads, int dim_head, void* stream);
 /* bf16 attention forward (avf_attn_fwd) also writing the MX-FP8 image of o [B*N, I] - the A operand of to_out (heads.py:215)
  * in the fp8 mode.  Head-resident kernel only: dim_head 64, tokens <= 576 (error otherwise). */
 int avf_attn_fwd_mx8(const void* qkv, void* o, float* lse2, void* o_q, void* o_scales, int batch, int tokens, int heads,

@@ -27,7 +27,7 @@ class LayerCfg(C.Structure):
                 ("dim_head", C.c_int32), ("mlp_dim", C.c_int32), ("dtype", C.c_int32), ("project_out", C.c_int32),
                 ("ln_eps", C.c_float), ("dropout_p", C.c_float), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32),
                 ("layer_index", C.c_int32), ("seed_dev", C.c_void_p), ("grad_stream_bf16", C.c_int32), ("mx8_fwd", C.c_int32),
-                ("resid_bf16", C.c_int32), ("mx8_bwd", C.c_int32), ("dx_out_mx8", C.c_int32)]
+                ("resid_bf16", C.c_int32), ("mx8_bwd", C.c_int32), ("dx_out_mx8", C.c_int32), ("key_mask", C.c_void_p)]
 
 
 PARAM_FIELDS = ("ln1_w", "ln1_b", "w_qkv", "w_out", "b_out", "ln2_w", "ln2_b", "w1", "b1", "w2", "b2")
@@ -86,6 +86,8 @@ SIGNATURES = {
     "avf_layer_lowp_bytes": (_sz, [C.POINTER(LayerCfg)]),
     "avf_layernorm_bwd_mx8": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp]),
     "avf_attn_fwd_mx8": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
+    "avf_attn_fwd_masked": (_int, [_int, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
+    "avf_attn_bwd_masked": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     "avf_layer_workspace_bytes": (_sz, [C.POINTER(LayerCfg)]),
     "avf_layer_grad_stream_bytes": (_sz, [C.POINTER(LayerCfg)]),
     "avf_layer_prepare_weights": (_int, [C.POINTER(LayerCfg), C.POINTER(LayerPtrs), _vp, _vp]),

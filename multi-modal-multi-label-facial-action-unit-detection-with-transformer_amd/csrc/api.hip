@@ -252,6 +252,18 @@ extern "C" int avf_layernorm_bwd_mx8(const void* dy_bf16, const float* x, const 
   return layernorm_bwd(dy_bf16, AVF_BF16, x, gamma, mean, rstd, dres, dx, dx_lo, dgamma, dbeta, nullptr, workspace, rows, dim,
                        (hipStream_t)stream, kNoDrop, nullptr, AVF_F32, AVF_F32, dx_q, dx_scales);
 }
+extern "C" int avf_attn_fwd_masked(int dtype, const void* qkv, void* o, float* lse2, const void* keep, int batch, int tokens,
+                                   int heads, int dim_head, void* stream) {
+  AVF_REQUIRE(qkv && o && lse2 && keep, "attn_fwd_masked: null pointer");
+  return attn_fwd_vec(dtype, qkv, o, lse2, batch, tokens, heads, dim_head, (hipStream_t)stream, keep, false);
+}
+extern "C" int avf_attn_bwd_masked(int dtype, const void* qkv, const void* o, const void* d_o, const float* lse2, void* dqkv,
+                                   void* workspace, const void* keep, int batch, int tokens, int heads, int dim_head,
+                                   void* stream) {
+  AVF_REQUIRE(qkv && o && d_o && lse2 && dqkv && workspace && keep, "attn_bwd_masked: null pointer");
+  return attn_bwd_vec(dtype, qkv, o, d_o, lse2, dqkv, (float*)workspace, batch, tokens, heads, dim_head, (hipStream_t)stream,
+                      keep, false);
+}
 extern "C" int avf_attn_fwd_mx8(const void* qkv, void* o, float* lse2, void* o_q, void* o_scales, int batch, int tokens,
                                 int heads, int dim_head, void* stream) {
   AVF_REQUIRE(qkv && o && lse2 && o_q && o_scales, "attn_fwd_mx8: null pointer");

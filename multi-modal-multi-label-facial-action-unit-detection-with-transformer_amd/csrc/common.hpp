@@ -429,6 +429,11 @@ size_t gemm_bf16_tn_group_ws(const TnGroupArgs& a);
 int gemm_bf16_tn_group(const TnGroupArgs& a, hipStream_t s, const FoldList* extra_folds = nullptr);
 
 int attn_fwd_f32(const float* qkv, float* o, float* lse2, int B, int N, int H, int dh, hipStream_t s);
+// fp32-arithmetic attention on fp32 / bf16 storage with the optional token mask keep [B, N] (bytes, 1 = kept; heads.py:225-232)
+int attn_fwd_vec(int dtype, const void* qkv, void* o, float* lse2, int B, int N, int H, int dh, hipStream_t s, const void* keep,
+                 bool q_prescaled);
+int attn_bwd_vec(int dtype, const void* qkv, const void* o, const void* d_o, const float* lse2, void* dqkv, float* delta,
+                 int B, int N, int H, int dh, hipStream_t s, const void* keep, bool q_prescaled);
 int attn_bwd_f32(const float* qkv, const float* o, const float* d_o, const float* lse2, float* dqkv, float* delta,
                  int B, int N, int H, int dh, hipStream_t s);
 // q_prescaled: the q columns of qkv already hold q * log2(e)/sqrt(dh) (the layer path: folded into the bf16 copy of

@@ -31,6 +31,7 @@ struct Dims {
   bool mx;    // forward nn.Linear GEMMs fed by LayerNorm / GELU (qkv, mlp1, mlp2) take MX-FP8 operands (config 5)
   bool rs16;  // the FORWARD residual stream (x_in, x_mid, x_out) is stored in bf16 (statistics / accumulation stay fp32)
   int xdt;    // storage type of the residual stream
+  const void* keep;  // optional token mask [B, N] bytes (1 = kept), heads.py:225-232: attention then runs on the fp32-arithmetic kernels
   bool mxb;   // backward dX GEMMs fed by LayerNorm backward / the dGELU epilogue take MX-FP8 operands too (config 5)
   bool gy_mx; // the caller's dx_out_lo buffer already carries the MX-FP8 image behind the bf16 one
 };
@@ -67,6 +68,7 @@ int make_dims(const avf_layer_cfg* c, Dims* d) {
   AVF_REQUIRE(!d->mx || (c->dtype == AVF_BF16 && c->dim % 128 == 0 && c->mlp_dim % 128 == 0 && c->dim <= 1536),
               "layer: mx8_fwd needs the bf16 path with dim and mlp_dim multiples of 128 (dim=%d mlp_dim=%d)", c->dim,
               c->mlp_dim);
+  d->keep = c->key_mask;
   d->mxb = c->mx8_bwd != 0;
   d->gy_mx = c->dx_out_mx8 != 0;
   AVF_REQUIRE(!d->mxb || d->mx, "layer: mx8_bwd needs mx8_fwd");
@@ -425,9 +427,12 @@ extern "C" int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p
       const char* e = getenv("AVF_MX8_OUTPROJ");  // tuning / A-B aid: 0 = out-projection on bf16 operands
       return e ? atoi(e) : 1;
     }();
-    const bool o_mx = o_mx_on && attn_fwd_emits_mx8(d.N, d.dh) && d.I % 128 == 0;
-    AVF_TRY(attn_fwd_bf16((const bf16*)sv.qkv, (bf16*)sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s, attn_q_prescale_on(),
-                          o_mx ? w.oq : nullptr, o_mx ? w.os : nullptr));
+    const bool o_mx = o_mx_on && !d.keep && attn_fwd_emits_mx8(d.N, d.dh) && d.I % 128 == 0;
+    if (d.keep)
+      AVF_TRY(attn_fwd_vec(AVF_BF16, sv.qkv, sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s, d.keep, attn_q_prescale_on()));
+    else
+      AVF_TRY(attn_fwd_bf16((const bf16*)sv.qkv, (bf16*)sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s, attn_q_prescale_on(),
+                            o_mx ? w.oq : nullptr, o_mx ? w.os : nullptr));
     if (o_mx)
       AVF_TRY(linear_fwd_mx(d, w.oq, w.os, d.I, l.wo_q, l.wo_s, d.D, sv.x_mid, d.xdt, AVF_EPI_BIAS_RES, p->b_out, x_in, nullptr,
                             s, dr0));
@@ -440,7 +445,7 @@ extern "C" int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p
                           s, dr2));
     return 0;
   }
-  if (!d.rs16 && small_layer_ok(d.dt, d.N, d.D, d.H, d.dh, d.M)) {  // short sequences: the whole layer in one launch
+  if (!d.rs16 && !d.keep && small_layer_ok(d.dt, d.N, d.D, d.H, d.dh, d.M)) {  // short sequences: the whole layer in one launch
     const float sc = attn_q_prescale_on() ? 1.0f : 1.4426950408889634f / sqrtf((float)d.dh);
     return layer_fwd_small(d.B, d.N, d.D, d.H, d.M, cfg->ln_eps, sc, p, wqkv, wo, w1, w2, (const float*)x_in, (float*)x_out, sv.h1,
                            sv.mean1, sv.rstd1, sv.qkv, sv.o, sv.lse2, (float*)sv.x_mid, sv.h2, sv.mean2, sv.rstd2, sv.u, sv.g,
@@ -449,7 +454,8 @@ extern "C" int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   }
   AVF_TRY(layernorm_fwd(x_in, p->ln1_w, p->ln1_b, sv.h1, d.dt, sv.mean1, sv.rstd1, d.R, d.D, cfg->ln_eps, s, nullptr, nullptr, d.xdt));
   AVF_TRY(linear_fwd(d, sv.h1, d.D, wqkv, 3 * d.I, sv.qkv, d.dt, AVF_EPI_NONE, nullptr, nullptr, nullptr, s));
-  if (lo) AVF_TRY(attn_fwd_bf16((const bf16*)sv.qkv, (bf16*)sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s, attn_q_prescale_on()));
+  if (d.keep) AVF_TRY(attn_fwd_vec(d.dt, sv.qkv, sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s, d.keep, lo && attn_q_prescale_on()));
+  else if (lo) AVF_TRY(attn_fwd_bf16((const bf16*)sv.qkv, (bf16*)sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s, attn_q_prescale_on()));
   else AVF_TRY(attn_fwd_f32((const float*)sv.qkv, (float*)sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s));
   const DropCfg dr0 = make_drop(d.p, d.seed, d.layer, 0, d.seed_dev), dr1 = make_drop(d.p, d.seed, d.layer, 1, d.seed_dev),
                 dr2 = make_drop(d.p, d.seed, d.layer, 2, d.seed_dev);
@@ -492,7 +498,7 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
     const char* e = getenv("AVF_LAYER_SMALL_BWD");  // tuning / A-B aid
     return e ? atoi(e) : 1;
   }();
-  const bool small_bwd = lo && !d.rs16 && !d.mx && small_bwd_on && small_layer_ok(d.dt, d.N, d.D, d.H, d.dh, d.M);
+  const bool small_bwd = lo && !d.rs16 && !d.mx && !d.keep && small_bwd_on && small_layer_ok(d.dt, d.N, d.D, d.H, d.dh, d.M);
   const void* gy = dx_out;
   bool own_copy = false;
   if (lo) {
@@ -632,7 +638,10 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
                          nullptr));
   else
     AVF_TRY(linear_dx(d, gm, d.D, p->w_out, l.wo_t, d.I, w.d_o, AVF_EPI_NONE, nullptr, s));
-  if (lo)
+  if (d.keep)
+    AVF_TRY(attn_bwd_vec(d.dt, sv.qkv, sv.o, w.d_o, sv.lse2, w.dqkv, w.delta, d.B, d.N, d.H, d.dh, s, d.keep,
+                         lo && attn_q_prescale_on()));
+  else if (lo)
     AVF_TRY(attn_bwd_bf16((const bf16*)sv.qkv, (const bf16*)sv.o, (const bf16*)w.d_o, sv.lse2, (bf16*)w.dqkv, w.delta,
                           d.B, d.N, d.H, d.dh, s, attn_q_prescale_on(), w.delta + (size_t)d.B * d.H * d.N));
   else

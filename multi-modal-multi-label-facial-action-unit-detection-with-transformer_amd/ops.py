@@ -313,6 +313,33 @@ def attn_bwd(qkv, o, d_o, lse2, batch: int, tokens: int, heads: int, dim_head: i
     return dqkv
 
 
+def attn_fwd_masked(qkv: torch.Tensor, keep: torch.Tensor, batch: int, tokens: int, heads: int, dim_head: int):
+    """attn_fwd with the token mask of heads.py:225-232: keep [B, N] uint8 / bool, 1 = token kept (the reference's mask after
+    its leading-True pad).  fp32 arithmetic on fp32 or bf16 storage."""
+    _need_cuda(qkv, keep)
+    qkv = qkv.contiguous()
+    keep = keep.to(torch.uint8).contiguous()
+    inner = heads * dim_head
+    assert qkv.shape == (batch * tokens, 3 * inner) and keep.shape == (batch, tokens)
+    o = torch.empty((batch * tokens, inner), dtype=qkv.dtype, device=qkv.device)
+    lse2 = torch.empty((batch, heads, tokens), dtype=torch.float32, device=qkv.device)
+    _lib.check(_lib.load().avf_attn_fwd_masked(avf_dtype(qkv.dtype), _ptr(qkv), _ptr(o), _ptr(lse2), _ptr(keep), batch, tokens,
+                                               heads, dim_head, _stream()), "attn_fwd_masked")
+    return o, lse2
+
+
+def attn_bwd_masked(qkv, o, d_o, lse2, keep, batch: int, tokens: int, heads: int, dim_head: int) -> torch.Tensor:
+    _need_cuda(qkv, o, d_o, lse2, keep)
+    lib = _lib.load()
+    qkv, o, d_o = qkv.contiguous(), o.contiguous(), d_o.contiguous()
+    keep = keep.to(torch.uint8).contiguous()
+    dqkv = torch.empty_like(qkv)
+    ws = _bytes(lib.avf_attn_bwd_workspace_bytes(batch, tokens, heads, dim_head), qkv.device)
+    _lib.check(lib.avf_attn_bwd_masked(avf_dtype(qkv.dtype), _ptr(qkv), _ptr(o), _ptr(d_o), _ptr(lse2), _ptr(dqkv), _ptr(ws),
+                                       _ptr(keep), batch, tokens, heads, dim_head, _stream()), "attn_bwd_masked")
+    return dqkv
+
+
 # ---- token producers / consumers either side of the stack (csrc/heads.hip) ---------------------------------------
 def bn1d_fwd(x, gamma, beta, running_mean, running_var, num_batches_tracked, eps: float, momentum: float, training: bool):
     """nn.BatchNorm1d on [B, C] -> (y, mean, invstd); training updates the running statistics in place"""

@@ -98,7 +98,7 @@ class _StackFn(torch.autograd.Function):
     """x -> L layers.  Saved activations live in per-layer byte buffers carved by the library."""
 
     @staticmethod
-    def forward(ctx, x, audio, pos, mod, pool, *params):
+    def forward(ctx, x, audio, pos, mod, pool, keep, *params):
         """audio / pos not None: x is the video token tensor and the stack's input is the fused sequence
         cat([x, audio], 1) + pos (avformer.py:95-103 on the sequence axis), built by the library in the residual stream's
         storage type; backward then hands d clip / d audio / d pos back from the fp32 gradient of that sequence."""
@@ -116,7 +116,10 @@ class _StackFn(torch.autograd.Function):
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         L = mod.depth
         seed_t = mod._advance_seed(dev)  # None unless dropout is live; a device tensor otherwise (graph-replayable)
-        cfgs = [mod._cfg(B, N, l, seed_t) for l in range(L)]
+        if keep is not None and keep.shape != (B, N):
+            raise ValueError(f"mask has incorrect dimensions: {tuple(keep.shape)} after the leading True, tokens {(B, N)}")
+        ctx.keep = keep  # token mask bytes (heads.py:225-232); the layer configurations carry its device pointer
+        cfgs = [mod._cfg(B, N, l, seed_t, keep) for l in range(L)]
         cfg = cfgs[0]
         params = [p.detach() for p in params]
         need_grad = any(ctx.needs_input_grad)  # (grad mode is off inside Function.forward)
@@ -252,7 +255,7 @@ class _StackFn(torch.autograd.Function):
         _check_canaries()
         ctx.saved_bufs = None
         ctx.xs = None
-        tail = (None, None, *([None] * (L * PARAMS_PER_LAYER)))
+        tail = (None, None, None, *([None] * (L * PARAMS_PER_LAYER)))
         dx = dx.view(B, N, D)
         if not ctx.fused:
             return (dx, None, None) + tail
@@ -355,7 +358,8 @@ class Transformer(nn.Module):
         return a callable that makes the current stream wait for that reduction."""
         self._grad_hook = hook
 
-    def _cfg(self, B: int, N: int, layer: int = 0, seed_t: Optional[torch.Tensor] = None) -> _lib.LayerCfg:
+    def _cfg(self, B: int, N: int, layer: int = 0, seed_t: Optional[torch.Tensor] = None,
+             keep: Optional[torch.Tensor] = None) -> _lib.LayerCfg:
         p = self.dropout if self.training else 0.0  # nn.Dropout semantics: identity in eval()
         if p != 0.0 and self.compute_dtype != _lib.BF16:
             raise NotImplementedError(
@@ -365,7 +369,7 @@ class Transformer(nn.Module):
                              int(self.project_out), 1e-5, float(p), 0, 0, layer,
                              seed_t.data_ptr() if (seed_t is not None and p != 0.0) else None,
                              int(self._grad_stream_bf16(p)), int(self.mx8), int(self.resid_bf16), int(self.mx8_bwd),
-                             int(self.mx8_bwd and layer < self.depth - 1))
+                             int(self.mx8_bwd and layer < self.depth - 1), None if keep is None else keep.data_ptr())
 
     def _grad_stream_bf16(self, p: float) -> bool:
         """backward keeps the residual gradient between the LayerNorm backward kernels in bf16 (the GEMMs read that image
@@ -464,14 +468,21 @@ class Transformer(nn.Module):
             raise ValueError(f"pool must be None or 'mean', got {pool!r}")
         if pool == 'mean' and self.dim % 4 != 0:
             raise ValueError("pool='mean' needs dim % 4 == 0 (use .mean(dim=1) on the unpooled output otherwise)")
-        if mask is not None:
-            # dead branch in the reference (no caller passes a mask); not built.
-            raise NotImplementedError("mask is not supported by the HIP path (no reference caller uses it)")
         if not x.is_cuda:
             raise RuntimeError("Transformer (HIP) needs its input on the MI355X; there is no CPU fallback - "
                                "use oracle/ only as a test checker")
         if x.dim() != 3 or x.shape[-1] != self.dim:
             raise ValueError(f"expected [B, N, {self.dim}], got {tuple(x.shape)}")
+        keep = None
+        if mask is not None:
+            # heads.py:225-232 (no reference caller passes a mask, but it is part of the signature): [B, ...] bool over the
+            # tokens AFTER the first one; the reference pads a leading True.  The library takes the padded mask as bytes.
+            if fuse is not None:
+                raise ValueError("mask and fuse= cannot be combined")
+            keep = torch.nn.functional.pad(mask.flatten(1).to(torch.bool), (1, 0), value=True)
+            if keep.shape[0] != x.shape[0] or keep.shape[-1] != x.shape[1]:
+                raise AssertionError("mask has incorrect dimensions")  # the reference's assert (heads.py:229)
+            keep = keep.to(device=x.device, dtype=torch.uint8).contiguous()
         audio = pos = None
         if fuse is not None:
             audio, pos = fuse
@@ -489,4 +500,4 @@ class Transformer(nn.Module):
             if p.dtype != torch.float32 or not p.is_cuda:
                 raise RuntimeError("Transformer (HIP): parameters must be fp32 tensors on the GPU (model.to('cuda'))")
         with torch.cuda.device(x.device):  # launches go to the input's device and its current stream
-            return _StackFn.apply(x.to(torch.float32), audio, pos, self, pool == 'mean', *params)
+            return _StackFn.apply(x.to(torch.float32), audio, pos, self, pool == 'mean', keep, *params)

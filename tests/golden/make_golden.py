@@ -15,7 +15,8 @@ Fixture list: G1 attention, G2 feed-forward, G3 transform
 G4 transformer with inner != dim at N in {12, 17, 49}, G5 AU_former (eval), G6 tformer_AU_head
 (emb 64), G7 TFormer, G8 AULoss with/without ignored rows, G9 tiny pipeline TFormer -> AU_former
 -> AULoss with gradients, G10 tanh-GELU on a grid, G11 the token section of ResFormer.forward, G12 the evaluation
-score of metrics/accf1.py (MultiLabelAccF1, the reference's own sklearn-backed implementation) on seeded batches.
+score of metrics/accf1.py (MultiLabelAccF1, the reference's own sklearn-backed implementation) on seeded batches, G13 the
+Transformer with a token mask (the branch heads.py:225-232).
 
     python tests/golden/make_golden.py --only g12        (re)generates just that fixture
 """
@@ -246,9 +247,39 @@ def metric_fixture():
     print("g12_metric", {k: float(v) for k, v in out.items() if k.endswith((".acc", ".f1"))})
 
 
+def mask_fixture():
+    """G13: Transformer.forward(x, mask) - the key/query mask branch of Attention (models/heads.py:225-232), which no caller
+    of the reference uses but which is part of forward()'s signature.  mask is [B, N-1] bool (the reference pads a True for
+    the first token); clip 0 keeps everything, clip 1 drops three tokens, clip 2 drops all but one."""
+    heads, _, _, _ = load_reference()
+    sq = lambda y: y.pow(2).mean()
+    for tag, (dim, depth, h, dh, mlp, n) in {"a": (32, 2, 4, 8, 64, 9), "b": (64, 2, 2, 32, 128, 12),
+                                            "c": (64, 1, 2, 64, 128, 40)}.items():
+        torch.manual_seed(1300 + n)
+        tr = heads.Transformer(dim, depth, h, dh, mlp)
+        x = torch.randn(3, n, dim)
+        mask = torch.ones(3, n - 1, dtype=torch.bool)
+        mask[1, [1, 4, n - 2]] = False
+        mask[2, 1:] = False
+        xx = x.clone().requires_grad_(True)
+        y = tr(xx, mask=mask)
+        loss = sq(y)
+        loss.backward()
+        out = {"x": x, "mask": mask, "y": y.detach(), "dx": xx.grad, "loss": loss.detach()}
+        for k, v in tr.state_dict().items():
+            out["p." + k] = v
+        for k, p in tr.named_parameters():
+            out["g." + k] = p.grad
+        save(f"g13_transformer_mask_{tag}", dim=dim, depth=depth, heads=h, dim_head=dh, mlp_dim=mlp, **out)
+
+
 if __name__ == "__main__":
-    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "g12":
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
+    if only == "g12":
         metric_fixture()
+    elif only == "g13":
+        mask_fixture()
     else:
         main()
         metric_fixture()
+        mask_fixture()

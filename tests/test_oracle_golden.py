@@ -63,6 +63,18 @@ def test_transformer(name):
     check_grads(ps, g)
 
 
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_g13_transformer_with_token_mask(tag):
+    """the mask branch of Attention (heads.py:225-232): clip 1 drops three tokens, clip 2 all but the first"""
+    p, g, r = split_golden(load_golden(f"g13_transformer_mask_{tag}"))
+    mask = r["mask"].bool()
+    x, ps, y = run_with_grads(lambda x, ps: oracle.transformer_forward(x, ps, r["depth"], r["heads"], mask=mask), r["x"], p)
+    close(y, r["y"])
+    y.pow(2).mean().backward()
+    close(x.grad, r["dx"])
+    check_grads(ps, g)
+
+
 def test_param_names_match_reference_schema():
     p, _, r = split_golden(load_golden("g3_transformer_c1"))
     names = []
