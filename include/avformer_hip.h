@@ -47,7 +47,7 @@ typedef struct avf_layer_cfg {
   int32_t project_out; /* 0 iff heads==1 && dim_head==dim (nn.Identity)   heads.py:207          */
   float ln_eps;        /* nn.LayerNorm default 1e-5                       heads.py:181          */
   float dropout_p;     /* nn.Dropout p of the three sites (after to_out, after GELU, after net.3)
-                          heads.py:194-196,216; 0 = eval()/no dropout.  p > 0 needs AVF_BF16.  Masks are a pure
+                          heads.py:194-196,216; 0 = eval()/no dropout.  p > 0 needs dim % 4 == 0, dim <= 1536.  Masks are a pure
                           function of (seed, layer_index, site, element), regenerated in backward.               */
   uint32_t seed_lo, seed_hi; /* dropout seed: use a fresh value per forward, the same one in its backward        */
   int32_t layer_index; /* position of this layer in its stack (keys the dropout masks)                          */

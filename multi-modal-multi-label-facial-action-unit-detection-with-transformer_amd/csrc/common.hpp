@@ -268,6 +268,12 @@ __device__ __forceinline__ float4 drop_factor4(const DropCfg& d, uint64_t key, u
   return f;
 }
 
+// the factor of the single element idx (the same hash word as its group of four)
+__device__ __forceinline__ float drop_factor1(const DropCfg& d, uint64_t key, uint64_t idx) {
+  const uint64_t h = mix64(key + (idx & ~3ULL) * 0x9E3779B97F4A7C15ULL);
+  return ((uint32_t)(h >> (16 * (idx & 3))) & 0xffffu) >= d.thresh16 ? d.scale : 0.f;
+}
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // "dynamic-LDS limit raised" bookkeeping, one bit per device (hipFuncSetAttribute is per device; a process that runs stacks
@@ -309,6 +315,8 @@ int layernorm_bwd(const void* dy, int dy_dtype, const void* x, const float* gamm
 size_t colsum_ws(int64_t rows, int cols);
 int colsum(const void* in, int in_dtype, int64_t rows, int cols, int64_t ld, float* out, void* ws, hipStream_t s);
 int cast_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t s, const DropCfg& drop = kNoDrop);
+// out = in * dropout factors (fp32 parity mode: the gradient a Linear behind a dropout site sees); n % 4 == 0
+int mask_copy_f32(const float* in, float* out, int64_t n, hipStream_t s, const DropCfg& drop);
 int dropout_factors(const DropCfg& drop, float* out, int64_t n, hipStream_t s);  // test aid: keep*scale per element
 // out[c] = sum_b partial[b][c]
 int fold_partials(const float* partial, int nb, int width, float* out, hipStream_t s);

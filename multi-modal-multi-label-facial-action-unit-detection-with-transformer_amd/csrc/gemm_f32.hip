@@ -29,6 +29,7 @@ struct F32GemmParams {
   float* aux;
   int64_t ldaux;
   int M, N, K;
+  DropCfg drop;    // dropout site fused in the epilogue (thresh16 == 0: none); element index = m * N + n, as the bf16 kernels
   int kchunk;      // split-K (gridDim.z > 1): k-range per split, a multiple of the K-step
   float* slabs;    // split-K: raw partial accumulators [split][M][N] (dense); the fold kernel applies the epilogue
 };
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(F32GemmParams p) {
     __syncthreads();
   }
 
+  const uint64_t dkey = (!SPLIT && p.drop.thresh16) ? drop_key(p.drop) : 0;
   // C/D map of the 16x16 tile: col = lane&15, row = (lane>>4)*4 + reg
 #pragma unroll
   for (int i = 0; i < T; ++i)
@@ -131,13 +133,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(F32GemmParams p) {
           continue;
         }
         if (p.bias) v += p.bias[gn];
-        if (EPI == AVF_EPI_BIAS_RES) {
-          v += p.residual[(int64_t)gm * p.ldres + gn];
-        } else if (EPI == AVF_EPI_BIAS_GELU) {
+        const float df = p.drop.thresh16 ? drop_factor1(p.drop, dkey, (uint64_t)gm * p.N + gn) : 1.0f;  // wave-uniform branch
+        if (EPI == AVF_EPI_BIAS_RES) {  // x + Dropout(Linear(.))
+          v = v * df + p.residual[(int64_t)gm * p.ldres + gn];
+        } else if (EPI == AVF_EPI_BIAS_GELU) {  // Dropout(GELU(u)); u is saved unmasked
           p.aux[(int64_t)gm * p.ldaux + gn] = v;
-          v = gelu_tanh_f(v);
-        } else if (EPI == AVF_EPI_DGELU) {
-          v *= dgelu_tanh_f(p.aux[(int64_t)gm * p.ldaux + gn]);
+          v = gelu_tanh_f(v) * df;
+        } else if (EPI == AVF_EPI_DGELU) {  // backward through Dropout then GELU
+          v *= df * dgelu_tanh_f(p.aux[(int64_t)gm * p.ldaux + gn]);
         }
         p.C[(int64_t)gm * p.ldc + gn] = v;
       }
@@ -152,7 +155,10 @@ __global__ __launch_bounds__(256) void gemm_f32_fold_kernel(F32GemmParams p, int
   float v = p.slabs[i];
   for (int z = 1; z < S; ++z) v += p.slabs[(int64_t)z * mn + i];
   if (p.bias) v += p.bias[n];
-  if (with_res) v += p.residual[(int64_t)m * p.ldres + n];
+  if (with_res) {
+    if (p.drop.thresh16) v *= drop_factor1(p.drop, drop_key(p.drop), (uint64_t)i);
+    v += p.residual[(int64_t)m * p.ldres + n];
+  }
   p.C[(int64_t)m * p.ldc + n] = v;
 }
 
@@ -176,7 +182,7 @@ size_t gemm_f32_ws(int64_t M, int64_t N, int64_t K) {
 
 int gemm_f32(const GemmArgs& a, hipStream_t s) {
   AVF_REQUIRE(a.c_dtype == AVF_F32, "gemm_f32: C must be fp32");
-  AVF_REQUIRE(!a.drop.thresh16, "gemm_f32: dropout is only implemented on the bf16 path");
+  AVF_REQUIRE(!a.drop.thresh16 || a.epilogue != AVF_EPI_NONE, "gemm_f32: dropout needs a fused epilogue");
   AVF_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm_f32: bad shape");
   AVF_REQUIRE(a.M < (1LL << 31) && a.N < (1LL << 31) && a.K < (1LL << 31), "gemm_f32: shape too large");
   F32GemmParams p;
@@ -193,6 +199,7 @@ int gemm_f32(const GemmArgs& a, hipStream_t s) {
   p.aux = (float*)a.aux;
   p.ldaux = a.ldaux;
   p.M = (int)a.M; p.N = (int)a.N; p.K = (int)a.K;
+  p.drop = a.drop;
   p.kchunk = 0; p.slabs = nullptr;
   // skinny GEMMs with a long reduction (the heads' projections on a few dozen clips): split K over the grid, raw partials
   // into the caller's workspace, one fold launch with the epilogue - deterministic (no atomics)

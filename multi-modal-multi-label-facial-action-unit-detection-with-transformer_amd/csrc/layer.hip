@@ -49,9 +49,6 @@ int make_dims(const avf_layer_cfg* c, Dims* d) {
               "layer: non-positive shape in cfg");
   AVF_REQUIRE(c->dtype == AVF_F32 || c->dtype == AVF_BF16, "layer: bad dtype %d", c->dtype);
   AVF_REQUIRE(c->dropout_p >= 0.0f && c->dropout_p < 1.0f, "layer: dropout_p=%g out of range", (double)c->dropout_p);
-  AVF_REQUIRE(c->dropout_p == 0.0f || c->dtype == AVF_BF16,
-              "layer: dropout_p=%g needs the bf16 path (the fp32 parity mode is defined at p=0 / eval())",
-              (double)c->dropout_p);
   AVF_REQUIRE(c->dropout_p == 0.0f || (c->dim % 4 == 0 && c->dim <= 1536 && c->mlp_dim % 4 == 0),
               "layer: dropout needs dim %% 4 == 0, dim <= 1536");
   AVF_REQUIRE(c->project_out == 1,
@@ -180,6 +177,7 @@ struct Work {
   void *hq, *hs, *gq, *gs;  // mx8_fwd only: MX-FP8 images of the LayerNorm output and of gelu(u), forward scratch
   void *oq, *os;            // mx8_fwd: image of the attention output (forward scratch)
   void *duq, *dus, *mq, *ms, *gyq, *gys;  // mx8_bwd: images of du, of dx_mid, and of dx_out when the caller brought none
+  float *gy_m, *gm_m;       // fp32 mode with live dropout: masked copies of dx_out / dx_mid (what the Linears behind sites 2 / 0 see)
   float* small_part;        // short-sequence backward: per-clip partial rows (pb1 [B][M] | pln2 [B][3D] | pln1 [B][3D])
 };
 size_t carve_work(const Dims& d, void* base, Work* w) {
@@ -232,6 +230,9 @@ size_t carve_work(const Dims& d, void* base, Work* w) {
   } else {
     t.duq = t.dus = t.mq = t.ms = t.gyq = t.gys = nullptr;
   }
+  const bool f32_drop = d.dt == AVF_F32 && d.p > 0.f;
+  t.gy_m = (float*)c.take(f32_drop ? d.R * d.D * 4 : 0);
+  t.gm_m = (float*)c.take(f32_drop ? d.R * d.D * 4 : 0);
   if (w) *w = t;
   return c.off;
 }
@@ -510,7 +511,13 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
       own_copy = true;
     }
   }
-  const void* gm = lo ? (const void*)w.dx_mid_lo : (const void*)w.dx_mid;
+  const bool f32_drop = !lo && d.p > 0.f;
+  if (f32_drop) {  // fp32 mode with live dropout: net.3 sees the gradient through its site-2 mask
+    AVF_TRY(mask_copy_f32(dx_out, w.gy_m, d.R * d.D, s, dr2));
+    gy = w.gy_m;
+    own_copy = true;
+  }
+  const void* gm = lo ? (const void*)w.dx_mid_lo : (f32_drop ? (const void*)w.gm_m : (const void*)w.dx_mid);
   // bf16 mode: the four dW GEMMs run as ONE grouped launch at the end of the layer (their operands all stay
   // alive in the workspace), when the shapes allow the LDS-DMA kernel
   TnGroupArgs grp = dw_group(d, gy, sv.g, w.du, sv.h2, gm, sv.o, w.dqkv, sv.h1, g);
@@ -582,7 +589,7 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   else if (!dx_out_colsum) {
     if (d.p > 0.f) {  // db2 sums the MASKED gradient
       AVF_REQUIRE(own_copy, "layer_bwd: with dropout pass dx_out_colsum together with dx_out_lo");
-      AVF_TRY(colsum(gy, AVF_BF16, d.R, d.D, d.D, g->b2, w.cs_ws, s));
+      AVF_TRY(colsum(gy, d.dt, d.R, d.D, d.D, g->b2, w.cs_ws, s));
     } else if (dx_out) {
       AVF_TRY(colsum(dx_out, AVF_F32, d.R, d.D, d.D, g->b2, w.cs_ws, s));
     } else {
@@ -615,7 +622,7 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
     AVF_TRY(linear_dx(d, gy, d.D, p->w2, l.w2_t, d.M, w.du, AVF_EPI_DGELU, sv.u, s, g->b1, w.cs_ws, dr1,
                       grouped ? &folds.job[0] : nullptr));
   } else {
-    AVF_TRY(linear_dx(d, gy, d.D, p->w2, l.w2_t, d.M, w.du, AVF_EPI_DGELU, sv.u, s));
+    AVF_TRY(linear_dx(d, gy, d.D, p->w2, l.w2_t, d.M, w.du, AVF_EPI_DGELU, sv.u, s, nullptr, nullptr, dr1));
     AVF_TRY(colsum(w.du, d.dt, d.R, d.M, d.M, g->b1, w.cs_ws, s));
   }
   if (!grouped) AVF_TRY(linear_dw(d, w.du, d.M, sv.h2, d.D, g->w1, w.gemm_ws, s));
@@ -632,6 +639,7 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
                           lo ? w.dx_mid_lo : nullptr, g->ln2_w, g->ln2_b, g->b_out, w.ln_ws, d.R, d.D, s, dr0,
                           grouped ? &folds.job[1] : nullptr, AVF_F32, d.xdt, w.mq, w.ms));
   // ---- attention half ----------------------------------------------------------------------
+  if (f32_drop) AVF_TRY(mask_copy_f32(w.dx_mid, w.gm_m, d.R * d.D, s, dr0));  // to_out sees dx_mid through its site-0 mask
   if (!grouped) AVF_TRY(linear_dw(d, gm, d.D, sv.o, d.I, g->w_out, w.gemm_ws, s));
   if (d.mxb)
     AVF_TRY(linear_dx_mx(d, w.mq, w.ms, d.D, l.wot_q, l.wot_s, d.I, w.d_o, AVF_EPI_NONE, nullptr, s, nullptr, nullptr, kNoDrop,

@@ -626,6 +626,26 @@ int dropout_factors(const DropCfg& drop, float* out, int64_t n, hipStream_t s) {
   return check_launch("dropout_factors_kernel");
 }
 
+__global__ __launch_bounds__(256) void mask_copy_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n,
+                                                            DropCfg drop) {
+  const uint64_t dkey = drop_key(drop);
+  int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+  for (; i + 3 < n; i += stride) {
+    float4 v = *reinterpret_cast<const float4*>(in + i);
+    const float4 f = drop_factor4(drop, dkey, (uint64_t)i);
+    *reinterpret_cast<float4*>(out + i) = make_float4(v.x * f.x, v.y * f.y, v.z * f.z, v.w * f.w);
+  }
+}
+int mask_copy_f32(const float* in, float* out, int64_t n, hipStream_t s, const DropCfg& drop) {
+  AVF_REQUIRE(n > 0 && n % 4 == 0 && drop.thresh16, "mask_copy_f32: n %% 4 == 0 and p > 0 required");
+  AVF_REQUIRE((((uintptr_t)in) & 15) == 0 && (((uintptr_t)out) & 15) == 0, "mask_copy_f32: pointers must be 16B aligned");
+  int64_t blocks = ceil_div(n, 1024);
+  if (blocks > 2048) blocks = 2048;
+  mask_copy_f32_kernel<<<(unsigned)blocks, 256, 0, s>>>(in, out, n, drop);
+  return check_launch("mask_copy_f32_kernel");
+}
+
 int cast_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t s, const DropCfg& drop) {
   AVF_REQUIRE(n > 0, "cast: n must be positive");
   AVF_REQUIRE(!drop.thresh16 || n % 4 == 0, "cast: dropout needs n %% 4 == 0");

@@ -361,10 +361,6 @@ class Transformer(nn.Module):
     def _cfg(self, B: int, N: int, layer: int = 0, seed_t: Optional[torch.Tensor] = None,
              keep: Optional[torch.Tensor] = None) -> _lib.LayerCfg:
         p = self.dropout if self.training else 0.0  # nn.Dropout semantics: identity in eval()
-        if p != 0.0 and self.compute_dtype != _lib.BF16:
-            raise NotImplementedError(
-                f"dropout={p} in training mode needs compute_dtype='bf16'; the fp32 parity mode is defined at "
-                f"p=0 / eval() (SURVEY.md section 7)")
         return _lib.LayerCfg(B, N, self.dim, self.heads, self.dim_head, self.mlp_dim, self.compute_dtype,
                              int(self.project_out), 1e-5, float(p), 0, 0, layer,
                              seed_t.data_ptr() if (seed_t is not None and p != 0.0) else None,

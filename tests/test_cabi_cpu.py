@@ -47,8 +47,13 @@ def test_size_queries_and_config_validation(lib):
     bad = A._lib.LayerCfg(4, 64, 128, 8, 48, 256, A._lib.BF16, 1, 1e-5, 0.0)
     assert lib.avf_layer_saved_bytes(ctypes.byref(bad)) == 0
     assert b"dim_head" in lib.avf_last_error()
-    drop = A._lib.LayerCfg(4, 64, 128, 8, 32, 256, A._lib.F32, 1, 1e-5, 0.2)
-    assert lib.avf_layer_saved_bytes(ctypes.byref(drop)) == 0
+    drop = A._lib.LayerCfg(4, 64, 128, 8, 32, 256, A._lib.F32, 1, 1e-5, 0.2)  # fp32 mode with live dropout (round 2)
+    assert lib.avf_layer_saved_bytes(ctypes.byref(drop)) > 0
+    nodrop = A._lib.LayerCfg(4, 64, 128, 8, 32, 256, A._lib.F32, 1, 1e-5, 0.0)
+    # ... which needs two fp32 masked gradient copies in the workspace
+    assert lib.avf_layer_workspace_bytes(ctypes.byref(drop)) >= lib.avf_layer_workspace_bytes(ctypes.byref(nodrop)) + 2 * 256 * 128 * 4
+    bad_drop = A._lib.LayerCfg(4, 64, 130, 8, 32, 256, A._lib.F32, 1, 1e-5, 0.2)  # dropout needs dim % 4 == 0
+    assert lib.avf_layer_saved_bytes(ctypes.byref(bad_drop)) == 0
     assert b"dropout" in lib.avf_last_error()
     assert lib.avf_gemm_workspace_bytes(A._lib.BF16, 1, 0, 1536, 512, 16384) > 0
     assert lib.avf_gemm_workspace_bytes(A._lib.F32, 1, 0, 1536, 512, 16384) == 0
@@ -94,8 +99,7 @@ def test_no_cpu_fallback():
 def test_dropout_configuration():
     t = A.Transformer(32, 1, 8, 32, 64, dropout=0.2, compute_dtype="f32")
     t.train()
-    with pytest.raises(NotImplementedError, match="bf16"):  # parity mode is defined at p=0 / eval()
-        t._cfg(1, 4)
+    assert abs(t._cfg(1, 4).dropout_p - 0.2) < 1e-7  # live in both modes since round 2
     t.eval()
     assert t._cfg(1, 4).dropout_p == 0.0
     t = A.Transformer(32, 1, 8, 32, 64, dropout=0.2)  # bf16: dropout is live in train(), identity in eval()

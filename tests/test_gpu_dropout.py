@@ -78,13 +78,40 @@ def test_mask_replay_against_oracle(cfg):
     check_rel(tag + ":eval_y", ye, y_nodrop, 1.5e-2)
 
 
-def test_dropout_needs_bf16_mode():
+@pytest.mark.parametrize("cfg", [(3, 77, 128, 2, 8, 32, 256), (2, 100, 64, 3, 2, 16, 96), (4, 12, 128, 2, 8, 32, 256)])
+def test_mask_replay_against_oracle_fp32_mode(cfg):
+    """the fp32 parity mode with live dropout (round 2): the same counter-based masks ride in the fp32 GEMM epilogues and in
+    fp32 masked copies of the two gradients a Linear behind a dropout site sees; replayed through the oracle the whole
+    forward / backward must agree at fp32 level - a far tighter check of the mask bookkeeping (which site masks which
+    gradient, bias gradients of MASKED sums, the residual stream never masked) than the bf16 replay above."""
     import avformer_amd as A
-    t = A.Transformer(64, 1, 8, 32, 128, dropout=0.2, compute_dtype="f32").to(DEV).train()
-    with pytest.raises(NotImplementedError, match="bf16"):
-        t(torch.randn(2, 8, 64, device=DEV))
+    B, N, D, L, H, dh, M = cfg
+    p = 0.3
+    g = torch.Generator().manual_seed(6)
+    sd = oracle.init_transformer_state(D, L, H, dh, M, generator=g)
+    x = torch.randn(B, N, D, generator=g)
+    t = A.Transformer(D, L, H, dh, M, dropout=p, compute_dtype="f32")
+    t.load_state_dict(sd)
+    t = t.to(DEV).train()
+    xg = x.to(DEV).requires_grad_(True)
+    y = t(xg)
+    y.pow(2).mean().backward()
+    seed = t.last_seed
+    R = B * N
+    drop = [tuple(A.ops.dropout_factors(seed, l, s, p, R, cols).cpu().view(B, N, cols)
+                  for s, cols in ((0, D), (1, M), (2, D))) for l in range(L)]
+    xr = x.clone().requires_grad_(True)
+    pr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    yr = oracle.transformer_forward(xr, pr, L, H, drop=drop)
+    yr.pow(2).mean().backward()
+    torch.testing.assert_close(y.cpu(), yr.detach(), atol=5e-5, rtol=1e-3)
+    torch.testing.assert_close(xg.grad.cpu(), xr.grad, atol=1e-6, rtol=2e-3)
+    for k, prm in t.named_parameters():
+        torch.testing.assert_close(prm.grad.cpu(), pr[k].grad, atol=2e-6, rtol=2e-3, msg=lambda m, k=k: f"{k}: {m}")
+    assert rel_fro(yr, oracle.transformer_forward(x, sd, L, H)) > 0.1  # the masks really changed the result
     t.eval()
-    t(torch.randn(2, 8, 64, device=DEV))
+    with torch.no_grad():
+        torch.testing.assert_close(t(xg).cpu(), oracle.transformer_forward(x, sd, L, H), atol=5e-5, rtol=1e-3)
 
 
 def test_avformer_model_trains_with_its_reference_dropout():
