@@ -44,7 +44,8 @@ typedef struct avf_layer_cfg {
   int32_t dim_head;    /* dh ; inner I = H*dh                             heads.py:206          */
   int32_t mlp_dim;     /* M                                               heads.py:189          */
   int32_t dtype;       /* AVF_F32 | AVF_BF16                                                    */
-  int32_t project_out; /* 0 iff heads==1 && dim_head==dim (nn.Identity)   heads.py:207          */
+  int32_t project_out; /* 0 iff heads==1 && dim_head==dim (nn.Identity)   heads.py:207: pass the identity matrix as w_out and
+                          zeros as b_out (the GEMM then returns the attention output exactly); no dropout site 0 */
   float ln_eps;        /* nn.LayerNorm default 1e-5                       heads.py:181          */
   float dropout_p;     /* nn.Dropout p of the three sites (after to_out, after GELU, after net.3)
                           heads.py:194-196,216; 0 = eval()/no dropout.  p > 0 needs dim % 4 == 0, dim <= 1536.  Masks are a pure

@@ -31,6 +31,7 @@ struct Dims {
   bool mx;    // forward nn.Linear GEMMs fed by LayerNorm / GELU (qkv, mlp1, mlp2) take MX-FP8 operands (config 5)
   bool rs16;  // the FORWARD residual stream (x_in, x_mid, x_out) is stored in bf16 (statistics / accumulation stay fp32)
   int xdt;    // storage type of the residual stream
+  float p0;   // dropout probability of site 0 (after to_out): 0 when to_out is nn.Identity (no Dropout in it, heads.py:214-217)
   const void* keep;  // optional token mask [B, N] bytes (1 = kept), heads.py:225-232: attention then runs on the fp32-arithmetic kernels
   bool mxb;   // backward dX GEMMs fed by LayerNorm backward / the dGELU epilogue take MX-FP8 operands too (config 5)
   bool gy_mx; // the caller's dx_out_lo buffer already carries the MX-FP8 image behind the bf16 one
@@ -51,8 +52,11 @@ int make_dims(const avf_layer_cfg* c, Dims* d) {
   AVF_REQUIRE(c->dropout_p >= 0.0f && c->dropout_p < 1.0f, "layer: dropout_p=%g out of range", (double)c->dropout_p);
   AVF_REQUIRE(c->dropout_p == 0.0f || (c->dim % 4 == 0 && c->dim <= 1536 && c->mlp_dim % 4 == 0),
               "layer: dropout needs dim %% 4 == 0, dim <= 1536");
-  AVF_REQUIRE(c->project_out == 1,
-              "layer: the nn.Identity to_out case (heads==1 && dim_head==dim, heads.py:207) is not supported");
+  // nn.Identity to_out (heads == 1 && dim_head == dim, heads.py:207; never instantiated by the reference): the caller passes the
+  // identity matrix as w_out and zeros as b_out (x 1.0 and + 0.0 are exact in fp32 and in bf16 with fp32 accumulation, so the
+  // projection GEMM returns the attention output bit for bit) and the library drops the dropout site that nn.Identity lacks
+  AVF_REQUIRE(c->project_out == 1 || (c->heads == 1 && c->dim_head == c->dim),
+              "layer: project_out = 0 is the nn.Identity to_out case: it needs heads == 1 and dim_head == dim (heads.py:207)");
   d->B = c->batch; d->N = c->tokens; d->D = c->dim; d->H = c->heads; d->dh = c->dim_head;
   d->I = c->heads * c->dim_head; d->M = c->mlp_dim; d->R = (int64_t)c->batch * c->tokens;
   d->dt = c->dtype; d->es = c->dtype == AVF_BF16 ? 2 : 4;
@@ -65,6 +69,7 @@ int make_dims(const avf_layer_cfg* c, Dims* d) {
   AVF_REQUIRE(!d->mx || (c->dtype == AVF_BF16 && c->dim % 128 == 0 && c->mlp_dim % 128 == 0 && c->dim <= 1536),
               "layer: mx8_fwd needs the bf16 path with dim and mlp_dim multiples of 128 (dim=%d mlp_dim=%d)", c->dim,
               c->mlp_dim);
+  d->p0 = c->project_out ? c->dropout_p : 0.0f;
   d->keep = c->key_mask;
   d->mxb = c->mx8_bwd != 0;
   d->gy_mx = c->dx_out_mx8 != 0;
@@ -418,7 +423,7 @@ extern "C" int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p
     AVF_REQUIRE(workspace, "layer_fwd(mx8): workspace missing");
     Work w;
     carve_work(d, workspace, &w);
-    const DropCfg dr0 = make_drop(d.p, d.seed, d.layer, 0, d.seed_dev), dr1 = make_drop(d.p, d.seed, d.layer, 1, d.seed_dev),
+    const DropCfg dr0 = make_drop(d.p0, d.seed, d.layer, 0, d.seed_dev), dr1 = make_drop(d.p, d.seed, d.layer, 1, d.seed_dev),
                   dr2 = make_drop(d.p, d.seed, d.layer, 2, d.seed_dev);
     AVF_TRY(layernorm_fwd(x_in, p->ln1_w, p->ln1_b, sv.h1, d.dt, sv.mean1, sv.rstd1, d.R, d.D, cfg->ln_eps, s, w.hq, w.hs, d.xdt));
     AVF_TRY(linear_fwd_mx(d, w.hq, w.hs, d.D, l.wqkv_q, l.wqkv_s, 3 * d.I, sv.qkv, d.dt, AVF_EPI_NONE, nullptr, nullptr,
@@ -450,7 +455,7 @@ extern "C" int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p
     const float sc = attn_q_prescale_on() ? 1.0f : 1.4426950408889634f / sqrtf((float)d.dh);
     return layer_fwd_small(d.B, d.N, d.D, d.H, d.M, cfg->ln_eps, sc, p, wqkv, wo, w1, w2, (const float*)x_in, (float*)x_out, sv.h1,
                            sv.mean1, sv.rstd1, sv.qkv, sv.o, sv.lse2, (float*)sv.x_mid, sv.h2, sv.mean2, sv.rstd2, sv.u, sv.g,
-                           make_drop(d.p, d.seed, d.layer, 0, d.seed_dev), make_drop(d.p, d.seed, d.layer, 1, d.seed_dev),
+                           make_drop(d.p0, d.seed, d.layer, 0, d.seed_dev), make_drop(d.p, d.seed, d.layer, 1, d.seed_dev),
                            make_drop(d.p, d.seed, d.layer, 2, d.seed_dev), s);
   }
   AVF_TRY(layernorm_fwd(x_in, p->ln1_w, p->ln1_b, sv.h1, d.dt, sv.mean1, sv.rstd1, d.R, d.D, cfg->ln_eps, s, nullptr, nullptr, d.xdt));
@@ -458,7 +463,7 @@ extern "C" int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   if (d.keep) AVF_TRY(attn_fwd_vec(d.dt, sv.qkv, sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s, d.keep, lo && attn_q_prescale_on()));
   else if (lo) AVF_TRY(attn_fwd_bf16((const bf16*)sv.qkv, (bf16*)sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s, attn_q_prescale_on()));
   else AVF_TRY(attn_fwd_f32((const float*)sv.qkv, (float*)sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s));
-  const DropCfg dr0 = make_drop(d.p, d.seed, d.layer, 0, d.seed_dev), dr1 = make_drop(d.p, d.seed, d.layer, 1, d.seed_dev),
+  const DropCfg dr0 = make_drop(d.p0, d.seed, d.layer, 0, d.seed_dev), dr1 = make_drop(d.p, d.seed, d.layer, 1, d.seed_dev),
                 dr2 = make_drop(d.p, d.seed, d.layer, 2, d.seed_dev);
   AVF_TRY(linear_fwd(d, sv.o, d.I, wo, d.D, sv.x_mid, d.xdt, AVF_EPI_BIAS_RES, p->b_out, x_in, nullptr, s, dr0));
   AVF_TRY(layernorm_fwd(sv.x_mid, p->ln2_w, p->ln2_b, sv.h2, d.dt, sv.mean2, sv.rstd2, d.R, d.D, cfg->ln_eps, s, nullptr, nullptr, d.xdt));
@@ -490,7 +495,7 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
 
   // gradient of the layer output in the compute dtype (GEMM operand)
   // dropout: the Linears behind a dropout site see the masked, rescaled gradient (the residual stream does not)
-  const DropCfg dr0 = make_drop(d.p, d.seed, d.layer, 0, d.seed_dev), dr1 = make_drop(d.p, d.seed, d.layer, 1, d.seed_dev),
+  const DropCfg dr0 = make_drop(d.p0, d.seed, d.layer, 0, d.seed_dev), dr1 = make_drop(d.p, d.seed, d.layer, 1, d.seed_dev),
                 dr2 = make_drop(d.p, d.seed, d.layer, 2, d.seed_dev);
   const DropCfg dr_prev2 = d.layer > 0 ? make_drop(d.p, d.seed, d.layer - 1, 2, d.seed_dev) : kNoDrop;
   // short sequences (the reference's 12-token stacks): the six dependent launches around the attention backward run as two
@@ -517,7 +522,8 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
     gy = w.gy_m;
     own_copy = true;
   }
-  const void* gm = lo ? (const void*)w.dx_mid_lo : (f32_drop ? (const void*)w.gm_m : (const void*)w.dx_mid);
+  const bool f32_drop0 = f32_drop && d.p0 > 0.f;  // (no site 0 behind an nn.Identity to_out)
+  const void* gm = lo ? (const void*)w.dx_mid_lo : (f32_drop0 ? (const void*)w.gm_m : (const void*)w.dx_mid);
   // bf16 mode: the four dW GEMMs run as ONE grouped launch at the end of the layer (their operands all stay
   // alive in the workspace), when the shapes allow the LDS-DMA kernel
   TnGroupArgs grp = dw_group(d, gy, sv.g, w.du, sv.h2, gm, sv.o, w.dqkv, sv.h1, g);
@@ -639,7 +645,7 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
                           lo ? w.dx_mid_lo : nullptr, g->ln2_w, g->ln2_b, g->b_out, w.ln_ws, d.R, d.D, s, dr0,
                           grouped ? &folds.job[1] : nullptr, AVF_F32, d.xdt, w.mq, w.ms));
   // ---- attention half ----------------------------------------------------------------------
-  if (f32_drop) AVF_TRY(mask_copy_f32(w.dx_mid, w.gm_m, d.R * d.D, s, dr0));  // to_out sees dx_mid through its site-0 mask
+  if (f32_drop0) AVF_TRY(mask_copy_f32(w.dx_mid, w.gm_m, d.R * d.D, s, dr0));  // to_out sees dx_mid through its site-0 mask
   if (!grouped) AVF_TRY(linear_dw(d, gm, d.D, sv.o, d.I, g->w_out, w.gemm_ws, s));
   if (d.mxb)
     AVF_TRY(linear_dx_mx(d, w.mq, w.ms, d.D, l.wot_q, l.wot_s, d.I, w.d_o, AVF_EPI_NONE, nullptr, s, nullptr, nullptr, kNoDrop,

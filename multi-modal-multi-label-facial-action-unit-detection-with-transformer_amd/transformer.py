@@ -299,6 +299,9 @@ class Transformer(nn.Module):
             raise ValueError("residual_dtype='bf16' needs compute_dtype 'bf16' / 'mx8', dim % 8 == 0 and dim <= 1536")
         self.project_out = not (heads == 1 and dim_head == dim)
         self.layers = nn.ModuleList([_make_layer(dim, heads, dim_head, mlp_dim, dropout) for _ in range(depth)])
+        if not self.project_out:
+            self.register_buffer("_identity_w", torch.eye(dim), persistent=False)
+            self.register_buffer("_identity_b", torch.zeros(dim), persistent=False)
         self._ws = None
         self._lowp_bufs = None
         self._lowp_ptrs = None
@@ -332,9 +335,13 @@ class Transformer(nn.Module):
         """The 11 tensors of layer ``l`` in state_dict order."""
         attn_w, ff_w = self.layers[l]
         a, f = attn_w.fn, ff_w.fn
-        if not self.project_out:
-            raise NotImplementedError("heads==1 and dim_head==dim (nn.Identity to_out) is not supported by the HIP path")
-        return [a.norm.weight, a.norm.bias, a.fn.to_qkv.weight, a.fn.to_out[0].weight, a.fn.to_out[0].bias,
+        if self.project_out:
+            w_out, b_out = a.fn.to_out[0].weight, a.fn.to_out[0].bias
+        else:  # nn.Identity to_out (heads.py:207): the library's projection GEMM runs on the identity matrix and a zero bias -
+            # exact in every mode - held as non-persistent buffers (state_dict keeps the reference's keys), frozen, shared by
+            # the layers; the library drops the dropout site nn.Identity does not have (cfg.project_out = 0)
+            w_out, b_out = self._identity_w, self._identity_b
+        return [a.norm.weight, a.norm.bias, a.fn.to_qkv.weight, w_out, b_out,
                 f.norm.weight, f.norm.bias, f.fn.net[0].weight, f.fn.net[0].bias, f.fn.net[3].weight, f.fn.net[3].bias]
 
     def flat_parameters(self) -> List[torch.Tensor]:
@@ -344,7 +351,7 @@ class Transformer(nn.Module):
         if cache is not None:
             first = self.layers[0][0].fn.norm.weight
             last = self.layers[self.depth - 1][1].fn.fn.net[3].bias
-            if cache[0] is first and cache[-1] is last:
+            if cache[0] is first and cache[-1] is last and (self.project_out or cache[3] is self._identity_w):
                 return cache
         out = []
         for l in range(self.depth):

@@ -16,7 +16,7 @@ G4 transformer with inner != dim at N in {12, 17, 49}, G5 AU_former (eval), G6 t
 (emb 64), G7 TFormer, G8 AULoss with/without ignored rows, G9 tiny pipeline TFormer -> AU_former
 -> AULoss with gradients, G10 tanh-GELU on a grid, G11 the token section of ResFormer.forward, G12 the evaluation
 score of metrics/accf1.py (MultiLabelAccF1, the reference's own sklearn-backed implementation) on seeded batches, G13 the
-Transformer with a token mask (the branch heads.py:225-232).
+Transformer with a token mask (the branch heads.py:225-232), G14 the Transformer whose to_out is nn.Identity (heads.py:207).
 
     python tests/golden/make_golden.py --only g12        (re)generates just that fixture
 """
@@ -273,13 +273,27 @@ def mask_fixture():
         save(f"g13_transformer_mask_{tag}", dim=dim, depth=depth, heads=h, dim_head=dh, mlp_dim=mlp, **out)
 
 
+def identity_fixture():
+    """G14: Transformer with heads == 1 and dim_head == dim, where Attention.to_out is nn.Identity (models/heads.py:207,
+    214-217): no out-projection parameters in the state_dict, no Dropout after the attention output."""
+    heads, _, _, _ = load_reference()
+    torch.manual_seed(1400)
+    tr = heads.Transformer(32, 2, 1, 32, 64)
+    assert isinstance(tr.layers[0][0].fn.fn.to_out, torch.nn.Identity)
+    save("g14_transformer_identity_out", dim=32, depth=2, heads=1, dim_head=32, mlp_dim=64,
+         **module_io(tr, torch.randn(3, 10, 32), lambda y: y.pow(2).mean()))
+
+
 if __name__ == "__main__":
     only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
     if only == "g12":
         metric_fixture()
     elif only == "g13":
         mask_fixture()
+    elif only == "g14":
+        identity_fixture()
     else:
         main()
         metric_fixture()
         mask_fixture()
+        identity_fixture()

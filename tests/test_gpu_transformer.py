@@ -27,7 +27,8 @@ def _close(a, b, atol=5e-5, rtol=1e-3):
     torch.testing.assert_close(a.detach().float().cpu(), b.detach().float().cpu(), atol=atol, rtol=rtol)
 
 
-GOLDEN_TRANSFORMERS = ["g3_transformer_c1", "g4_transformer_n12", "g4_transformer_n17", "g4_transformer_n49"]
+GOLDEN_TRANSFORMERS = ["g3_transformer_c1", "g4_transformer_n12", "g4_transformer_n17", "g4_transformer_n49",
+                       "g14_transformer_identity_out"]  # G14: heads == 1, dim_head == dim: to_out is nn.Identity (heads.py:207)
 
 
 @pytest.mark.parametrize("name", GOLDEN_TRANSFORMERS)

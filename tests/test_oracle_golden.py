@@ -53,7 +53,7 @@ def test_g2_feedforward():
 
 
 @pytest.mark.parametrize("name", ["g3_transformer_c1", "g4_transformer_n12", "g4_transformer_n17",
-                                  "g4_transformer_n49"])
+                                  "g4_transformer_n49", "g14_transformer_identity_out"])
 def test_transformer(name):
     p, g, r = split_golden(load_golden(name))
     x, ps, y = run_with_grads(lambda x, ps: oracle.transformer_forward(x, ps, r["depth"], r["heads"]), r["x"], p)
