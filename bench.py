@@ -225,23 +225,35 @@ class Region:
         self.extra_warmup = extra
         self.fence()
         run = self.step
+        self.launch = "eager"
         if graph and self.dp is None:
-            if self.opt is not None:
-                for gdict in self.opt.param_groups:
-                    gdict["capturable"] = True
-                self.step()
-            gr = torch.cuda.CUDAGraph()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                self.step()
-            torch.cuda.current_stream().wait_stream(side)
-            with torch.cuda.graph(gr):
-                static_loss = self.step()
-            run = lambda: (gr.replay(), static_loss)[1]
-            for _ in range(3):
-                run()
-            self.fence()
+            # the whole step (zero_grad, forward, loss, backward, optimizer) captured once and replayed: the ~130 launches of a
+            # step no longer depend on the host keeping up (eager C2 needs ~1.8 ms of host time per 2.3 ms step)
+            try:
+                if self.opt is not None:
+                    for gdict in self.opt.param_groups:
+                        gdict["capturable"] = True
+                    self.step()
+                gr = torch.cuda.CUDAGraph()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    self.step()
+                torch.cuda.current_stream().wait_stream(side)
+                with torch.cuda.graph(gr):
+                    static_loss = self.step()
+                run = lambda: (gr.replay(), static_loss)[1]
+                for _ in range(3):
+                    run()
+                self.fence()
+                self.launch = "hipGraph replay"
+            except Exception as e:  # capture is an optimisation of the launch path, never a requirement
+                torch.cuda.synchronize()
+                run = self.step
+                self.launch = f"eager (graph capture failed: {type(e).__name__}: {str(e)[:120]})"
+                for _ in range(2):
+                    self.step()
+                self.fence()
         t0 = time.perf_counter()
         for _ in range(steps):
             loss = run()
@@ -302,7 +314,11 @@ def main():
                     help="step torch.optim.Adam(fused=True) instead of the library's Adam (same arithmetic; the library's "
                          "also rewrites the bf16 weight copies in its pass)")
     ap.add_argument("--cpu-steps", type=int, default=8)
-    ap.add_argument("--graph", action="store_true", help="capture the step into a HIP graph and replay it (1 GPU)")
+    ap.add_argument("--graph", action="store_true", help="same as --launch graph")
+    ap.add_argument("--launch", default="auto", choices=["auto", "graph", "eager"],
+                    help="how the timed steps are issued: graph = the step captured once into a HIP graph and replayed; eager = "
+                         "launched from Python every step; auto = graph on one GPU, eager under data parallelism (the RCCL "
+                         "all-reduce is not captured)")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the extra timed regions (north-star shape C3, fp32 parity mode); the contract line's own "
                          "fields are unaffected")
@@ -347,7 +363,8 @@ def main():
     # target is quoted on (C3: B=32/GPU, T=512, d=512 = BASELINE configs[2], which at N=8 is exactly its global batch of
     # 256) and, at N=1, the fp32 parity mode on the main workload (the mode that meets north_star's logits rtol 1e-3).
     main_r = mk(args.config, args.dtype, use_dist)
-    main_r.timed(args.steps, args.warmup, args.graph)
+    use_graph = (args.graph or args.launch in ("auto", "graph")) and args.launch != "eager" and not use_dist
+    main_r.timed(args.steps, args.warmup, use_graph)
     c, B = main_r.c, main_r.B
     Tv, Ta = c["t_video"], c["t_audio"]
     result = {
@@ -362,11 +379,12 @@ def main():
                    "step": "zero_grad+fwd+AULoss+bwd" + ("+allreduce" if use_dist else "") + ("+adam" if main_r.optimizer else ""),
                    "optimizer": main_r.optimizer, "residual_stream": main_r.residual, "loss": main_r.loss},
         "untimed_steps_beyond_warmup": main_r.extra_warmup,  # until the caching allocator stopped growing (Region.timed)
+        "launch": main_r.launch,
     }
     c3_r = f32_r = None
     if not args.no_extra and args.config == "c2" and args.dtype == "bf16":
         c3_r = mk("c3", "bf16", use_dist)
-        c3_r.timed(args.steps, args.warmup)
+        c3_r.timed(args.steps, args.warmup, use_graph)
         if world == 1:
             f32_r = mk(args.config, "f32", False)
             f32_r.timed(max(2, args.steps // 6), 1)
@@ -410,7 +428,7 @@ def main():
                 "workload": f"BASELINE.json configs[2] per GPU: d={cc['dim']} L={cc['depth']} T={cc['t_video'] + cc['t_audio']} "
                             f"B={c3_r.B}/GPU (global {c3_r.B * world}), same step as `value`",
                 "clips_per_s": round(c3_r.clips_per_s, 2), "ms_per_step": round(c3_r.ms, 4),
-                "steps": args.steps, "warmup": args.warmup,
+                "steps": args.steps, "warmup": args.warmup, "launch": c3_r.launch,
                 "stack_tflops_per_gpu": round(c3_r.tflops, 2),
                 "stack_frac_of_mfma_peak": round(c3_r.frac, 4),
                 "target_frac": 0.30, "kernel_classes": c3_r.classes if events else None}

@@ -36,7 +36,7 @@ __device__ __forceinline__ void stage_keep(uint8_t* dst, const uint8_t* keep, in
 }
 constexpr float MASKV = -3.4028234663852886e38f;  // -finfo(float32).max, heads.py:225
 
-template <int DH, typename T>
+template <int DH, typename T, bool MASKED>
 __global__ __launch_bounds__(64) void attn_fwd_f32_kernel(const T* __restrict__ qkv, T* __restrict__ o,
                                                           float* __restrict__ lse2, int /*B*/, int N, int H,
                                                           const uint8_t* __restrict__ keep, int qs) {
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64) void attn_fwd_f32_kernel(const T* __restrict__ 
   const T* base = qkv + (int64_t)b * N * ld + h * DH;
   const int qi = blockIdx.x * 64 + threadIdx.x;
   const bool valid = qi < N;
-  const bool mq = !keep || (valid && keep[(int64_t)b * N + qi]);
+  const bool mq = !MASKED || (valid && keep[(int64_t)b * N + qi]);
   const float c = qs ? 1.0f : LOG2E / sqrtf((float)DH);
   float q[DH], acc[DH];
 #pragma unroll
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(64) void attn_fwd_f32_kernel(const T* __restrict__ 
     const int nk = (N - kt) < KT ? (N - kt) : KT;
     stage_rows<DH, T>(Ks, base + I, ld, kt, nk);
     stage_rows<DH, T>(Vs, base + 2 * I, ld, kt, nk);
-    stage_keep(Ms, keep, (int64_t)b * N + kt, nk);
+    if (MASKED) stage_keep(Ms, keep, (int64_t)b * N + kt, nk);
     __syncthreads();
     float s[KT];
     float tmax = -INFINITY;
@@ -73,7 +73,8 @@ __global__ __launch_bounds__(64) void attn_fwd_f32_kernel(const T* __restrict__ 
       float a = 0.f;
 #pragma unroll
       for (int d = 0; d < DH; ++d) a = fmaf(q[d], Ks[j * DH + d], a);
-      s[j] = (j < nk) ? ((mq && Ms[j]) ? a : MASKV) : -INFINITY;
+      if (MASKED) s[j] = (j < nk) ? ((mq && Ms[j]) ? a : MASKV) : -INFINITY;
+      else s[j] = (j < nk) ? a : -INFINITY;
       tmax = fmaxf(tmax, s[j]);
     }
     const float mn = fmaxf(m, tmax);
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(64) void attn_fwd_f32_kernel(const T* __restrict__ 
 }
 
 // dQ: one lane per query.  dS = P o (dP - delta),  dq = dS k * dh^-0.5; no gradient through a filled score
-template <int DH, typename T>
+template <int DH, typename T, bool MASKED>
 __global__ __launch_bounds__(64) void attn_dq_f32_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o,
                                                          const float* __restrict__ lse2, const float* __restrict__ delta,
                                                          T* __restrict__ dqkv, int /*B*/, int N, int H,
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(64) void attn_dq_f32_kernel(const T* __restrict__ q
   const T* base = qkv + (int64_t)b * N * ld + h * DH;
   const int qi = blockIdx.x * 64 + threadIdx.x;
   const bool valid = qi < N;
-  const bool mq = !keep || (valid && keep[(int64_t)b * N + qi]);
+  const bool mq = !MASKED || (valid && keep[(int64_t)b * N + qi]);
   const float scale = 1.0f / sqrtf((float)DH);
   const float c = qs ? 1.0f : LOG2E * scale;
   float q[DH], g[DH], dq[DH];
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(64) void attn_dq_f32_kernel(const T* __restrict__ q
     const int nk = (N - kt) < KT ? (N - kt) : KT;
     stage_rows<DH, T>(Ks, base + I, ld, kt, nk);
     stage_rows<DH, T>(Vs, base + 2 * I, ld, kt, nk);
-    stage_keep(Ms, keep, (int64_t)b * N + kt, nk);
+    if (MASKED) stage_keep(Ms, keep, (int64_t)b * N + kt, nk);
     __syncthreads();
 #pragma unroll 4
     for (int j = 0; j < KT; ++j) {
@@ -147,7 +148,8 @@ __global__ __launch_bounds__(64) void attn_dq_f32_kernel(const T* __restrict__ q
         s = fmaf(q[d], Ks[j * DH + d], s);
         dp = fmaf(g[d], Vs[j * DH + d], dp);
       }
-      const float pj = (j < nk && mq && Ms[j]) ? exp2f(s - L) : 0.f;  // filled scores: dS = 0
+      const bool live = MASKED ? (j < nk && mq && Ms[j]) : (j < nk);  // filled scores: dS = 0
+      const float pj = live ? exp2f(s - L) : 0.f;
       const float ds = pj * (dp - dl);
 #pragma unroll
       for (int d = 0; d < DH; ++d) dq[d] = fmaf(ds, Ks[j * DH + d], dq[d]);
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(64) void attn_dq_f32_kernel(const T* __restrict__ q
 
 // dK / dV: one lane per key.  PASS 0: dv = P^T dO.  PASS 1: dk = dS^T q * dh^-0.5
 // (a dropped query's row of P is the constant 1/N - dV receives it - and its dS is 0)
-template <int DH, int PASS, typename T>
+template <int DH, int PASS, typename T, bool MASKED>
 __global__ __launch_bounds__(64) void attn_dkv_f32_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o,
                                                           const float* __restrict__ lse2,
                                                           const float* __restrict__ delta, T* __restrict__ dqkv,
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(64) void attn_dkv_f32_kernel(const T* __restrict__ 
   const T* base = qkv + (int64_t)b * N * ld + h * DH;
   const int ki = blockIdx.x * 64 + threadIdx.x;
   const bool valid = ki < N;
-  const bool mk = !keep || (valid && keep[(int64_t)b * N + ki]);
+  const bool mk = !MASKED || (valid && keep[(int64_t)b * N + ki]);
   const float scale = 1.0f / sqrtf((float)DH);
   const float c = qs ? 1.0f : LOG2E * scale;
   const float uniform = 1.0f / (float)N;
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(64) void attn_dkv_f32_kernel(const T* __restrict__ 
     const int nq = (N - qt) < KT ? (N - qt) : KT;
     stage_rows<DH, T>(Qs, base, ld, qt, nq);
     stage_rows<DH, T>(Gs, d_o + (int64_t)b * N * I + h * DH, I, qt, nq);
-    stage_keep(Ms, keep, (int64_t)b * N + qt, nq);
+    if (MASKED) stage_keep(Ms, keep, (int64_t)b * N + qt, nq);
     if (threadIdx.x < KT) {
       const bool ok = (int)threadIdx.x < nq;
       Ls[threadIdx.x] = ok ? lse2[(int64_t)bh * N + qt + threadIdx.x] : INFINITY;  // 2^(s - inf) = 0
@@ -213,9 +215,9 @@ __global__ __launch_bounds__(64) void attn_dkv_f32_kernel(const T* __restrict__ 
       float s = 0.f;
 #pragma unroll
       for (int d = 0; d < DH; ++d) s = fmaf(k[d], Qs[j * DH + d], s);
-      const bool pair = Ms[j] && mk;  // Ms[j] = 0 past the end and for a dropped query
+      const bool pair = !MASKED || (Ms[j] && mk);  // Ms[j] = 0 past the end and for a dropped query (Ls = inf past the end)
       float pj = pair ? exp2f(s - Ls[j]) : 0.f;
-      if (keep && j < nq && !Ms[j]) pj = uniform;  // dropped query: every score was filled, softmax is uniform over all N keys
+      if (MASKED && j < nq && !Ms[j]) pj = uniform;  // dropped query: every score was filled, softmax is uniform over all N keys
       if (PASS == 0) {
 #pragma unroll
         for (int d = 0; d < DH; ++d) acc[d] = fmaf(pj, Gs[j * DH + d], acc[d]);
@@ -306,11 +308,16 @@ int attn_fwd_vec(int dtype, const void* qkv, void* o, float* lse2, int B, int N,
   dim3 grid((unsigned)ceil_div(N, 64), (unsigned)(B * H));
   const uint8_t* kp = (const uint8_t*)keep;
   const int qs = q_prescaled ? 1 : 0;
-#define L(D)                                                                                                      \
-  if (dtype == AVF_F32) attn_fwd_f32_kernel<D, float><<<grid, 64, 0, s>>>((const float*)qkv, (float*)o, lse2, B, N, H, kp, qs); \
-  else attn_fwd_f32_kernel<D, bf16><<<grid, 64, 0, s>>>((const bf16*)qkv, (bf16*)o, lse2, B, N, H, kp, qs)
+#define LT(D, T, MK) attn_fwd_f32_kernel<D, T, MK><<<grid, 64, 0, s>>>((const T*)qkv, (T*)o, lse2, B, N, H, kp, qs)
+#define L(D)                                                  \
+  if (dtype == AVF_F32) {                                     \
+    if (kp) LT(D, float, true); else LT(D, float, false);     \
+  } else {                                                    \
+    if (kp) LT(D, bf16, true); else LT(D, bf16, false);       \
+  }
   AVF_DH_DISPATCH(dh, L)
 #undef L
+#undef LT
   return check_launch("attn_fwd_f32_kernel");
 }
 
@@ -329,13 +336,16 @@ int attn_bwd_vec(int dtype, const void* qkv, const void* o, const void* d_o, con
   dim3 grid((unsigned)ceil_div(N, 64), (unsigned)(B * H));
   const uint8_t* kp = (const uint8_t*)keep;
   const int qs = q_prescaled ? 1 : 0;
-#define LT(D, T)                                                                                                       \
-  attn_dq_f32_kernel<D, T><<<grid, 64, 0, s>>>((const T*)qkv, (const T*)d_o, lse2, delta, (T*)dqkv, B, N, H, kp, qs);     \
-  attn_dkv_f32_kernel<D, 0, T><<<grid, 64, 0, s>>>((const T*)qkv, (const T*)d_o, lse2, delta, (T*)dqkv, B, N, H, kp, qs); \
-  attn_dkv_f32_kernel<D, 1, T><<<grid, 64, 0, s>>>((const T*)qkv, (const T*)d_o, lse2, delta, (T*)dqkv, B, N, H, kp, qs)
-#define L(D)                          \
-  if (dtype == AVF_F32) { LT(D, float); } \
-  else { LT(D, bf16); }
+#define LT(D, T, MK)                                                                                                       \
+  attn_dq_f32_kernel<D, T, MK><<<grid, 64, 0, s>>>((const T*)qkv, (const T*)d_o, lse2, delta, (T*)dqkv, B, N, H, kp, qs);     \
+  attn_dkv_f32_kernel<D, 0, T, MK><<<grid, 64, 0, s>>>((const T*)qkv, (const T*)d_o, lse2, delta, (T*)dqkv, B, N, H, kp, qs); \
+  attn_dkv_f32_kernel<D, 1, T, MK><<<grid, 64, 0, s>>>((const T*)qkv, (const T*)d_o, lse2, delta, (T*)dqkv, B, N, H, kp, qs)
+#define L(D)                                                        \
+  if (dtype == AVF_F32) {                                           \
+    if (kp) { LT(D, float, true); } else { LT(D, float, false); }   \
+  } else {                                                          \
+    if (kp) { LT(D, bf16, true); } else { LT(D, bf16, false); }     \
+  }
   AVF_DH_DISPATCH(dh, L)
 #undef L
 #undef LT
