@@ -207,17 +207,20 @@ class _StackFn(torch.autograd.Function):
         # one flat fp32 gradient bucket per layer; the tensors' .grad become views of it.  The buckets of all layers are
         # consecutive slices of ONE allocation, so a data-parallel wrapper can reduce several adjacent layers with one
         # collective (fewer, larger all-reduces: less host time per step, better xGMI efficiency)
-        flats, views = [], []
         per_layer = sum(sizes)
         flat_all = torch.empty(L * per_layer, dtype=torch.float32, device=dev)
-        for l in range(L):
-            flat = flat_all[l * per_layer:(l + 1) * per_layer]
-            vs, off = [], 0
-            for i, n in enumerate(sizes):
-                vs.append(flat[off:off + n].view_as(ctx.params[l * PARAMS_PER_LAYER + i]))
-                off += n
-            flats.append(flat)
-            views.append(vs)
+        # (one split call for all L * 11 views, a reshape only for the four matrices of a layer, gradient pointers by
+        # arithmetic on the bucket's base address: this loop runs on the autograd thread once per step per stack)
+        shapes = [p.shape for p in ctx.params[:PARAMS_PER_LAYER]]
+        parts = flat_all.split_with_sizes(sizes * L)
+        views = [[parts[l * PARAMS_PER_LAYER + i] if len(shapes[i]) == 1 else parts[l * PARAMS_PER_LAYER + i].view(shapes[i])
+                  for i in range(PARAMS_PER_LAYER)] for l in range(L)]
+        flats = list(flat_all.split(per_layer))
+        offs, acc = [], 0
+        for n in sizes:
+            offs.append(4 * acc)
+            acc += n
+        base = flat_all.data_ptr()
         B2 = PARAMS_PER_LAYER - 1  # index of net.3.bias: its gradient = column sums of the layer's dx_out
         gs16 = bool(cfg.grad_stream_bf16)
         if ctx.pool:
@@ -226,7 +229,7 @@ class _StackFn(torch.autograd.Function):
                                               _ptr(views[L - 1][B2]) if top_colsum else None, B, N, D, stream),
                        "token_mean_bwd")
         for l in reversed(range(L)):
-            gp = _lib.LayerPtrs(*[v.data_ptr() for v in views[l]])
+            gp = _lib.LayerPtrs(*[base + 4 * l * per_layer + o for o in offs])
             pp = mod._param_struct(ctx.params, l)
             # LN1' of this layer writes the column sums of dx_in directly into the previous layer's b2 gradient
             # bf16 gradient stream: the fp32 buffer carries the gradient only into the top layer (when no bf16 image came
