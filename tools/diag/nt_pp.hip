@@ -2,6 +2,7 @@
 // plain bf16 epilogue, timed back to back and checked against a host reference on sampled elements.
 //   K0  the shipped structure: 128 x 128 tile, 8 waves of 64 x 32, 2 LDS stages, one barrier per K-step, 2 workgroups / CU
 //   K0A K0 with inline-asm fragment reads (variant 5: one wait, 6: split wait) - what the product kernel now does
+//   K0B K0A with a 3- / 4-slot ring (variants 7 / 8; one workgroup per CU): 15-20 % slower
 //   K1  256 x 128 tile, 8 waves of 64 x 64 in two groups that alternate LOAD and COMPUTE phases (ping-pong), 3-slot
 //       LDS-DMA ring, fragment reads by inline asm (no compiler-inserted vmcnt(0)), 1 workgroup / CU
 // Build here (cross-compile), run on the GPU box:
@@ -188,6 +189,89 @@ __global__ __launch_bounds__(512) void k(const uint16_t* A, const uint16_t* B, u
   }
 }
 }  // namespace k0a
+
+// ------------------------------------------------------------------------------------------------ K0B (K0A with an NS-slot ring)
+// the same tile and waves with NS LDS slots (counted vmcnt: tiles t+1 .. t+NS-2 stay in flight): does a deeper DMA ring pay now
+// that the compiler no longer drains it?  NS = 3: 96 KB, one workgroup per CU; NS = 2 is K0A
+namespace k0b {
+using namespace k0;
+template <int NS>
+__global__ __launch_bounds__(512) void k(const uint16_t* A, const uint16_t* B, uint16_t* C, int M, int N, int K, int tiles_n,
+                                         int nwg) {
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN, li = lane & 15, lg = lane >> 4;
+  const int wg = xcd_remap(blockIdx.x, nwg);
+  const int m0 = (wg / tiles_n) * BMT, n0 = (wg % tiles_n) * BNT;
+  const int lrow = lane >> 3, lchunk = (lane & 7) ^ (lane >> 3);
+  const uint16_t* ga[A_INS];
+  const uint16_t* gb[B_INS];
+  for (int j = 0; j < A_INS; ++j) { int r = m0 + (wave * A_INS + j) * 8 + lrow; r = r < M ? r : M - 1; ga[j] = A + (int64_t)r * K + lchunk * 8; }
+  for (int j = 0; j < B_INS; ++j) { int r = n0 + (wave * B_INS + j) * 8 + lrow; r = r < N ? r : N - 1; gb[j] = B + (int64_t)r * K + lchunk * 8; }
+  auto stage = [&](int st, int k0) {
+    char* sa = dsm + st * STAGE; char* sb = sa + A_BYTES;
+    for (int j = 0; j < A_INS; ++j) glds16(ga[j] + k0, sa + (wave * A_INS + j) * 1024);
+    for (int j = 0; j < B_INS; ++j) glds16(gb[j] + k0, sb + (wave * B_INS + j) * 1024);
+  };
+  f32x4_t acc[MI][NI];
+  for (int i = 0; i < MI; ++i) for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0, 0, 0, 0};
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char*)dsm;
+  uint32_t abase[2], bbase[2];
+  for (int ks = 0; ks < 2; ++ks) {
+    abase[ks] = lds0 + nt_off(wm * 64 + li, ks * 4 + lg);
+    bbase[ks] = lds0 + A_BYTES + nt_off(wn * 32 + li, ks * 4 + lg);
+  }
+  constexpr int INS = A_INS + B_INS;
+  const int nt = K / TK;
+  for (int i = 0; i < NS - 1; ++i)
+    if (i < nt) stage(i, i * TK);
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    const int ahead = (nt - 1 - t) < (NS - 2) ? (nt - 1 - t) : (NS - 2);
+    if (ahead >= 2) wait_vmcnt<2 * INS>();
+    else if (ahead == 1) wait_vmcnt<INS>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (t + NS - 1 < nt) {
+      int slot = cur + NS - 1;
+      slot = slot >= NS ? slot - NS : slot;
+      stage(slot, (t + NS - 1) * TK);
+    }
+    const uint32_t so = cur * STAGE;
+    bf16x8_t fa[2][MI], fb[2][NI];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      fa[ks][0] = lds_b128<0>(abase[ks] + so); fa[ks][1] = lds_b128<2048>(abase[ks] + so);
+      fa[ks][2] = lds_b128<4096>(abase[ks] + so); fa[ks][3] = lds_b128<6144>(abase[ks] + so);
+      fb[ks][0] = lds_b128<0>(bbase[ks] + so); fb[ks][1] = lds_b128<2048>(bbase[ks] + so);
+    }
+    asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0][j], fa[0][i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[1][j], fa[1][i], acc[i][j], 0, 0, 0);
+    cur = (cur + 1 == NS) ? 0 : cur + 1;
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + li;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = n0 + wn * 32 + j * 16 + 4 * lg;
+      if (m < M && n < N) store_bf16x4(C + (int64_t)m * N + n, acc[i][j]);
+    }
+  }
+}
+}  // namespace k0b
 
 // ------------------------------------------------------------------------------------------------ K1 (ping-pong, 256 x 128)
 // PH = compute phases per K-tile per wave (1: 32 MFMAs per phase, 2: 16 per phase)
@@ -587,7 +671,16 @@ int main(int argc, char** argv) {
       }
       return;
     }
-    if (variant == 5 || variant == 6) {
+    if (variant == 7 || variant == 8) {
+      tiles_n = (N + 127) / 128; nwg = ((M + 127) / 128) * tiles_n;
+      if (variant == 7) {
+        hipFuncSetAttribute((const void*)k0b::k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * k0::STAGE);
+        k0b::k<3><<<nwg, 512, 3 * k0::STAGE>>>(A, B, C, M, N, K, tiles_n, nwg);
+      } else {
+        hipFuncSetAttribute((const void*)k0b::k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * k0::STAGE);
+        k0b::k<4><<<nwg, 512, 4 * k0::STAGE>>>(A, B, C, M, N, K, tiles_n, nwg);
+      }
+    } else if (variant == 5 || variant == 6) {
       tiles_n = (N + 127) / 128; nwg = ((M + 127) / 128) * tiles_n;
       if (variant == 5) {
         hipFuncSetAttribute((const void*)k0a::k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * k0::STAGE);
