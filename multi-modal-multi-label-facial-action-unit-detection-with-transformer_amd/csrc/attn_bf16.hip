@@ -1329,7 +1329,7 @@ namespace {
 bool use_resident(int N, int dh) {
   static const int allow = [] {
     const char* e = getenv("AVF_ATTN_RESIDENT");
-    return e ? atoi(e) : 1;
+    return (e && *e) ? atoi(e) : 1;
   }();
   return allow && dh == 64 && N <= RES_MAX_N;
 }
@@ -1375,7 +1375,7 @@ int res_launch(const TimingScope* ts, K kernel, const char* name, int blocks, in
 bool attn_q_prescale_on() {
   static const int on = [] {
     const char* e = getenv("AVF_ATTN_QS");
-    return e ? atoi(e) : 1;
+    return (e && *e) ? atoi(e) : 1;
   }();
   return on != 0;
 }

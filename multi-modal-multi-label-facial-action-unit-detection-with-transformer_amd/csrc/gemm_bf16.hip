@@ -736,7 +736,7 @@ __global__ __launch_bounds__(256) void fold_group_kernel(TnGroup g, int nslab, F
 int tn_group_splits(int total_tiles, int64_t K, int slots = 512) {
   static const int forced = [] {
     const char* e = getenv("AVF_TN_SPLITS");  // tuning aid
-    return e ? atoi(e) : 0;
+    return (e && *e) ? atoi(e) : 0;
   }();
   if (forced > 0) return forced;
   // 512 workgroup slots (2 per CU at 72 KiB of LDS).  Pick the split count whose total workgroup count fills whole rounds of
@@ -905,7 +905,7 @@ bool gemm_bf16_tn_group_ok(const TnGroupArgs& a) {
 static bool tn_group_big(const TnGroupArgs& a) {
   static const int forced = [] {
     const char* e = getenv("AVF_TN_BIG");  // tuning aid: 0 = always the 128 x 128 kernel, 1 = always the 256 x 128 one
-    return e ? atoi(e) : -1;
+    return (e && *e) ? atoi(e) : -1;
   }();
   if (forced >= 0) return forced != 0;
   int64_t tiles = 0;
@@ -960,7 +960,7 @@ int gemm_bf16_tn_group(const TnGroupArgs& a, hipStream_t s, const FoldList* extr
   TimingScope ts(KC_GEMM_BF16_TN, flops, bytes, s, /*per_kernel=*/true);
   static const int tn_waves = [] {
     const char* e = getenv("AVF_TN_WAVES");  // tuning aid
-    return e ? atoi(e) : 4;  // 8 waves measured 5 % slower here (unlike the NT kernel)
+    return (e && *e) ? atoi(e) : 4;  // 8 waves measured 5 % slower here (unlike the NT kernel)
   }();
   if (big) {
     static PerDeviceOnce raised3;
@@ -971,7 +971,7 @@ int gemm_bf16_tn_group(const TnGroupArgs& a, hipStream_t s, const FoldList* extr
     }
     static const int xcd_order = [] {
       const char* e = getenv("AVF_TN_XCD");  // tuning aid: 0 = tile-major block ids
-      return e ? atoi(e) : 1;
+      return (e && *e) ? atoi(e) : 1;
     }();
     int nblocks = tiles * g.S;
     g.xcd_groups = 0;

@@ -261,7 +261,7 @@ __device__ __forceinline__ void lds_read_words(uint32_t* dst, uint32_t addr, std
 int nt_wide_stores() {
   static const int on = [] {
     const char* e = getenv("AVF_NT_WIDE");  // tuning aid: 0 = the plain per-block stores
-    return e ? atoi(e) : 1;
+    return (e && *e) ? atoi(e) : 1;
   }();
   return on;
 }
@@ -269,7 +269,7 @@ int nt_wide_stores() {
 int pick_nt_tile(int64_t M, int64_t N, int64_t K) {
   static const int override_tile = [] {
     const char* e = getenv("AVF_NT_TILE");  // tuning aid: force one configuration
-    return e ? atoi(e) : -1;
+    return (e && *e) ? atoi(e) : -1;
   }();
   if (override_tile >= 0) return override_tile;
   const int64_t wg128 = ceil_div(M, 128) * ceil_div(N, 128);

@@ -431,7 +431,7 @@ extern "C" int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p
     // out-proj: its A operand is produced per head; the head-resident attention kernel writes the image from its epilogue
     static const int o_mx_on = [] {
       const char* e = getenv("AVF_MX8_OUTPROJ");  // tuning / A-B aid: 0 = out-projection on bf16 operands
-      return e ? atoi(e) : 1;
+      return (e && *e) ? atoi(e) : 1;
     }();
     const bool o_mx = o_mx_on && !d.keep && attn_fwd_emits_mx8(d.N, d.dh) && d.I % 128 == 0;
     if (d.keep)
@@ -502,7 +502,7 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   // fused kernels (layer_small.hip), which also make the bf16 image of the incoming gradient when the caller gave none
   static const int small_bwd_on = [] {
     const char* e = getenv("AVF_LAYER_SMALL_BWD");  // tuning / A-B aid
-    return e ? atoi(e) : 1;
+    return (e && *e) ? atoi(e) : 1;
   }();
   const bool small_bwd = lo && !d.rs16 && !d.mx && !d.keep && small_bwd_on && small_layer_ok(d.dt, d.N, d.D, d.H, d.dh, d.M);
   const void* gy = dx_out;
@@ -555,7 +555,7 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
     }
     static const int small_att_on = [] {
       const char* e = getenv("AVF_LAYER_SMALL_ATT");  // tuning / A-B aid: 0 = per-operator attention backward
-      return e ? atoi(e) : 1;
+      return (e && *e) ? atoi(e) : 1;
     }();
     const bool fuse_att = small_att_on && d.H <= 16;
     if (!fuse_att)

@@ -714,7 +714,7 @@ int launch_small(const SmallArgs& a, int B, hipStream_t s) {
 bool small_layer_ok(int dtype, int tokens, int dim, int heads, int dim_head, int mlp_dim) {
   static const int on = [] {
     const char* e = getenv("AVF_LAYER_SMALL");
-    return e ? atoi(e) : 1;
+    return (e && *e) ? atoi(e) : 1;
   }();
   const int inner = heads * dim_head;
   auto ok = [](int v) { return v == 128 || v == 256; };
