@@ -193,9 +193,9 @@ def test_rejects_unsupported_widths():
 
 def test_training_trajectory_tracks_bf16_mode():
     """40 Adam steps on a fixed regression batch (the loss falls 2.1 -> 0.05): the mx8 run's loss stays within 1 % of the
-    INITIAL loss of the bf16 run's at every step (observed 0.45 %; same initial weights; the weight images are re-quantised
-    after every optimizer step) and ends within 20 % of it in relative terms (observed 13 %: the e4m3 noise floor shows
-    once the batch is nearly memorised)."""
+    INITIAL loss of the bf16 run's at every step (observed 0.62 % with e4m3 backward operands, 0.45 % with forward operands
+    only; same initial weights; the weight images are re-quantised after every optimizer step) and ends within 20 % of it in
+    relative terms (observed 12 %: the e4m3 noise floor shows once the batch is nearly memorised)."""
     import avformer_amd as A
     ref, mx = _pair(CFG)
     g = torch.Generator().manual_seed(9)
