@@ -61,3 +61,39 @@ def test_graph_replay_draws_fresh_dropout_masks():
         seeds.append(head.last_seed)
     assert seeds == [seeds[0] + i for i in range(4)]        # the captured in-place add advances the device seed
     assert len(set(round(l, 6) for l in losses)) == 4       # same inputs, same weights, different masks
+
+
+@pytest.mark.parametrize("mode", ["bf16", "mx8"])
+def test_graph_replay_of_the_synthetic_model_step(mode):
+    """the C2-style step (SyntheticAVFormer + AULoss + the library Adam) as bench.py replays it; mx8: the weight
+    re-quantisation, the producer-side image emitters and the top layer's quantiser pass must all be capture-safe"""
+    import avformer_amd as A
+    torch.manual_seed(1)
+    mk = lambda: A.SyntheticAVFormer(256, 2, 4, 64, 512, 24, 16, task="AU", compute_dtype=mode).cuda()
+    m_g = mk()
+    m_e = mk()
+    m_e.load_state_dict(m_g.state_dict())
+    opt_g = A.optim.FusedAdam(m_g, lr=1e-3)
+    opt_e = A.optim.FusedAdam(m_e, lr=1e-3)
+
+    def batch(seed, B=6):
+        g = torch.Generator().manual_seed(seed)
+        return {"clip": torch.randn(B, 24, 256, generator=g).cuda(), "audio_features": torch.randn(B, 16, 256, generator=g).cuda(),
+                "labels": (torch.rand(B, 12, generator=g) > 0.5).float().cuda()}
+
+    gs = A.graphs.GraphedTrainStep(m_g, opt_g, _loss, batch(1), warmup=2)
+    for _ in range(2):
+        opt_e.zero_grad(set_to_none=True)
+        _loss(m_e, batch(1)).backward()
+        opt_e.step()
+    for i in range(3):
+        b = batch(20 + i)
+        lg = gs(b).clone()
+        opt_e.zero_grad(set_to_none=True)
+        le = _loss(m_e, b)
+        le.backward()
+        opt_e.step()
+        torch.cuda.synchronize()
+        assert torch.equal(lg, le.detach()), (i, lg.item(), le.item())
+    for (n, p), (_, q) in zip(m_g.named_parameters(), m_e.named_parameters()):
+        assert torch.equal(p, q), n
