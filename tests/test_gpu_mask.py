@@ -97,3 +97,24 @@ def test_mask_shape_is_checked():
         t(x, mask=torch.ones(2, 9, dtype=torch.bool, device=DEV))  # must have N - 1 entries
     y = t(x, mask=torch.ones(2, 8, dtype=torch.bool, device=DEV))
     torch.testing.assert_close(y, t(x), atol=1e-6, rtol=1e-6)  # an all-True mask is the unmasked result
+
+
+def test_mask_in_the_mx8_mode_against_the_bf16_mode():
+    """with a mask the fp8 mode keeps its MX-FP8 GEMMs and only the attention core moves to the fp32-arithmetic kernels
+    (the out-projection falls back to bf16 operands: the masked kernel writes no image)"""
+    import avformer_amd as A
+    torch.manual_seed(4)
+    a = A.Transformer(128, 2, 2, 64, 256, compute_dtype="bf16").to(DEV)
+    b = A.Transformer(128, 2, 2, 64, 256, compute_dtype="mx8").to(DEV)
+    b.load_state_dict(a.state_dict())
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 30, 128, generator=g)
+    mask = torch.rand(3, 29, generator=g) > 0.3
+    outs = [_run(t, x, mask) for t in (a, b)]
+    (y0, dx0, g0), (y1, dx1, g1) = outs
+    check_rel("mask_mx8:y", y1, y0, 3e-2)
+    check_rel("mask_mx8:dx", dx1, dx0, 8e-2)
+    for k in g0:
+        check_rel(f"mask_mx8:g.{k}", g1[k], g0[k], 1.2e-1)
+    sd = {k: v.detach().cpu() for k, v in a.state_dict().items()}
+    check_rel("mask_mx8:y_vs_oracle", y1, oracle.transformer_forward(x, sd, 2, 2, mask=mask), 4e-2)
