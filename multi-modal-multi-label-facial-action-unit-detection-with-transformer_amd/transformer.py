@@ -119,9 +119,17 @@ class _StackFn(torch.autograd.Function):
         if keep is not None and keep.shape != (B, N):
             raise ValueError(f"mask has incorrect dimensions: {tuple(keep.shape)} after the leading True, tokens {(B, N)}")
         ctx.keep = keep  # token mask bytes (heads.py:225-232); the layer configurations carry its device pointer
-        cfgs = [mod._cfg(B, N, l, seed_t, keep) for l in range(L)]
+        # the L layer configurations are rebuilt only when something in them changes (shape, live dropout, seed / mask pointers)
+        ckey = (B, N, mod.training, mod.dropout, None if seed_t is None else seed_t.data_ptr(),
+                None if keep is None else keep.data_ptr(), mod.compute_dtype, mod.mx8, mod.mx8_bwd, mod.resid_bf16)
+        chit = mod.__dict__.get("_cfg_cache")
+        if chit is not None and chit[0] == ckey:
+            cfgs = chit[1]
+        else:
+            cfgs = [mod._cfg(B, N, l, seed_t, keep) for l in range(L)]
+            mod.__dict__["_cfg_cache"] = (ckey, cfgs)
         cfg = cfgs[0]
-        params = [p.detach() for p in params]
+        params = list(params)  # (grad mode is off inside Function.forward: the Parameters are used for their storage only)
         need_grad = any(ctx.needs_input_grad)  # (grad mode is off inside Function.forward)
         ctx.grad_in = ctx.needs_input_grad[:3]
         saved_bytes = lib.avf_layer_saved_bytes(C.byref(cfg))
@@ -322,7 +330,7 @@ class Transformer(nn.Module):
     # per-process caches (ctypes structs, device scratch, bf16 weight images): never copied or pickled with the module
     _CACHES = {"_ws": None, "_lowp_bufs": None, "_lowp_ptrs": None, "_lowp_versions": None, "_lowp_ready": False,
                "_seed_dev": None, "_last_seed_t": None}
-    _LAZY_CACHES = ("_pstruct_cache", "_mx_ptr_array", "_flat_cache")  # created on first use
+    _LAZY_CACHES = ("_pstruct_cache", "_mx_ptr_array", "_flat_cache", "_cfg_cache")  # created on first use
 
     def __getstate__(self):
         d = self.__dict__.copy()
