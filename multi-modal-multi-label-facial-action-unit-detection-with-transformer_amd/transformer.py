@@ -183,6 +183,9 @@ class _StackFn(torch.autograd.Function):
 
     @staticmethod
     def _backward(ctx, dy):
+        if ctx.saved_bufs is None:
+            raise RuntimeError("Transformer (HIP): backward through the stack a second time - its saved activations are released "
+                               "after the first backward (retain_graph=True is not supported; run the forward again)")
         lib = _lib.load()
         mod = ctx.mod
         cfgs = ctx.cfgs

@@ -436,3 +436,13 @@ def test_empty_batch_and_empty_sequence():
         assert all(p.grad is not None and float(p.grad.abs().sum()) == 0.0 for p in t.parameters())
         t.zero_grad()
     assert t(torch.zeros((0, 7, 64), device="cuda"), pool="mean").shape == (0, 64)
+
+
+def test_second_backward_fails_loudly():
+    import avformer_amd as A
+    t = A.Transformer(128, 1, 4, 32, 256).to(DEV)
+    x = torch.randn(2, 8, 128, device=DEV, requires_grad=True)
+    loss = t(x).pow(2).mean()
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second time"):
+        loss.backward()
