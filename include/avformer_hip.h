@@ -247,6 +247,13 @@ int avf_cat_features(const float* a, const float* v, const float* pos, float* ou
                      int emb_v, void* stream);
 int avf_transpose_add(const float* in, const float* pos, float* out, int batch, int rows, int cols, void* stream);
 int avf_zero_cols(float* out, int64_t ld, int rows, int c0, int c1, void* stream);
+/* a small nn.Linear on a few rows written into a zero-padded row - the AU logits of a pooled feature in the reference's [B,21]
+ * layout (avformer.py:101-105): out[r, o] = x[r,:] . w[o,:] + bias[o] (o < out_features), 0 up to `width`; one launch.
+ * Backward: dx = dout[:, :O] w, dw = dout[:, :O]^T x, db = column sums (any of them may be null); dout rows are ldd apart. */
+int avf_linear_pad_fwd(const float* x, const float* w, const float* bias, float* out, int rows, int in_features, int out_features,
+                       int width, void* stream);
+int avf_linear_pad_bwd(const float* dout, int64_t ldd, const float* x, const float* w, float* dx, float* dw, float* db, int rows,
+                       int in_features, int out_features, void* stream);
 
 /* AULoss - loss.py:63-103.  logits/labels fp32 [rows, 12] (ld given); rows whose FIRST label == ignore
  * are dropped; loss[0] = mean over kept rows x 12 of BCE-with-logits(pos_weight); grad_unit [rows,12]

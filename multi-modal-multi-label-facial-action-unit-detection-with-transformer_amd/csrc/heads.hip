@@ -212,6 +212,81 @@ __global__ __launch_bounds__(256) void zero_cols_kernel(float* __restrict__ out,
   out[(i / w) * ld + c0 + (int)(i % w)] = 0.f;
 }
 
+// ---------------------------------------------------------------------------------------------
+// A small nn.Linear on a handful of rows, written into a zero-padded row: out[b, o] = x[b, :] . w[o, :] + bias[o] for o < O,
+// 0 for O <= o < width - the AU logits of a pooled feature in the reference's [B, 21] layout (avformer.py:101-105) in ONE
+// launch (the fp32 GEMM takes a split-K launch, a fold and a zero fill for the same 32 x 12 x 512 product).  One workgroup
+// per row; a wave owns outputs wave, wave + 4, ...; the row sits in registers.
+// ---------------------------------------------------------------------------------------------
+constexpr int LP_MAXK = 4096;  // 16 values per lane
+__global__ __launch_bounds__(256) void linear_pad_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ out, int K,
+                                                             int O, int width) {
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nper = (K + 255) / 256;  // float4 chunks per lane (K % 4 == 0)
+  float4 xv[LP_MAXK / 256];
+#pragma unroll
+  for (int i = 0; i < LP_MAXK / 256; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    xv[i] = (i < nper && c < K) ? *reinterpret_cast<const float4*>(x + (int64_t)b * K + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int o = wave; o < width; o += 4) {
+    float v = 0.f;
+    if (o < O) {
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < LP_MAXK / 256; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (i < nper && c < K) {
+          const float4 ww = *reinterpret_cast<const float4*>(w + (int64_t)o * K + c);
+          a += (xv[i].x * ww.x + xv[i].y * ww.y) + (xv[i].z * ww.z + xv[i].w * ww.w);
+        }
+      }
+      v = wave_sum(a) + (bias ? bias[o] : 0.f);
+    }
+    if (lane == 0) out[(int64_t)b * width + o] = v;
+  }
+}
+
+// backward of the same: blocks [0, B): dx[b, :] = sum_o dl[b, o] w[o, :]; blocks [B, B + O): dw[o, :] = sum_b dl[b, o] x[b, :]
+// and db[o] = sum_b dl[b, o] (rows summed in order: deterministic).  dl rows are ldd apart (the padded row is read in place).
+__global__ __launch_bounds__(256) void linear_pad_bwd_kernel(const float* __restrict__ dl, int64_t ldd,
+                                                             const float* __restrict__ x, const float* __restrict__ w,
+                                                             float* __restrict__ dx, float* __restrict__ dw,
+                                                             float* __restrict__ db, int B, int K, int O) {
+  const int blk = blockIdx.x;
+  if (blk < B) {
+    if (!dx) return;
+    for (int c = threadIdx.x * 4; c < K; c += 1024) {
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int o = 0; o < O; ++o) {
+        const float g = dl[(int64_t)blk * ldd + o];
+        const float4 ww = *reinterpret_cast<const float4*>(w + (int64_t)o * K + c);
+        a.x = fmaf(g, ww.x, a.x); a.y = fmaf(g, ww.y, a.y); a.z = fmaf(g, ww.z, a.z); a.w = fmaf(g, ww.w, a.w);
+      }
+      *reinterpret_cast<float4*>(dx + (int64_t)blk * K + c) = a;
+    }
+    return;
+  }
+  const int o = blk - B;
+  if (dw) {
+    for (int c = threadIdx.x * 4; c < K; c += 1024) {
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int b = 0; b < B; ++b) {
+        const float g = dl[(int64_t)b * ldd + o];
+        const float4 xx = *reinterpret_cast<const float4*>(x + (int64_t)b * K + c);
+        a.x = fmaf(g, xx.x, a.x); a.y = fmaf(g, xx.y, a.y); a.z = fmaf(g, xx.z, a.z); a.w = fmaf(g, xx.w, a.w);
+      }
+      *reinterpret_cast<float4*>(dw + (int64_t)o * K + c) = a;
+    }
+  }
+  if (db && threadIdx.x == 0) {
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += dl[(int64_t)b * ldd + o];
+    db[o] = a;
+  }
+}
+
 inline unsigned blocks_for(int64_t n) { return (unsigned)ceil_div(n, 256); }
 
 }  // namespace
@@ -296,4 +371,26 @@ extern "C" int avf_zero_cols(float* out, int64_t ld, int rows, int c0, int c1, v
   if (c1 == c0) return 0;
   zero_cols_kernel<<<blocks_for((int64_t)rows * (c1 - c0)), 256, 0, (hipStream_t)stream>>>(out, ld, rows, c0, c1);
   return check_launch("zero_cols_kernel");
+}
+
+extern "C" int avf_linear_pad_fwd(const float* x, const float* w, const float* bias, float* out, int rows, int in_features,
+                                  int out_features, int width, void* stream) {
+  AVF_REQUIRE(x && w && out && rows > 0 && in_features > 0 && out_features > 0 && width >= out_features,
+              "linear_pad_fwd: bad arguments");
+  AVF_REQUIRE(in_features % 4 == 0 && in_features <= LP_MAXK && (((uintptr_t)x | (uintptr_t)w) & 15) == 0,
+              "linear_pad_fwd: in_features must be a multiple of 4, at most %d, operands 16-byte aligned", LP_MAXK);
+  linear_pad_fwd_kernel<<<rows, 256, 0, (hipStream_t)stream>>>(x, w, bias, out, in_features, out_features, width);
+  return check_launch("linear_pad_fwd_kernel");
+}
+
+extern "C" int avf_linear_pad_bwd(const float* dout, int64_t ldd, const float* x, const float* w, float* dx, float* dw,
+                                  float* db, int rows, int in_features, int out_features, void* stream) {
+  AVF_REQUIRE(dout && x && w && rows > 0 && in_features > 0 && out_features > 0 && ldd >= out_features,
+              "linear_pad_bwd: bad arguments");
+  AVF_REQUIRE(in_features % 4 == 0 && (((uintptr_t)x | (uintptr_t)w | (uintptr_t)dx | (uintptr_t)dw) & 15) == 0,
+              "linear_pad_bwd: in_features must be a multiple of 4, operands 16-byte aligned");
+  if (!dx && !dw && !db) return 0;
+  linear_pad_bwd_kernel<<<rows + out_features, 256, 0, (hipStream_t)stream>>>(dout, ldd, x, w, dx, dw, db, rows, in_features,
+                                                                               out_features);
+  return check_launch("linear_pad_bwd_kernel");
 }

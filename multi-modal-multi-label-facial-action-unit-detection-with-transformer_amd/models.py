@@ -128,10 +128,14 @@ class _LinearPadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, width):
         x = x.detach().float().contiguous()
-        out = torch.empty((x.shape[0], width), dtype=torch.float32, device=x.device)
         O = w.shape[0]
-        ops.gemm(x, w.detach(), bias=b.detach(), out=out[:, :O])  # the fp32 kernel adds a non-null bias in every epilogue
-        ops.zero_cols(out, O, width)
+        ctx.small = x.shape[1] % 4 == 0 and x.shape[1] <= 4096 and w.is_contiguous()
+        if ctx.small:  # one launch (a few rows x a dozen outputs: the GEMM path is a split-K launch, a fold and a zero fill)
+            out = ops.linear_pad_fwd(x, w.detach(), b.detach(), width)
+        else:
+            out = torch.empty((x.shape[0], width), dtype=torch.float32, device=x.device)
+            ops.gemm(x, w.detach(), bias=b.detach(), out=out[:, :O])  # the fp32 kernel adds a non-null bias in every epilogue
+            ops.zero_cols(out, O, width)
         ctx.save_for_backward(x, w.detach())
         ctx.O = O
         return out
@@ -139,6 +143,9 @@ class _LinearPadFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         x, w = ctx.saved_tensors
+        if ctx.small and dout.stride(1) == 1 and dout.dtype == torch.float32:
+            dx, dw, db = ops.linear_pad_bwd(dout, x, w, *ctx.needs_input_grad[:3])
+            return dx, dw, db, None
         dl = dout[:, :ctx.O]                                        # row stride `width`: read in place
         dw = ops.gemm(dl, x, trans_a=True, trans_b=False) if ctx.needs_input_grad[1] else None
         db = ops.colsum(dl) if ctx.needs_input_grad[2] else None

@@ -430,6 +430,32 @@ def transpose_add(x: torch.Tensor, pos: Optional[torch.Tensor]) -> torch.Tensor:
     return out
 
 
+def linear_pad_fwd(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], width: int) -> torch.Tensor:
+    """[B, K] x [O, K]^T + b into a zero-padded [B, width] row, one launch (K % 4 == 0, K <= 4096)"""
+    _need_cuda(x, w, b)
+    x, w = x.contiguous(), w.contiguous()
+    B, K = x.shape
+    out = torch.empty((B, width), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().avf_linear_pad_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(out), B, K, w.shape[0], width, _stream()),
+               "linear_pad_fwd")
+    return out
+
+
+def linear_pad_bwd(dout: torch.Tensor, x: torch.Tensor, w: torch.Tensor, need_dx=True, need_dw=True, need_db=True):
+    """-> (dx [B, K], dw [O, K], db [O]) of linear_pad_fwd from the gradient of the padded row (read in place)"""
+    _need_cuda(dout, x, w)
+    assert dout.dim() == 2 and dout.stride(1) == 1 and dout.dtype == torch.float32
+    B, K = x.shape
+    O = w.shape[0]
+    dev = x.device
+    dx = torch.empty((B, K), dtype=torch.float32, device=dev) if need_dx else None
+    dw = torch.empty((O, K), dtype=torch.float32, device=dev) if need_dw else None
+    db = torch.empty(O, dtype=torch.float32, device=dev) if need_db else None
+    _lib.check(_lib.load().avf_linear_pad_bwd(_ptr(dout), dout.stride(0), _ptr(x), _ptr(w), _ptr(dx), _ptr(dw), _ptr(db), B, K, O,
+                                              _stream()), "linear_pad_bwd")
+    return dx, dw, db
+
+
 def zero_cols(t: torch.Tensor, c0: int, c1: int):
     _need_cuda(t)
     assert t.dim() == 2 and t.stride(1) == 1 and t.dtype == torch.float32

@@ -162,3 +162,25 @@ def test_flat_parameter_groups_survive_device_moves_and_state_dict():
             p.mul_(0.5)
     y4, _ = m(x)
     assert not torch.equal(y4, y0)
+
+
+@pytest.mark.parametrize("B,K,O,width", [(32, 512, 12, 21), (5, 128, 12, 21), (64, 768, 7, 7), (1, 4096, 3, 8)])
+def test_linear_pad_one_launch_forward_backward(B, K, O, width):
+    """the AU logits Linear written into the reference's zero-padded [B, 21] row (avformer.py:101-105) as one launch each way"""
+    import avformer_amd as A
+    g = torch.Generator().manual_seed(B + K)
+    x = torch.randn(B, K, generator=g)
+    w = torch.randn(O, K, generator=g) / K ** 0.5
+    b = torch.randn(O, generator=g)
+    dout = torch.randn(B, width, generator=g)
+    out = A.ops.linear_pad_fwd(x.cuda(), w.cuda(), b.cuda(), width)
+    ref = x.double() @ w.double().t() + b.double()
+    torch.testing.assert_close(out[:, :O].cpu().double(), ref, atol=2e-6, rtol=1e-5)
+    assert torch.all(out[:, O:] == 0)
+    dx, dw, db = A.ops.linear_pad_bwd(dout.cuda(), x.cuda(), w.cuda())
+    dl = dout[:, :O].double()
+    torch.testing.assert_close(dx.cpu().double(), dl @ w.double(), atol=2e-6, rtol=1e-5)
+    torch.testing.assert_close(dw.cpu().double(), dl.t() @ x.double(), atol=5e-6, rtol=1e-5)
+    torch.testing.assert_close(db.cpu().double(), dl.sum(0), atol=5e-6, rtol=1e-5)
+    dx2, dw2, db2 = A.ops.linear_pad_bwd(dout.cuda(), x.cuda(), w.cuda(), need_dx=False, need_db=False)
+    assert dx2 is None and db2 is None and torch.equal(dw2, dw)
