@@ -1422,6 +1422,7 @@ int attn_bwd_bf16(const bf16* qkv, const bf16* o, const bf16* d_o, const float* 
   AVF_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)d_o & 15) == 0 && ((uintptr_t)dqkv & 7) == 0,
               "attn_bwd_bf16: misaligned pointers");
   TimingScope ts(KC_ATTN_BWD, 10.0 * B * H * (double)N * N * dh, 2.0 * 8.0 * B * N * H * dh, s, /*per_kernel=*/true);
+  if (attn_bwd_merged_ok(N, dh, q_prescaled)) return attn_bwd_merged(&ts, qkv, o, d_o, lse2, dqkv, B, N, H, s);
   if (use_resident(N, dh)) {  // delta comes out of the dQ kernel
     const int W = res_waves(N);
     const size_t smem = (size_t)((N + 31) & ~31) * 128 * 2, smem_kv = smem + (size_t)((N + 63) & ~63) * 8;

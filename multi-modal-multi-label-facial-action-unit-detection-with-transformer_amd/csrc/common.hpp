@@ -477,5 +477,9 @@ bool attn_fwd_emits_mx8(int N, int dh);  // mx_q / mx_s: MX-FP8 image of o, writ
 int attn_bwd_bf16(const bf16* qkv, const bf16* o, const bf16* d_o, const float* lse2, bf16* dqkv, float* delta,
                   int B, int N, int H, int dh, hipStream_t s, bool q_prescaled = false, float* nlse = nullptr);
 int attn_delta(int dtype, const void* o, const void* d_o, float* delta, int B, int N, int H, int dh, hipStream_t s);
+// merged dQ + dK/dV kernel (attn_bwd_merged.hip): dim_head 64, pre-scaled q, N <= 512
+bool attn_bwd_merged_ok(int N, int dh, bool q_prescaled);
+int attn_bwd_merged(const TimingScope* ts, const bf16* qkv, const bf16* o, const bf16* d_o, const float* lse2, bf16* dqkv,
+                    int B, int N, int H, hipStream_t s);
 
 }  // namespace avf
