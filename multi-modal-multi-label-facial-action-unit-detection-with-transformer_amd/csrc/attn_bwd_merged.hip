@@ -1,5 +1,5 @@
 // attn_bwd_merged.hip - throughput-mode attention backward as ONE kernel per (clip, head): dQ, dK and dV from a
-// single recomputation of the probabilities, on v_mfma_f32_32x32x16_bf16.
+// single recomputation of the probabilities, on v_mfma_f32_32x32x16_bf16 (dQ: v_mfma_f32_16x16x32_bf16).
 //
 // Reference: autograd of models/heads.py:222-237 (dots = q k^T * dh^-0.5, softmax over keys, out = attn v).
 //
@@ -8,22 +8,27 @@
 //
 //   one workgroup = 4 wavefronts (one per SIMD, the whole 512-register file each) = one (clip, head), N <= 512, dim_head 64;
 //   wave w OWNS key blocks [w KB, (w+1) KB) of 32 keys: dK^T and dV^T of its keys stay in 64 KB accumulators for the whole
-//   kernel, V fragments of its keys stay in registers, the head's K image is resident in LDS (row reads for S, transposed
-//   reads for dQ); the workgroup sweeps the queries in SLICES of 32 rows (Q and dO slices arrive by LDS-DMA, one slice
-//   ahead, one barrier per slice).  Per (slice, key block), key on the lane:
-//     S  = Q K^T - lse2      (the row statistic rides in the C operand; q carries log2(e)/sqrt(dh))
-//     dP = dO V^T - delta    (likewise)
-//     P = exp2(S), dS = P * dP                                   (32 values per lane)
-//     dV^T += dO^T P,  dK^T += Q^T dS                            (the accumulator tiles ARE the B operands)
-//     dS crosses LDS once (8-byte stores of the accumulator rows, transposed reads back), dQ_partial += dS K
-//   The four waves' dQ partials of a slice go to four fp32 slabs in LDS (two sets in rotation), are summed in a fixed
-//   order and leave as bf16 rows at the top of the next slice (ds_add_f32 into one shared tile measured 600 cycles per
-//   instruction: 55 % of the kernel).  delta = rowsum(dO * O) of the NEXT slice is computed at the bottom of each slice
-//   from the dO rows already in LDS and an O chunk fetched at the top.
-// No atomics anywhere, fixed summation order: bitwise deterministic.
+//   kernel (AGPRs), V fragments of its keys stay in registers, the head's K image is resident in LDS; the workgroup
+//   sweeps the queries in SLICES of 32 rows (Q and dO slices arrive by LDS-DMA, one slice ahead, one barrier per slice).
+//   Per (slice, key block), key on the lane:
+//     A:  S  = Q K^T - lse2, dP = dO V^T - delta     (the row statistics ride in the C operand; q carries log2(e)/sqrt(dh))
+//     B:  P = exp2(S), dS = P * dP, packed to bf16   (48 VALU instructions per lane)
+//     C:  dV^T += dO^T P,  dK^T += Q^T dS            (the accumulator tiles ARE the B operands)
+//         dS^T goes to a [key][query] image in LDS (8-byte stores of the accumulator rows).
+//   dQ of slice s is computed DURING slice s+1 from the dS^T images of all the key blocks (written by all four waves,
+//   visible after the slice barrier): wave w owns columns [16 w, 16 w + 16) of dQ and runs the reduction over the keys as
+//   16x16x32 MFMAs (dQ^T = K^T dS^T, both operands by transposed LDS reads), interleaved with the VALU work of the new
+//   slice's first key block - no cross-wave reduction, no atomics, the rows leave straight from the accumulators.
+//   (A first version summed four per-wave dQ partials: ds_add_f32 into one tile measured 600 cycles per instruction - 55 %
+//   of the kernel -, four fp32 slabs plus a summing pass still 15 %.)
+//   delta = rowsum(dO * O) of the NEXT slice is computed at the bottom of each slice from the dO rows already in LDS
+//   and an O chunk fetched at the top.
+// One wave per SIMD: nothing but the wave's own instruction order overlaps VALU and matrix pipe, so the slice body is
+// software-pipelined by hand (see the stages below) and fenced with sched_barrier.  Bitwise deterministic.
 //
 // Rows past N: K rows are zero in the image and V fragments zero (so dS K and the discarded dK/dV columns are finite and
-// contribute nothing), query rows are copies of row N-1 with lse = +inf (P = 0) and delta = 0.
+// contribute nothing), padded keys are masked to P = 0 (RAGGED), query rows are copies of row N-1 with lse = +inf
+// (P = 0) and delta = 0.
 #include <type_traits>
 
 #include "common.hpp"
@@ -51,24 +56,27 @@ typedef __attribute__((address_space(3))) char m_lds_char;
 constexpr float kLog2E = 1.4426950408889634f;
 
 #define AVF_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define AVF_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#define AVF_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // The kernel is built with -mllvm -amdgpu-mfma-vgpr-form (see _build.py): the builtin MFMAs keep C / D in the
 // architectural VGPRs, so S, dP and dQ feed the VALU without v_accvgpr_read copies.  The dK^T / dV^T accumulators - 64
 // registers per key block, up to all 256 accumulation registers - are pinned to the AGPR half by the "+a" constraint of
-// these two-instruction statements (hipcc picks one MFMA form per function and cannot mix them itself).  s_nop 1: the
-// B operands were just written by v_cvt_pk (VALU write -> MFMA operand read, two wait states; hipcc pads nothing
-// inside an asm string).
-__device__ __forceinline__ void m_mfma_pair_acc(f32x16_t& acc0, const bf16x8_t& a0, const bf16x8_t& b0, f32x16_t& acc1,
-                                                const bf16x8_t& a1, const bf16x8_t& b1) {
-  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %4, %5, %1"
-               : "+a"(acc0), "+a"(acc1)
-               : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
+// this statement (hipcc picks one MFMA form per function and cannot mix them itself).  hipcc pads nothing inside an asm
+// string: the callers keep a VALU write of an operand at least two instructions away (m_operand_settle).
+__device__ __forceinline__ void m_mfma_acc(f32x16_t& acc, const bf16x8_t& a, const bf16x8_t& b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
+__device__ __forceinline__ void m_operand_settle() { asm volatile("s_nop 1"); }
 
 // 16-byte chunk permutation of a 128-byte row (8 chunks): conflict-free for the ds_read_b128 row fragments of the
 // 32x32x16 operands (rows of equal parity inside one 16-lane service group get 8 distinct values) and for the
 // ds_read_b64_tr_b16 fragments (rows r, r+2 of a 4-row block land in different 64-byte halves).
 __device__ __forceinline__ int m_swz(int row) { return (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1); }
+// 8-byte slot permutation of a 64-byte row of a dS^T image (8 slots): a permutation of the bits of (key>>1)&7, so the
+// 8-byte stores of 16 consecutive keys hit distinct banks, with (key>>2)&1 on slot bit 2, so the two 4-row blocks a
+// 16x16x32 transposed read takes from rows k .. k+3 and k+4 .. k+7 use different halves of their rows.
+__device__ __forceinline__ int m_txor(int key) { return (((key >> 2) & 1) << 2) | (((key >> 1) & 1) << 1) | ((key >> 3) & 1); }
 
 __device__ __forceinline__ void m_glds16(const void* g, char* l) {  // LDS-DMA, opaque to hipcc's wait-count pass
   const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(m_lds_char*)l);
@@ -85,12 +93,6 @@ __device__ __forceinline__ bf16x8_t m_tr_frag(const char* p0, const char* p1) {
   s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(const m_lds_char*)p0);
   s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(const m_lds_char*)p1);
   m_s16x8_t r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf16x8_t, r);
-}
-
-__device__ __forceinline__ bf16x8_t m_pack8(const f32x16_t& a, int s2) {  // registers 8 s2 .. 8 s2 + 7 as one k-step
-  m_u32x4_t r = {pack_bf16x2(a[8 * s2 + 0], a[8 * s2 + 1]), pack_bf16x2(a[8 * s2 + 2], a[8 * s2 + 3]),
-                 pack_bf16x2(a[8 * s2 + 4], a[8 * s2 + 5]), pack_bf16x2(a[8 * s2 + 6], a[8 * s2 + 7])};
   return __builtin_bit_cast(bf16x8_t, r);
 }
 
@@ -112,28 +114,19 @@ __device__ __forceinline__ f32x16_t m_zero16() {
   return z;
 }
 
-// LDS map (bytes): K image | ring (2 slots x (Q 4 KB | dO 4 KB)) | NL | ND | T (4 x 2 KB) | R (2 buffers x 4 wave slabs x
-// 8 KB: the waves' dQ partials of a slice, [32 q][64 d] fp32 each) | V image of the key blocks whose V fragments do not
-// stay in registers (blocks VR .. KB-1 of every wave, [wave][block][32][128 B])
+// LDS map (bytes): K image [4 KB x 32 rows][128 B] | ring (2 slots x (Q 4 KB | dO 4 KB)) | NL | ND | T (2 buffers x 4 KB
+// key blocks x 2 KB: the dS^T images of a slice, [32 keys][32 queries] bf16 each)
 struct MLayout {
-  int kimg, ring, nl, nd, t, r, vimg, total;
-  __host__ __device__ MLayout(int KB, int VR, int NS) {
+  int kimg, ring, nl, nd, t, total;
+  __host__ __device__ MLayout(int KB, int NS) {
     kimg = 0;
     ring = kimg + 4 * KB * 32 * 128;
     nl = ring + 2 * 8192;
     nd = nl + NS * 32 * 4;
     t = nd + NS * 32 * 4;
-    r = t + 4 * 2048;
-    vimg = r + 2 * 4 * 8192;
-    total = vimg + 4 * (KB - VR) * 4096;
+    total = t + 2 * 4 * KB * 2048;
   }
 };
-
-// key blocks per wave whose V fragments stay in registers (the rest would be read from an LDS V image every slice; with
-// the fp32 slabs of the dQ reduction there is no room for one at 4 blocks per wave, and the registers just suffice)
-__host__ __device__ constexpr int m4_vr(int KB) { return KB; }
-// key blocks per wave whose K fragments (row and transposed: 48 registers) may stay in registers
-__host__ __device__ constexpr int m4_holdk(int KB) { return KB <= 2 ? KB : 0; }
 
 // RAGGED: N < 4 KB 32 - key blocks that hold rows past N mask them (P = 0: -lse2 alone can be a large positive
 // exponent when every score of a row is very negative)
@@ -142,6 +135,7 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
                                                           const bf16* __restrict__ d_o, const float* __restrict__ lse2,
                                                           bf16* __restrict__ dqkv, int N, int H) {
   constexpr int DH = 64;
+  constexpr int NKB = 4 * KB;  // key blocks of the head (padded ones included)
   extern __shared__ __attribute__((aligned(16))) char m_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -154,49 +148,51 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
   const bf16* vbase = qbase + 2 * I;
   const bf16* gbase = d_o + (int64_t)b * N * I + h * DH;
   const bf16* obase = o + (int64_t)b * N * I + h * DH;
-  const int NS = (N + 31) >> 5;   // query slices == key blocks with valid rows
-  constexpr int VR = m4_vr(KB);
-  constexpr int HOLDK = m4_holdk(KB);
-  const MLayout L(KB, VR, NS);
+  const int NS = (N + 31) >> 5;  // query slices
+  const MLayout L(KB, NS);
   char* kimg = m_smem + L.kimg;
-  char* vimg = m_smem + L.vimg + wave * (KB - VR) * 4096;
   char* ring = m_smem + L.ring;
   float* NLs = reinterpret_cast<float*>(m_smem + L.nl);
   float* NDs = reinterpret_cast<float*>(m_smem + L.nd);
-  char* timg = m_smem + L.t + wave * 2048;
-  float* Rs = reinterpret_cast<float*>(m_smem + L.r);
-  const int kb0 = wave * KB;                                   // first key block of this wave
+  char* tbuf = m_smem + L.t;
+  const int kb0 = wave * KB;  // first key block of this wave
 
   // ---- per-lane LDS byte offsets -------------------------------------------------------------------------------
   // row fragment of a 32-row block (128-byte rows): row r, logical chunk 2 ks + hf
   int off_row[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) off_row[ks] = r * 128 + (((2 * ks + hf) ^ m_swz(r)) << 4);
-  // transposed fragments: 16-lane group G = lane>>4 (gg = G&1: column half, hh = G>>1 = hf), lane 4 qq + p of the group
-  const int li = lane & 15, gg = (lane >> 4) & 1, qq = li >> 2, p = li & 3;
-  // (a) accumulator k-order (element j of k-step s2 <-> row 16 s2 + 8 (j>>2) + 4 hf + (j&3)): rows 4 hf + qq and + 8
+  // transposed fragments: 16-lane group G = lane>>4, lane 4 qq + p of the group supplies row qq, columns 4 p .. 4 p + 3
+  const int li = lane & 15, G = lane >> 4, gg = G & 1, qq = li >> 2, p = li & 3;
+  // (a) 32x32x16 A operand in accumulator k-order (element j of k-step s2 <-> row 16 s2 + 8 (j>>2) + 4 hf + (j&3)) of a
+  //     32-row slice: rows 4 hf + qq and + 8, columns 32 db + 16 gg + 4 p
   int off_tra[2][2];
-  // (b) natural k-order (element j <-> row 16 ks + 8 hf + j): rows 8 hf + qq and + 4
-  int off_trn[2][2];
 #pragma unroll
   for (int db = 0; db < 2; ++db) {
     const int ch = 4 * db + 2 * gg + (p >> 1), byte = (p & 1) * 8;
-    const int ra = 4 * hf + qq, rn = 8 * hf + qq;
+    const int ra = 4 * hf + qq;
     off_tra[db][0] = ra * 128 + ((ch ^ m_swz(ra)) << 4) + byte;
     off_tra[db][1] = (ra + 8) * 128 + ((ch ^ m_swz(ra + 8)) << 4) + byte;
-    off_trn[db][0] = rn * 128 + ((ch ^ m_swz(rn)) << 4) + byte;
-    off_trn[db][1] = (rn + 4) * 128 + ((ch ^ m_swz(rn + 4)) << 4) + byte;
   }
-  // T image (this wave's dS^T block, [key][query], 64-byte rows, 8-byte slot u at u ^ ((key>>1)&7))
-  int off_tw[4];  // store of registers 4 g .. 4 g + 3: row r (key), slot 2 g + hf
-#pragma unroll
-  for (int g = 0; g < 4; ++g) off_tw[g] = r * 64 + (((2 * g + hf) ^ ((r >> 1) & 7)) << 3);
-  int off_tr_t[2];  // transposed read: keys 8 hf + qq (+4), slot 4 gg + p; k-step ks adds 16 rows = 1024 bytes
+  // (b) 16x16x32 operands of the dQ job, k-order of a 32-key block: element j of lane group G <-> key 4 G + (j&3) + 16 (j>>2):
+  //     rows 4 G + qq and + 16.  A = K^T: columns d = 16 w + 4 p of the K image.  B = dS^T: query columns 16 qt + 4 p of a
+  //     T image (64-byte rows; 8-byte slot 4 qt + p).
+  int off_kq[2], off_tq[2][2];
   {
-    const int k0 = 8 * hf + qq, k1 = k0 + 4, u = 4 * gg + p;
-    off_tr_t[0] = k0 * 64 + ((u ^ ((k0 >> 1) & 7)) << 3);
-    off_tr_t[1] = k1 * 64 + ((u ^ ((k1 >> 1) & 7)) << 3);
+    const int rk = 4 * G + qq;
+    const int ch = 2 * wave + (p >> 1), byte = (p & 1) * 8;
+    off_kq[0] = rk * 128 + ((ch ^ m_swz(rk)) << 4) + byte;
+    off_kq[1] = (rk + 16) * 128 + ((ch ^ m_swz(rk + 16)) << 4) + byte;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      off_tq[qt][0] = rk * 64 + (((4 * qt + p) ^ m_txor(rk)) << 3);
+      off_tq[qt][1] = (rk + 16) * 64 + (((4 * qt + p) ^ m_txor(rk + 16)) << 3);
+    }
   }
+  // store of accumulator registers 4 g .. 4 g + 3 (queries 8 g + 4 hf ..) of key r into a T image: slot 2 g + hf
+  int off_tw[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) off_tw[g] = r * 64 + (((2 * g + hf) ^ m_txor(r)) << 3);
 
   // ---- prologue --------------------------------------------------------------------------------------------------
   AVF_PHASE_INIT();
@@ -206,14 +202,6 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
     const int row = pc * 8 + lrow;
     const int src = row < N ? row : N - 1;
     m_glds16(kbase + (int64_t)src * ld + ((lslot ^ m_swz(row)) << 3), kimg + pc * 1024);
-  }
-  if constexpr (VR < KB) {  // V rows of this wave's blocks VR .. KB-1 (rows past N: fetched from row N-1, zeroed below)
-    for (int pc = 0; pc < 4 * (KB - VR); ++pc) {
-      const int lr = pc * 8 + lrow;                                  // row inside the wave's V image
-      const int row = 32 * (kb0 + VR) + lr;                          // key
-      const int src = row < N ? row : N - 1;
-      m_glds16(vbase + (int64_t)src * ld + ((lslot ^ m_swz(lr)) << 3), vimg + pc * 1024);
-    }
   }
   auto issue_slice = [&](int s) {  // wave w brings rows 8 w .. 8 w + 7 of the slice's Q and dO
     char* slot = ring + (s & 1) * 8192;
@@ -226,9 +214,9 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
   };
   issue_slice(0);
   // V fragments of the wave's keys (B operand of dP = dO V^T: lane (r, hf) holds V[key r][16 ks + 8 hf ..])
-  bf16x8_t vfr[VR][4];
+  bf16x8_t vfr[KB][4];
 #pragma unroll
-  for (int j = 0; j < VR; ++j)
+  for (int j = 0; j < KB; ++j)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int key = 32 * (kb0 + j) + r;
@@ -257,15 +245,9 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt unconstrained
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (N < 4 * KB * 32) {  // zero the K (and V image) rows past N (wave-uniform condition)
-    for (int idx = N * 8 + tid; idx < 4 * KB * 32 * 8; idx += 256)
+  if (N < NKB * 32) {  // zero the K rows past N (wave-uniform condition)
+    for (int idx = N * 8 + tid; idx < NKB * 32 * 8; idx += 256)
       *reinterpret_cast<uint4*>(kimg + idx * 16) = make_uint4(0, 0, 0, 0);
-    if constexpr (VR < KB) {
-      for (int idx = lane; idx < (KB - VR) * 32 * 8; idx += 64) {  // each wave its own image
-        const int key = 32 * (kb0 + VR) + (idx >> 3);
-        if (key >= N) *reinterpret_cast<uint4*>(vimg + idx * 16) = make_uint4(0, 0, 0, 0);
-      }
-    }
     __syncthreads();
   }
 
@@ -280,52 +262,42 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
     }
   const float qscale = 0.125f;  // dh^-0.5
 
-  // dQ rows of slice s leave the reduction tile (thread t: row t>>3, 8 columns)
-  auto finish_slice = [&](int s) {
-    const float4* rp = reinterpret_cast<const float4*>(Rs + (s & 1) * 8192 + drow * 64 + dch * 8);
-    float4 a = rp[0], c = rp[1];
-#pragma unroll
-    for (int w = 1; w < 4; ++w) {  // fixed order: wave 0 + wave 1 + wave 2 + wave 3 (deterministic)
-      const float4 a2 = rp[w * 512], c2 = rp[w * 512 + 1];
-      a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
-      c.x += c2.x; c.y += c2.y; c.z += c2.z; c.w += c2.w;
-    }
-    const int q = 32 * s + drow;
-    if (q < N) {
-      uint4 w;
-      w.x = pack_bf16x2(a.x * qscale, a.y * qscale);
-      w.y = pack_bf16x2(a.z * qscale, a.w * qscale);
-      w.z = pack_bf16x2(c.x * qscale, c.y * qscale);
-      w.w = pack_bf16x2(c.z * qscale, c.w * qscale);
-      *reinterpret_cast<uint4*>(dqkv + ((int64_t)b * N + q) * ld + h * DH + dch * 8) = w;
-    }
-  };
+  // ---- the pieces of one (slice, key block) --------------------------------------------------------------------
+  const float* nl = nullptr;
+  const float* nd = nullptr;
+  const char *qsl = nullptr, *gsl = nullptr;
+  char* tcur = nullptr;  // the T images this slice writes (this wave's blocks)
+  int kopq = 0;
+  bf16x8_t qa[4], ga[4], kf[4];
+  f32x16_t sacc, pacc;
+  m_u32x4_t pk[2], dk[2];  // bf16 pairs of P and dS of the block whose stage C is pending, one k-step (8 registers) each
 
-  // one (slice, key block): everything between the operand fragments and the three accumulations
-  auto block = [&](auto jtag, const char* qsl, const char* gsl, const bf16x8_t (&qa)[4], const bf16x8_t (&ga)[4],
-                   const float* nlp, const float* ndp, f32x16_t (&dq)[2], int kopq) {
-    constexpr int j = decltype(jtag)::value;
-    __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from hoisting the next block's reads over this one (registers)
-    const char* kblk = kimg + (kb0 + j) * 4096 + (j < HOLDK ? 0 : kopq);
-    const char* vblk = vimg + (j - VR) * 4096 + kopq;
-    // the row statistics of the lane's 16 query rows ARE the initial accumulators (broadcast LDS reads)
-    f32x16_t sacc, pacc;
+  auto load_stats_s = [&]() {  // the row statistics of the lane's 16 query rows ARE the initial accumulators
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const float4 a = *reinterpret_cast<const float4*>(nlp + 8 * g);
-      const float4 c = *reinterpret_cast<const float4*>(ndp + 8 * g);
+      const float4 a = *reinterpret_cast<const float4*>(nl + 8 * g);
       sacc[4 * g + 0] = a.x; sacc[4 * g + 1] = a.y; sacc[4 * g + 2] = a.z; sacc[4 * g + 3] = a.w;
+    }
+  };
+  auto load_stats_p = [&]() {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 c = *reinterpret_cast<const float4*>(nd + 8 * g);
       pacc[4 * g + 0] = c.x; pacc[4 * g + 1] = c.y; pacc[4 * g + 2] = c.z; pacc[4 * g + 3] = c.w;
     }
+  };
+  auto load_kf = [&](int j) {
+    const char* kblk = kimg + (kb0 + j) * 4096 + kopq;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const bf16x8_t kf = m_row_frag(kblk + off_row[ks]);
-      sacc = AVF_MFMA32(qa[ks], kf, sacc);
-      bf16x8_t vf;
-      if constexpr (j < VR) vf = vfr[j][ks];
-      else vf = m_row_frag(vblk + off_row[ks]);
-      pacc = AVF_MFMA32(ga[ks], vf, pacc);
-    }
+    for (int ks = 0; ks < 4; ++ks) kf[ks] = m_row_frag(kblk + off_row[ks]);
+  };
+  // stage A(j): eight MFMAs, S chain first (its statistics were loaded first)
+  auto stage_a = [&](auto jtag) {
+    constexpr int j = decltype(jtag)::value;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) sacc = AVF_MFMA32(qa[ks], kf[ks], sacc);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) pacc = AVF_MFMA32(ga[ks], vfr[j][ks], pacc);
     if constexpr (RAGGED) {
       if (32 * (kb0 + j) + 32 > N) {  // wave-uniform: the block holds padded keys
         const bool dead = 32 * (kb0 + j) + r >= N;
@@ -333,49 +305,124 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
         for (int i = 0; i < 16; ++i) sacc[i] = dead ? -INFINITY : sacc[i];
       }
     }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      sacc[i] = __builtin_amdgcn_exp2f(sacc[i]);
-      pacc[i] = sacc[i] * pacc[i];
-    }
-    bf16x8_t pk[2], dk[2];
+  };
+  // stage B in eight chunks of six VALU instructions: chunk c turns elements 2 c, 2 c + 1 into one dword of P and of dS
+  auto b_chunk = [&](int c, m_u32x4_t (&pkn)[2], m_u32x4_t (&dkn)[2]) {
+    const float p0 = __builtin_amdgcn_exp2f(sacc[2 * c]), p1 = __builtin_amdgcn_exp2f(sacc[2 * c + 1]);
+    const float d0 = p0 * pacc[2 * c], d1 = p1 * pacc[2 * c + 1];
+    pkn[c >> 2][c & 3] = pack_bf16x2(p0, p1);
+    dkn[c >> 2][c & 3] = pack_bf16x2(d0, d1);
+  };
+  auto write_t = [&](auto jtag, const m_u32x4_t (&d)[2]) {  // dS^T of block j: registers 4 g .. 4 g + 3 are dwords 2 g, 2 g + 1
+    constexpr int j = decltype(jtag)::value;
+    char* timg = tcur + j * 2048;
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
-      pk[s2] = m_pack8(sacc, s2);
-      dk[s2] = m_pack8(pacc, s2);
+      *reinterpret_cast<uint2*>(timg + off_tw[2 * s2]) = make_uint2(d[s2][0], d[s2][1]);
+      *reinterpret_cast<uint2*>(timg + off_tw[2 * s2 + 1]) = make_uint2(d[s2][2], d[s2][3]);
     }
-    // dS^T to the wave's T image
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      const m_u32x4_t w = __builtin_bit_cast(m_u32x4_t, dk[s2]);
-      *reinterpret_cast<uint2*>(timg + off_tw[2 * s2]) = make_uint2(w[0], w[1]);
-      *reinterpret_cast<uint2*>(timg + off_tw[2 * s2 + 1]) = make_uint2(w[2], w[3]);
+  };
+  auto tr_qg = [&](int db, int s2, bf16x8_t& gt, bf16x8_t& qt) {
+    gt = m_tr_frag(gsl + s2 * 2048 + off_tra[db][0], gsl + s2 * 2048 + off_tra[db][1]);
+    qt = m_tr_frag(qsl + s2 * 2048 + off_tra[db][0], qsl + s2 * 2048 + off_tra[db][1]);
+  };
+  // stage C(j) - eight accumulating MFMAs - with stage B(j+1) riding between them (NX) and the operands of A(j+2)
+  // preloaded into the registers B(j+1) has finished with (NX2).  The LDS reads run two slots ahead of their MFMAs.
+  auto phase_c = [&](auto jtag) {
+    constexpr int j = decltype(jtag)::value;
+    constexpr bool NX = j + 1 < KB, NX2 = j + 2 < KB;
+    bf16x8_t g0, q0, g1, q1;
+    m_u32x4_t pkn[2], dkn[2];
+    const bf16x8_t pk0 = __builtin_bit_cast(bf16x8_t, pk[0]), pk1 = __builtin_bit_cast(bf16x8_t, pk[1]);
+    const bf16x8_t dk0 = __builtin_bit_cast(bf16x8_t, dk[0]), dk1 = __builtin_bit_cast(bf16x8_t, dk[1]);
+    tr_qg(0, 0, g0, q0);
+    m_operand_settle();
+    AVF_FENCE();
+    tr_qg(0, 1, g1, q1);
+    m_mfma_acc(dvacc[j][0], g0, pk0);
+    if constexpr (NX) b_chunk(0, pkn, dkn);
+    AVF_FENCE();
+    m_mfma_acc(dkacc[j][0], q0, dk0);
+    if constexpr (NX) b_chunk(1, pkn, dkn);
+    AVF_FENCE();
+    tr_qg(1, 0, g0, q0);
+    m_mfma_acc(dvacc[j][0], g1, pk1);
+    if constexpr (NX) b_chunk(2, pkn, dkn);
+    AVF_FENCE();
+    m_mfma_acc(dkacc[j][0], q1, dk1);
+    if constexpr (NX) b_chunk(3, pkn, dkn);
+    AVF_FENCE();
+    tr_qg(1, 1, g1, q1);
+    m_mfma_acc(dvacc[j][1], g0, pk0);
+    if constexpr (NX) b_chunk(4, pkn, dkn);
+    AVF_FENCE();
+    m_mfma_acc(dkacc[j][1], q0, dk0);
+    if constexpr (NX) b_chunk(5, pkn, dkn);
+    AVF_FENCE();
+    m_mfma_acc(dvacc[j][1], g1, pk1);
+    if constexpr (NX) b_chunk(6, pkn, dkn);
+    AVF_FENCE();
+    m_mfma_acc(dkacc[j][1], q1, dk1);
+    if constexpr (NX) b_chunk(7, pkn, dkn);
+    AVF_FENCE();
+    if constexpr (NX) {
+      write_t(std::integral_constant<int, j + 1>{}, dkn);
+      pk[0] = pkn[0]; pk[1] = pkn[1]; dk[0] = dkn[0]; dk[1] = dkn[1];
     }
-    // dV^T += dO^T P ; dK^T += Q^T dS
+    if constexpr (NX2) { load_stats_s(); load_stats_p(); load_kf(j + 2); }
+    AVF_FENCE();
+  };
+  // dQ of slice sp (the dS^T images of its key blocks in T buffer sp & 1): this wave's 16 columns, two 16x16x32 MFMAs per
+  // key block; WITHB: the VALU work of the new slice's first key block (stage B(0)) rides between them
+  auto dq_job = [&](int sp, auto withb_tag) {
+    constexpr bool WITHB = decltype(withb_tag)::value;
+    const char* tb = tbuf + (sp & 1) * (NKB * 2048);
+    const char* kb = kimg + kopq;
+    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    m_u32x4_t pkn[2], dkn[2];
+    bf16x8_t ka = m_tr_frag(kb + off_kq[0], kb + off_kq[1]);
+    bf16x8_t t0 = m_tr_frag(tb + off_tq[0][0], tb + off_tq[0][1]);
+    bf16x8_t t1 = m_tr_frag(tb + off_tq[1][0], tb + off_tq[1][1]);
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8_t gt = m_tr_frag(gsl + s2 * 2048 + off_tra[db][0], gsl + s2 * 2048 + off_tra[db][1]);
-        const bf16x8_t qt = m_tr_frag(qsl + s2 * 2048 + off_tra[db][0], qsl + s2 * 2048 + off_tra[db][1]);
-        m_mfma_pair_acc(dvacc[j][db], gt, pk[s2], dkacc[j][db], qt, dk[s2]);
+    for (int kbk = 0; kbk < NKB; ++kbk) {
+      AVF_FENCE();
+      bf16x8_t kan = ka, t0n = t0, t1n = t1;
+      if (kbk + 1 < NKB) {
+        const char* kn = kb + (kbk + 1) * 4096;
+        const char* tn = tb + (kbk + 1) * 2048;
+        kan = m_tr_frag(kn + off_kq[0], kn + off_kq[1]);
+        t0n = m_tr_frag(tn + off_tq[0][0], tn + off_tq[0][1]);
+        t1n = m_tr_frag(tn + off_tq[1][0], tn + off_tq[1][1]);
       }
-    // dQ[q][d] += dS[q][key] K[key][d]
+      acc0 = AVF_MFMA16(ka, t0, acc0);
+      acc1 = AVF_MFMA16(ka, t1, acc1);
+      if constexpr (WITHB) {  // chunk c rides behind the MFMAs of key block floor(c NKB / 8)
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const bf16x8_t da = m_tr_frag(timg + ks * 1024 + off_tr_t[0], timg + ks * 1024 + off_tr_t[1]);
-#pragma unroll
-      for (int db = 0; db < 2; ++db) {
-        const bf16x8_t kt = m_tr_frag(kblk + ks * 2048 + off_trn[db][0], kblk + ks * 2048 + off_trn[db][1]);
-        dq[db] = AVF_MFMA32(da, kt, dq[db]);
+        for (int c = 0; c < 8; ++c)
+          if (c * NKB / 8 == kbk) b_chunk(c, pkn, dkn);
       }
+      ka = kan; t0 = t0n; t1 = t1n;
+    }
+    AVF_FENCE();
+    if constexpr (WITHB) {
+      pk[0] = pkn[0]; pk[1] = pkn[1]; dk[0] = dkn[0]; dk[1] = dkn[1];
+    }
+    // rows leave from the accumulators: lane (query li of tile qt, group G) holds columns 16 w + 4 G .. + 3
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const int q = 32 * sp + 16 * qt + li;
+      const f32x4_t a = qt ? acc1 : acc0;
+      if (q < N)
+        store4<bf16>(dqkv + ((int64_t)b * N + q) * ld + h * DH + 16 * wave + 4 * G,
+                     make_float4(a[0] * qscale, a[1] * qscale, a[2] * qscale, a[3] * qscale));
     }
   };
 
   // ---- the sweep over the query slices ---------------------------------------------------------------------------
   for (int s = 0; s < NS; ++s) {
-    const char* qsl = ring + (s & 1) * 8192;
-    const char* gsl = qsl + 4096;
+    qsl = ring + (s & 1) * 8192;
+    gsl = qsl + 4096;
+    tcur = tbuf + (s & 1) * (NKB * 2048) + kb0 * 2048;
     uint4 onext = make_uint4(0, 0, 0, 0);
     const bool more = s + 1 < NS;
     if (more) {
@@ -383,40 +430,52 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
       const int q = 32 * (s + 1) + drow;
       if (q < N) onext = *reinterpret_cast<const uint4*>(obase + (int64_t)q * I + dch * 8);
     }
-    if (s > 0) finish_slice(s - 1);
     AVF_PHASE_MARK(1);
 
-    bf16x8_t qa[4], ga[4];
+    nl = NLs + 32 * s + 4 * hf;
+    nd = NDs + 32 * s + 4 * hf;
+    // the K image never changes, so the compiler would hoist every fragment read of it out of the slice loop (48
+    // registers per key block); an opaque per-slice copy of the image offset keeps the reads inside
+    kopq = 0;
+    asm volatile("" : "+v"(kopq));
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       qa[ks] = m_row_frag(qsl + off_row[ks]);
       ga[ks] = m_row_frag(gsl + off_row[ks]);
     }
-    const float* nl = NLs + 32 * s + 4 * hf;
-    const float* nd = NDs + 32 * s + 4 * hf;
-    // the K (and V) images never change, so the compiler would hoist every fragment read of them out of the slice loop
-    // - 48 registers per key block; an opaque per-slice copy of the image offset keeps the reads inside (HOLDK blocks
-    // are left to the compiler: their fragments stay in registers for the whole kernel)
-    int kopq = 0;
-    asm volatile("" : "+v"(kopq));
-    f32x16_t dq[2] = {m_zero16(), m_zero16()};
+    load_stats_s();
+    load_stats_p();
+    load_kf(0);
     // every wave runs all its KB blocks, padded ones included (zero K rows and V, masked scores): the slice barrier
     // would make a wave that skipped them wait for the others anyway, and one straight-line body keeps the 64 KB
     // accumulators in place (two code paths made the compiler shuffle all of them at the join)
-    block(std::integral_constant<int, 0>{}, qsl, gsl, qa, ga, nl, nd, dq, kopq);
-    if constexpr (KB > 1) block(std::integral_constant<int, 1>{}, qsl, gsl, qa, ga, nl, nd, dq, kopq);
-    if constexpr (KB > 2) block(std::integral_constant<int, 2>{}, qsl, gsl, qa, ga, nl, nd, dq, kopq);
-    if constexpr (KB > 3) block(std::integral_constant<int, 3>{}, qsl, gsl, qa, ga, nl, nd, dq, kopq);
+    stage_a(std::integral_constant<int, 0>{});
+    AVF_FENCE();
     AVF_PHASE_MARK(2);
-    // the wave's dQ partial joins the slice's reduction tile: register i <-> row (i&3) + 8 (i>>2) + 4 hf, column 32 db + r
-    {
-      float* rt = Rs + (s & 1) * 8192 + wave * 2048 + r;
+    if (s > 0) {
+      dq_job(s - 1, std::true_type{});
+    } else {
+      m_u32x4_t pkn[2], dkn[2];
 #pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) rt[((i & 3) + 8 * (i >> 2) + 4 * hf) * 64 + 32 * db] = dq[db][i];
+      for (int c = 0; c < 8; ++c) b_chunk(c, pkn, dkn);
+      pk[0] = pkn[0]; pk[1] = pkn[1]; dk[0] = dkn[0]; dk[1] = dkn[1];
     }
+    write_t(std::integral_constant<int, 0>{}, dk);
+    if constexpr (KB > 1) { load_stats_s(); load_stats_p(); load_kf(1); }
+    AVF_FENCE();
     AVF_PHASE_MARK(3);
+    if constexpr (KB > 1) stage_a(std::integral_constant<int, 1>{});
+    phase_c(std::integral_constant<int, 0>{});
+    if constexpr (KB > 1) {
+      if constexpr (KB > 2) stage_a(std::integral_constant<int, 2>{});
+      phase_c(std::integral_constant<int, 1>{});
+    }
+    if constexpr (KB > 2) {
+      if constexpr (KB > 3) stage_a(std::integral_constant<int, 3>{});
+      phase_c(std::integral_constant<int, 2>{});
+    }
+    if constexpr (KB > 3) phase_c(std::integral_constant<int, 3>{});
+    AVF_PHASE_MARK(4);
     if (more) {
       // delta of the next slice: its dO rows 8 w .. 8 w + 7 were brought in by THIS wave (own vmcnt suffices)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -429,11 +488,12 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
       part += __shfl_xor(part, 4, 64);
       if (dch == 0) NDs[32 * (s + 1) + drow] = (32 * (s + 1) + drow < N) ? -part : 0.f;
     }
-    AVF_PHASE_MARK(4);
     __syncthreads();
     AVF_PHASE_MARK(5);
   }
-  finish_slice(NS - 1);
+  kopq = 0;
+  asm volatile("" : "+v"(kopq));
+  dq_job(NS - 1, std::false_type{});
 
   // ---- dK, dV of the wave's keys ---------------------------------------------------------------------------------
   asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");  // the last accumulating MFMA has retired before the AGPRs are read
@@ -464,7 +524,7 @@ template <int KB, bool RAGGED>
 int m4_launch(const TimingScope* ts, const bf16* qkv, const bf16* o, const bf16* d_o, const float* lse2, bf16* dqkv, int B,
               int N, int H, hipStream_t s) {
   static PerDeviceOnce once;
-  const MLayout L(KB, m4_vr(KB), (N + 31) >> 5);
+  const MLayout L(KB, (N + 31) >> 5);
   if (once.need()) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_m4_kernel<KB, RAGGED>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);
@@ -478,16 +538,17 @@ int m4_launch(const TimingScope* ts, const bf16* qkv, const bf16* o, const bf16*
 
 }  // namespace
 
-// merged backward: dim_head 64, pre-scaled q, N <= 512.  AVF_ATTN_MERGED=0 restores the two-kernel path;
-// AVF_ATTN_MERGED_MIN_N sets the shortest sequence that takes it.
+// merged backward: dim_head 64, pre-scaled q, N <= 512.  It is the default where it measured faster than the two
+// head-resident kernels - four key blocks per wave, 385 <= N <= 512 (B = 32 / 64, N = 512: 77.9 / 149.9 us against 80.1 /
+// 160.2 us; N = 324: 47.0 against 44.2 us) - AVF_ATTN_MERGED=0 turns it off, AVF_ATTN_MERGED_MIN_N moves the threshold.
 bool attn_bwd_merged_ok(int N, int dh, bool q_prescaled) {
   static const int allow = [] {
     const char* e = getenv("AVF_ATTN_MERGED");
-    return (e && *e) ? atoi(e) : 0;  // off until it beats the two-kernel path
+    return (e && *e) ? atoi(e) : 1;
   }();
   static const int min_n = [] {
     const char* e = getenv("AVF_ATTN_MERGED_MIN_N");
-    return (e && *e) ? atoi(e) : 1;
+    return (e && *e) ? atoi(e) : 385;
   }();
   return allow && q_prescaled && dh == 64 && N <= 512 && N >= min_n;
 }

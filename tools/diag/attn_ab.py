@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Attention operator check + timing on the MI355X (tuning aid).  Pre-scaled q (the layer path's form).
-usage: python tools/diag/attn_ab.py [--shapes B,N,H ...] [--check]     (AVF_ATTN_MERGED=0/1 selects the backward)"""
+usage: python tools/diag/attn_ab.py [--shapes B,N,H ...] [--check]     (AVF_ATTN_MERGED=0 and AVF_ATTN_MERGED_MIN_N select the backward)"""
 import argparse
 import math
 import os
