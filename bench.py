@@ -153,6 +153,9 @@ def spawn_ranks(n):
     return rc
 
 
+SETTLE_S = float(os.environ.get("AVF_BENCH_SETTLE_S", "0.3"))  # untimed busy time in front of every timed region
+
+
 class Region:
     """one configuration on this rank: model, resident synthetic batch, optimizer, the step closure"""
 
@@ -208,7 +211,7 @@ class Region:
             self.dist.barrier()
             self.torch.cuda.synchronize()
 
-    def timed(self, steps, warmup, graph=False):
+    def timed(self, steps, warmup, graph=False, eager_too=True):
         """W untimed steps, then exactly K steps between two fences, no instrumentation; MAX over ranks"""
         torch = self.torch
         for _ in range(warmup):
@@ -222,10 +225,27 @@ class Region:
             self.step()
             extra += 1
             quiet = quiet + 1 if torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0) == before else 0
+        # ... and until the device has been busy for SETTLE_S seconds, so that the clock / power state the timed steps see is
+        # the steady one of this workload and not whatever the few warm-up steps left (a 20-step region is 45 ms long)
+        t_settle = time.perf_counter()
+        while time.perf_counter() - t_settle < SETTLE_S:
+            for _ in range(5):
+                self.step()
+                extra += 1
+            torch.cuda.synchronize()
         self.extra_warmup = extra
         self.fence()
         run = self.step
         self.launch = "eager"
+        self.eager_ms = None
+        if graph and self.dp is None and eager_too:
+            # the same K steps launched from Python, timed the same way: reported beside the graph-replay number so that the
+            # N = 1 line can be compared like for like with lines that cannot replay a graph
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step()
+            self.fence()
+            self.eager_ms = (time.perf_counter() - t0) / steps * 1e3
         if graph and self.dp is None:
             # the whole step (zero_grad, forward, loss, backward, optimizer) captured once and replayed: the ~130 launches of a
             # step no longer depend on the host keeping up (eager C2 needs ~1.8 ms of host time per 2.3 ms step)
@@ -298,7 +318,7 @@ class Region:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=120)  # 0.27 s of device time at C2
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "mx8", "mx8-fwd"],
@@ -380,6 +400,9 @@ def main():
                    "optimizer": main_r.optimizer, "residual_stream": main_r.residual, "loss": main_r.loss},
         "untimed_steps_beyond_warmup": main_r.extra_warmup,  # until the caching allocator stopped growing (Region.timed)
         "launch": main_r.launch,
+        # the same step launched eagerly from Python (None when `value` itself is the eager number)
+        "eager_ms_per_step": None if main_r.eager_ms is None else round(main_r.eager_ms, 4),
+        "eager_clips_per_s": None if main_r.eager_ms is None else round(B * world / (main_r.eager_ms * 1e-3), 2),
     }
     c3_r = f32_r = None
     if not args.no_extra and args.config == "c2" and args.dtype == "bf16":
@@ -387,7 +410,7 @@ def main():
         c3_r.timed(args.steps, args.warmup, use_graph)
         if world == 1:
             f32_r = mk(args.config, "f32", False)
-            f32_r.timed(max(2, args.steps // 6), 1)
+            f32_r.timed(max(2, min(20, args.steps // 6)), 1)
             f32_steps = f32_r.steps
             f32_r.model = f32_r.opt = f32_r.step = None  # free it before the instrumented passes
     # ---- then the instrumented passes (per-kernel-class HIP events) of the regions that report classes
@@ -429,6 +452,7 @@ def main():
                             f"B={c3_r.B}/GPU (global {c3_r.B * world}), same step as `value`",
                 "clips_per_s": round(c3_r.clips_per_s, 2), "ms_per_step": round(c3_r.ms, 4),
                 "steps": args.steps, "warmup": args.warmup, "launch": c3_r.launch,
+                "eager_ms_per_step": None if c3_r.eager_ms is None else round(c3_r.eager_ms, 4),
                 "stack_tflops_per_gpu": round(c3_r.tflops, 2),
                 "stack_frac_of_mfma_peak": round(c3_r.frac, 4),
                 "target_frac": 0.30, "kernel_classes": c3_r.classes if events else None}

@@ -63,6 +63,16 @@ class DataParallel:
         if broadcast_parameters:
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, src=0, group=process_group)
+            # the broadcast wrote through ``.data`` (no version bump): stacks that cached bf16 / MX-FP8 weight images
+            # (frozen pretrained branches, cache_weights) must rebuild them
+            for st in self._stacks:
+                if hasattr(st, "refresh_weights"):
+                    st.refresh_weights()
+        # rank-distinct dropout streams: ranks that seed torch identically would otherwise draw identical masks
+        rank = dist.get_rank(process_group)
+        for st in self._stacks:
+            if hasattr(st, "set_seed_rank"):
+                st.set_seed_rank(rank)
 
     # -- called from Transformer backward, once per layer ------------------------------------------
     def _on_layer_grads(self, layer: int, flat: torch.Tensor):

@@ -40,9 +40,17 @@ class _FlatGroup:
     ``.cuda()`` give every Parameter fresh storage: the next ``get()`` notices (addresses are no longer adjacent) and
     re-packs once."""
 
-    def __init__(self, params: List[nn.Parameter]):
-        self.params = params
+    def __init__(self, owners: List[nn.Module], attr: str):
+        # the Parameters are looked up on their modules at every use: ``load_state_dict(assign=True)``, parametrizations or
+        # a plain ``lin.weight = nn.Parameter(...)`` REPLACE the objects, and a list captured here would go stale (forward
+        # on old tensors, gradients to orphans)
+        self._owners = list(owners)
+        self._attr = attr
         self.flat: Optional[torch.Tensor] = None
+
+    @property
+    def params(self) -> List[nn.Parameter]:
+        return [getattr(m, self._attr) for m in self._owners]
 
     def get(self) -> torch.Tensor:
         ps = self.params
@@ -201,7 +209,7 @@ class _AUHeadBase(nn.Module):
     def _make_last(self, emb_dim):
         for i in range(1, 13):
             setattr(self, f"AU_linear_last{i}", nn.Linear(emb_dim, 1, bias=False))
-        self._last_w = _FlatGroup([getattr(self, f"AU_linear_last{i}").weight for i in range(1, 13)])
+        self._last_w = _FlatGroup([getattr(self, f"AU_linear_last{i}") for i in range(1, 13)], "weight")
 
     def _last_logits(self, tokens, pad_to=None):
         # token i -> bias-free Linear(emb,1) number i+1  == batched row-dot [B,12,E] . [12,E]
@@ -219,8 +227,8 @@ class AU_former(_AUHeadBase):
         self.corr_transformer = Transformer(emb_dim, depth=2, heads=8, mlp_dim=256, dim_head=32, dropout=dropout,
                                             compute_dtype=compute_dtype)
         self._make_last(emb_dim)
-        self._proj_w = _FlatGroup([getattr(self, f"AU_linear_p{i}").weight for i in range(1, 13)])
-        self._proj_b = _FlatGroup([getattr(self, f"AU_linear_p{i}").bias for i in range(1, 13)])
+        self._proj_w = _FlatGroup([getattr(self, f"AU_linear_p{i}") for i in range(1, 13)], "weight")
+        self._proj_b = _FlatGroup([getattr(self, f"AU_linear_p{i}") for i in range(1, 13)], "bias")
 
     def tokens(self, emb):
         """the AU tokens [B, 12, E] after the correlation transformer (what avformer.py:96-99 keeps of this head)"""

@@ -61,14 +61,18 @@ class AULoss(nn.Module):
         self.ignore = ignore
         self.register_buffer("pos_weight", torch.tensor(AU_POS_WEIGHT, dtype=torch.float32), persistent=False)
         # set by dp.DataParallel: callable (local_sum, local_kept) -> global mean whose backward, AVERAGED over the ranks,
-        # is the gradient of that global mean (ranks may hold different numbers of ignored rows)
+        # is the gradient of that global mean (ranks may hold different numbers of ignored rows).  It is a COLLECTIVE: it
+        # is taken only for a training-mode loss with gradients enabled - the one call every rank makes once per step -
+        # or when ``reduce_eval`` is set (then EVERY rank must call the loss the same number of times); a validation
+        # loss on one rank, or on ranks with different batch counts, stays local and cannot deadlock.
         self.global_mean = None
+        self.reduce_eval = False
 
     def forward(self, y_pred, y_true):
         if not y_pred.is_cuda:
             raise RuntimeError("AULoss (HIP) needs its inputs on the MI355X; there is no CPU fallback")
         pw = self.pos_weight if self.pos_weight.device == y_pred.device else self.pos_weight.to(y_pred.device)
-        if self.global_mean is not None:
+        if self.global_mean is not None and ((self.training and torch.is_grad_enabled()) or self.reduce_eval):
             s, k = _AULossSumFn.apply(y_pred, y_true, pw, float(self.ignore))
             return self.global_mean(s, k)
         return _AULossFn.apply(y_pred, y_true, pw, float(self.ignore))

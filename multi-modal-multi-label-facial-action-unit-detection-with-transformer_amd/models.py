@@ -18,7 +18,6 @@ import os
 from collections import OrderedDict
 
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from . import ops

@@ -403,7 +403,8 @@ class Transformer(nn.Module):
         if not (self.training and self.dropout > 0.0):
             return None
         if self._seed_dev is None or self._seed_dev.device != dev:
-            host = (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._seed_salt * 0xD1B54A32D192ED03) & 0x7FFFFFFFFFFFFFFF
+            host = (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._seed_salt * 0xD1B54A32D192ED03
+                    + self.__dict__.get("_seed_rank", 0) * 0xA0761D6478BD642F) & 0x7FFFFFFFFFFFFFFF
             self._seed_dev = torch.tensor([host], dtype=torch.int64, device=dev)
         self._seed_dev.add_(1)
         self._last_seed_t = self._seed_dev.clone()
@@ -469,6 +470,12 @@ class Transformer(nn.Module):
             _lib.check(lib.avf_stack_quant_weights_mx8(C.byref(cfg), self.depth, self._mx_ptr_array, stream),
                        "stack_quant_weights_mx8")
         return self._lowp_bufs
+
+    def set_seed_rank(self, rank: int):
+        """mix the data-parallel rank into the dropout seed (dp.DataParallel calls this): ranks that call
+        torch.manual_seed with the same value still draw different masks"""
+        self._seed_rank = int(rank)
+        self._seed_dev = None
 
     def refresh_weights(self):
         self._lowp_ptrs = None

@@ -45,3 +45,25 @@ def test_traffic_is_only_quoted_for_the_profiled_kernel_sources(tmp_path, monkey
     (tmp_path / bench.PKG_DIR / "csrc" / "k.hip").write_text("kernel v2")  # the kernels changed: the number is stale
     v, note = bench.pmc_traffic("gemm_bf16_nt", "c2")
     assert v is None and "other kernel sources" in note
+
+
+def test_calibration_file_is_frozen_against_regressions(tmp_path):
+    """tools/calibrate_bounds.py refuses to RAISE a recorded error without --allow-regress <reason>"""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("calibrate_bounds", os.path.join(ROOT, "tools", "calibrate_bounds.py"))
+    cb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cb)
+    out = tmp_path / "lowp.json"
+    json.dump({"measured": {"a": 1e-3, "b": 2e-3}}, open(out, "w"))
+    run = tmp_path / "run.json"
+    json.dump({"a": 2e-3, "b": 1e-3, "c": 5e-4}, open(run, "w"))
+    assert cb.main([str(run), "--merge"], out_path=str(out)) == 2                     # "a" would go up: refused
+    assert json.load(open(out))["measured"] == {"a": 1e-3, "b": 2e-3}                  # nothing written
+    assert cb.main([str(run), "--merge", "--allow-regress"], out_path=str(out)) == 2  # a reason is mandatory
+    assert cb.main([str(run), "--merge", "--allow-regress", "new kernel rounds P once more"], out_path=str(out)) == 0
+    doc = json.load(open(out))
+    assert doc["measured"] == {"a": 2e-3, "b": 1e-3, "c": 5e-4}
+    assert doc["regress_log"][-1]["raised"] == {"a": [1e-3, 2e-3]} and "rounds P" in doc["regress_log"][-1]["reason"]
+    json.dump({"b": 5e-4, "d": 1.0}, open(run, "w"))
+    assert cb.main([str(run), "--merge"], out_path=str(out)) == 0                      # lower values and new tags pass freely

@@ -56,3 +56,22 @@ def test_reference_weights_load_into_heads():
         p = {k: v for k, v in p.items() if torch.is_tensor(v)}
         res = mod.load_state_dict(A.checkpoint.remap_state_dict({"module." + k: v for k, v in p.items()}), strict=False)
         assert not res.unexpected_keys and all("num_batches_tracked" in k for k in res.missing_keys), (name, res)
+
+
+def test_flat_group_follows_replaced_parameters():
+    """the packed weight groups of the AU heads resolve their Parameters on the owning modules at every use, so a
+    replaced Parameter (load_state_dict(assign=True), manual reassignment) is the one that is packed and differentiated"""
+    import torch
+    import avformer_amd as A
+    head = A.heads.tformer_AU_head(emb_dim=16)
+    g = head._last_w
+    flat0 = g.get()
+    assert all(p.data_ptr() == flat0[i].data_ptr() for i, p in enumerate(g.params))
+    new = torch.nn.Parameter(torch.full((1, 16), 3.0))
+    head.AU_linear_last5.weight = new
+    assert g.params[4] is new
+    flat1 = g.get()                      # addresses no longer adjacent: re-packed from the CURRENT objects
+    assert torch.equal(flat1[4], torch.full((1, 16), 3.0)) and new.data_ptr() == flat1[4].data_ptr()
+    sd = {k: torch.zeros_like(v) for k, v in head.state_dict().items()}
+    head.load_state_dict(sd, assign=True)
+    assert float(g.get().abs().sum()) == 0.0

@@ -119,12 +119,14 @@ class OracleAULoss(torch.nn.Module):
     def __init__(self):
         super().__init__()
         self.global_mean = None
+        self.reduce_eval = False
 
     def forward(self, z, y):
         keep = y[:, 0] != -1
         k = keep.sum()
         s = oracle.au_loss(z[keep], y[keep]) * k if int(k) > 0 else z.sum() * 0.0
-        if self.global_mean is not None:
+        # the same gate as loss.AULoss.forward: the collective only for the training-mode loss with gradients enabled
+        if self.global_mean is not None and ((self.training and torch.is_grad_enabled()) or self.reduce_eval):
             return self.global_mean(s, k.float())
         return s / k
 
@@ -183,6 +185,54 @@ def test_dp_global_mean_loss_with_unequal_ignored_rows(ignored):
     for rank, worst, loss_err in res:
         assert worst < 1e-5, (rank, worst)
         assert loss_err < 1e-6, (rank, loss_err)
+
+
+def _worker_eval_loss(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100)
+        model = TinyModelWithLoss()
+        A.dp.DataParallel(model)
+        g = torch.Generator().manual_seed(9)
+        x = torch.randn(4, 6, D, generator=g)
+        y = (torch.rand(4, 12, generator=g) > 0.5).float()
+        local = oracle.au_loss(model(x), y).item()
+        got = []
+        if rank == 0:  # a validation loss on ONE rank: eval mode, then train mode under no_grad - neither may be a collective
+            model.eval()
+            got.append(model.loss_AU(model(x), y).item())
+            model.train()
+            with torch.no_grad():
+                got.append(model.loss_AU(model(x), y).item())
+        dist.barrier()
+        out.put((rank, local, got))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_eval_loss_on_one_rank_is_local():
+    """a loss call that not every rank makes (rank-0 validation) must not enter the (sum, count) all-reduce"""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_eval_loss, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, local, got in res:
+        for v in got:
+            assert abs(v - local) < 1e-6
+
+
+def test_auloss_gate_matches_stand_in():
+    """the product's AULoss applies the same gate as the stand-in above (source check: the HIP loss cannot run here)"""
+    import inspect
+    src = inspect.getsource(A.loss.AULoss.forward)
+    assert "self.training and torch.is_grad_enabled()" in src and "self.reduce_eval" in src
 
 
 def test_dp_requires_process_group():

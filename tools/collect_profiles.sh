@@ -1,19 +1,22 @@
 #!/bin/bash
 # Runs the rocprofv3 passes profiles/README.md lists (on the GPU box) and condenses them into profiles/<tag>_*.
-#   bash tools/collect_profiles.sh r02        (from the repo root; raw output under gpurun_out/final)
+#   bash tools/collect_profiles.sh r03        (from the repo root; raw output under gpurun_out/final)
 # Each pass is its own rocprofv3 process with the program directly after "--" (no wrappers); counters are collected
 # without any trace domain beside the kernel trace.  C2 (the bench's `value` workload): kernel stats, FETCH / WRITE traffic,
-# two SQ counter passes.  C3 (the north-star shape): kernel stats and traffic.  The reference's real head shapes: kernel stats.  C5 in the mx8 mode: kernel stats.
+# two SQ counter passes.  C3 (the north-star shape) and C4 (d=768, T=1024: streaming attention): kernel stats and traffic.  The reference's real head shapes: kernel stats.  C5 in the mx8 mode: kernel stats.
 set -e -o pipefail
-TAG=${1:-r02}
+export AVF_BENCH_SETTLE_S=0  # profiler passes: the trace should hold the requested steps, not the settling ones
+TAG=${1:-r03}
 R=$PWD
 O=$R/gpurun_out/final
 mkdir -p $O
 cd /tmp
 export TMPDIR=/tmp
-for CFG in c2 c3; do
+# every traced pass runs WITHOUT the per-dispatch event pass (--no-kernel-events): a third of the launches averaged in the
+# round-2 summaries were the instrumented ones (8-13 % slower), which made rocprof and the bench line disagree
+for CFG in c2 c3 c4; do
   B="python $R/bench.py --config $CFG --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-events --no-extra"
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$CFG -o s -- python $R/bench.py --config $CFG --steps 10 --warmup 3 --no-cpu-baseline --no-extra > $O/stats_$CFG.json 2> $O/stats_$CFG.err
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$CFG -o s -- python $R/bench.py --config $CFG --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-events --no-extra > $O/stats_$CFG.json 2> $O/stats_$CFG.err
   echo "$CFG stats done"
   timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_$CFG -o f -- $B > /dev/null 2> $O/fetch_$CFG.err
   echo "$CFG fetch done"
@@ -27,11 +30,12 @@ timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_I
 echo "sq2 done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_real -o s -- python $R/tools/bench_real_model.py 64 > $O/stats_real.log 2> $O/stats_real.err
 echo "real-model stats done"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c5 -o s -- python $R/bench.py --config c5 --dtype mx8 --steps 10 --warmup 3 --no-cpu-baseline --no-extra > $O/stats_c5.json 2> $O/stats_c5.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c5 -o s -- python $R/bench.py --config c5 --dtype mx8 --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-events --no-extra > $O/stats_c5.json 2> $O/stats_c5.err
 echo "c5 (mx8) stats done"
 cd $R
 python tools/pmc_traffic.py $O/stats_c2/s_kernel_stats.csv $O/fetch_c2/f_counter_collection.csv $O/write_c2/w_counter_collection.csv $TAG c2
 python tools/pmc_traffic.py $O/stats_c3/s_kernel_stats.csv $O/fetch_c3/f_counter_collection.csv $O/write_c3/w_counter_collection.csv ${TAG}_c3 c3
+python tools/pmc_traffic.py $O/stats_c4/s_kernel_stats.csv $O/fetch_c4/f_counter_collection.csv $O/write_c4/w_counter_collection.csv ${TAG}_c4 c4
 python tools/sq_summary.py $O/sq1/q_counter_collection.csv $O/sq2/q_counter_collection.csv $TAG
 cp $O/stats_real/s_kernel_stats.csv profiles/${TAG}_real_heads_kernel_stats.csv
 cp $O/stats_c5/s_kernel_stats.csv profiles/${TAG}_c5_mx8_kernel_stats.csv
