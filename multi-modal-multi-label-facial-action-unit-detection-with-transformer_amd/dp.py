@@ -127,9 +127,8 @@ class DataParallel:
     def global_mean(self, local_sum: torch.Tensor, local_count: torch.Tensor) -> torch.Tensor:
         """mean over the GLOBAL batch of a per-row quantity from each rank's (sum over its kept rows, number of kept rows):
         equals the single-process loss on the concatenated batch for any split of the ignored rows over the ranks"""
-        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("DataParallel: the loss reduction (a blocking collective) cannot be captured into a hipGraph; "
-                               "capture forward/backward of the stack only, or run the data-parallel step eagerly")
+        # on the GPU the "blocking" all-reduce only makes the current stream wait for the group's communication stream (no host
+        # block), so it is recorded by a hipGraph capture like the gradient collectives (graphs.GraphedTrainStep(dp=...))
         return _GlobalMeanFn.apply(local_sum, local_count, self.world, self.group)
 
     # -- called once per step, after loss.backward() and before optimizer.step() -------------------

@@ -18,18 +18,27 @@ class GraphedTrainStep:
 
     ``loss_fn(model, batch) -> scalar loss`` must only use the tensors in ``batch`` (a dict); they are copied into
     static buffers before each replay.  The optimizer must be capturable (e.g. ``torch.optim.Adam(..., fused=True,
-    capturable=True)``).  Refuses (RuntimeError) a model that dp.DataParallel has wrapped.
+    capturable=True)``).
+
+    Data parallelism: pass the wrapper as ``dp=``.  The step then is zero_grad, forward, loss (its (sum, count) all-reduce),
+    backward (the bucketed gradient all-reduces issued from the layer hooks), ``dp.finish()``, optimizer - and ALL of it is
+    recorded: RCCL collectives enqueued through torch's process group are capturable (they are stream operations on the
+    group's communication stream, joined to the capture by events), so a replay re-runs the reductions with no Python and
+    no host issue time on the critical path.  Every rank must construct (and later call) the step the same number of
+    times.  A wrapped model WITHOUT ``dp=`` is refused: its collectives would be recorded but ``finish()`` would not run.
     """
 
     def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer,
                  loss_fn: Callable[[torch.nn.Module, Dict[str, torch.Tensor]], torch.Tensor],
-                 example_batch: Dict[str, torch.Tensor], warmup: int = 3):
-        self.model, self.optimizer, self.loss_fn = model, optimizer, loss_fn
-        # the data-parallel wrapper launches process-group collectives from the backward hook and reduces the loss with a
-        # blocking one: neither is recorded by this capture, a replay would silently step on UNREDUCED gradients
-        if any(getattr(m, "_grad_hook", None) is not None or callable(getattr(m, "global_mean", None)) for m in model.modules()):
+                 example_batch: Dict[str, torch.Tensor], warmup: int = 3, dp=None):
+        self.model, self.optimizer, self.loss_fn, self.dp = model, optimizer, loss_fn, dp
+        wrapped = any(getattr(m, "_grad_hook", None) is not None or callable(getattr(m, "global_mean", None))
+                      for m in model.modules())
+        if wrapped and dp is None:
             raise RuntimeError("GraphedTrainStep: the model is wrapped by dp.DataParallel (gradient hooks / loss reduction "
-                               "are installed); hipGraph replay of a data-parallel step is not supported - run it eagerly")
+                               "are installed); pass the wrapper as dp= so that its finish() is part of the captured step")
+        if dp is not None and dp.model is not model:
+            raise ValueError("GraphedTrainStep: dp= wraps another model")
         self.static = {k: v.clone() for k, v in example_batch.items()}
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -45,6 +54,8 @@ class GraphedTrainStep:
         self.optimizer.zero_grad(set_to_none=True)
         loss = self.loss_fn(self.model, self.static)
         loss.backward()
+        if self.dp is not None:
+            self.dp.finish()
         self.optimizer.step()
         return loss
 

@@ -41,9 +41,65 @@ def test_dp_single_rank_nccl_matches_plain_step():
                 err = ((p.grad - q.grad).norm() / (q.grad.norm() + 1e-30)).item()
                 assert err < 1e-3, (n, err)
         assert len(dp._pending) == 0
-        # a wrapped model must not be captured into a hipGraph (the collectives would not be replayed)
-        with pytest.raises(RuntimeError, match="DataParallel"):
+        # a wrapped model is captured only together with its wrapper (finish() must be part of the recorded step)
+        with pytest.raises(RuntimeError, match="dp="):
             A.graphs.GraphedTrainStep(m_dp, torch.optim.Adam(m_dp.parameters()), lambda m, b: m.get_au_loss(m(b), labels), batch)
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+def test_dp_step_captured_into_a_hipgraph_equals_the_eager_dp_step():
+    """forward + loss reduction + backward + bucketed RCCL all-reduces + finish() + Adam recorded into ONE
+    hipGraph (1-rank RCCL group: all a one-GPU box allows).  Replays must leave exactly the parameters the eager
+    data-parallel loop leaves - bit for bit (same kernels, same order, no dropout) - over several steps on changing batches."""
+    import avformer_amd as A
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        torch.manual_seed(5)
+        kw = dict(dim=128, depth=3, heads=8, dim_head=32, mlp_dim=256, t_video=20, t_audio=13, compute_dtype="bf16")
+        m_g = A.SyntheticAVFormer(**kw).cuda()
+        m_e = A.SyntheticAVFormer(**kw).cuda()
+        m_e.load_state_dict(m_g.state_dict())
+        dp_g, dp_e = A.dp.DataParallel(m_g), A.dp.DataParallel(m_e)
+        opt_g = A.optim.FusedAdam(m_g, lr=1e-3, weight_decay=5e-5)
+        opt_e = A.optim.FusedAdam(m_e, lr=1e-3, weight_decay=5e-5)
+        for o in (opt_g, opt_e):
+            for gd in o.param_groups:
+                gd["capturable"] = True  # the group of the parameters outside the stacks steps through torch's Adam
+        g = torch.Generator().manual_seed(6)
+
+        def make_batch():
+            b = {"clip": torch.randn(6, 20, 128, generator=g).cuda(), "audio_features": torch.randn(6, 13, 128, generator=g).cuda(),
+                 "labels": (torch.rand(6, 12, generator=g) > 0.5).float().cuda()}
+            b["labels"][0] = -1
+            return b
+
+        loss_fn = lambda m, b: m.get_au_loss(m({"clip": b["clip"], "audio_features": b["audio_features"]}), b["labels"])
+        first = make_batch()
+        step = A.graphs.GraphedTrainStep(m_g, opt_g, loss_fn, first, warmup=2, dp=dp_g)   # 2 warm-up steps (capture records, it does not run)
+        for _ in range(2):                                                                  # the same two steps, eagerly
+            opt_e.zero_grad(set_to_none=True)
+            loss_fn(m_e, first).backward()
+            dp_e.finish()
+            opt_e.step()
+        for _ in range(3):
+            b = make_batch()
+            lg = step(b)
+            opt_e.zero_grad(set_to_none=True)
+            le = loss_fn(m_e, b)
+            le.backward()
+            dp_e.finish()
+            opt_e.step()
+            torch.cuda.synchronize()
+            assert torch.equal(lg, le.detach()), (lg.item(), le.item())
+        for (n, p), (_, q) in zip(m_g.named_parameters(), m_e.named_parameters()):
+            assert torch.equal(p, q), n
     finally:
         if created:
             dist.destroy_process_group()
