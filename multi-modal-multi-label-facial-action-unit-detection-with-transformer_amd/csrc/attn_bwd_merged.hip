@@ -224,8 +224,8 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
       if (key < N) v = *reinterpret_cast<const uint4*>(vbase + (int64_t)key * ld + 16 * ks + 8 * hf);
       vfr[j][ks] = __builtin_bit_cast(bf16x8_t, v);
     }
-  // statistics: NL = -lse2 (-inf past N: P = 0)
-  for (int q = tid; q < NS * 32; q += 256) NLs[q] = q < N ? -lse2[(int64_t)bh * N + q] : -INFINITY;
+  // statistics: NL = -lse2 (past N: -3e38, finite so that it splits into bf16 pieces; P = exp2(s - 3e38) = 0)
+  for (int q = tid; q < NS * 32; q += 256) NLs[q] = q < N ? -lse2[(int64_t)bh * N + q] : -3.0e38f;
   // delta of slice 0 straight from global memory: thread t = row t>>3, chunk t&7
   const int drow = tid >> 3, dch = tid & 7;
   {
@@ -263,8 +263,6 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
   const float qscale = 0.125f;  // dh^-0.5
 
   // ---- the pieces of one (slice, key block) --------------------------------------------------------------------
-  const float* nl = nullptr;
-  const float* nd = nullptr;
   const char *qsl = nullptr, *gsl = nullptr;
   char* tcur = nullptr;  // the T images this slice writes (this wave's blocks)
   int kopq = 0;
@@ -272,32 +270,38 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
   f32x16_t sacc, pacc;
   m_u32x4_t pk[2], dk[2];  // bf16 pairs of P and dS of the block whose stage C is pending, one k-step (8 registers) each
 
-  auto load_stats_s = [&]() {  // the row statistics of the lane's 16 query rows ARE the initial accumulators
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 a = *reinterpret_cast<const float4*>(nl + 8 * g);
-      sacc[4 * g + 0] = a.x; sacc[4 * g + 1] = a.y; sacc[4 * g + 2] = a.z; sacc[4 * g + 3] = a.w;
-    }
-  };
-  auto load_stats_p = [&]() {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 c = *reinterpret_cast<const float4*>(nd + 8 * g);
-      pacc[4 * g + 0] = c.x; pacc[4 * g + 1] = c.y; pacc[4 * g + 2] = c.z; pacc[4 * g + 3] = c.w;
-    }
+  // The row statistics enter S and dP through the matrix pipe: a fifth k-step whose A operand holds, for query row r, the
+  // three bf16 pieces hi + mid + lo = -lse2[r] (exactly: 3 x 8 significand bits) in its first three k slots and whose B
+  // operand is 1 there - S = Q K^T + (-lse2) 1^T.  Loading them into the C operand instead (the first version) cost 8
+  // broadcast ds_read_b128 per key block and made the first MFMA of every block wait for LDS; this costs two MFMAs.
+  bf16x8_t nlA, ndA;
+  const bf16x8_t onesB = __builtin_bit_cast(bf16x8_t, m_u32x4_t{hf ? 0u : 0x3F803F80u, hf ? 0u : 0x00003F80u, 0u, 0u});
+  auto split3 = [&](float x) {
+    const float hi = __uint_as_float(__float_as_uint(x) & 0xffff0000u);
+    const float r1 = x - hi;
+    const float mid = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+    const float lo = r1 - mid;
+    const uint32_t w0 = (__float_as_uint(hi) >> 16) | (__float_as_uint(mid) & 0xffff0000u);
+    const uint32_t w1 = pack_bf16x2(lo, 0.f);
+    return __builtin_bit_cast(bf16x8_t, m_u32x4_t{hf ? 0u : w0, hf ? 0u : w1, 0u, 0u});
   };
   auto load_kf = [&](int j) {
     const char* kblk = kimg + (kb0 + j) * 4096 + kopq;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) kf[ks] = m_row_frag(kblk + off_row[ks]);
   };
-  // stage A(j): eight MFMAs, S chain first (its statistics were loaded first)
+  // stage A(j): ten MFMAs, no operand fresher than a whole phase
   auto stage_a = [&](auto jtag) {
     constexpr int j = decltype(jtag)::value;
+    sacc = AVF_MFMA32(qa[0], kf[0], m_zero16());
+    pacc = AVF_MFMA32(ga[0], vfr[j][0], m_zero16());
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) sacc = AVF_MFMA32(qa[ks], kf[ks], sacc);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) pacc = AVF_MFMA32(ga[ks], vfr[j][ks], pacc);
+    for (int ks = 1; ks < 4; ++ks) {
+      sacc = AVF_MFMA32(qa[ks], kf[ks], sacc);
+      pacc = AVF_MFMA32(ga[ks], vfr[j][ks], pacc);
+    }
+    sacc = AVF_MFMA32(nlA, onesB, sacc);
+    pacc = AVF_MFMA32(ndA, onesB, pacc);
     if constexpr (RAGGED) {
       if (32 * (kb0 + j) + 32 > N) {  // wave-uniform: the block holds padded keys
         const bool dead = 32 * (kb0 + j) + r >= N;
@@ -328,6 +332,8 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
   };
   // stage C(j) - eight accumulating MFMAs - with stage B(j+1) riding between them (NX) and the operands of A(j+2)
   // preloaded into the registers B(j+1) has finished with (NX2).  The LDS reads run two slots ahead of their MFMAs.
+  bf16x8_t cg0, cq0, cg1, cq1;  // the first two fragment pairs of the pending stage C
+  auto prefetch_c = [&]() { tr_qg(0, 0, cg0, cq0); tr_qg(0, 1, cg1, cq1); };
   auto phase_c = [&](auto jtag) {
     constexpr int j = decltype(jtag)::value;
     constexpr bool NX = j + 1 < KB, NX2 = j + 2 < KB;
@@ -335,24 +341,24 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
     m_u32x4_t pkn[2], dkn[2];
     const bf16x8_t pk0 = __builtin_bit_cast(bf16x8_t, pk[0]), pk1 = __builtin_bit_cast(bf16x8_t, pk[1]);
     const bf16x8_t dk0 = __builtin_bit_cast(bf16x8_t, dk[0]), dk1 = __builtin_bit_cast(bf16x8_t, dk[1]);
-    tr_qg(0, 0, g0, q0);
+    g0 = cg0; q0 = cq0; g1 = cg1; q1 = cq1;  // (0,0) and (0,1): requested before stage A(j+1)
     m_operand_settle();
     AVF_FENCE();
-    tr_qg(0, 1, g1, q1);
+    if constexpr (NX2) load_kf(j + 2);  // K fragments of the block after next: a whole phase ahead of their MFMAs
     m_mfma_acc(dvacc[j][0], g0, pk0);
     if constexpr (NX) b_chunk(0, pkn, dkn);
     AVF_FENCE();
     m_mfma_acc(dkacc[j][0], q0, dk0);
     if constexpr (NX) b_chunk(1, pkn, dkn);
+    tr_qg(1, 0, g0, q0);                // four slots ahead of its MFMAs
     AVF_FENCE();
-    tr_qg(1, 0, g0, q0);
     m_mfma_acc(dvacc[j][0], g1, pk1);
     if constexpr (NX) b_chunk(2, pkn, dkn);
     AVF_FENCE();
     m_mfma_acc(dkacc[j][0], q1, dk1);
     if constexpr (NX) b_chunk(3, pkn, dkn);
-    AVF_FENCE();
     tr_qg(1, 1, g1, q1);
+    AVF_FENCE();
     m_mfma_acc(dvacc[j][1], g0, pk0);
     if constexpr (NX) b_chunk(4, pkn, dkn);
     AVF_FENCE();
@@ -369,7 +375,6 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
       write_t(std::integral_constant<int, j + 1>{}, dkn);
       pk[0] = pkn[0]; pk[1] = pkn[1]; dk[0] = dkn[0]; dk[1] = dkn[1];
     }
-    if constexpr (NX2) { load_stats_s(); load_stats_p(); load_kf(j + 2); }
     AVF_FENCE();
   };
   // dQ of slice sp (the dS^T images of its key blocks in T buffer sp & 1): this wave's 16 columns, two 16x16x32 MFMAs per
@@ -432,8 +437,8 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
     }
     AVF_PHASE_MARK(1);
 
-    nl = NLs + 32 * s + 4 * hf;
-    nd = NDs + 32 * s + 4 * hf;
+    nlA = split3(NLs[32 * s + r]);
+    ndA = split3(NDs[32 * s + r]);
     // the K image never changes, so the compiler would hoist every fragment read of it out of the slice loop (48
     // registers per key block); an opaque per-slice copy of the image offset keeps the reads inside
     kopq = 0;
@@ -443,14 +448,13 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
       qa[ks] = m_row_frag(qsl + off_row[ks]);
       ga[ks] = m_row_frag(gsl + off_row[ks]);
     }
-    load_stats_s();
-    load_stats_p();
     load_kf(0);
     // every wave runs all its KB blocks, padded ones included (zero K rows and V, masked scores): the slice barrier
     // would make a wave that skipped them wait for the others anyway, and one straight-line body keeps the 64 KB
     // accumulators in place (two code paths made the compiler shuffle all of them at the join)
     stage_a(std::integral_constant<int, 0>{});
     AVF_FENCE();
+    if constexpr (KB > 1) load_kf(1);
     AVF_PHASE_MARK(2);
     if (s > 0) {
       dq_job(s - 1, std::true_type{});
@@ -461,21 +465,35 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
       pk[0] = pkn[0]; pk[1] = pkn[1]; dk[0] = dkn[0]; dk[1] = dkn[1];
     }
     write_t(std::integral_constant<int, 0>{}, dk);
-    if constexpr (KB > 1) { load_stats_s(); load_stats_p(); load_kf(1); }
+    prefetch_c();
     AVF_FENCE();
     AVF_PHASE_MARK(3);
     if constexpr (KB > 1) stage_a(std::integral_constant<int, 1>{});
+    AVF_PHASE_MARK(4);
     phase_c(std::integral_constant<int, 0>{});
+    AVF_PHASE_MARK(7);
     if constexpr (KB > 1) {
+      prefetch_c();
+      AVF_FENCE();
       if constexpr (KB > 2) stage_a(std::integral_constant<int, 2>{});
+      AVF_PHASE_MARK(4);
       phase_c(std::integral_constant<int, 1>{});
+      AVF_PHASE_MARK(7);
     }
     if constexpr (KB > 2) {
+      prefetch_c();
+      AVF_FENCE();
       if constexpr (KB > 3) stage_a(std::integral_constant<int, 3>{});
+      AVF_PHASE_MARK(4);
       phase_c(std::integral_constant<int, 2>{});
+      AVF_PHASE_MARK(7);
     }
-    if constexpr (KB > 3) phase_c(std::integral_constant<int, 3>{});
-    AVF_PHASE_MARK(4);
+    if constexpr (KB > 3) {
+      prefetch_c();
+      AVF_FENCE();
+      phase_c(std::integral_constant<int, 3>{});
+    }
+    AVF_PHASE_MARK(7);
     if (more) {
       // delta of the next slice: its dO rows 8 w .. 8 w + 7 were brought in by THIS wave (own vmcnt suffices)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

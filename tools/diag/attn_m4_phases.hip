@@ -83,8 +83,8 @@ int main(int argc, char** argv) {
       life += (double)(r[9] - r[8]); ++nw; wall += (double)r[10];
     }
   printf("B=%d N=%d H=%d: kernel %.1f us (stamped build), mean wave life %.0f ticks, tick rate %.0f MHz\n", B, N, H, ms * 1e3, life / nw, life / wall * 100.0);
-  const char* names[8] = {"prologue", "slice top", "loads + A(0)", "dQ job + B(0)", "blocks", "delta+barrier", "last dQ + epilogue", "-"};
+  const char* names[8] = {"prologue", "slice top", "loads + A(0)", "dQ job + B(0)", "stages A(1..)", "delta+barrier", "last dQ + epilogue", "phases C"};
   const int NS = (N + 31) / 32;
-  for (int i = 0; i < 7; ++i) printf("  %-12s %9.0f ticks/wave  %5.1f %%   (%.0f per slice)\n", names[i], acc[i] / nw, 100.0 * acc[i] / life, acc[i] / nw / NS);
+  for (int i = 0; i < 8; ++i) printf("  %-12s %9.0f ticks/wave  %5.1f %%   (%.0f per slice)\n", names[i], acc[i] / nw, 100.0 * acc[i] / life, acc[i] / nw / NS);
   return 0;
 }
