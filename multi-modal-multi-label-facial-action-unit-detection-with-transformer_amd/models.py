@@ -189,11 +189,20 @@ MODEL_REGISTRY = {
 }
 
 
+def _register_former_models():
+    # sformer / vformer / tformer (train.py:292-303): the token sections on the HIP path around a caller's CNN backbone
+    from . import former_models as fm
+    MODEL_REGISTRY.update({'sformer': fm.SpatialFormerModel, 'vformer': fm.VisualFormerModel,
+                           'tformer': fm.SpatialTemporalFormerModel})
+
+
 def build_model(model_name: str, modality: str = 'A;V;M', task: str = 'AU', **kw) -> nn.Module:
+    if 'sformer' not in MODEL_REGISTRY:
+        _register_former_models()
     if model_name not in MODEL_REGISTRY:
         raise KeyError(f"model {model_name!r} is not provided by the MI355X hot-path build; available: "
-                       f"{sorted(MODEL_REGISTRY)} (the CNN-backbone models of the reference are out of scope)")
+                       f"{sorted(MODEL_REGISTRY)} (the CNN-only models of the reference are out of scope)")
     cls = MODEL_REGISTRY[model_name]
-    if cls is TwoStreamAuralVisualFormer:
-        return cls(modality=modality, task=task, **kw)
-    return cls(task=task, **kw)
+    if cls is SyntheticAVFormer:
+        return cls(task=task, **kw)
+    return cls(modality=modality, task=task, **kw)

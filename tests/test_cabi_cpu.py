@@ -114,6 +114,25 @@ def test_dropout_configuration():
     assert t._cfg(1, 4, seed_t=seed_t).dropout_p == 0.0 and t._advance_seed(torch.device("cpu")) is None
 
 
+def test_registry_has_the_former_entries_of_train_py():
+    """train.py:292-303: avformer / vformer / tformer / sformer resolve; constructor kwargs, .modes, .task and the
+    reference's parameter names (checkpoints load with strict=False) are in place - no GPU needed to construct"""
+    for name in ("sformer", "vformer", "tformer"):
+        m = A.models.build_model(name, modality="A;V;M", task="AU")
+        assert m.modes == ["clip"] and m.task == "AU"
+        assert hasattr(m, "get_au_loss") and hasattr(m, "get_ex_loss") and hasattr(m, "get_va_loss")
+    sd = A.models.build_model("sformer").state_dict()
+    assert "base_model.pos_embedding" in sd and "base_model.spatial_transformer.layers.0.0.fn.fn.to_qkv.weight" in sd
+    assert "au_head.AU_linear_p1.weight" in sd and "fc.1.weight" in sd
+    sd = A.models.build_model("tformer").state_dict()
+    assert "video_model.s_former.pos_embedding" in sd and "video_model.t_former.cls_token" in sd
+    assert sd["video_model.t_former.pos_embedding"].shape == (1, 17, 1536) and "au_head.AU_linear_last12.weight" in sd
+    sd = A.models.build_model("vformer").state_dict()
+    assert sd["video_model.t_former.pos_embedding"].shape == (1, 17, 512) and sd["fc.3.weight"].shape == (21, 256)
+    with pytest.raises(KeyError):
+        A.models.build_model("emonet")
+
+
 def test_registry():
     assert "avformer" in A.MODEL_REGISTRY
     m = A.build_model("avformer", modality="A;V;M", task="AU")

@@ -184,3 +184,23 @@ def test_linear_pad_one_launch_forward_backward(B, K, O, width):
     torch.testing.assert_close(db.cpu().double(), dl.sum(0), atol=5e-6, rtol=1e-5)
     dx2, dw2, db2 = A.ops.linear_pad_bwd(dout.cuda(), x.cuda(), w.cuda(), need_dx=False, need_db=False)
     assert dx2 is None and db2 is None and torch.equal(dw2, dw)
+
+
+@pytest.mark.parametrize("name", ["sformer", "vformer", "tformer"])
+def test_former_registry_models_run_a_training_step(name):
+    """train.py:292-303 registry entries on the device: [B,21] layout, AU loss, gradients reach the token sections and heads.
+    Without a backbone the models take the stage-3 feature map ([B*16, 256, 7, 7]) the reference's ResNet stem would produce."""
+    import avformer_amd as A
+    torch.manual_seed(0)
+    m = A.models.build_model(name, task="AU").cuda()
+    B = 2
+    frames = B if name == "sformer" else B * 16
+    x = {"clip": torch.randn(frames, 256, 7, 7, device="cuda")}
+    y = (torch.rand(B, 12, device="cuda") > 0.5).float()
+    out = m(x)
+    assert out.shape == (B, 21) and torch.isfinite(out).all()
+    m.get_au_loss(out, y).backward()
+    tok = m.base_model if name == "sformer" else m.video_model.s_former
+    assert tok.pos_embedding.grad is not None and torch.isfinite(tok.pos_embedding.grad).all()
+    g = [p.grad for n, p in m.named_parameters() if "to_qkv" in n]
+    assert g and all(t is not None and torch.isfinite(t).all() and float(t.abs().sum()) > 0 for t in g)
