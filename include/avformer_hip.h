@@ -79,6 +79,14 @@ typedef struct avf_layer_cfg {
                           (i, j) with either token dropped scores -FLT_MAX: a dropped query attends uniformly to all keys, a kept
                           query gives dropped keys zero weight; no gradient flows through a filled score.  With a mask the
                           attention core runs on the fp32-arithmetic kernels in every mode (correct, not tuned).            */
+  int32_t ln_fuse;     /* bit 0 (needs resid_bf16, no mx8_fwd, no key_mask, dim % 64 == 0): PreNorm's LayerNorm (heads.py:178-185) is
+                          folded into the GEMM behind it - to_qkv and net.0 read the raw bf16 residual stream against gamma-scaled
+                          weight images (refresh them with avf_stack_ln_fold whenever weights, gamma, beta or b1 changed) and finish
+                          rstd (acc - mean s) + c in their epilogues; the normalised rows are not written in forward (avf_layer_bwd
+                          rebuilds them for its weight-gradient GEMM), the residual GEMM epilogues emit the row statistics.
+                          avf_layer_fwd then needs the workspace.  bit 1: the partial row statistics of x_in are already in the
+                          workspace - set it for a layer whose x_in is the x_out of the preceding avf_layer_fwd call with the SAME
+                          workspace and shapes (the layers of a stack above the first).                                  */
 } avf_layer_cfg;
 
 /* fp32 master parameters of one layer, in state_dict order:
@@ -156,6 +164,11 @@ int avf_gemm_tn_group(int count, int64_t K, const void* const* A, const void* co
  * bf16 images, one launch (cfg.mx8_fwd = 1);
  * lowp[i] = the avf_layer_lowp_bytes buffer of layer i, after avf_layer_prepare_weights / the library Adam wrote it */
 int avf_stack_quant_weights_mx8(const avf_layer_cfg* cfg, int layers, void* const* lowp, void* stream);
+/* cfg.ln_fuse: the gamma-scaled images of to_qkv / net.0 and their s / c vectors (heads.py:178-185 folded into heads.py:212,191)
+ * for every layer of a stack in one launch; params[i] / lowp[i]: the fp32 masters and the weight-image buffer of layer i
+ * (avf_layer_lowp_bytes with the same cfg).  Call whenever a weight, a LayerNorm gamma / beta or b1 changed.            */
+int avf_stack_ln_fold(const avf_layer_cfg* cfg, int layers, const avf_layer_params* const* params, void* const* lowp,
+                      void* stream);
 int avf_quant_mx8(int dtype, const void* x, int64_t rows, int64_t cols, void* q, void* scales, void* stream);
 int avf_gemm_mx8_nt(int64_t M, int64_t N, int64_t K, const void* a_q, const void* a_scales, const void* b_q,
                     const void* b_scales, void* C, int64_t ldc, int c_dtype, int epilogue, const float* bias,

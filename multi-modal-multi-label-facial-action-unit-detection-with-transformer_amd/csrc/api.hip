@@ -50,6 +50,25 @@ int timing_take_slot(int cls, double flops, double bytes) {
 }
 }  // namespace
 
+static FILE* shape_log_file() {
+  static FILE* f = [] {
+    const char* e = getenv("AVF_SHAPE_LOG");
+    return (e && *e) ? fopen(e, "a") : (FILE*)nullptr;
+  }();
+  return f;
+}
+bool shape_log_on() { return shape_log_file() != nullptr; }
+void shape_log(const char* fmt, ...) {
+  FILE* f = shape_log_file();
+  if (!f) return;
+  va_list ap;
+  va_start(ap, fmt);
+  vfprintf(f, fmt, ap);
+  va_end(ap);
+  fputc('\n', f);
+  fflush(f);
+}
+
 TimingScope::TimingScope(int c, double f, double b, hipStream_t s, bool pk)
     : slot(-1), stream(s), per_kernel(pk), cls(c), flops(f), bytes(b), issued(0) {
   if (per_kernel) return;  // records are taken per launch

@@ -1392,6 +1392,9 @@ int attn_fwd_bf16(const bf16* qkv, bf16* o, float* lse2, int B, int N, int H, in
   AVF_REQUIRE(ceil_div(N, 128) * B * H < (1LL << 31), "attn_fwd_bf16: grid too large");
   AVF_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)o & 7) == 0, "attn_fwd_bf16: misaligned pointers");
   TimingScope ts(KC_ATTN_FWD, 4.0 * B * H * (double)N * N * dh, 2.0 * 4.0 * B * N * H * dh, s, /*per_kernel=*/true);
+  if (shape_log_on())
+    shape_log("attn_fwd,attn_fwd,%d,%d,%d,%d,%d,%.0f,%.0f", B * H, B, N, H * dh, -1, 4.0 * B * H * (double)N * N * dh,
+              2.0 * 4.0 * B * N * H * dh);
   if (use_resident(N, dh)) {
     const int W = res_waves(N);
     const size_t smem = (size_t)((N + 31) & ~31) * 128 * 2;
@@ -1422,6 +1425,9 @@ int attn_bwd_bf16(const bf16* qkv, const bf16* o, const bf16* d_o, const float* 
   AVF_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)d_o & 15) == 0 && ((uintptr_t)dqkv & 7) == 0,
               "attn_bwd_bf16: misaligned pointers");
   TimingScope ts(KC_ATTN_BWD, 10.0 * B * H * (double)N * N * dh, 2.0 * 8.0 * B * N * H * dh, s, /*per_kernel=*/true);
+  if (shape_log_on())
+    shape_log("attn_bwd,%s,%d,%d,%d,%d,%d,%.0f,%.0f", attn_bwd_merged_ok(N, dh, q_prescaled) ? "attn_bwd_m4_kernel" : "attn_dq+attn_dkv",
+              B * H, B, N, H * dh, -1, 10.0 * B * H * (double)N * N * dh, 2.0 * 8.0 * B * N * H * dh);
   if (attn_bwd_merged_ok(N, dh, q_prescaled)) return attn_bwd_merged(&ts, qkv, o, d_o, lse2, dqkv, B, N, H, s);
   if (use_resident(N, dh)) {  // delta comes out of the dQ kernel
     const int W = res_waves(N);

@@ -35,6 +35,8 @@ struct Dims {
   const void* keep;  // optional token mask [B, N] bytes (1 = kept), heads.py:225-232: attention then runs on the fp32-arithmetic kernels
   bool mxb;   // backward dX GEMMs fed by LayerNorm backward / the dGELU epilogue take MX-FP8 operands too (config 5)
   bool gy_mx; // the caller's dx_out_lo buffer already carries the MX-FP8 image behind the bf16 one
+  bool lnf;   // LayerNorm forward folded into the to_qkv / net.0 GEMMs (cfg.ln_fuse bit 0)
+  bool ln1_ready;  // ... and the partial row statistics of x_in already sit in the workspace (bit 1: the previous layer's call)
 };
 
 // bf16 gradient-stream buffers in the mx8_bwd mode: [R, D] bf16 | [R, D] e4m3 | [R, D / 32] E8M0, each part 256-aligned
@@ -78,6 +80,11 @@ int make_dims(const avf_layer_cfg* c, Dims* d) {
   d->xdt = d->rs16 ? AVF_BF16 : AVF_F32;
   AVF_REQUIRE(!d->rs16 || (c->dtype == AVF_BF16 && c->dim % 8 == 0 && c->dim <= 1536),
               "layer: resid_bf16 needs the bf16 path, dim %% 8 == 0 and dim <= 1536 (dim=%d)", c->dim);
+  d->lnf = (c->ln_fuse & 1) != 0;
+  d->ln1_ready = d->lnf && (c->ln_fuse & 2) != 0;
+  AVF_REQUIRE(!d->lnf || (d->rs16 && !d->mx && !c->key_mask && c->dim % 64 == 0 && (c->heads * c->dim_head) % 4 == 0 &&
+                          c->mlp_dim % 4 == 0),
+              "layer: ln_fuse needs resid_bf16, no mx8, no key mask and dim %% 64 == 0 (dim=%d)", c->dim);
   if (c->dtype == AVF_BF16) {
     AVF_REQUIRE(d->D % 8 == 0 && d->I % 8 == 0 && d->M % 8 == 0, "layer(bf16): dim, inner and mlp_dim must be multiples of 8");
     AVF_REQUIRE(d->dh == 32 || d->dh == 64, "layer(bf16): dim_head must be 32 or 64 (got %d)", d->dh);
@@ -126,6 +133,8 @@ struct LowP {
   void *wqkv_q, *wqkv_s, *w1_q, *w1_s, *w2_q, *w2_s;  // mx8_fwd only
   void *wo_q, *wo_s;                                  // mx8_fwd: out-projection (used when the attention kernel emits the image of o)
   void *w2t_q, *w2t_s, *w1t_q, *w1t_s, *wot_q, *wot_s;  // mx8_bwd: images of the transposed weights (K = out features)
+  void *wqkv_ln, *w1_ln;                // ln_fuse: gamma-scaled images of Wqkv (query rows also carry the softmax scale) and W1
+  float *s_qkv, *c_qkv, *s_1, *c_1;     // ln_fuse: their s / c vectors
 };
 size_t carve_lowp(const Dims& d, void* base, LowP* l) {
   if (d.dt != AVF_BF16) {
@@ -153,6 +162,15 @@ size_t carve_lowp(const Dims& d, void* base, LowP* l) {
   } else {
     t.wqkv_q = t.wqkv_s = t.w1_q = t.w1_s = t.w2_q = t.w2_s = nullptr;
     t.wo_q = t.wo_s = t.w2t_q = t.w2t_s = t.w1t_q = t.w1t_s = t.wot_q = t.wot_s = nullptr;
+  }
+  if (d.lnf) {
+    t.wqkv_ln = c.take((size_t)3 * d.I * d.D * 2);
+    t.w1_ln = c.take((size_t)d.M * d.D * 2);
+    t.s_qkv = (float*)c.take((size_t)3 * d.I * 4); t.c_qkv = (float*)c.take((size_t)3 * d.I * 4);
+    t.s_1 = (float*)c.take((size_t)d.M * 4);       t.c_1 = (float*)c.take((size_t)d.M * 4);
+  } else {
+    t.wqkv_ln = t.w1_ln = nullptr;
+    t.s_qkv = t.c_qkv = t.s_1 = t.c_1 = nullptr;
   }
   if (l) *l = t;
   return c.off;
@@ -184,6 +202,7 @@ struct Work {
   void *duq, *dus, *mq, *ms, *gyq, *gys;  // mx8_bwd: images of du, of dx_mid, and of dx_out when the caller brought none
   float *gy_m, *gm_m;       // fp32 mode with live dropout: masked copies of dx_out / dx_mid (what the Linears behind sites 2 / 0 see)
   float* small_part;        // short-sequence backward: per-clip partial rows (pb1 [B][M] | pln2 [B][3D] | pln1 [B][3D])
+  float *ln_part_a, *ln_part_b;  // ln_fuse: per-row partial statistics [R][D/32][2] of x_in (LN1) and of x_mid (LN2)
 };
 size_t carve_work(const Dims& d, void* base, Work* w) {
   Carver c(base);
@@ -238,13 +257,18 @@ size_t carve_work(const Dims& d, void* base, Work* w) {
   const bool f32_drop = d.dt == AVF_F32 && d.p > 0.f;
   t.gy_m = (float*)c.take(f32_drop ? d.R * d.D * 4 : 0);
   t.gm_m = (float*)c.take(f32_drop ? d.R * d.D * 4 : 0);
+  // LAST, so that every layer of a stack (same shapes, same flags) finds the two tables at the same place in the shared
+  // workspace: layer l's net.3 epilogue leaves the statistics of ITS output where layer l+1's to_qkv GEMM looks for them
+  t.ln_part_a = (float*)c.take(d.lnf ? (size_t)d.R * (d.D / 32) * 8 : 0);
+  t.ln_part_b = (float*)c.take(d.lnf ? (size_t)d.R * (d.D / 32) * 8 : 0);
   if (w) *w = t;
   return c.off;
 }
 
 // C[R, out] = A[R, in] * W[out, in]^T  (nn.Linear forward)
 int linear_fwd(const Dims& d, const void* A, int in, const void* W, int out, void* C, int c_dtype, int epi,
-               const float* bias, const void* res, void* aux, hipStream_t s, const DropCfg& drop = kNoDrop) {
+               const float* bias, const void* res, void* aux, hipStream_t s, const DropCfg& drop = kNoDrop,
+               float* rs_out = nullptr) {  // rs_out: partial row statistics of the stored C (ln_fuse)
   GemmArgs a;
   a.dtype = d.dt; a.transA = 0; a.transB = 1;
   a.M = d.R; a.N = out; a.K = in;
@@ -252,6 +276,23 @@ int linear_fwd(const Dims& d, const void* A, int in, const void* W, int out, voi
   a.C = C; a.ldc = out; a.c_dtype = c_dtype; a.epilogue = epi;
   a.bias = bias; a.residual = res; a.ldres = out; a.aux = aux; a.ldaux = out; a.workspace = nullptr; a.colsum = nullptr;
   a.drop = drop; a.defer_fold = nullptr;
+  a.rs_out = rs_out;
+  return gemm(a, s);
+}
+
+// C = LayerNorm(X) W^T (+ b) with the LayerNorm folded into the GEMM: X is the raw bf16 residual stream, W_ln the gamma-scaled
+// image, part the partial row statistics of X; the row statistics land in mean / rstd (PreNorm, heads.py:178-185)
+int linear_fwd_ln(const Dims& d, const void* X, int in, const void* W_ln, const float* sv, const float* cv, const float* part,
+                  int out, void* C, int epi, void* aux, float* mean, float* rstd, float eps, hipStream_t s,
+                  const DropCfg& drop = kNoDrop) {
+  GemmArgs a;
+  a.dtype = AVF_BF16; a.transA = 0; a.transB = 1;
+  a.M = d.R; a.N = out; a.K = in;
+  a.A = X; a.lda = in; a.B = W_ln; a.ldb = in;
+  a.C = C; a.ldc = out; a.c_dtype = AVF_BF16; a.epilogue = epi;
+  a.bias = nullptr; a.residual = nullptr; a.ldres = 0; a.aux = aux; a.ldaux = out; a.workspace = nullptr; a.colsum = nullptr;
+  a.drop = drop; a.defer_fold = nullptr;
+  a.ln_part = part; a.ln_s = sv; a.ln_c = cv; a.ln_mean = mean; a.ln_rstd = rstd; a.ln_eps = eps;
   return gemm(a, s);
 }
 
@@ -375,6 +416,27 @@ extern "C" int avf_layer_prepare_weights(const avf_layer_cfg* cfg, const avf_lay
   return prep_weights_multi(b, 4, s);
 }
 
+extern "C" int avf_stack_ln_fold(const avf_layer_cfg* cfg, int layers, const avf_layer_params* const* params,
+                                 void* const* lowp, void* stream) {
+  Dims d;
+  AVF_TRY(make_dims(cfg, &d));
+  AVF_REQUIRE(d.lnf, "stack_ln_fold: cfg.ln_fuse is not set");
+  AVF_REQUIRE(layers > 0 && layers <= 64 && params && lowp, "stack_ln_fold: bad arguments");
+  LnFoldJob jobs[64 * 2];
+  int n = 0;
+  for (int i = 0; i < layers; ++i) {
+    AVF_REQUIRE(params[i] && lowp[i], "stack_ln_fold: null pointer (layer %d)", i);
+    LowP l;
+    carve_lowp(d, lowp[i], &l);
+    const avf_layer_params* p = params[i];
+    // to_qkv has no bias (heads.py:212); its query rows carry the softmax scale like the plain image (attn_q_prescale)
+    jobs[n++] = LnFoldJob{p->w_qkv, p->ln1_w, p->ln1_b, nullptr, (bf16*)l.wqkv_ln, l.s_qkv, l.c_qkv, 3 * d.I, d.D,
+                          attn_q_prescale(d.dh), d.I};
+    jobs[n++] = LnFoldJob{p->w1, p->ln2_w, p->ln2_b, p->b1, (bf16*)l.w1_ln, l.s_1, l.c_1, d.M, d.D, 1.0f, 0};
+  }
+  return ln_fold_weights(jobs, n, (hipStream_t)stream);
+}
+
 extern "C" int avf_stack_quant_weights_mx8(const avf_layer_cfg* cfg, int layers, void* const* lowp, void* stream) {
   Dims d;
   AVF_TRY(make_dims(cfg, &d));
@@ -458,6 +520,24 @@ extern "C" int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p
                            make_drop(d.p0, d.seed, d.layer, 0, d.seed_dev), make_drop(d.p, d.seed, d.layer, 1, d.seed_dev),
                            make_drop(d.p, d.seed, d.layer, 2, d.seed_dev), s);
   }
+  if (d.lnf) {
+    // LayerNorm folded into the two GEMMs behind it: h1 / h2 are not written (backward's LayerNorm kernels rebuild them for
+    // the weight-gradient GEMM); the residual GEMM epilogues leave the row statistics of what they store
+    AVF_REQUIRE(workspace, "layer_fwd(ln_fuse): workspace missing");
+    Work w;
+    carve_work(d, workspace, &w);
+    const DropCfg dr0 = make_drop(d.p0, d.seed, d.layer, 0, d.seed_dev), dr1 = make_drop(d.p, d.seed, d.layer, 1, d.seed_dev),
+                  dr2 = make_drop(d.p, d.seed, d.layer, 2, d.seed_dev);
+    if (!d.ln1_ready) AVF_TRY(row_stats(x_in, AVF_BF16, d.R, d.D, w.ln_part_a, s));
+    AVF_TRY(linear_fwd_ln(d, x_in, d.D, l.wqkv_ln, l.s_qkv, l.c_qkv, w.ln_part_a, 3 * d.I, sv.qkv, AVF_EPI_NONE, nullptr,
+                          sv.mean1, sv.rstd1, cfg->ln_eps, s));
+    AVF_TRY(attn_fwd_bf16((const bf16*)sv.qkv, (bf16*)sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s, attn_q_prescale_on()));
+    AVF_TRY(linear_fwd(d, sv.o, d.I, wo, d.D, sv.x_mid, d.xdt, AVF_EPI_BIAS_RES, p->b_out, x_in, nullptr, s, dr0, w.ln_part_b));
+    AVF_TRY(linear_fwd_ln(d, sv.x_mid, d.D, l.w1_ln, l.s_1, l.c_1, w.ln_part_b, d.M, sv.g, AVF_EPI_BIAS_GELU, sv.u, sv.mean2,
+                          sv.rstd2, cfg->ln_eps, s, dr1));
+    AVF_TRY(linear_fwd(d, sv.g, d.M, w2, d.D, x_out, d.xdt, AVF_EPI_BIAS_RES, p->b2, sv.x_mid, nullptr, s, dr2, w.ln_part_a));
+    return 0;
+  }
   AVF_TRY(layernorm_fwd(x_in, p->ln1_w, p->ln1_b, sv.h1, d.dt, sv.mean1, sv.rstd1, d.R, d.D, cfg->ln_eps, s, nullptr, nullptr, d.xdt));
   AVF_TRY(linear_fwd(d, sv.h1, d.D, wqkv, 3 * d.I, sv.qkv, d.dt, AVF_EPI_NONE, nullptr, nullptr, nullptr, s));
   if (d.keep) AVF_TRY(attn_fwd_vec(d.dt, sv.qkv, sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s, d.keep, lo && attn_q_prescale_on()));
@@ -529,6 +609,8 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   TnGroupArgs grp = dw_group(d, gy, sv.g, w.du, sv.h2, gm, sv.o, w.dqkv, sv.h1, g);
   grp.workspace = w.gemm_ws;
   const bool grouped = lo && gemm_bf16_tn_group_ok(grp);
+  // (ln_fuse: h1 / h2 are rebuilt by this call's LayerNorm backward kernels - the weight-gradient GEMMs that read them run
+  //  after those: the grouped launch at the end, or the separate dW1 / dWqkv calls right behind LN2' / LN1')
   FoldList folds;
   memset(&folds, 0, sizeof(folds));
   folds.count = 3;
@@ -631,7 +713,6 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
     AVF_TRY(linear_dx(d, gy, d.D, p->w2, l.w2_t, d.M, w.du, AVF_EPI_DGELU, sv.u, s, nullptr, nullptr, dr1));
     AVF_TRY(colsum(w.du, d.dt, d.R, d.M, d.M, g->b1, w.cs_ws, s));
   }
-  if (!grouped) AVF_TRY(linear_dw(d, w.du, d.M, sv.h2, d.D, g->w1, w.gemm_ws, s));
   if (d.mxb)
     AVF_TRY(linear_dx_mx(d, w.duq, w.dus, d.M, l.w1t_q, l.w1t_s, d.D, w.dh, AVF_EPI_NONE, nullptr, s, nullptr, nullptr, kNoDrop,
                          nullptr));
@@ -639,11 +720,13 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
     AVF_TRY(linear_dx(d, w.du, d.M, p->w1, l.w1_t, d.D, w.dh, AVF_EPI_NONE, nullptr, s));
   if (d.gs16)  // residual gradient in: the bf16 image the GEMMs read; out: the bf16 dx_mid only
     AVF_TRY(layernorm_bwd(w.dh, d.dt, sv.x_mid, p->ln2_w, sv.mean2, sv.rstd2, gy, nullptr, w.dx_mid_lo, g->ln2_w, g->ln2_b,
-                          g->b_out, w.ln_ws, d.R, d.D, s, dr0, grouped ? &folds.job[1] : nullptr, AVF_BF16, d.xdt, w.mq, w.ms));
+                          g->b_out, w.ln_ws, d.R, d.D, s, dr0, grouped ? &folds.job[1] : nullptr, AVF_BF16, d.xdt, w.mq, w.ms,
+                          d.lnf ? sv.h2 : nullptr, p->ln2_b));
   else
     AVF_TRY(layernorm_bwd(w.dh, d.dt, sv.x_mid, p->ln2_w, sv.mean2, sv.rstd2, dx_out, w.dx_mid,
                           lo ? w.dx_mid_lo : nullptr, g->ln2_w, g->ln2_b, g->b_out, w.ln_ws, d.R, d.D, s, dr0,
-                          grouped ? &folds.job[1] : nullptr, AVF_F32, d.xdt, w.mq, w.ms));
+                          grouped ? &folds.job[1] : nullptr, AVF_F32, d.xdt, w.mq, w.ms, d.lnf ? sv.h2 : nullptr, p->ln2_b));
+  if (!grouped) AVF_TRY(linear_dw(d, w.du, d.M, sv.h2, d.D, g->w1, w.gemm_ws, s));  // (behind LN2': ln_fuse rebuilds h2 there)
   // ---- attention half ----------------------------------------------------------------------
   if (f32_drop0) AVF_TRY(mask_copy_f32(w.dx_mid, w.gm_m, d.R * d.D, s, dr0));  // to_out sees dx_mid through its site-0 mask
   if (!grouped) AVF_TRY(linear_dw(d, gm, d.D, sv.o, d.I, g->w_out, w.gemm_ws, s));
@@ -661,17 +744,17 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   else
     AVF_TRY(attn_bwd_f32((const float*)sv.qkv, (const float*)sv.o, (const float*)w.d_o, sv.lse2, (float*)w.dqkv,
                          w.delta, d.B, d.N, d.H, d.dh, s));
-  if (!grouped) AVF_TRY(linear_dw(d, w.dqkv, 3 * d.I, sv.h1, d.D, g->w_qkv, w.gemm_ws, s));
   AVF_TRY(linear_dx(d, w.dqkv, 3 * d.I, p->w_qkv, l.wqkv_t, d.D, w.dh, AVF_EPI_NONE, nullptr, s));
   // dx_in may alias dx_out, which the grouped dW2 GEMM does not read (it uses the bf16 copy gy)
   if (d.gs16)
     AVF_TRY(layernorm_bwd(w.dh, d.dt, x_in, p->ln1_w, sv.mean1, sv.rstd1, w.dx_mid_lo, dx_in, dx_in_lo, g->ln1_w, g->ln1_b,
                           dx_in_colsum, w.ln_ws1, d.R, d.D, s, dr_prev2, grouped ? &folds.job[2] : nullptr, AVF_BF16, d.xdt,
-                          inq, ins));
+                          inq, ins, d.lnf ? sv.h1 : nullptr, p->ln1_b));
   else
     AVF_TRY(layernorm_bwd(w.dh, d.dt, x_in, p->ln1_w, sv.mean1, sv.rstd1, w.dx_mid, dx_in, lo ? dx_in_lo : nullptr,
                           g->ln1_w, g->ln1_b, dx_in_colsum, w.ln_ws1, d.R, d.D, s, dr_prev2,
-                          grouped ? &folds.job[2] : nullptr, AVF_F32, d.xdt, inq, ins));
+                          grouped ? &folds.job[2] : nullptr, AVF_F32, d.xdt, inq, ins, d.lnf ? sv.h1 : nullptr, p->ln1_b));
+  if (!grouped) AVF_TRY(linear_dw(d, w.dqkv, 3 * d.I, sv.h1, d.D, g->w_qkv, w.gemm_ws, s));  // (behind LN1': ln_fuse rebuilds h1)
   // one launch folds the split-K slabs of the four weight gradients and the three deferred column folds
   // (db1; dgamma2/dbeta2/dbo; dgamma1/dbeta1/previous layer's db2)
   if (grouped) AVF_TRY(gemm_bf16_tn_group(grp, s, &folds));

@@ -301,19 +301,24 @@ __global__ __launch_bounds__(256) void ln_bwd_reg_kernel(const DyT* __restrict__
                                                          bf16* __restrict__ dx_lo, float* __restrict__ partial,
                                                          int64_t rows, int D, int want_colsum, DropCfg drop,
                                                          uint8_t* __restrict__ dxq = nullptr,
-                                                         uint8_t* __restrict__ dxs = nullptr) {
+                                                         uint8_t* __restrict__ dxs = nullptr,
+                                                         bf16* __restrict__ h_out = nullptr,
+                                                         const float* __restrict__ beta = nullptr) {
+  // h_out (LayerNorm folded into the forward GEMM: the normalised rows were never stored): also write
+  // h = xhat * gamma + beta, the operand of this layer's weight-gradient GEMM
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [4 waves][3][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t row0 = (int64_t)blockIdx.x * LNR_ROWS_PER_BLOCK;
   const float invD = 1.0f / (float)D;
   const uint64_t dkey = drop.thresh16 ? drop_key(drop) : 0;
-  float4 g[NV], adg[NV], adb[NV], acs[NV];
+  float4 g[NV], adg[NV], adb[NV], acs[NV], bt[NV];
   bool act[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane * 4 + 256 * i;
     act[i] = c < D;
     g[i] = act[i] ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    bt[i] = (act[i] && h_out) ? *reinterpret_cast<const float4*>(beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     adg[i] = adb[i] = acs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   for (int rr = wave; rr < LNR_ROWS_PER_BLOCK; rr += 4) {
@@ -359,6 +364,9 @@ __global__ __launch_bounds__(256) void ln_bwd_reg_kernel(const DyT* __restrict__
       o.z = rs * (d[i].z * g[i].z - s1 - xh[i].z * s2) + r.z;
       o.w = rs * (d[i].w * g[i].w - s1 - xh[i].w * s2) + r.w;
       if (dx) *reinterpret_cast<float4*>(dx + row * D + c) = o;
+      if (h_out)  // wave-uniform
+        store4<bf16>(h_out + row * D + c, make_float4(fmaf(xh[i].x, g[i].x, bt[i].x), fmaf(xh[i].y, g[i].y, bt[i].y),
+                                                      fmaf(xh[i].z, g[i].z, bt[i].z), fmaf(xh[i].w, g[i].w, bt[i].w)));
       if (drop.thresh16) {  // what the Linear behind the dropout site sees: masked, rescaled
         const float4 f = drop_factor4(drop, dkey, (uint64_t)row * D + c);
         o.x *= f.x; o.y *= f.y; o.z *= f.z; o.w *= f.w;
@@ -447,8 +455,10 @@ size_t layernorm_bwd_ws(int64_t rows, int dim) {
 int layernorm_bwd(const void* dy, int dy_dtype, const void* xv, const float* gamma, const float* mean,
                   const float* rstd, const void* dres, float* dx, void* dx_lo, float* dgamma, float* dbeta,
                   float* dcolsum, void* ws, int64_t rows, int dim, hipStream_t s, const DropCfg& drop,
-                  FoldJob* defer_fold, int dres_dtype, int x_dtype, void* mx_q, void* mx_s) {
+                  FoldJob* defer_fold, int dres_dtype, int x_dtype, void* mx_q, void* mx_s, void* h_out, const float* beta) {
   AVF_REQUIRE(rows > 0 && dim > 0 && ws, "layernorm_bwd: bad arguments");
+  AVF_REQUIRE(!h_out || (beta && x_dtype == AVF_BF16 && dy_dtype == AVF_BF16 && dim % 4 == 0 && dim <= 1536),
+              "layernorm_bwd: the normalised rows (h_out) are written on the bf16 residual stream only, and need beta");
   AVF_REQUIRE(!mx_q || (mx_s && dy_dtype == AVF_BF16 && dim % 32 == 0 && dim <= 1536 && ((uintptr_t)mx_q & 3) == 0),
               "layernorm_bwd: the MX-FP8 image of dx needs bf16 dy, dim %% 32 == 0 and dim <= 1536 (dim=%d)", dim);
   AVF_REQUIRE(x_dtype == AVF_F32 || (x_dtype == AVF_BF16 && dy_dtype == AVF_BF16 && dim % 4 == 0 && dim <= 1536),
@@ -462,7 +472,7 @@ int layernorm_bwd(const void* dy, int dy_dtype, const void* xv, const float* gam
   AVF_REQUIRE((size_t)3 * dim * sizeof(float) <= 64 * 1024, "layernorm_bwd: dim %d too large", dim);
   TimingScope ts(KC_LAYERNORM, 0.0,
                  (double)rows * dim * ((dy_dtype == AVF_BF16 ? 2.0 : 4.0) + (x_dtype == AVF_BF16 ? 2.0 : 4.0) + (dres ? (dres_dtype == AVF_BF16 ? 2.0 : 4.0) : 0.0) +
-                                       (dx ? 4.0 : 0.0) + (dx_lo ? 2.0 : 0.0)), s, /*per_kernel=*/true);
+                                       (dx ? 4.0 : 0.0) + (dx_lo ? 2.0 : 0.0) + (h_out ? 2.0 : 0.0)), s, /*per_kernel=*/true);
   float* partial = (float*)ws;
   const int wc = dcolsum ? 1 : 0;
   int nb;
@@ -493,18 +503,18 @@ int layernorm_bwd(const void* dy, int dy_dtype, const void* xv, const float* gam
   do {                                                                                                                      \
     if (x_dtype == AVF_BF16 && dres_dtype == AVF_BF16)                                                                      \
       launch_in_scope(&ts, ln_bwd_reg_kernel<bf16, NVV, bf16, bf16>, dim3(nb), dim3(256), (uint32_t)lds, s, (const bf16*)dy,   \
-                      (const bf16*)xv, gamma, mean, rstd, (const bf16*)dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop, (uint8_t*)mx_q, (uint8_t*)mx_s); \
+                      (const bf16*)xv, gamma, mean, rstd, (const bf16*)dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop, (uint8_t*)mx_q, (uint8_t*)mx_s, (bf16*)h_out, beta); \
     else if (x_dtype == AVF_BF16)                                                                                           \
       launch_in_scope(&ts, ln_bwd_reg_kernel<bf16, NVV, float, bf16>, dim3(nb), dim3(256), (uint32_t)lds, s, (const bf16*)dy,  \
-                      (const bf16*)xv, gamma, mean, rstd, (const float*)dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop, (uint8_t*)mx_q, (uint8_t*)mx_s); \
+                      (const bf16*)xv, gamma, mean, rstd, (const float*)dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop, (uint8_t*)mx_q, (uint8_t*)mx_s, (bf16*)h_out, beta); \
     else if (dres_dtype == AVF_BF16)                                                                                        \
       launch_in_scope(&ts, ln_bwd_reg_kernel<bf16, NVV, bf16>, dim3(nb), dim3(256), (uint32_t)lds, s, (const bf16*)dy, x, gamma, \
                       mean, rstd, (const bf16*)dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop, (uint8_t*)mx_q,         \
-                      (uint8_t*)mx_s);                                                                                      \
+                      (uint8_t*)mx_s, (bf16*)nullptr, (const float*)nullptr);                                                \
     else                                                                                                                    \
       launch_in_scope(&ts, ln_bwd_reg_kernel<T, NVV, float>, dim3(nb), dim3(256), (uint32_t)lds, s, (const T*)dy, x, gamma, mean, \
                       rstd, (const float*)dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop, (uint8_t*)mx_q,              \
-                      (uint8_t*)mx_s);                                                                                      \
+                      (uint8_t*)mx_s, (bf16*)nullptr, (const float*)nullptr);                                                \
   } while (0)
 #define LAUNCH_T(T)                                   \
   switch (nv) {                                       \

@@ -18,6 +18,9 @@ for CFG in c2 c3 c4; do
   B="python $R/bench.py --config $CFG --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-events --no-extra"
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$CFG -o s -- python $R/bench.py --config $CFG --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-events --no-extra > $O/stats_$CFG.json 2> $O/stats_$CFG.err
   echo "$CFG stats done"
+  rm -f $O/shapes_$CFG.csv
+  AVF_SHAPE_LOG=$O/shapes_$CFG.csv timeout -k 10 300 python $R/bench.py --config $CFG --steps 1 --warmup 0 --launch eager --no-cpu-baseline --no-kernel-events --no-extra > /dev/null 2> $O/shapes_$CFG.err
+  echo "$CFG shape log done"
   timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_$CFG -o f -- $B > /dev/null 2> $O/fetch_$CFG.err
   echo "$CFG fetch done"
   timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_$CFG -o w -- $B > /dev/null 2> $O/write_$CFG.err
@@ -36,6 +39,9 @@ cd $R
 python tools/pmc_traffic.py $O/stats_c2/s_kernel_stats.csv $O/fetch_c2/f_counter_collection.csv $O/write_c2/w_counter_collection.csv $TAG c2
 python tools/pmc_traffic.py $O/stats_c3/s_kernel_stats.csv $O/fetch_c3/f_counter_collection.csv $O/write_c3/w_counter_collection.csv ${TAG}_c3 c3
 python tools/pmc_traffic.py $O/stats_c4/s_kernel_stats.csv $O/fetch_c4/f_counter_collection.csv $O/write_c4/w_counter_collection.csv ${TAG}_c4 c4
+for CFG in c2 c3 c4; do
+  python tools/shape_table.py $O/stats_$CFG/s_kernel_trace.csv $O/shapes_$CFG.csv profiles/${TAG}_${CFG}_shapes.csv $O/fetch_$CFG/f_counter_collection.csv $O/write_$CFG/w_counter_collection.csv > /dev/null
+done
 python tools/sq_summary.py $O/sq1/q_counter_collection.csv $O/sq2/q_counter_collection.csv $TAG
 cp $O/stats_real/s_kernel_stats.csv profiles/${TAG}_real_heads_kernel_stats.csv
 cp $O/stats_c5/s_kernel_stats.csv profiles/${TAG}_c5_mx8_kernel_stats.csv

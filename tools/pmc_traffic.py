@@ -28,7 +28,7 @@ def short(n):
 
 
 def klass(k):
-    for c in ("gemm_bf16_nt", "gemm_bf16_tn", "gemm_f32", "attn_fwd", "attn_dq", "attn_dkv", "ln_fwd", "ln_bwd"):
+    for c in ("gemm_bf16_nt", "gemm_bf16_tn", "gemm_f32", "attn_fwd", "attn_dq", "attn_dkv", "attn_bwd_m4", "ln_fwd", "ln_bwd"):
         if k.startswith(c):
             return c
     return None
