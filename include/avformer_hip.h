@@ -87,6 +87,14 @@ typedef struct avf_layer_cfg {
                           avf_layer_fwd then needs the workspace.  bit 1: the partial row statistics of x_in are already in the
                           workspace - set it for a layer whose x_in is the x_out of the preceding avf_layer_fwd call with the SAME
                           workspace and shapes (the layers of a stack above the first).                                  */
+  int32_t dw_overlap;  /* avf_layer_bwd, bf16 grouped weight-gradient path: the grouped dW launch (+ its fold) of a layer with
+                          layer_index > 0 goes to a low-priority side HIP stream owned by the library (ordered by events, recorded
+                          into a hipGraph capture like any other work) and runs UNDER the gradient chain of the next call, which
+                          must be the layer below with the SAME workspace; that call joins it before its last kernel.  The layer
+                          with layer_index 0 launches in-stream, so a stack walked top-down to layer 0 leaves nothing pending
+                          (avf_stack_join joins by hand).  The workspace holds two copies of the scratch (layer parity):
+                          avf_layer_workspace_bytes doubles.  A layer's weight gradients are complete on `stream` only after the
+                          NEXT avf_layer_bwd call (or avf_stack_join) returned.                                              */
 } avf_layer_cfg;
 
 /* fp32 master parameters of one layer, in state_dict order:
@@ -286,6 +294,9 @@ size_t avf_layer_lowp_bytes(const avf_layer_cfg* cfg);      /* bf16 weight copie
 size_t avf_layer_workspace_bytes(const avf_layer_cfg* cfg); /* scratch, reusable across layers      */
 size_t avf_layer_grad_stream_bytes(const avf_layer_cfg* cfg); /* bytes of one dx_out_lo / dx_in_lo buffer of avf_layer_bwd:
                                                                  R*D bf16, plus the MX-FP8 image behind it when cfg.mx8_bwd */
+/* cfg.dw_overlap: make `stream` wait for a weight-gradient launch still pending on the side stream of `workspace`
+ * (no-op when there is none) */
+int avf_stack_join(void* workspace, void* stream);
 
 /* refresh the bf16 weight copies from the fp32 masters (no-op in AVF_F32 mode) */
 int avf_layer_prepare_weights(const avf_layer_cfg* cfg, const avf_layer_params* p, void* lowp, void* stream);

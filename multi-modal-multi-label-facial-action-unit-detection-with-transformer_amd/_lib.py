@@ -28,7 +28,7 @@ class LayerCfg(C.Structure):
                 ("ln_eps", C.c_float), ("dropout_p", C.c_float), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32),
                 ("layer_index", C.c_int32), ("seed_dev", C.c_void_p), ("grad_stream_bf16", C.c_int32), ("mx8_fwd", C.c_int32),
                 ("resid_bf16", C.c_int32), ("mx8_bwd", C.c_int32), ("dx_out_mx8", C.c_int32), ("key_mask", C.c_void_p),
-                ("ln_fuse", C.c_int32)]
+                ("ln_fuse", C.c_int32), ("dw_overlap", C.c_int32)]
 
 
 PARAM_FIELDS = ("ln1_w", "ln1_b", "w_qkv", "w_out", "b_out", "ln2_w", "ln2_b", "w1", "b1", "w2", "b2")
@@ -60,6 +60,7 @@ SIGNATURES = {
     "avf_gemm_tn_group": (_int, [_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "avf_stack_quant_weights_mx8": (_int, [_vp, _int, _vp, _vp]),
     "avf_stack_ln_fold": (_int, [_vp, _int, _vp, _vp, _vp]),
+    "avf_stack_join": (_int, [_vp, _vp]),
     "avf_quant_mx8": (_int, [_int, _vp, _i64, _i64, _vp, _vp, _vp]),
     "avf_gemm_mx8_nt": (_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _i64, _vp, _i64,
                                _vp, _vp, _vp]),

@@ -178,15 +178,29 @@ __device__ __forceinline__ void store4<bf16>(bf16* p, float4 v) {
 // ---------------------------------------------------------------------------------------------
 // wave (64 lanes) reductions
 // ---------------------------------------------------------------------------------------------
+// Wave-wide reductions on the VALU: four DPP steps inside each row of 16 lanes (quad_perm [1,0,3,2] and [2,3,0,1], row_ror 4
+// and 8), then v_permlane16_swap / v_permlane32_swap across the four rows.  (__shfl_xor is a ds_bpermute - an LDS round trip
+// - and six dependent ones per reduction were most of a LayerNorm row's latency.)  Every lane ends with the same value.
+#define AVF_DPP_F32(v, ctrl) __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), (ctrl), 0xF, 0xF, true))
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += AVF_DPP_F32(v, 0xB1);
+  v += AVF_DPP_F32(v, 0x4E);
+  v += AVF_DPP_F32(v, 0x124);
+  v += AVF_DPP_F32(v, 0x128);
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, AVF_DPP_F32(v, 0xB1));
+  v = fmaxf(v, AVF_DPP_F32(v, 0x4E));
+  v = fmaxf(v, AVF_DPP_F32(v, 0x124));
+  v = fmaxf(v, AVF_DPP_F32(v, 0x128));
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
 // tanh-GELU exactly as models/heads.py:166 and its derivative

@@ -12,11 +12,72 @@
 //            dx_mid = dx_out + LN2'(dh2) ; dgamma2, dbeta2 ; dbo = colsum(dx_mid)   [fused in LN bwd]
 //            do = dx_mid Wo ; dWo = dx_mid^T o ; dqkv = attn'(do) ; dWqkv = dqkv^T h1 ; dh1 = dqkv Wqkv
 //            dx_in = dx_mid + LN1'(dh1) ; dgamma1, dbeta1
+#include <mutex>
+#include <vector>
+
 #include "common.hpp"
 
 namespace avf {
 
 namespace {
+
+// ---- cfg.dw_overlap: the grouped weight-gradient launch of a layer on a side stream -------------------------------
+// One record per workspace (= per stack): a low-priority non-blocking stream and two events.  The calls only enqueue
+// (event record / stream wait), so a hipGraph capture of the calling stream pulls the side stream into the capture and
+// the replayed graph carries the same fork / join edges.  The stream and events are created on first use - do a step
+// outside a capture first (a capture forbids nothing here, but a stream created inside one would outlive its graph idle).
+struct SideState {
+  void* ws;
+  int dev;
+  hipStream_t side;
+  hipEvent_t chain_done, group_done;
+  bool pending;
+};
+std::mutex g_side_mu;
+std::vector<SideState*> g_side;
+
+SideState* side_state(void* ws, bool create) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  for (SideState* t : g_side)
+    if (t->ws == ws && t->dev == dev) return t;
+  if (!create) return nullptr;
+  SideState* t = nullptr;
+  if (g_side.size() >= 64) {  // workspaces come and go with their stacks: recycle a record with nothing pending
+    for (SideState* o : g_side)
+      if (!o->pending && o->dev == dev) { t = o; break; }
+    if (!t) return nullptr;
+    t->ws = ws;
+    return t;
+  }
+  t = new SideState();
+  t->ws = ws;
+  t->dev = dev;
+  t->pending = false;
+  int least = 0, greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+  if (const char* e = getenv("AVF_DW_PRIO")) {  // tuning aid: 0 = default priority, 1 = highest
+    if (atoi(e) == 0) least = 0;
+    else if (atoi(e) == 1) least = greatest;
+  }
+  if (hipStreamCreateWithPriority(&t->side, hipStreamNonBlocking, least) != hipSuccess ||
+      hipEventCreateWithFlags(&t->chain_done, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&t->group_done, hipEventDisableTiming) != hipSuccess) {
+    delete t;
+    return nullptr;
+  }
+  g_side.push_back(t);
+  return t;
+}
+
+int side_join(SideState* t, hipStream_t s) {
+  if (t && t->pending) {
+    AVF_REQUIRE(hipStreamWaitEvent(s, t->group_done, 0) == hipSuccess, "layer_bwd: hipStreamWaitEvent failed");
+    t->pending = false;
+  }
+  return 0;
+}
 
 struct Dims {
   int64_t R;  // rows = batch * tokens
@@ -394,7 +455,12 @@ extern "C" size_t avf_layer_grad_stream_bytes(const avf_layer_cfg* cfg) {
 extern "C" size_t avf_layer_workspace_bytes(const avf_layer_cfg* cfg) {
   Dims d;
   if (make_dims(cfg, &d)) return 0;
-  return carve_work(d, nullptr, nullptr);
+  const size_t one = align_up(carve_work(d, nullptr, nullptr), 256);
+  return cfg->dw_overlap ? 2 * one : one;  // dw_overlap: one copy of the scratch per layer parity
+}
+
+extern "C" int avf_stack_join(void* workspace, void* stream) {
+  return side_join(side_state(workspace, false), (hipStream_t)stream);
 }
 
 extern "C" int avf_layer_prepare_weights(const avf_layer_cfg* cfg, const avf_layer_params* p, void* lowp,
@@ -569,9 +635,13 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   carve_saved(d, (void*)saved, &sv);
   LowP l;
   carve_lowp(d, (void*)lowp, &l);
-  Work w;
-  carve_work(d, workspace, &w);
   const bool lo = d.dt == AVF_BF16;
+  // dw_overlap: odd layers use the second copy of the scratch, so the chain of the layer below cannot overwrite what this
+  // layer's weight-gradient launch is still reading on the side stream
+  const bool ovl = cfg->dw_overlap && lo;
+  Work w;
+  carve_work(d, (char*)workspace + ((ovl && (d.layer & 1)) ? align_up(carve_work(d, nullptr, nullptr), 256) : 0), &w);
+  SideState* side = ovl ? side_state(workspace, true) : nullptr;
 
   // gradient of the layer output in the compute dtype (GEMM operand)
   // dropout: the Linears behind a dropout site see the masked, rescaled gradient (the residual stream does not)
@@ -617,6 +687,7 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
 
   // the grouped dW launch and its fold are shared with the general path
   if (small_bwd) {
+    AVF_TRY(side_join(side, s));  // (this path launches everything in-stream)
     float* pb1 = w.small_part;
     float* pln2 = pb1 + (size_t)d.B * d.M;
     float* pln1 = pln2 + (size_t)d.B * 3 * d.D;
@@ -745,6 +816,9 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
     AVF_TRY(attn_bwd_f32((const float*)sv.qkv, (const float*)sv.o, (const float*)w.d_o, sv.lse2, (float*)w.dqkv,
                          w.delta, d.B, d.N, d.H, d.dh, s));
   AVF_TRY(linear_dx(d, w.dqkv, 3 * d.I, p->w_qkv, l.wqkv_t, d.D, w.dh, AVF_EPI_NONE, nullptr, s));
+  // dw_overlap: the layer above may still be reading its gy - the buffer this layer's LN1' writes dx_in_lo into - and the
+  // scratch copy the layer below will use: join its weight-gradient launch here, as late as the data allows
+  AVF_TRY(side_join(side, s));
   // dx_in may alias dx_out, which the grouped dW2 GEMM does not read (it uses the bf16 copy gy)
   if (d.gs16)
     AVF_TRY(layernorm_bwd(w.dh, d.dt, x_in, p->ln1_w, sv.mean1, sv.rstd1, w.dx_mid_lo, dx_in, dx_in_lo, g->ln1_w, g->ln1_b,
@@ -757,6 +831,16 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   if (!grouped) AVF_TRY(linear_dw(d, w.dqkv, 3 * d.I, sv.h1, d.D, g->w_qkv, w.gemm_ws, s));  // (behind LN1': ln_fuse rebuilds h1)
   // one launch folds the split-K slabs of the four weight gradients and the three deferred column folds
   // (db1; dgamma2/dbeta2/dbo; dgamma1/dbeta1/previous layer's db2)
-  if (grouped) AVF_TRY(gemm_bf16_tn_group(grp, s, &folds));
+  if (grouped && side && d.layer > 0) {
+    // fork: the launch waits for this layer's chain, then runs beside the chain of the layer below (whose call joins it)
+    AVF_REQUIRE(hipEventRecord(side->chain_done, s) == hipSuccess &&
+                    hipStreamWaitEvent(side->side, side->chain_done, 0) == hipSuccess,
+                "layer_bwd: fork to the side stream failed");
+    AVF_TRY(gemm_bf16_tn_group(grp, side->side, &folds));
+    AVF_REQUIRE(hipEventRecord(side->group_done, side->side) == hipSuccess, "layer_bwd: hipEventRecord failed");
+    side->pending = true;
+  } else if (grouped) {
+    AVF_TRY(gemm_bf16_tn_group(grp, s, &folds));
+  }
   return 0;
 }

@@ -123,6 +123,110 @@ __global__ __launch_bounds__(256) void ln_fwd_reg_kernel(const InT* __restrict__
   }
 }
 
+static int ln_row8_on() {
+  static const int on = [] {
+    const char* e = getenv("AVF_LN_ROW8");  // tuning / A-B aid: 0 = the one-row-per-wave kernels
+    return (e && *e) ? atoi(e) : 1;
+  }();
+  return on;
+}
+
+// ---- the bf16 residual stream's kernels (bf16 in, bf16 out, D % 8 == 0, D <= 512 * NV8) -----------------------------
+// A lane owns 8 consecutive columns per 512 (one 16-byte access); a wave works on RU rows at once with all their loads in
+// flight before the first reduction: 4 x 4 rows per workgroup, ~10 waves per CU x RU KiB per stream in flight (the
+// one-row-per-wave form had 1 KiB per wave and ran at 2.5 TB/s).
+__device__ __forceinline__ void unpack8(const uint4& r, float (&v)[8]) {
+  v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+  v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+  v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
+  v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
+  return make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+}
+__device__ __forceinline__ void load8f(const float* p, float (&v)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+template <int NV8, int RU>
+__global__ __launch_bounds__(256) void ln_fwd_row8_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, bf16* __restrict__ y,
+                                                          float* __restrict__ mean, float* __restrict__ rstd, int64_t rows,
+                                                          int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RU;
+  if (row0 >= rows) return;
+  uint4 raw[RU][NV8];
+#pragma unroll
+  for (int r = 0; r < RU; ++r) {
+    const int64_t row = row0 + r < rows ? row0 + r : rows - 1;  // (rows past the end re-read the last one; nothing is stored)
+#pragma unroll
+    for (int i = 0; i < NV8; ++i) {
+      const int c = lane * 8 + 512 * i;
+      raw[r][i] = c < D ? *reinterpret_cast<const uint4*>(x + row * D + c) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+  float gm[NV8][8], bt[NV8][8];
+#pragma unroll
+  for (int i = 0; i < NV8; ++i) {
+    const int c = lane * 8 + 512 * i;
+    if (c < D) {
+      load8f(gamma + c, gm[i]);
+      load8f(beta + c, bt[i]);
+    }
+  }
+  const float invD = 1.0f / (float)D;
+  float mu[RU], rs[RU];
+#pragma unroll
+  for (int r = 0; r < RU; ++r) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV8; ++i) {
+      float v[8];
+      unpack8(raw[r][i], v);
+      s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    mu[r] = wave_sum(s) * invD;
+  }
+#pragma unroll
+  for (int r = 0; r < RU; ++r) {
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV8; ++i) {
+      if (lane * 8 + 512 * i < D) {
+        float v[8];
+        unpack8(raw[r][i], v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float a = v[k] - mu[r];
+          q = fmaf(a, a, q);
+        }
+      }
+    }
+    rs[r] = 1.0f / sqrtf(wave_sum(q) * invD + eps);
+  }
+#pragma unroll
+  for (int r = 0; r < RU; ++r) {
+    if (row0 + r >= rows) break;
+    if (lane == 0) {
+      mean[row0 + r] = mu[r];
+      rstd[row0 + r] = rs[r];
+    }
+#pragma unroll
+    for (int i = 0; i < NV8; ++i) {
+      const int c = lane * 8 + 512 * i;
+      if (c < D) {
+        float v[8], o[8];
+        unpack8(raw[r][i], v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (v[k] - mu[r]) * rs[r] * gm[i][k] + bt[i][k];
+        *reinterpret_cast<uint4*>(y + (row0 + r) * D + c) = pack8(o);
+      }
+    }
+  }
+}
+
 int layernorm_fwd(const void* xv, const float* gamma, const float* beta, void* y, int y_dtype, float* mean,
                   float* rstd, int64_t rows, int dim, float eps, hipStream_t s, void* mx_q, void* mx_s, int x_dtype) {
   AVF_REQUIRE(rows > 0 && dim > 0, "layernorm_fwd: bad shape rows=%lld dim=%d", (long long)rows, dim);
@@ -133,6 +237,20 @@ int layernorm_fwd(const void* xv, const float* gamma, const float* beta, void* y
   TimingScope ts(KC_LAYERNORM, 0.0, (double)rows * dim * ((x_dtype == AVF_BF16 ? 2.0 : 4.0) + (y_dtype == AVF_BF16 ? 2.0 : 4.0) +
                                                          (mx_q ? 1.03125 : 0.0)), s, /*per_kernel=*/true);
   dim3 grid((unsigned)ceil_div(rows, 4)), block(256);
+  if (x_dtype == AVF_BF16 && !mx_q && dim % 8 == 0 && ln_row8_on()) {  // four rows per wave, 16-byte accesses
+    const bf16* xb = (const bf16*)xv;
+    constexpr int RU = 4;
+    dim3 g8((unsigned)ceil_div(rows, 4 * RU));
+#define LAUNCH_R8(NVV)                                                                                                       \
+  launch_in_scope(&ts, ln_fwd_row8_kernel<NVV, RU>, g8, block, 0, s, xb, gamma, beta, (bf16*)y, mean, rstd, rows, dim, eps)
+    switch ((dim + 511) / 512) {
+      case 1: LAUNCH_R8(1); break;
+      case 2: LAUNCH_R8(2); break;
+      default: LAUNCH_R8(3); break;
+    }
+#undef LAUNCH_R8
+    return check_launch("ln_fwd_row8_kernel");
+  }
   if (x_dtype == AVF_BF16) {  // bf16 residual stream: bf16 in, bf16 out (+ optional MX-FP8 image)
     const bf16* xb = (const bf16*)xv;
 #define LAUNCH_LO(NVV)                                                                                                    \
@@ -448,6 +566,129 @@ int fold_partials(const float* partial, int nb, int width, float* out, hipStream
 
 int fold_job(const FoldJob& j, hipStream_t s) { return launch_fold(j.partial, j.nb, j.width, j.o0, j.o1, j.o2, j.seg, s); }
 
+// LayerNorm backward on the all-bf16 streams (dy, x, the incoming residual gradient and dx in bf16; no dropout, no MX image):
+// the row8 layout of ln_fwd_row8_kernel.  A workgroup owns LNR_ROWS_PER_BLOCK = 4 waves x RU rows; the per-column sums stay in
+// registers and are combined through LDS in wave order, so the partial of a block - and the folded result - is deterministic.
+template <int NV8, int RU, bool HOUT>
+__global__ __launch_bounds__(256) void ln_bwd_row8_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, const bf16* __restrict__ dres,
+                                                          bf16* __restrict__ dx_lo, float* __restrict__ partial, int64_t rows,
+                                                          int D, int want_colsum, bf16* __restrict__ h_out,
+                                                          const float* __restrict__ beta) {
+  static_assert((LNR_ROWS_PER_BLOCK / 4) % RU == 0, "a wave's rows come in whole batches of RU");
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [4 waves][3][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float gm[NV8][8], bt[NV8][8];
+#pragma unroll
+  for (int i = 0; i < NV8; ++i) {
+    const int c = lane * 8 + 512 * i;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) gm[i][k] = bt[i][k] = 0.f;
+    if (c < D) {
+      load8f(gamma + c, gm[i]);
+      if (HOUT) load8f(beta + c, bt[i]);
+    }
+  }
+  float adg[NV8][8], adb[NV8][8], acs[NV8][8];
+#pragma unroll
+  for (int i = 0; i < NV8; ++i)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) adg[i][k] = adb[i][k] = acs[i][k] = 0.f;
+  const float invD = 1.0f / (float)D;
+#pragma unroll 1
+  for (int batch = 0; batch < LNR_ROWS_PER_BLOCK / 4 / RU; ++batch) {
+  const int64_t row0 = (int64_t)blockIdx.x * LNR_ROWS_PER_BLOCK + wave * (LNR_ROWS_PER_BLOCK / 4) + batch * RU;
+  uint4 rd[RU][NV8], rx[RU][NV8], rr[RU][NV8];
+  float mu[RU], rs[RU];
+#pragma unroll
+  for (int r = 0; r < RU; ++r) {
+    const int64_t row = row0 + r < rows ? row0 + r : rows - 1;
+#pragma unroll
+    for (int i = 0; i < NV8; ++i) {
+      const int c = lane * 8 + 512 * i;
+      const bool ok = c < D;
+      rd[r][i] = ok ? *reinterpret_cast<const uint4*>(dy + row * D + c) : make_uint4(0u, 0u, 0u, 0u);
+      typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));  // last use of this x row in the step: non-temporal
+      u32x4_nt xv = {0u, 0u, 0u, 0u};
+      if (ok) xv = __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(x + row * D + c));
+      rx[r][i] = make_uint4(xv[0], xv[1], xv[2], xv[3]);
+      rr[r][i] = (ok && dres) ? *reinterpret_cast<const uint4*>(dres + row * D + c) : make_uint4(0u, 0u, 0u, 0u);
+    }
+    mu[r] = mean[row];
+    rs[r] = rstd[row];
+  }
+  float s1[RU], s2[RU];
+#pragma unroll
+  for (int r = 0; r < RU; ++r) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV8; ++i) {
+      float d[8], v[8];
+      unpack8(rd[r][i], d);
+      unpack8(rx[r][i], v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float g = d[k] * gm[i][k];
+        a += g;
+        b = fmaf(g, (v[k] - mu[r]) * rs[r], b);
+      }
+    }
+    s1[r] = a;
+    s2[r] = b;
+  }
+#pragma unroll
+  for (int r = 0; r < RU; ++r) {
+    s1[r] = wave_sum(s1[r]) * invD;
+    s2[r] = wave_sum(s2[r]) * invD;  // mean(g * xhat)
+  }
+#pragma unroll
+  for (int r = 0; r < RU; ++r) {
+    if (row0 + r >= rows) break;
+#pragma unroll
+    for (int i = 0; i < NV8; ++i) {
+      const int c = lane * 8 + 512 * i;
+      if (c >= D) continue;
+      float d[8], v[8], e[8], o[8];
+      unpack8(rd[r][i], d);
+      unpack8(rx[r][i], v);
+      unpack8(rr[r][i], e);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float xh = (v[k] - mu[r]) * rs[r];
+        o[k] = rs[r] * (d[k] * gm[i][k] - s1[r] - xh * s2[r]) + e[k];
+        adg[i][k] = fmaf(d[k], xh, adg[i][k]);
+        adb[i][k] += d[k];
+        acs[i][k] += o[k];
+        if (HOUT) v[k] = fmaf(xh, gm[i][k], bt[i][k]);
+      }
+      *reinterpret_cast<uint4*>(dx_lo + (row0 + r) * D + c) = pack8(o);
+      if (HOUT) *reinterpret_cast<uint4*>(h_out + (row0 + r) * D + c) = pack8(v);
+    }
+  }
+  }  // batch
+  float* mine = lds + wave * 3 * D;
+#pragma unroll
+  for (int i = 0; i < NV8; ++i) {
+    const int c = lane * 8 + 512 * i;
+    if (c >= D) continue;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      *reinterpret_cast<float4*>(mine + c + 4 * h) = make_float4(adg[i][4 * h], adg[i][4 * h + 1], adg[i][4 * h + 2], adg[i][4 * h + 3]);
+      *reinterpret_cast<float4*>(mine + D + c + 4 * h) = make_float4(adb[i][4 * h], adb[i][4 * h + 1], adb[i][4 * h + 2], adb[i][4 * h + 3]);
+      *reinterpret_cast<float4*>(mine + 2 * D + c + 4 * h) = make_float4(acs[i][4 * h], acs[i][4 * h + 1], acs[i][4 * h + 2], acs[i][4 * h + 3]);
+    }
+  }
+  __syncthreads();
+  float4* out = reinterpret_cast<float4*>(partial + (int64_t)blockIdx.x * 3 * D);
+  const float4* l4 = reinterpret_cast<const float4*>(lds);
+  const int n4 = (want_colsum ? 3 * D : 2 * D) >> 2, w4 = (3 * D) >> 2;
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    const float4 a = l4[i], b = l4[w4 + i], c = l4[2 * w4 + i], d = l4[3 * w4 + i];
+    out[i] = make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
+  }
+}
+
 size_t layernorm_bwd_ws(int64_t rows, int dim) {
   return (size_t)ceil_div(rows, LNR_ROWS_PER_BLOCK) * 3 * dim * sizeof(float);  // LNR < LNB: covers both paths
 }
@@ -499,6 +740,38 @@ int layernorm_bwd(const void* dy, int dy_dtype, const void* xv, const float* gam
         raised.mark();
       }
     }
+    const bool row8 = x_dtype == AVF_BF16 && dy_dtype == AVF_BF16 && (!dres || dres_dtype == AVF_BF16) && !dx && dx_lo &&
+                      !drop.thresh16 && !mx_q && dim % 8 == 0 && ln_row8_on();
+    if (row8) {
+      if (lds > 64 * 1024) {
+        static PerDeviceOnce raised8;
+        if (raised8.need()) {
+          hipError_t e1 = hipFuncSetAttribute((const void*)ln_bwd_row8_kernel<3, 1, false>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 3 * 1536 * 4);
+          hipError_t e2 = hipFuncSetAttribute((const void*)ln_bwd_row8_kernel<3, 1, true>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 3 * 1536 * 4);
+          AVF_REQUIRE(e1 == hipSuccess && e2 == hipSuccess, "layernorm_bwd: cannot raise dynamic LDS limit");
+          raised8.mark();
+        }
+      }
+#define LAUNCH_R8(NVV, RU)                                                                                                   \
+  do {                                                                                                                       \
+    if (h_out)                                                                                                               \
+      launch_in_scope(&ts, ln_bwd_row8_kernel<NVV, RU, true>, dim3(nb), dim3(256), (uint32_t)lds, s, (const bf16*)dy,         \
+                      (const bf16*)xv, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx_lo, partial, rows, dim, wc, (bf16*)h_out, beta); \
+    else                                                                                                                     \
+      launch_in_scope(&ts, ln_bwd_row8_kernel<NVV, RU, false>, dim3(nb), dim3(256), (uint32_t)lds, s, (const bf16*)dy,        \
+                      (const bf16*)xv, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx_lo, partial, rows, dim, wc, (bf16*)nullptr, \
+                      (const float*)nullptr);                                                                                \
+  } while (0)
+      switch ((dim + 511) / 512) {  // rows in flight per wave: what the register file allows at two waves per SIMD or more
+        case 1: LAUNCH_R8(1, 4); break;
+        case 2: LAUNCH_R8(2, 2); break;
+        default: LAUNCH_R8(3, 1); break;
+      }
+#undef LAUNCH_R8
+      AVF_TRY(check_launch("ln_bwd_row8_kernel"));
+    } else {
 #define LAUNCH_NV(T, NVV)                                                                                                   \
   do {                                                                                                                      \
     if (x_dtype == AVF_BF16 && dres_dtype == AVF_BF16)                                                                      \
@@ -528,6 +801,7 @@ int layernorm_bwd(const void* dy, int dy_dtype, const void* xv, const float* gam
 #undef LAUNCH_T
 #undef LAUNCH_NV
     AVF_TRY(check_launch("ln_bwd_reg_kernel"));
+    }
   } else {
     nb = (int)ceil_div(rows, LNB_ROWS_PER_BLOCK);
     const size_t lds = (size_t)3 * dim * sizeof(float);

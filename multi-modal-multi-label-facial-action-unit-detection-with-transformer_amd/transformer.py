@@ -122,7 +122,7 @@ class _StackFn(torch.autograd.Function):
         # the L layer configurations are rebuilt only when something in them changes (shape, live dropout, seed / mask pointers)
         ckey = (B, N, mod.training, mod.dropout, None if seed_t is None else seed_t.data_ptr(),
                 None if keep is None else keep.data_ptr(), mod.compute_dtype, mod.mx8, mod.mx8_bwd, mod.resid_bf16,
-                mod.__dict__.get("ln_fuse", False))
+                mod.__dict__.get("ln_fuse", False), mod.__dict__.get("dw_overlap", False))
         chit = mod.__dict__.get("_cfg_cache")
         if chit is not None and chit[0] == ckey:
             cfgs = chit[1]
@@ -240,6 +240,22 @@ class _StackFn(torch.autograd.Function):
                                               _ptr(lo_a) if have_lo else None,
                                               _ptr(views[L - 1][B2]) if top_colsum else None, B, N, D, stream),
                        "token_mean_bwd")
+        deferred = bool(cfg.dw_overlap)
+
+        def hand_over(l):
+            waiter = hook(l, flats[l]) if hook is not None else None  # e.g. launch this layer's all-reduce now
+            # Parameter gradients are handed over directly (views of the layer's flat buffer, no copy):
+            # ``.grad = view`` when empty, ``.grad += view`` when accumulating.
+            for p, v in zip(live[l * PARAMS_PER_LAYER:(l + 1) * PARAMS_PER_LAYER], views[l]):
+                if not p.requires_grad:
+                    continue
+                if p.grad is None:
+                    p.grad = v
+                else:
+                    if waiter is not None:
+                        waiter()  # accumulation needs the reduced values
+                    p.grad.add_(v)
+
         for l in reversed(range(L)):
             gp = _lib.LayerPtrs(*[base + 4 * l * per_layer + o for o in offs])
             pp = mod._param_struct(ctx.params, l)
@@ -255,18 +271,17 @@ class _StackFn(torch.autograd.Function):
                        f"layer_bwd[{l}]")
             lo_a, lo_b = lo_b, lo_a
             have_lo = bf16
-            waiter = hook(l, flats[l]) if hook is not None else None  # e.g. launch this layer's all-reduce now
-            # Parameter gradients are handed over directly (views of the layer's flat buffer, no copy):
-            # ``.grad = view`` when empty, ``.grad += view`` when accumulating.
-            for p, v in zip(live[l * PARAMS_PER_LAYER:(l + 1) * PARAMS_PER_LAYER], views[l]):
-                if not p.requires_grad:
-                    continue
-                if p.grad is None:
-                    p.grad = v
-                else:
-                    if waiter is not None:
-                        waiter()  # accumulation needs the reduced values
-                    p.grad.add_(v)
+            # dw_overlap: the weight gradients of layer l are complete on this stream once the call for layer l - 1 has
+            # joined the side stream (layer 0 launches in-stream) - hand a layer over one call late
+            if not deferred:
+                hand_over(l)
+            else:
+                if l < L - 1:
+                    hand_over(l + 1)
+                if l == 0:
+                    hand_over(0)
+        if deferred:
+            _lib.check(lib.avf_stack_join(_ptr(ws), stream), "stack_join")  # (nothing pending after layer 0: a no-op)
         _check_canaries()
         ctx.saved_bufs = None
         ctx.xs = None
@@ -318,6 +333,12 @@ class Transformer(nn.Module):
         # (or ``stack.ln_fuse = True`` where ``ln_fuse_ok``).
         self.ln_fuse_ok = bool(self.resid_bf16 and not self.mx8 and dim % 64 == 0 and mlp_dim % 4 == 0)
         self.ln_fuse = bool(self.ln_fuse_ok and os.environ.get("AVF_LN_FUSE", "0") == "1")
+        # backward: a layer's grouped weight-gradient launch on a low-priority side stream, under the gradient chain of the
+        # layer below (avformer_hip.h cfg.dw_overlap).  Built and measured in round 3: the launches do
+        # overlap (54 of 62 us, rocprofv3) but the step does not get shorter - the two kernels contend for the same L2 -> LDS
+        # path - and a hipGraph replay of the forked capture is 2.2x slower, so it is OFF unless AVF_DW_OVERLAP=1 (or
+        # ``stack.dw_overlap = True`` before the first step).
+        self.dw_overlap = bool(self.compute_dtype == _lib.BF16 and depth >= 2 and os.environ.get("AVF_DW_OVERLAP", "0") == "1")
         self.project_out = not (heads == 1 and dim_head == dim)
         self.layers = nn.ModuleList([_make_layer(dim, heads, dim_head, mlp_dim, dropout) for _ in range(depth)])
         if not self.project_out:
@@ -396,7 +417,8 @@ class Transformer(nn.Module):
                              int(self.mx8_bwd and layer < self.depth - 1), None if keep is None else keep.data_ptr(),
                              # LayerNorm folded into to_qkv / net.0 (bit 0); layers above the first find the row statistics
                              # of their input in the shared workspace, left there by the layer below (bit 1)
-                             ((1 | (2 if layer > 0 else 0)) if (self.ln_fuse and self.ln_fuse_ok and keep is None) else 0))
+                             ((1 | (2 if layer > 0 else 0)) if (self.ln_fuse and self.ln_fuse_ok and keep is None) else 0),
+                             int(bool(self.__dict__.get("dw_overlap", False)) and self.compute_dtype == _lib.BF16))
 
     def _grad_stream_bf16(self, p: float) -> bool:
         """backward keeps the residual gradient between the LayerNorm backward kernels in bf16 (the GEMMs read that image

@@ -67,7 +67,8 @@ def test_library_adam_and_checkpoint_round_trip():
             m(x).pow(2).mean().backward()
             o.step()
     for (k, a), (_, b) in zip(t.named_parameters(), ref.named_parameters()):
-        torch.testing.assert_close(a, b, atol=2e-4, rtol=2e-3, msg=lambda m, k=k: f"{k}: {m}")
+        # (Adam turns a last-bit difference of a near-zero gradient element into a visible fraction of one lr = 1e-2 step)
+        torch.testing.assert_close(a, b, atol=5e-4, rtol=2e-3, msg=lambda m, k=k: f"{k}: {m}")
     assert torch.equal(t._identity_w, torch.eye(r["dim"], device=DEV))  # the frozen identity is never stepped
     sd = opt.state_dict()  # only real parameters carry optimizer state
     assert len(sd["state"]) == len(list(t.parameters()))
