@@ -294,6 +294,19 @@ size_t avf_layer_lowp_bytes(const avf_layer_cfg* cfg);      /* bf16 weight copie
 size_t avf_layer_workspace_bytes(const avf_layer_cfg* cfg); /* scratch, reusable across layers      */
 size_t avf_layer_grad_stream_bytes(const avf_layer_cfg* cfg); /* bytes of one dx_out_lo / dx_in_lo buffer of avf_layer_bwd:
                                                                  R*D bf16, plus the MX-FP8 image behind it when cfg.mx8_bwd */
+/* ---- FeedForward sublayer (heads.py:188-199) as one launch per direction (csrc/mlp_fused.hip) ----
+ * bf16 operands; rows % 64 == 0, dim in {256, 512, 768}, mlp_dim % 128 == 0 (avf_mlp_fused_ok says).
+ * forward:  u = h W1^T + b1 (saved), g = gelu(u) (saved), x_out = g W2^T + b2 + x_mid;  x_dtype: type of x_mid / x_out.
+ * backward: du = (dy W2) o gelu'(u), dh = du W1; w2_t = W2^T [mlp_dim, dim], w1_t = W1^T [dim, mlp_dim] (the images
+ *           avf_layer_prepare_weights keeps); colsum_partial [avf_mlp_fused_bwd_partial_rows(rows)][mlp_dim] fp32: summed over
+ *           its rows it is db1.                                                                                             */
+int avf_mlp_fused_ok(int64_t rows, int dim, int mlp_dim);
+int avf_mlp_fused_fwd(const void* h, const void* w1, const float* b1, const void* w2, const float* b2, const void* x_mid,
+                      int x_dtype, void* x_out, void* u, void* g, int64_t rows, int dim, int mlp_dim, void* stream);
+size_t avf_mlp_fused_bwd_partial_rows(int64_t rows);
+int avf_mlp_fused_bwd(const void* dy, const void* w2_t, const void* w1_t, const void* u, void* du, void* dh,
+                      float* colsum_partial, int64_t rows, int dim, int mlp_dim, void* stream);
+
 /* cfg.dw_overlap: make `stream` wait for a weight-gradient launch still pending on the side stream of `workspace`
  * (no-op when there is none) */
 int avf_stack_join(void* workspace, void* stream);

@@ -61,6 +61,10 @@ SIGNATURES = {
     "avf_stack_quant_weights_mx8": (_int, [_vp, _int, _vp, _vp]),
     "avf_stack_ln_fold": (_int, [_vp, _int, _vp, _vp, _vp]),
     "avf_stack_join": (_int, [_vp, _vp]),
+    "avf_mlp_fused_ok": (_int, [_i64, _int, _int]),
+    "avf_mlp_fused_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _i64, _int, _int, _vp]),
+    "avf_mlp_fused_bwd_partial_rows": (_sz, [_i64]),
+    "avf_mlp_fused_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp]),
     "avf_quant_mx8": (_int, [_int, _vp, _i64, _i64, _vp, _vp, _vp]),
     "avf_gemm_mx8_nt": (_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _i64, _vp, _i64,
                                _vp, _vp, _vp]),

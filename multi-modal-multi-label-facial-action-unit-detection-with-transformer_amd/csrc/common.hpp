@@ -522,6 +522,12 @@ int attn_bwd_bf16(const bf16* qkv, const bf16* o, const bf16* d_o, const float* 
                   int B, int N, int H, int dh, hipStream_t s, bool q_prescaled = false, float* nlse = nullptr);
 int attn_delta(int dtype, const void* o, const void* d_o, float* delta, int B, int N, int H, int dh, hipStream_t s);
 // merged dQ + dK/dV kernel (attn_bwd_merged.hip): dim_head 64, pre-scaled q, N <= 512
+// mlp_fused.hip: the FeedForward sublayer as one kernel per direction (bf16 operands; R % 64 == 0, D in {256, 512, 768}, M % 128 == 0)
+bool mlp_fused_ok(int64_t R, int D, int M);
+int mlp_fused_fwd(const void* h, const void* w1, const float* b1, const void* w2, const float* b2, const void* x_mid, int x_dtype,
+                  void* x_out, void* u, void* g, int64_t R, int D, int M, hipStream_t s);
+int mlp_fused_bwd(const void* dy, const void* w2_t, const void* w1_t, const void* u, void* du, void* dh, float* cs_partial,
+                  int64_t R, int D, int M, hipStream_t s);
 bool attn_bwd_merged_ok(int N, int dh, bool q_prescaled);
 int attn_bwd_merged(const TimingScope* ts, const bf16* qkv, const bf16* o, const bf16* d_o, const float* lse2, bf16* dqkv,
                     int B, int N, int H, hipStream_t s);

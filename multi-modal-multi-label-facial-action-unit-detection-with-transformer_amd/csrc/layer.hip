@@ -71,6 +71,14 @@ SideState* side_state(void* ws, bool create) {
   return t;
 }
 
+int mlp_fused_on() {
+  static const int on = [] {
+    const char* e = getenv("AVF_MLP_FUSED");  // the FeedForward sublayer as one launch per direction
+    return (e && *e) ? atoi(e) : 0;
+  }();
+  return on;
+}
+
 int side_join(SideState* t, hipStream_t s) {
   if (t && t->pending) {
     AVF_REQUIRE(hipStreamWaitEvent(s, t->group_done, 0) == hipSuccess, "layer_bwd: hipStreamWaitEvent failed");
@@ -613,6 +621,8 @@ extern "C" int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p
                 dr2 = make_drop(d.p, d.seed, d.layer, 2, d.seed_dev);
   AVF_TRY(linear_fwd(d, sv.o, d.I, wo, d.D, sv.x_mid, d.xdt, AVF_EPI_BIAS_RES, p->b_out, x_in, nullptr, s, dr0));
   AVF_TRY(layernorm_fwd(sv.x_mid, p->ln2_w, p->ln2_b, sv.h2, d.dt, sv.mean2, sv.rstd2, d.R, d.D, cfg->ln_eps, s, nullptr, nullptr, d.xdt));
+  if (lo && d.p == 0.f && mlp_fused_on() && mlp_fused_ok(d.R, d.D, d.M))  // FeedForward as one launch (mlp_fused.hip)
+    return mlp_fused_fwd(sv.h2, w1, p->b1, w2, p->b2, sv.x_mid, d.xdt, x_out, sv.u, sv.g, d.R, d.D, d.M, s);
   AVF_TRY(linear_fwd(d, sv.h2, d.D, w1, d.M, sv.g, d.dt, AVF_EPI_BIAS_GELU, p->b1, nullptr, sv.u, s, dr1));
   AVF_TRY(linear_fwd(d, sv.g, d.M, w2, d.D, x_out, d.xdt, AVF_EPI_BIAS_RES, p->b2, sv.x_mid, nullptr, s, dr2));
   return 0;
@@ -774,9 +784,16 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
       ins = (char*)dx_in_lo + grad_s_off(d.R, d.D);
     }
   }
+  const bool fused_mlp = lo && !d.mxb && d.p == 0.f && mlp_fused_on() && mlp_fused_ok(d.R, d.D, d.M);
+  // (its column-sum partials, [R / 32][M] floats, fit the dGELU GEMM's: gemm_nt_colsum_ws)
   if (d.mxb) {
     AVF_TRY(linear_dx_mx(d, gyq, gys, d.D, l.w2t_q, l.w2t_s, d.M, w.du, AVF_EPI_DGELU, sv.u, s, g->b1, w.cs_ws, dr1,
                          grouped ? &folds.job[0] : nullptr, w.duq, w.dus));
+  } else if (fused_mlp) {  // du, db1 partials and dh2 in one launch (mlp_fused.hip)
+    AVF_TRY(mlp_fused_bwd(gy, l.w2_t, l.w1_t, sv.u, w.du, w.dh, (float*)w.cs_ws, d.R, d.D, d.M, s));
+    const FoldJob fj{(const float*)w.cs_ws, (int)(2 * (d.R / 64)), d.M, d.M, g->b1, nullptr, nullptr};
+    if (grouped) folds.job[0] = fj;
+    else AVF_TRY(fold_job(fj, s));
   } else if (lo) {  // db1 = colsum(du) fused into the dGELU GEMM epilogue
     AVF_TRY(linear_dx(d, gy, d.D, p->w2, l.w2_t, d.M, w.du, AVF_EPI_DGELU, sv.u, s, g->b1, w.cs_ws, dr1,
                       grouped ? &folds.job[0] : nullptr));
@@ -787,7 +804,7 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   if (d.mxb)
     AVF_TRY(linear_dx_mx(d, w.duq, w.dus, d.M, l.w1t_q, l.w1t_s, d.D, w.dh, AVF_EPI_NONE, nullptr, s, nullptr, nullptr, kNoDrop,
                          nullptr));
-  else
+  else if (!fused_mlp)
     AVF_TRY(linear_dx(d, w.du, d.M, p->w1, l.w1_t, d.D, w.dh, AVF_EPI_NONE, nullptr, s));
   if (d.gs16)  // residual gradient in: the bf16 image the GEMMs read; out: the bf16 dx_mid only
     AVF_TRY(layernorm_bwd(w.dh, d.dt, sv.x_mid, p->ln2_w, sv.mean2, sv.rstd2, gy, nullptr, w.dx_mid_lo, g->ln2_w, g->ln2_b,
