@@ -100,6 +100,28 @@ struct TileStager {
 // =============================================================================================
 // forward
 // =============================================================================================
+__device__ __forceinline__ float vmax(float a, float b) {  // v_max_f32 without the NaN-canonicalising pre-ops
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// max over the four lanes {li, li+16, li+32, li+48} (the four key groups of one query column), VALU only
+__device__ __forceinline__ float colmax4(float v) {
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = vmax(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return vmax(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
+// sum over the four lanes {li, li+16, li+32, li+48}
+__device__ __forceinline__ float colsum4(float v) {
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 template <int DH>
 __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
                                                             float* __restrict__ lse2, int /*B*/, int N, int H, int qs) {
@@ -195,8 +217,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16* __res
             if (TAIL && (t * 64 + kb * 16 + 4 * lg + r >= N)) st[kb][qb][r] = -INFINITY;
             tmax = fmaxf(tmax, st[kb][qb][r]);  // raw scores: the scale c > 0 commutes with max
           }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        tmax = colmax4(tmax);
         const float mn = fmaxf(m[qb], tmax * c);
         const float alpha = __builtin_amdgcn_exp2f(m[qb] - mn);
         m[qb] = mn;
@@ -247,8 +268,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16* __res
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     float l = lsum[qb];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    l = colsum4(l);
     const int q = q0 + qb * 16 + li;
     if (q < N) {
       const float inv = 1.0f / l;
@@ -324,28 +344,6 @@ __device__ __forceinline__ void glds4(const void* g, char* l) {
 }
 
 __device__ __forceinline__ void wait_all_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-__device__ __forceinline__ float vmax(float a, float b) {  // v_max_f32 without the NaN-canonicalising pre-ops
-  float r;
-  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-
-// max over the four lanes {li, li+16, li+32, li+48} (the four key groups of one query column), VALU only
-__device__ __forceinline__ float colmax4(float v) {
-  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  v = vmax(__uint_as_float(a[0]), __uint_as_float(a[1]));
-  auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return vmax(__uint_as_float(b[0]), __uint_as_float(b[1]));
-}
-
-// sum over the four lanes {li, li+16, li+32, li+48}
-__device__ __forceinline__ float colsum4(float v) {
-  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-  auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
-}
 
 // dot product of two 8-element bf16 fragments, fp32
 __device__ __forceinline__ float dot8(const bf16x8_t& x, const bf16x8_t& y) {

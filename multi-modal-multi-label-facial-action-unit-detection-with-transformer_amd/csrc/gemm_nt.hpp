@@ -243,11 +243,11 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
     for (int j = 0; j < NI; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float t = cs[j][r];
-        t += __shfl_xor(t, 1, 64);
-        t += __shfl_xor(t, 2, 64);
-        t += __shfl_xor(t, 4, 64);
-        t += __shfl_xor(t, 8, 64);
+        float t = cs[j][r];  // sum over the 16 lanes of a DPP row (= the 16 tile rows li): VALU only, no ds_bpermute
+        t += AVF_DPP_F32(t, 0xB1);
+        t += AVF_DPP_F32(t, 0x4E);
+        t += AVF_DPP_F32(t, 0x124);
+        t += AVF_DPP_F32(t, 0x128);
         cs[j][r] = t;
       }
     if (li == 0) {
