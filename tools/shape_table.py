@@ -93,6 +93,27 @@ def main():
             rows.append([cls, name, wgs, M, N, K, epi, len(sub), round(us, 2), round(tf, 1), round(tf / PEAK_TFLOPS, 4),
                          round(byts / 1e6, 2), "" if (name, wgs) not in hbm else round(hbm[(name, wgs)] / 1e6, 2),
                          round(byts / (us * 1e-6) / 1e9, 1)])
+    # attention launches are logged per CALL ("attn_fwd", "attn_dq+attn_dkv"), whatever kernel(s) the call dispatches to (head-
+    # resident, merged or the two-kernel / streaming forms, whose grids differ from the logged B*H): kernels not matched above
+    # are joined by name prefix, a call's row = the sum of the mean durations of its kernels
+    matched = {r[1] for r in rows}
+    for (tmpl, wgs), ents in by_key.items():
+        if not tmpl.startswith("attn"):
+            continue
+        parts = tmpl.split("+")
+        ks = [(name, w) for (name, w) in durs if name not in matched and any(name.startswith(pp) for pp in parts)]
+        if tmpl == "attn_dq+attn_dkv":
+            ks += [(name, w) for (name, w) in durs if name not in matched and name.startswith("attn_bwd") and (name, w) not in ks]
+        if not ks:
+            continue
+        cls, M, N, K, epi, flops, byts = ents[0]
+        us = sum(sum(d for _, d in durs[k]) / len(durs[k]) for k in ks) / 1e3
+        n = min(len(durs[k]) for k in ks)
+        tf = flops / (us * 1e-6) / 1e12
+        hb = sum(hbm.get(k, 0.0) for k in ks)
+        rows.append([cls, " + ".join(k[0] for k in ks), "/".join(str(k[1]) for k in ks), M, N, K, epi, n, round(us, 2), round(tf, 1),
+                     round(tf / PEAK_TFLOPS, 4), round(byts / 1e6, 2), round(hb / 1e6, 2) if hb else "", round(byts / (us * 1e-6) / 1e9, 1)])
+        matched.update(k[0] for k in ks)
     rows.sort(key=lambda r: -r[7] * r[8])
     with open(out, "w", newline="") as fh:
         w = csv.writer(fh)
