@@ -556,9 +556,11 @@ int m4_launch(const TimingScope* ts, const bf16* qkv, const bf16* o, const bf16*
 
 }  // namespace
 
-// merged backward: dim_head 64, pre-scaled q, N <= 512.  It is the default where it measured faster than the two
-// head-resident kernels - four key blocks per wave, 385 <= N <= 512 (B = 32 / 64, N = 512: 77.9 / 149.9 us against 80.1 /
-// 160.2 us; N = 324: 47.0 against 44.2 us) - AVF_ATTN_MERGED=0 turns it off, AVF_ATTN_MERGED_MIN_N moves the threshold.
+// merged backward: dim_head 64, pre-scaled q, N <= 512.  It is the default from three key blocks per wave up (N >= 257):
+// back to back in the harness it wins at N = 512 (B = 32 / 64: 77.3 / 155 us against 80.1 / 160.2 us) and loses at N = 324
+// (46.2 against 44.2 us), but IN THE STEP the single launch - which reads q, k, v, dO once, not twice - is the faster one there
+// too: C2 (N = 324) 2.107 / 2.113 ms per step against 2.141 / 2.129 with the two kernels (same box, alternating runs).
+// AVF_ATTN_MERGED=0 turns it off, AVF_ATTN_MERGED_MIN_N moves the threshold.
 bool attn_bwd_merged_ok(int N, int dh, bool q_prescaled) {
   static const int allow = [] {
     const char* e = getenv("AVF_ATTN_MERGED");
@@ -566,7 +568,7 @@ bool attn_bwd_merged_ok(int N, int dh, bool q_prescaled) {
   }();
   static const int min_n = [] {
     const char* e = getenv("AVF_ATTN_MERGED_MIN_N");
-    return (e && *e) ? atoi(e) : 385;
+    return (e && *e) ? atoi(e) : 257;
   }();
   return allow && q_prescaled && dh == 64 && N <= 512 && N >= min_n;
 }
