@@ -259,6 +259,7 @@ __global__ __launch_bounds__(256) void linear_pad_bwd_kernel(const float* __rest
     if (!dx) return;
     for (int c = threadIdx.x * 4; c < K; c += 1024) {
       float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4  // independent loads of several iterations in flight (the loop is latency-bound: a dozen rows)
       for (int o = 0; o < O; ++o) {
         const float g = dl[(int64_t)blk * ldd + o];
         const float4 ww = *reinterpret_cast<const float4*>(w + (int64_t)o * K + c);
@@ -272,6 +273,7 @@ __global__ __launch_bounds__(256) void linear_pad_bwd_kernel(const float* __rest
   if (dw) {
     for (int c = threadIdx.x * 4; c < K; c += 1024) {
       float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
       for (int b = 0; b < B; ++b) {
         const float g = dl[(int64_t)b * ldd + o];
         const float4 xx = *reinterpret_cast<const float4*>(x + (int64_t)b * K + c);
