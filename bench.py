@@ -251,6 +251,7 @@ class Region:
             # once and replayed: the ~130 launches of a step no longer depend on the host keeping up (eager C2 needs ~1.8 ms
             # of host time per 2.3 ms step; under data parallelism 1.7-2.65 ms).  The collectives are stream operations of
             # torch's process group and are recorded like kernels.
+            err = None
             try:
                 if self.opt is not None:
                     for gdict in self.opt.param_groups:
@@ -264,15 +265,23 @@ class Region:
                 torch.cuda.current_stream().wait_stream(side)
                 with torch.cuda.graph(gr):
                     static_loss = self.step()
+            except Exception as e:  # capture is an optimisation of the launch path, never a requirement
+                err = f"{type(e).__name__}: {str(e)[:120]}"
+                torch.cuda.synchronize()
+            # Recording executes nothing, so the ranks are still in step here.  They must also AGREE on the launch mode before
+            # the first replay: a rank that failed to capture would issue eager collectives against its peers' replayed ones.
+            ok = torch.tensor([0.0 if err else 1.0], device=self.dev)
+            if self.use_dist:
+                self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN)
+            if ok.item() > 0.5:
                 run = lambda: (gr.replay(), static_loss)[1]
                 for _ in range(3):
                     run()
                 self.fence()
                 self.launch = "hipGraph replay" + (" (RCCL all-reduces captured)" if self.dp is not None else "")
-            except Exception as e:  # capture is an optimisation of the launch path, never a requirement
-                torch.cuda.synchronize()
+            else:
                 run = self.step
-                self.launch = f"eager (graph capture failed: {type(e).__name__}: {str(e)[:120]})"
+                self.launch = f"eager (graph capture failed: {err or 'on another rank'})"
                 for _ in range(2):
                     self.step()
                 self.fence()
