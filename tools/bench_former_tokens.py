@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Step time (forward + backward, no optimizer) of the token sections of the reference's other *former models at their REAL
+shapes, on the per-operator path of the library (VERDICT r02 item 8 asks for the numbers):
+  TFormer          (vformer.py:271-288): B clips x (16 frames + cls) = 17 tokens, d=512, 8 heads x 64, mlp 1024, depth 3
+  ResFormerTokens  (sformer.py:313-327): B x 16 frames feature maps [256, 7, 7] = 49 tokens, d=256, 8 heads x 32, mlp 512, depth 1
+Eager launches and one captured hipGraph of the same fwd+bwd; rocprofv3 --kernel-trace on this script gives the per-kernel view."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import avformer_amd as A  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+dev = "cuda"
+torch.manual_seed(0)
+
+
+def bench(name, model, x, iters=100):
+    model = model.to(dev).train()
+    x = x.to(dev).requires_grad_(True)
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        x.grad = None
+        y = model(x)
+        y.float().pow(2).mean().backward()
+
+    for _ in range(30):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    torch.cuda.synchronize()
+    eager = (time.perf_counter() - t0) / iters
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step()
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(g):
+        step()
+    for _ in range(10):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        g.replay()
+    torch.cuda.synchronize()
+    rep = (time.perf_counter() - t0) / iters
+    L = sum(1 for _ in model.modules() if type(_).__name__ == "Transformer" for __ in range(_.depth))
+    print(f"{name}: eager {eager * 1e3:.3f} ms, hipGraph replay {rep * 1e3:.3f} ms per fwd+bwd "
+          f"({rep * 1e6 / max(L, 1):.0f} us per layer, {L} layer(s))", flush=True)
+
+
+bench(f"TFormer B={B} (17 tokens, d=512, L=3)", A.heads.TFormer(), torch.randn(B, 16, 512))
+bench(f"ResFormerTokens B'={B * 16} (49 tokens, d=256, L=1)", A.heads.ResFormerTokens(), torch.randn(B * 16, 256, 7, 7))
