@@ -218,9 +218,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(NtParam
   int cur = 0;
   for (int t = 0; t < nt; ++t) {
     const int ahead = (nt - 1 - t) < (NS - 2) ? (nt - 1 - t) : (NS - 2);  // tiles issued after tile t
-    if (ahead >= 2) wait_vmcnt<2 * INS>();
-    else if (ahead == 1) wait_vmcnt<INS>();
-    else wait_vmcnt<0>();
+    if constexpr (NS <= 4) {
+      if (ahead >= 2) wait_vmcnt<2 * INS>();
+      else if (ahead == 1) wait_vmcnt<INS>();
+      else wait_vmcnt<0>();
+    } else {  // deep rings (the small-M tile: the whole K panel of a short problem in flight)
+      switch (ahead) {
+        case 0: wait_vmcnt<0>(); break;
+        case 1: wait_vmcnt<INS>(); break;
+        case 2: wait_vmcnt<2 * INS>(); break;
+        case 3: wait_vmcnt<3 * INS>(); break;
+        case 4: wait_vmcnt<4 * INS>(); break;
+        case 5: wait_vmcnt<5 * INS>(); break;
+        default: wait_vmcnt<6 * INS>(); break;
+      }
+    }
     __builtin_amdgcn_s_barrier();
     if (t + NS - 1 < nt) {
       int slot = cur + NS - 1;
@@ -262,7 +274,7 @@ template <int EPI, typename CT, int WM, int WN, int MI, int NI, int NS, bool LNF
 int launch_nt_glds(const NtParams& p, hipStream_t s, int* part_rows, TimingScope* ts) {
   constexpr int BMT = 16 * MI * WM, BNT = 16 * NI * WN;
   constexpr int SMEM = NS * (BMT + BNT) * 128 + (LNF ? BMT * 8 : 0);
-  static_assert(NS >= 2 && NS <= 4 && SMEM <= 160 * 1024, "stage count / LDS budget");
+  static_assert(NS >= 2 && NS <= 8 && SMEM <= 160 * 1024, "stage count / LDS budget");
   static PerDeviceOnce raised;
   if (SMEM > 64 * 1024 && raised.need()) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_glds_kernel<EPI, CT, WM, WN, MI, NI, NS, LNF>,
@@ -292,7 +304,9 @@ int launch_nt_glds_any(const NtParams& p, hipStream_t s, int* part_rows, TimingS
     if (pick_nt_tile(p.M, p.N, p.K) == 5) return launch_nt_glds<EPI, CT, 2, 4, 3, 2, 2, true>(p, s, part_rows, ts);
     return launch_nt_glds<EPI, CT, 2, 4, 4, 2, 2, true>(p, s, part_rows, ts);
   } else {
-    switch (pick_nt_tile(p.M, p.N, p.K)) {
+    // (the row-statistics epilogue of the LayerNorm fold needs column-block pairs: not on the small-M tile)
+    switch (p.rs_out ? pick_nt_tile(p.M, p.N, p.K) : pick_nt_tile_bf16(p.M, p.N, p.K)) {
+      case 6: return launch_nt_glds<EPI, CT, 1, 4, 2, 1, 6>(p, s, part_rows, ts);  // 72 KiB: two workgroups per CU
       case 0: return launch_nt_glds<EPI, CT, 2, 2, 4, 4, 2>(p, s, part_rows, ts);
       case 1: return launch_nt_glds<EPI, CT, 2, 2, 2, 4, 2>(p, s, part_rows, ts);
       case 3: return launch_nt_glds<EPI, CT, 2, 2, 3, 4, 2>(p, s, part_rows, ts);
@@ -880,9 +894,9 @@ int gemm_bf16_nt(const GemmArgs& a, hipStream_t s) {
     // the partial rows the chosen tile will write must fit the workspace - checked BEFORE anything is enqueued
     int planned = part_rows;
     if (dma) {
-      const int t = pick_nt_tile(a.M, a.N, a.K);
-      const int bmt = (t == 0 || t == 2) ? 128 : (t == 1 ? 64 : 96);
-      planned = (int)ceil_div(a.M, bmt) * 2;  // every configuration has two wave rows per block tile
+      const int t = (lnf || a.rs_out) ? pick_nt_tile(a.M, a.N, a.K) : pick_nt_tile_bf16(a.M, a.N, a.K);
+      const int bmt = (t == 0 || t == 2) ? 128 : (t == 1 ? 64 : (t == 6 ? 32 : 96));
+      planned = (int)ceil_div(a.M, bmt) * (t == 6 ? 1 : 2);  // two wave rows per block tile (the small-M tile: one)
     }
     AVF_REQUIRE((size_t)planned * a.N * sizeof(float) <= gemm_nt_colsum_ws(a.M, a.N),
                 "gemm_bf16_nt: column-sum partials exceed their workspace (internal error)");

@@ -341,5 +341,22 @@ int pick_nt_tile(int64_t M, int64_t N, int64_t K) {
   return ceil_div(M, 96) * ceil_div(N, 128) <= 512 ? 5 : 1;
 }
 
+// bf16 NT kernel only: problems with few token rows (the reference's 12- / 17-token stacks at batch 64: ~1 k rows) put a few
+// dozen 96 x 128 tiles on 256 CUs, and with one stage of look-ahead every K-step of such a lone workgroup pays a full memory
+// round trip (measured: 10.9 us for 1088 x 512 x 512).  Tile 6 = 32 x 64, four waves, a 6-slot ring of 12 KiB stages (two
+// workgroups per CU): eight times the workgroups, five K-steps of a workgroup in flight at once.
+int pick_nt_tile_bf16(int64_t M, int64_t N, int64_t K) {
+  static const int small_on = [] {
+    const char* e = getenv("AVF_NT_SMALL_M");  // A/B aid: 0 = the large tiles for every shape
+    return (e && *e) ? atoi(e) : 1;
+  }();
+  static const int forced = [] {
+    const char* e = getenv("AVF_NT_TILE");
+    return (e && *e) ? atoi(e) : -1;
+  }();
+  if (forced < 0 && small_on && M <= 2048 && ceil_div(M, 96) * ceil_div(N, 128) <= 160) return 6;
+  return pick_nt_tile(M, N, K);
+}
+
 }  // namespace
 }  // namespace avf

@@ -421,12 +421,15 @@ __global__ __launch_bounds__(256) void ln_bwd_reg_kernel(const DyT* __restrict__
                                                          uint8_t* __restrict__ dxq = nullptr,
                                                          uint8_t* __restrict__ dxs = nullptr,
                                                          bf16* __restrict__ h_out = nullptr,
-                                                         const float* __restrict__ beta = nullptr) {
+                                                         const float* __restrict__ beta = nullptr,
+                                                         int rpb = LNR_ROWS_PER_BLOCK) {
+  // rpb: rows per workgroup (16; 4 - one row per wave - for short inputs, where 16-row blocks leave most CUs empty and the
+  //      four rows of a wave run one after the other)
   // h_out (LayerNorm folded into the forward GEMM: the normalised rows were never stored): also write
   // h = xhat * gamma + beta, the operand of this layer's weight-gradient GEMM
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [4 waves][3][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t row0 = (int64_t)blockIdx.x * LNR_ROWS_PER_BLOCK;
+  const int64_t row0 = (int64_t)blockIdx.x * rpb;
   const float invD = 1.0f / (float)D;
   const uint64_t dkey = drop.thresh16 ? drop_key(drop) : 0;
   float4 g[NV], adg[NV], adb[NV], acs[NV], bt[NV];
@@ -439,7 +442,7 @@ __global__ __launch_bounds__(256) void ln_bwd_reg_kernel(const DyT* __restrict__
     bt[i] = (act[i] && h_out) ? *reinterpret_cast<const float4*>(beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     adg[i] = adb[i] = acs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  for (int rr = wave; rr < LNR_ROWS_PER_BLOCK; rr += 4) {
+  for (int rr = wave; rr < rpb; rr += 4) {
     const int64_t row = row0 + rr;
     if (row >= rows) break;
     const float mu = mean[row], rs = rstd[row];
@@ -689,8 +692,10 @@ __global__ __launch_bounds__(256) void ln_bwd_row8_kernel(const bf16* __restrict
   }
 }
 
+constexpr int64_t LNR_SHORT_ROWS = 4096;  // up to here the register-path backward runs 4 rows per workgroup
+static inline int lnr_rows_per_block(int64_t rows) { return rows <= LNR_SHORT_ROWS ? 4 : LNR_ROWS_PER_BLOCK; }
 size_t layernorm_bwd_ws(int64_t rows, int dim) {
-  return (size_t)ceil_div(rows, LNR_ROWS_PER_BLOCK) * 3 * dim * sizeof(float);  // LNR < LNB: covers both paths
+  return (size_t)ceil_div(rows, lnr_rows_per_block(rows)) * 3 * dim * sizeof(float);  // LNR < LNB: covers both paths
 }
 
 int layernorm_bwd(const void* dy, int dy_dtype, const void* xv, const float* gamma, const float* mean,
@@ -719,7 +724,10 @@ int layernorm_bwd(const void* dy, int dy_dtype, const void* xv, const float* gam
   int nb;
   const bool fast = (dim % 4 == 0) && dim <= 1536 && (dy_dtype == AVF_F32 || dy_dtype == AVF_BF16);
   if (fast) {
-    nb = (int)ceil_div(rows, LNR_ROWS_PER_BLOCK);
+    const bool row8 = x_dtype == AVF_BF16 && dy_dtype == AVF_BF16 && (!dres || dres_dtype == AVF_BF16) && !dx && dx_lo &&
+                      !drop.thresh16 && !mx_q && dim % 8 == 0 && ln_row8_on();
+    const int rpb = row8 ? LNR_ROWS_PER_BLOCK : lnr_rows_per_block(rows);
+    nb = (int)ceil_div(rows, rpb);
     const size_t lds = (size_t)4 * 3 * dim * sizeof(float);
     const int nv = (dim + 255) / 256;
     if (lds > 64 * 1024) {  // only the NV=6 instantiations (D up to 1536) can exceed the default dynamic-LDS limit
@@ -740,8 +748,6 @@ int layernorm_bwd(const void* dy, int dy_dtype, const void* xv, const float* gam
         raised.mark();
       }
     }
-    const bool row8 = x_dtype == AVF_BF16 && dy_dtype == AVF_BF16 && (!dres || dres_dtype == AVF_BF16) && !dx && dx_lo &&
-                      !drop.thresh16 && !mx_q && dim % 8 == 0 && ln_row8_on();
     if (row8) {
       if (lds > 64 * 1024) {
         static PerDeviceOnce raised8;
@@ -776,18 +782,18 @@ int layernorm_bwd(const void* dy, int dy_dtype, const void* xv, const float* gam
   do {                                                                                                                      \
     if (x_dtype == AVF_BF16 && dres_dtype == AVF_BF16)                                                                      \
       launch_in_scope(&ts, ln_bwd_reg_kernel<bf16, NVV, bf16, bf16>, dim3(nb), dim3(256), (uint32_t)lds, s, (const bf16*)dy,   \
-                      (const bf16*)xv, gamma, mean, rstd, (const bf16*)dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop, (uint8_t*)mx_q, (uint8_t*)mx_s, (bf16*)h_out, beta); \
+                      (const bf16*)xv, gamma, mean, rstd, (const bf16*)dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop, (uint8_t*)mx_q, (uint8_t*)mx_s, (bf16*)h_out, beta, rpb); \
     else if (x_dtype == AVF_BF16)                                                                                           \
       launch_in_scope(&ts, ln_bwd_reg_kernel<bf16, NVV, float, bf16>, dim3(nb), dim3(256), (uint32_t)lds, s, (const bf16*)dy,  \
-                      (const bf16*)xv, gamma, mean, rstd, (const float*)dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop, (uint8_t*)mx_q, (uint8_t*)mx_s, (bf16*)h_out, beta); \
+                      (const bf16*)xv, gamma, mean, rstd, (const float*)dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop, (uint8_t*)mx_q, (uint8_t*)mx_s, (bf16*)h_out, beta, rpb); \
     else if (dres_dtype == AVF_BF16)                                                                                        \
       launch_in_scope(&ts, ln_bwd_reg_kernel<bf16, NVV, bf16>, dim3(nb), dim3(256), (uint32_t)lds, s, (const bf16*)dy, x, gamma, \
                       mean, rstd, (const bf16*)dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop, (uint8_t*)mx_q,         \
-                      (uint8_t*)mx_s, (bf16*)nullptr, (const float*)nullptr);                                                \
+                      (uint8_t*)mx_s, (bf16*)nullptr, (const float*)nullptr, rpb);                                           \
     else                                                                                                                    \
       launch_in_scope(&ts, ln_bwd_reg_kernel<T, NVV, float>, dim3(nb), dim3(256), (uint32_t)lds, s, (const T*)dy, x, gamma, mean, \
                       rstd, (const float*)dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop, (uint8_t*)mx_q,              \
-                      (uint8_t*)mx_s, (bf16*)nullptr, (const float*)nullptr);                                                \
+                      (uint8_t*)mx_s, (bf16*)nullptr, (const float*)nullptr, rpb);                                           \
   } while (0)
 #define LAUNCH_T(T)                                   \
   switch (nv) {                                       \

@@ -58,5 +58,8 @@ def bench(name, model, x, iters=100):
           f"({rep * 1e6 / max(L, 1):.0f} us per layer, {L} layer(s))", flush=True)
 
 
-bench(f"TFormer B={B} (17 tokens, d=512, L=3)", A.heads.TFormer(), torch.randn(B, 16, 512))
-bench(f"ResFormerTokens B'={B * 16} (49 tokens, d=256, L=1)", A.heads.ResFormerTokens(), torch.randn(B * 16, 256, 7, 7))
+which = sys.argv[2] if len(sys.argv) > 2 else "both"
+if which in ("both", "tformer"):
+    bench(f"TFormer B={B} (17 tokens, d=512, L=3)", A.heads.TFormer(), torch.randn(B, 16, 512))
+if which in ("both", "resformer"):
+    bench(f"ResFormerTokens B'={B * 16} (49 tokens, d=256, L=1)", A.heads.ResFormerTokens(), torch.randn(B * 16, 256, 7, 7))
