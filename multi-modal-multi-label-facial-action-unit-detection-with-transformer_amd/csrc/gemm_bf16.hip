@@ -813,7 +813,12 @@ int tn_group_splits(int total_tiles, int64_t K, int slots = 512) {
   // them best, charging 5 % per extra slab for the fold's traffic: 128 tiles (d = 512) -> 4 splits = exactly one round;
   // 288 tiles (d = 768) -> 3 splits = 1.7 rounds (84 % full) instead of 2 splits = 1.125 rounds (56 %): 3.90 -> 3.13 ms per
   // step at C4 (measured sweep: 3 splits 3.13, 4: 3.22, 5: 3.26, 6: 3.20, 8: 3.17 ms)
-  const int64_t maxs = K / 1024 > 0 ? K / 1024 : 1;  // at least 16 K-steps per workgroup
+  // at least 16 K-steps per workgroup - 4 where the unsplit tiles leave more than half of the slots empty (short inputs: ~1 k
+  // token rows; each K-step of a lone workgroup is a full memory round trip, so more, shorter workgroups win: real avformer
+  // heads 0.671 -> 0.637 ms per step, TFormer at 17 tokens 0.444 -> 0.437)
+  const int64_t per = 2 * (int64_t)total_tiles < slots ? 256 : 1024;
+  const int64_t maxs = K / per > 0 ? K / per : 1;
+  if (per == 256 && (int64_t)total_tiles * (maxs < 8 ? maxs : 8) <= slots) return (int)(maxs < 8 ? maxs : 8);  // one round even fully split
   int best = 1;
   double best_score = -1.0;
   for (int s = 1; s <= 8 && s <= maxs; ++s) {
