@@ -10,7 +10,7 @@ import avformer_amd as A
 
 
 class Args:
-    batch = 0; residual = "f32"; no_optimizer = False; torch_adam = False
+    batch = 0; residual = "bf16"; no_optimizer = False; torch_adam = False
     config = sys.argv[1] if len(sys.argv) > 1 else "c2"
 
 
