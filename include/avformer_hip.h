@@ -77,8 +77,9 @@ typedef struct avf_layer_cfg {
   const void* key_mask; /* optional token mask of Transformer.forward(x, mask) (heads.py:225-232; no reference caller passes one):
                           device bytes [batch, tokens], 1 = token kept - the reference's mask padded with a leading True.  A pair
                           (i, j) with either token dropped scores -FLT_MAX: a dropped query attends uniformly to all keys, a kept
-                          query gives dropped keys zero weight; no gradient flows through a filled score.  With a mask the
-                          attention core runs on the fp32-arithmetic kernels in every mode (correct, not tuned).            */
+                          query gives dropped keys zero weight; no gradient flows through a filled score.  bf16 layers with
+                          dim_head 64 and <= 512 tokens apply it inside the MFMA attention kernels (head-resident forward, merged
+                          backward); every other case runs the attention core on the fp32-arithmetic kernels (correct, not tuned). */
   int32_t ln_fuse;     /* bit 0 (needs resid_bf16, no mx8_fwd, no key_mask, dim % 64 == 0): PreNorm's LayerNorm (heads.py:178-185) is
                           folded into the GEMM behind it - to_qkv and net.0 read the raw bf16 residual stream against gamma-scaled
                           weight images (refresh them with avf_stack_ln_fold whenever weights, gamma, beta or b1 changed) and finish

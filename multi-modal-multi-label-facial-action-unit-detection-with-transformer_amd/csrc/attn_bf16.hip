@@ -460,11 +460,17 @@ __device__ __forceinline__ void tr4x4(uint32_t (&a)[4]) {
 // MULTI: more 32-row groups than waves (each wave loops over its groups); otherwise exactly one group per wave.
 // QS: the q columns already carry log2(e)/sqrt(dh) (layer path) - the scores leave the MFMA in the log2 domain, and the
 // subtraction of the running maximum (forward) / of lse2 (backward) rides in the MFMA's C operand: no per-score FMA.
-template <int MAXW, bool MULTI, bool QS>
+// MASKED (QS only): the token mask of heads.py:225-232 - keep[b][n] != 0 keeps token n.  A pair (query, key) with either
+// token dropped scores -FLT_MAX in the reference: a kept query gives dropped keys zero weight (score -inf here), a dropped
+// query's row is one constant, i.e. uniform attention over ALL its keys (score 0 here: lse2 = log2 N exactly, which the
+// backward kernel relies on).  The flags of the clip's keys sit in LDS behind the V image.
+template <int MAXW, bool MULTI, bool QS, bool MASKED = false>
 __global__ __launch_bounds__(MAXW * 64) void attn_fwd_res_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
                                                                 float* __restrict__ lse2, int N, int H,
                                                                 uint8_t* __restrict__ oq = nullptr,
-                                                                uint8_t* __restrict__ osc = nullptr) {
+                                                                uint8_t* __restrict__ osc = nullptr,
+                                                                const uint8_t* __restrict__ keep = nullptr) {
+  static_assert(!MASKED || QS, "the masked form exists for pre-scaled queries only");
   constexpr int DH = 64, KS = 2, DB = 4;
   extern __shared__ __attribute__((aligned(16))) char res_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -486,11 +492,26 @@ __global__ __launch_bounds__(MAXW * 64) void attn_fwd_res_kernel(const bf16* __r
   ResOffsets off;
   off.init(li, lg);
   const bf16x8_t ones = ones_frag();
+  const uint8_t* keepl = reinterpret_cast<const uint8_t*>(res_smem + 2 * NP * 128);  // MASKED: [ceil64(N)] key flags
+  if constexpr (MASKED) {
+    uint8_t* kw = reinterpret_cast<uint8_t*>(res_smem + 2 * NP * 128);
+    for (int i = tid; i < ((N + 63) & ~63); i += blockDim.x) kw[i] = i < N ? keep[(int64_t)b * N + i] : (uint8_t)0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the first arrival barrier of the sweep publishes them)
+  }
 
   int grp = wave;
   do {
     const bool first_pass = !MULTI || grp == wave;
     const int q0 = grp * 32;
+    bool qkeep[2] = {true, true};  // MASKED: is this lane's query row a kept token
+    bool cen[2] = {false, false};  // MASKED: has the row's running maximum been centred on a finite score yet
+    if constexpr (MASKED) {
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        const int q = q0 + qb * 16 + li;
+        qkeep[qb] = q < N ? keep[(int64_t)b * N + q] != 0 : true;
+      }
+    }
     bf16x8_t fq[2][KS];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb)
@@ -549,7 +570,12 @@ __global__ __launch_bounds__(MAXW * 64) void attn_fwd_res_kernel(const bf16* __r
         // st = log2-domain score - m.  Re-centre when a row maximum exceeds m by more than RES_TAU (and always on the
         // first tile, which fixes m): only then are the accumulators and this tile's scores shifted.
         float cm[2];
-        bool grow = first_tile;
+        bool grow = MASKED ? false : first_tile;
+        uint32_t kflag[4] = {0u, 0u, 0u, 0u};
+        if constexpr (MASKED) {
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb) kflag[kb] = *reinterpret_cast<const uint32_t*>(keepl + t * 64 + kb * 16 + 4 * lg);
+        }
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
           float tmax = -INFINITY;
@@ -557,17 +583,33 @@ __global__ __launch_bounds__(MAXW * 64) void attn_fwd_res_kernel(const bf16* __r
           for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              if (TAIL && (t * 64 + kb * 16 + 4 * lg + r >= N)) st[kb][qb][r] = -INFINITY;
+              if constexpr (MASKED) {
+                const bool kk = ((kflag[kb] >> (8 * r)) & 255u) != 0;  // (rows past N carry flag 0)
+                const bool real = !TAIL || (t * 64 + kb * 16 + 4 * lg + r < N);
+                st[kb][qb][r] = qkeep[qb] ? (kk ? st[kb][qb][r] : -INFINITY) : (real ? -m[qb] : -INFINITY);
+              } else {
+                if (TAIL && (t * 64 + kb * 16 + 4 * lg + r >= N)) st[kb][qb][r] = -INFINITY;
+              }
               tmax = fmaxf(tmax, st[kb][qb][r]);
             }
           cm[qb] = colmax4(tmax);
-          grow = grow || (cm[qb] > RES_TAU);
+          if constexpr (MASKED) grow = grow || (cen[qb] ? cm[qb] > RES_TAU : cm[qb] > -1.0e30f);  // (a tile may hold no kept key)
+          else grow = grow || (cm[qb] > RES_TAU);
         }
         if (__builtin_amdgcn_ballot_w64(grow) != 0) {  // wave-uniform
 #pragma unroll
           for (int qb = 0; qb < 2; ++qb) {
-            const float shift = first_tile ? cm[qb] : fmaxf(cm[qb], 0.f);
-            const float alpha = first_tile ? 1.0f : __builtin_amdgcn_exp2f(-shift);  // accumulators are 0 on the first tile
+            float shift, alpha;
+            if constexpr (MASKED) {
+              // a row is centred on its first tile with a finite score (any sign); its accumulators are 0 until then
+              const bool fin = cm[qb] > -1.0e30f;
+              shift = cen[qb] ? fmaxf(cm[qb], 0.f) : (fin ? cm[qb] : 0.f);
+              alpha = cen[qb] ? __builtin_amdgcn_exp2f(-shift) : 1.0f;
+              cen[qb] = cen[qb] || fin;
+            } else {
+              shift = first_tile ? cm[qb] : fmaxf(cm[qb], 0.f);
+              alpha = first_tile ? 1.0f : __builtin_amdgcn_exp2f(-shift);  // accumulators are 0 on the first tile
+            }
             m[qb] += shift;
             minit[qb] = f32x4_t{-m[qb], -m[qb], -m[qb], -m[qb]};
             ls[qb][0] *= alpha; ls[qb][1] *= alpha; ls[qb][2] *= alpha; ls[qb][3] *= alpha;
@@ -1382,8 +1424,18 @@ float attn_q_prescale(int dh) { return attn_q_prescale_on() ? LOG2E / sqrtf((flo
 // the head-resident forward kernel can also write the MX-FP8 image of its output
 bool attn_fwd_emits_mx8(int N, int dh) { return use_resident(N, dh); }
 
+bool attn_masked_bf16_ok(int N, int dh, bool q_prescaled) {
+  static const int on = [] {
+    const char* e = getenv("AVF_ATTN_MASK_MFMA");  // A/B aid: 0 = every masked call on the fp32-arithmetic kernels
+    return (e && *e) ? atoi(e) : 1;
+  }();
+  return on && q_prescaled && use_resident(N, dh) && N >= 1 && N <= 512;
+}
+
 int attn_fwd_bf16(const bf16* qkv, bf16* o, float* lse2, int B, int N, int H, int dh, hipStream_t s, bool q_prescaled,
-                  void* mx_q, void* mx_s) {
+                  void* mx_q, void* mx_s, const void* keep) {
+  AVF_REQUIRE(!keep || (attn_masked_bf16_ok(N, dh, q_prescaled) && !mx_q),
+              "attn_fwd_bf16: the token mask runs on the MFMA kernels for dim_head 64, N <= 512, pre-scaled q, no fp8 image");
   AVF_REQUIRE(!mx_q || (mx_s && attn_fwd_emits_mx8(N, dh) && ((uintptr_t)mx_q & 3) == 0),
               "attn_fwd_bf16: the MX-FP8 output image exists on the head-resident kernel only (N=%d dh=%d)", N, dh);
   AVF_REQUIRE(B > 0 && N > 0 && H > 0, "attn_fwd_bf16: bad shape");
@@ -1397,7 +1449,16 @@ int attn_fwd_bf16(const bf16* qkv, bf16* o, float* lse2, int B, int N, int H, in
     const int W = res_waves(N);
     const size_t smem = (size_t)((N + 31) & ~31) * 128 * 2;
 #define AVF_FWD_RES(MW, MU, Q, NAME) res_launch(&ts, attn_fwd_res_kernel<MW, MU, Q>, NAME, B * H, W, smem, s, qkv, o, lse2, N, H, \
-                                                (uint8_t*)mx_q, (uint8_t*)mx_s)
+                                                (uint8_t*)mx_q, (uint8_t*)mx_s, (const uint8_t*)nullptr)
+    if (keep) {
+      const size_t smem_k = smem + (size_t)((N + 63) & ~63);
+#define AVF_FWD_RES_M(MW, MU, NAME) res_launch(&ts, attn_fwd_res_kernel<MW, MU, true, true>, NAME, B * H, W, smem_k, s, qkv, o, lse2, N, \
+                                              H, (uint8_t*)nullptr, (uint8_t*)nullptr, (const uint8_t*)keep)
+      if (res_multi(N)) return AVF_FWD_RES_M(8, true, "attn_fwd_res<8,multi,qs,mask>");
+      if (W <= 8) return AVF_FWD_RES_M(8, false, "attn_fwd_res<8,qs,mask>");
+      return AVF_FWD_RES_M(12, false, "attn_fwd_res<12,qs,mask>");
+#undef AVF_FWD_RES_M
+    }
     if (q_prescaled) {
       if (res_multi(N)) return AVF_FWD_RES(8, true, true, "attn_fwd_res<8,multi,qs>");
       if (W <= 8) return AVF_FWD_RES(8, false, true, "attn_fwd_res<8,qs>");
@@ -1417,7 +1478,9 @@ int attn_fwd_bf16(const bf16* qkv, bf16* o, float* lse2, int B, int N, int H, in
 }
 
 int attn_bwd_bf16(const bf16* qkv, const bf16* o, const bf16* d_o, const float* lse2, bf16* dqkv, float* delta, int B,
-                  int N, int H, int dh, hipStream_t s, bool q_prescaled, float* nlse) {
+                  int N, int H, int dh, hipStream_t s, bool q_prescaled, float* nlse, const void* keep) {
+  AVF_REQUIRE(!keep || attn_masked_bf16_ok(N, dh, q_prescaled),
+              "attn_bwd_bf16: the token mask runs on the MFMA kernels for dim_head 64, N <= 512, pre-scaled q");
   AVF_REQUIRE(B > 0 && N > 0 && H > 0, "attn_bwd_bf16: bad shape");
   AVF_REQUIRE(ceil_div(N, 128) * B * H < (1LL << 31), "attn_bwd_bf16: grid too large");
   AVF_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)d_o & 15) == 0 && ((uintptr_t)dqkv & 7) == 0,
@@ -1426,6 +1489,7 @@ int attn_bwd_bf16(const bf16* qkv, const bf16* o, const bf16* d_o, const float* 
   if (shape_log_on())
     shape_log("attn_bwd,%s,%d,%d,%d,%d,%d,%.0f,%.0f", attn_bwd_merged_ok(N, dh, q_prescaled) ? "attn_bwd_m4_kernel" : "attn_dq+attn_dkv",
               B * H, B, N, H * dh, -1, 10.0 * B * H * (double)N * N * dh, 2.0 * 8.0 * B * N * H * dh);
+  if (keep) return attn_bwd_merged(&ts, qkv, o, d_o, lse2, dqkv, B, N, H, s, keep);  // (the merged kernel at every N <= 512)
   if (attn_bwd_merged_ok(N, dh, q_prescaled)) return attn_bwd_merged(&ts, qkv, o, d_o, lse2, dqkv, B, N, H, s);
   if (use_resident(N, dh)) {  // delta comes out of the dQ kernel
     const int W = res_waves(N);

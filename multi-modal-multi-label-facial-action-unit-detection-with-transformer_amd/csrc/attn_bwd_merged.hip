@@ -130,10 +130,14 @@ struct MLayout {
 
 // RAGGED: N < 4 KB 32 - key blocks that hold rows past N mask them (P = 0: -lse2 alone can be a large positive
 // exponent when every score of a row is very negative)
-template <int KB, bool RAGGED>
+// MASKED: the token mask of heads.py:225-232 (keep[b][n] != 0 keeps token n), as attn_fwd_res_kernel<.., MASKED> applied it:
+// a kept query gives dropped keys P = 0; a dropped query attended uniformly (P = 1/N on every real key: its lse2 is
+// log2 N exactly) and no gradient flows through its scores - dS = 0, so only dV sees the row.
+template <int KB, bool RAGGED, bool MASKED = false>
 __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                           const bf16* __restrict__ d_o, const float* __restrict__ lse2,
-                                                          bf16* __restrict__ dqkv, int N, int H) {
+                                                          bf16* __restrict__ dqkv, int N, int H,
+                                                          const uint8_t* __restrict__ keep = nullptr) {
   constexpr int DH = 64;
   constexpr int NKB = 4 * KB;  // key blocks of the head (padded ones included)
   extern __shared__ __attribute__((aligned(16))) char m_smem[];
@@ -240,6 +244,21 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
     part += __shfl_xor(part, 4, 64);
     if (dch == 0) NDs[drow] = -part;
   }
+  // MASKED: is this lane's key of block j a kept token (padded keys: no); the query flags of a slice as a bit mask,
+  // fetched one slice ahead (bit i of qm: query 32 s + i, already shifted by this lane's 4 hf)
+  bool kk[KB];
+  uint32_t qf = 1u, qm = 0xffffffffu;
+  const float dropv = -log2f((float)N);
+#pragma unroll
+  for (int j = 0; j < KB; ++j) kk[j] = true;
+  if constexpr (MASKED) {
+#pragma unroll
+    for (int j = 0; j < KB; ++j) {
+      const int key = 32 * (kb0 + j) + r;
+      kk[j] = key < N ? keep[(int64_t)b * N + key] != 0 : false;
+    }
+    qf = r < N ? keep[(int64_t)b * N + r] : 1u;
+  }
   // the builtin form is VISIBLE to hipcc's wait-count pass (it retires the V fragment loads in its books: with the asm form
   // alone it put a vmcnt(0) in front of their first use in EVERY slice, exposing the latency of that slice's own DMA)
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt unconstrained
@@ -302,18 +321,30 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
     }
     sacc = AVF_MFMA32(nlA, onesB, sacc);
     pacc = AVF_MFMA32(ndA, onesB, pacc);
-    if constexpr (RAGGED) {
+    if constexpr (RAGGED && !MASKED) {
       if (32 * (kb0 + j) + 32 > N) {  // wave-uniform: the block holds padded keys
         const bool dead = 32 * (kb0 + j) + r >= N;
 #pragma unroll
         for (int i = 0; i < 16; ++i) sacc[i] = dead ? -INFINITY : sacc[i];
       }
     }
+    if constexpr (MASKED) {  // element i of this lane = query 8 (i >> 2) + 4 hf + (i & 3) of the slice, key r of block j
+      const bool real = 32 * (kb0 + j) + r < N;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const bool qkept = ((qm >> (8 * (i >> 2) + (i & 3))) & 1u) != 0;
+        sacc[i] = qkept ? (kk[j] ? sacc[i] : -INFINITY) : (real ? dropv : -INFINITY);
+      }
+    }
   };
   // stage B in eight chunks of six VALU instructions: chunk c turns elements 2 c, 2 c + 1 into one dword of P and of dS
   auto b_chunk = [&](int c, m_u32x4_t (&pkn)[2], m_u32x4_t (&dkn)[2]) {
     const float p0 = __builtin_amdgcn_exp2f(sacc[2 * c]), p1 = __builtin_amdgcn_exp2f(sacc[2 * c + 1]);
-    const float d0 = p0 * pacc[2 * c], d1 = p1 * pacc[2 * c + 1];
+    float d0 = p0 * pacc[2 * c], d1 = p1 * pacc[2 * c + 1];
+    if constexpr (MASKED) {  // no gradient through the (filled) scores of a dropped query
+      d0 = ((qm >> (8 * ((2 * c) >> 2) + ((2 * c) & 3))) & 1u) ? d0 : 0.f;
+      d1 = ((qm >> (8 * ((2 * c + 1) >> 2) + ((2 * c + 1) & 3))) & 1u) ? d1 : 0.f;
+    }
     pkn[c >> 2][c & 3] = pack_bf16x2(p0, p1);
     dkn[c >> 2][c & 3] = pack_bf16x2(d0, d1);
   };
@@ -430,10 +461,18 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
     tcur = tbuf + (s & 1) * (NKB * 2048) + kb0 * 2048;
     uint4 onext = make_uint4(0, 0, 0, 0);
     const bool more = s + 1 < NS;
+    if constexpr (MASKED) {  // lanes r and r + 32 carry the same flag: the low word of the ballot is the slice's mask
+      const uint32_t all = (uint32_t)__builtin_amdgcn_ballot_w64(qf != 0);
+      qm = all >> (4 * hf);
+    }
     if (more) {
       issue_slice(s + 1);
       const int q = 32 * (s + 1) + drow;
       if (q < N) onext = *reinterpret_cast<const uint4*>(obase + (int64_t)q * I + dch * 8);
+      if constexpr (MASKED) {
+        const int qn = 32 * (s + 1) + r;
+        qf = qn < N ? keep[(int64_t)b * N + qn] : 1u;
+      }
     }
     AVF_PHASE_MARK(1);
 
@@ -538,19 +577,20 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
   AVF_PHASE_FLUSH();
 }
 
-template <int KB, bool RAGGED>
+template <int KB, bool RAGGED, bool MASKED = false>
 int m4_launch(const TimingScope* ts, const bf16* qkv, const bf16* o, const bf16* d_o, const float* lse2, bf16* dqkv, int B,
-              int N, int H, hipStream_t s) {
+              int N, int H, hipStream_t s, const uint8_t* keep = nullptr) {
   static PerDeviceOnce once;
   const MLayout L(KB, (N + 31) >> 5);
   if (once.need()) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_m4_kernel<KB, RAGGED>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_m4_kernel<KB, RAGGED, MASKED>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     AVF_REQUIRE(e == hipSuccess, "attn_bwd_m4: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
     once.mark();
   }
   AVF_REQUIRE(L.total <= 160 * 1024, "attn_bwd_m4: %d bytes of LDS", L.total);
-  launch_in_scope(ts, attn_bwd_m4_kernel<KB, RAGGED>, dim3(B * H), dim3(256), (uint32_t)L.total, s, qkv, o, d_o, lse2, dqkv, N, H);
+  launch_in_scope(ts, attn_bwd_m4_kernel<KB, RAGGED, MASKED>, dim3(B * H), dim3(256), (uint32_t)L.total, s, qkv, o, d_o, lse2, dqkv,
+                  N, H, keep);
   return check_launch("attn_bwd_m4_kernel");
 }
 
@@ -574,11 +614,24 @@ bool attn_bwd_merged_ok(int N, int dh, bool q_prescaled) {
 }
 
 int attn_bwd_merged(const TimingScope* ts, const bf16* qkv, const bf16* o, const bf16* d_o, const float* lse2, bf16* dqkv,
-                    int B, int N, int H, hipStream_t s) {
+                    int B, int N, int H, hipStream_t s, const void* keep) {
   AVF_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)o & 15) == 0 && ((uintptr_t)d_o & 15) == 0 &&
                   ((uintptr_t)dqkv & 15) == 0,
               "attn_bwd_merged: misaligned pointers");
   const int KB = (((N + 31) >> 5) + 3) >> 2;
+  if (keep) {  // token mask: the masked instantiation (which treats padded keys as dropped ones)
+    switch (KB) {
+      case 1: return m4_launch<1, true, true>(ts, qkv, o, d_o, lse2, dqkv, B, N, H, s, (const uint8_t*)keep);
+      case 2: return m4_launch<2, true, true>(ts, qkv, o, d_o, lse2, dqkv, B, N, H, s, (const uint8_t*)keep);
+#if AVF_M4_MAXKB >= 3
+      case 3: return m4_launch<3, true, true>(ts, qkv, o, d_o, lse2, dqkv, B, N, H, s, (const uint8_t*)keep);
+#endif
+#if AVF_M4_MAXKB >= 4
+      case 4: return m4_launch<4, true, true>(ts, qkv, o, d_o, lse2, dqkv, B, N, H, s, (const uint8_t*)keep);
+#endif
+    }
+    AVF_REQUIRE(false, "attn_bwd_merged: N=%d out of range", N);
+  }
   const bool ragged = N != 4 * KB * 32;
 #define AVF_M4(K) return ragged ? m4_launch<K, true>(ts, qkv, o, d_o, lse2, dqkv, B, N, H, s) \
                                 : m4_launch<K, false>(ts, qkv, o, d_o, lse2, dqkv, B, N, H, s)

@@ -515,11 +515,14 @@ int layer_bwd_small_a(int B, int N, int D, int I, int M, const SmallBwdAHost& h,
 int layer_bwd_small_b(int B, int N, int D, int I, const SmallBwdBHost& h, hipStream_t s);
 float attn_q_prescale(int dh);
 bool attn_q_prescale_on();
+// keep (optional, [B][N] bytes): the token mask of heads.py:225-232 on the MFMA kernels - attn_masked_bf16_ok says where
 int attn_fwd_bf16(const bf16* qkv, bf16* o, float* lse2, int B, int N, int H, int dh, hipStream_t s,
-                  bool q_prescaled = false, void* mx_q = nullptr, void* mx_s = nullptr);
+                  bool q_prescaled = false, void* mx_q = nullptr, void* mx_s = nullptr, const void* keep = nullptr);
+bool attn_masked_bf16_ok(int N, int dh, bool q_prescaled);  // head-resident forward + merged backward: dh 64, N <= 512, pre-scaled q
 bool attn_fwd_emits_mx8(int N, int dh);  // mx_q / mx_s: MX-FP8 image of o, written by the head-resident kernel only
 int attn_bwd_bf16(const bf16* qkv, const bf16* o, const bf16* d_o, const float* lse2, bf16* dqkv, float* delta,
-                  int B, int N, int H, int dh, hipStream_t s, bool q_prescaled = false, float* nlse = nullptr);
+                  int B, int N, int H, int dh, hipStream_t s, bool q_prescaled = false, float* nlse = nullptr,
+                  const void* keep = nullptr);
 int attn_delta(int dtype, const void* o, const void* d_o, float* delta, int B, int N, int H, int dh, hipStream_t s);
 // merged dQ + dK/dV kernel (attn_bwd_merged.hip): dim_head 64, pre-scaled q, N <= 512
 // mlp_fused.hip: the FeedForward sublayer as one kernel per direction (bf16 operands; R % 64 == 0, D in {256, 512, 768}, M % 128 == 0)
@@ -530,6 +533,6 @@ int mlp_fused_bwd(const void* dy, const void* w2_t, const void* w1_t, const void
                   int64_t R, int D, int M, hipStream_t s);
 bool attn_bwd_merged_ok(int N, int dh, bool q_prescaled);
 int attn_bwd_merged(const TimingScope* ts, const bf16* qkv, const bf16* o, const bf16* d_o, const float* lse2, bf16* dqkv,
-                    int B, int N, int H, hipStream_t s);
+                    int B, int N, int H, hipStream_t s, const void* keep = nullptr);
 
 }  // namespace avf

@@ -614,7 +614,12 @@ extern "C" int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   }
   AVF_TRY(layernorm_fwd(x_in, p->ln1_w, p->ln1_b, sv.h1, d.dt, sv.mean1, sv.rstd1, d.R, d.D, cfg->ln_eps, s, nullptr, nullptr, d.xdt));
   AVF_TRY(linear_fwd(d, sv.h1, d.D, wqkv, 3 * d.I, sv.qkv, d.dt, AVF_EPI_NONE, nullptr, nullptr, nullptr, s));
-  if (d.keep) AVF_TRY(attn_fwd_vec(d.dt, sv.qkv, sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s, d.keep, lo && attn_q_prescale_on()));
+  // token mask (heads.py:225-232): on the MFMA kernels where they carry it (bf16, dim_head 64, up to 512 tokens), else on
+  // the fp32-arithmetic ones
+  const bool mask_mfma = d.keep && lo && attn_masked_bf16_ok(d.N, d.dh, attn_q_prescale_on());
+  if (mask_mfma)
+    AVF_TRY(attn_fwd_bf16((const bf16*)sv.qkv, (bf16*)sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s, true, nullptr, nullptr, d.keep));
+  else if (d.keep) AVF_TRY(attn_fwd_vec(d.dt, sv.qkv, sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s, d.keep, lo && attn_q_prescale_on()));
   else if (lo) AVF_TRY(attn_fwd_bf16((const bf16*)sv.qkv, (bf16*)sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s, attn_q_prescale_on()));
   else AVF_TRY(attn_fwd_f32((const float*)sv.qkv, (float*)sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s));
   const DropCfg dr0 = make_drop(d.p0, d.seed, d.layer, 0, d.seed_dev), dr1 = make_drop(d.p, d.seed, d.layer, 1, d.seed_dev),
@@ -823,7 +828,10 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
                          nullptr));
   else
     AVF_TRY(linear_dx(d, gm, d.D, p->w_out, l.wo_t, d.I, w.d_o, AVF_EPI_NONE, nullptr, s));
-  if (d.keep)
+  if (d.keep && lo && !d.mx && attn_masked_bf16_ok(d.N, d.dh, attn_q_prescale_on()))  // (as the forward chose)
+    AVF_TRY(attn_bwd_bf16((const bf16*)sv.qkv, (const bf16*)sv.o, (const bf16*)w.d_o, sv.lse2, (bf16*)w.dqkv, w.delta,
+                          d.B, d.N, d.H, d.dh, s, true, w.delta + (size_t)d.B * d.H * d.N, d.keep));
+  else if (d.keep)
     AVF_TRY(attn_bwd_vec(d.dt, sv.qkv, sv.o, w.d_o, sv.lse2, w.dqkv, w.delta, d.B, d.N, d.H, d.dh, s, d.keep,
                          lo && attn_q_prescale_on()));
   else if (lo)

@@ -118,3 +118,31 @@ def test_mask_in_the_mx8_mode_against_the_bf16_mode():
         check_rel(f"mask_mx8:g.{k}", g1[k], g0[k], 1.2e-1)
     sd = {k: v.detach().cpu() for k, v in a.state_dict().items()}
     check_rel("mask_mx8:y_vs_oracle", y1, oracle.transformer_forward(x, sd, 2, 2, mask=mask), 4e-2)
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 40, 2), (3, 324, 2), (2, 512, 1), (2, 257, 3)])
+def test_mask_on_the_mfma_kernels_against_the_oracle(B, N, H):
+    """bf16 stacks with dim_head 64 and up to 512 tokens carry the mask on the head-resident forward and the merged backward
+    kernel (round 3; before, every masked call ran the fp32-arithmetic attention core): output and every gradient against
+    the CPU oracle's autograd, and against the same stack on the fp32-arithmetic core."""
+    import avformer_amd as A
+    torch.manual_seed(N)
+    D, M = 64 * H, 128
+    t = A.Transformer(D, 2, H, 64, M, compute_dtype="bf16").to(DEV)
+    sd = {k: v.detach().cpu().clone() for k, v in t.state_dict().items()}
+    g = torch.Generator().manual_seed(N + 1)
+    x = torch.randn(B, N, D, generator=g)
+    mask = torch.rand(B, N - 1, generator=g) > 0.3
+    mask[-1, 1:] = False          # one clip keeps only the leading token and its first neighbour
+    mask[0] = True                # one clip keeps everything
+    y, dx, grads = _run(t, x, mask)
+    xc = x.clone().requires_grad_(True)
+    ps = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    yc = oracle.transformer_forward(xc, ps, 2, H, mask=mask)
+    SQ(yc).backward()
+    tag = f"mask_mfma[{B}x{N}x{H}]"
+    check_rel(tag + ":y", y, yc.detach(), 1.5e-2)
+    check_rel(tag + ":dx", dx, xc.grad, 3e-2)
+    for k, p in ps.items():
+        check_rel(tag + f":g.{k}", grads[k], p.grad, 4e-2)
+    assert all(bool(torch.isfinite(v).all()) for v in grads.values())
