@@ -128,8 +128,9 @@ __device__ __forceinline__ MxBlock mx8_encode(const float (&v)[8]) {
   float am = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) am = fmaxf(am, fabsf(v[i]));
-  am = fmaxf(am, __shfl_xor(am, 1, 64));
-  am = fmaxf(am, __shfl_xor(am, 2, 64));
+  // the other three lanes of the quad through DPP (quad_perm [1,0,3,2], [2,3,0,1]): VALU only
+  am = fmaxf(am, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(am), 0xB1, 0xF, 0xF, true)));
+  am = fmaxf(am, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(am), 0x4E, 0xF, 0xF, true)));
   float inv;
   MxBlock b;
   b.scale = mx8_scale_byte(am, &inv);  // biased exponent of the block maximum - 8; inv = 2^(127 - scale)

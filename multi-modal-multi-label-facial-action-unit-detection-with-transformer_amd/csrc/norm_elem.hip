@@ -149,11 +149,13 @@ __device__ __forceinline__ void load8f(const float* p, float (&v)[8]) {
   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
 
-template <int NV8, int RU>
+// MX: also the MX-FP8 image of the rows (D % 32 == 0: a 32-block is the 8 columns of the four lanes of a quad)
+template <int NV8, int RU, bool MX = false>
 __global__ __launch_bounds__(256) void ln_fwd_row8_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, bf16* __restrict__ y,
                                                           float* __restrict__ mean, float* __restrict__ rstd, int64_t rows,
-                                                          int D, float eps) {
+                                                          int D, float eps, uint8_t* __restrict__ yq = nullptr,
+                                                          uint8_t* __restrict__ ys = nullptr) {
   const int lane = threadIdx.x & 63;
   const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RU;
   if (row0 >= rows) return;
@@ -222,6 +224,11 @@ __global__ __launch_bounds__(256) void ln_fwd_row8_kernel(const bf16* __restrict
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[k] = (v[k] - mu[r]) * rs[r] * gm[i][k] + bt[i][k];
         *reinterpret_cast<uint4*>(y + (row0 + r) * D + c) = pack8(o);
+        if constexpr (MX) {  // (c < D is uniform over a quad: D % 32 == 0)
+          const MxBlock mb = mx8_encode(o);
+          *reinterpret_cast<uint2*>(yq + (row0 + r) * D + c) = mb.q;
+          if ((lane & 3) == 0) ys[(row0 + r) * (D >> 5) + (c >> 5)] = (uint8_t)mb.scale;
+        }
       }
     }
   }
@@ -237,12 +244,17 @@ int layernorm_fwd(const void* xv, const float* gamma, const float* beta, void* y
   TimingScope ts(KC_LAYERNORM, 0.0, (double)rows * dim * ((x_dtype == AVF_BF16 ? 2.0 : 4.0) + (y_dtype == AVF_BF16 ? 2.0 : 4.0) +
                                                          (mx_q ? 1.03125 : 0.0)), s, /*per_kernel=*/true);
   dim3 grid((unsigned)ceil_div(rows, 4)), block(256);
-  if (x_dtype == AVF_BF16 && !mx_q && dim % 8 == 0 && ln_row8_on()) {  // four rows per wave, 16-byte accesses
+  if (x_dtype == AVF_BF16 && dim % 8 == 0 && (!mx_q || (mx_s && dim % 32 == 0)) && ln_row8_on()) {  // four rows per wave, 16-byte accesses
     const bf16* xb = (const bf16*)xv;
     constexpr int RU = 4;
     dim3 g8((unsigned)ceil_div(rows, 4 * RU));
 #define LAUNCH_R8(NVV)                                                                                                       \
-  launch_in_scope(&ts, ln_fwd_row8_kernel<NVV, RU>, g8, block, 0, s, xb, gamma, beta, (bf16*)y, mean, rstd, rows, dim, eps)
+  do {                                                                                                                       \
+    if (mx_q) launch_in_scope(&ts, ln_fwd_row8_kernel<NVV, RU, true>, g8, block, 0, s, xb, gamma, beta, (bf16*)y, mean, rstd,  \
+                              rows, dim, eps, (uint8_t*)mx_q, (uint8_t*)mx_s);                                               \
+    else launch_in_scope(&ts, ln_fwd_row8_kernel<NVV, RU, false>, g8, block, 0, s, xb, gamma, beta, (bf16*)y, mean, rstd,      \
+                         rows, dim, eps, (uint8_t*)nullptr, (uint8_t*)nullptr);                                              \
+  } while (0)
     switch ((dim + 511) / 512) {
       case 1: LAUNCH_R8(1); break;
       case 2: LAUNCH_R8(2); break;
@@ -578,7 +590,8 @@ __global__ __launch_bounds__(256) void ln_bwd_row8_kernel(const bf16* __restrict
                                                           const float* __restrict__ rstd, const bf16* __restrict__ dres,
                                                           bf16* __restrict__ dx_lo, float* __restrict__ partial, int64_t rows,
                                                           int D, int want_colsum, bf16* __restrict__ h_out,
-                                                          const float* __restrict__ beta) {
+                                                          const float* __restrict__ beta, uint8_t* __restrict__ dxq = nullptr,
+                                                          uint8_t* __restrict__ dxs = nullptr) {
   static_assert((LNR_ROWS_PER_BLOCK / 4) % RU == 0, "a wave's rows come in whole batches of RU");
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [4 waves][3][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -666,6 +679,11 @@ __global__ __launch_bounds__(256) void ln_bwd_row8_kernel(const bf16* __restrict
         if (HOUT) v[k] = fmaf(xh, gm[i][k], bt[i][k]);
       }
       *reinterpret_cast<uint4*>(dx_lo + (row0 + r) * D + c) = pack8(o);
+      if (dxq) {  // wave-uniform: MX-FP8 image of the same values (D % 32 == 0: the four lanes of a block are live together)
+        const MxBlock mb = mx8_encode(o);
+        *reinterpret_cast<uint2*>(dxq + (row0 + r) * D + c) = mb.q;
+        if ((lane & 3) == 0) dxs[(row0 + r) * (D >> 5) + (c >> 5)] = (uint8_t)mb.scale;
+      }
       if (HOUT) *reinterpret_cast<uint4*>(h_out + (row0 + r) * D + c) = pack8(v);
     }
   }
@@ -725,7 +743,7 @@ int layernorm_bwd(const void* dy, int dy_dtype, const void* xv, const float* gam
   const bool fast = (dim % 4 == 0) && dim <= 1536 && (dy_dtype == AVF_F32 || dy_dtype == AVF_BF16);
   if (fast) {
     const bool row8 = x_dtype == AVF_BF16 && dy_dtype == AVF_BF16 && (!dres || dres_dtype == AVF_BF16) && !dx && dx_lo &&
-                      !drop.thresh16 && !mx_q && dim % 8 == 0 && ln_row8_on();
+                      !drop.thresh16 && (!mx_q || dim % 32 == 0) && dim % 8 == 0 && ln_row8_on();
     const int rpb = row8 ? LNR_ROWS_PER_BLOCK : lnr_rows_per_block(rows);
     nb = (int)ceil_div(rows, rpb);
     const size_t lds = (size_t)4 * 3 * dim * sizeof(float);
@@ -764,11 +782,12 @@ int layernorm_bwd(const void* dy, int dy_dtype, const void* xv, const float* gam
   do {                                                                                                                       \
     if (h_out)                                                                                                               \
       launch_in_scope(&ts, ln_bwd_row8_kernel<NVV, RU, true>, dim3(nb), dim3(256), (uint32_t)lds, s, (const bf16*)dy,         \
-                      (const bf16*)xv, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx_lo, partial, rows, dim, wc, (bf16*)h_out, beta); \
+                      (const bf16*)xv, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx_lo, partial, rows, dim, wc, (bf16*)h_out, beta, \
+                      (uint8_t*)mx_q, (uint8_t*)mx_s);                                                                       \
     else                                                                                                                     \
       launch_in_scope(&ts, ln_bwd_row8_kernel<NVV, RU, false>, dim3(nb), dim3(256), (uint32_t)lds, s, (const bf16*)dy,        \
                       (const bf16*)xv, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx_lo, partial, rows, dim, wc, (bf16*)nullptr, \
-                      (const float*)nullptr);                                                                                \
+                      (const float*)nullptr, (uint8_t*)mx_q, (uint8_t*)mx_s);                                                \
   } while (0)
       switch ((dim + 511) / 512) {  // rows in flight per wave: what the register file allows at two waves per SIMD or more
         case 1: LAUNCH_R8(1, 4); break;
