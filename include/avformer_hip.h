@@ -202,6 +202,12 @@ int avf_attn_bwd_masked(int dtype, const void* qkv, const void* o, const void* d
  * in the fp8 mode.  Head-resident kernel only: dim_head 64, tokens <= 576 (error otherwise). */
 int avf_attn_fwd_mx8(const void* qkv, void* o, float* lse2, void* o_q, void* o_scales, int batch, int tokens, int heads,
                      int dim_head, void* stream);
+/* bf16 attention backward for PRE-SCALED queries (the q columns of qkv carry log2(e) / sqrt(dim_head), as the layer's Wqkv
+ * image produces them) also writing the MX-FP8 image of dqkv [B*N, 3I] - the A operand of the dqkv -> dh1 GEMM (autograd of
+ * heads.py:212) in the fp8 mode.  Merged kernel only: avf_attn_bwd_emits_mx8(tokens, dim_head) says (error otherwise). */
+int avf_attn_bwd_emits_mx8(int tokens, int dim_head);
+int avf_attn_bwd_mx8(const void* qkv, const void* o, const void* d_o, const float* lse2, void* dqkv, void* dqkv_q,
+                     void* dqkv_scales, int batch, int tokens, int heads, int dim_head, void* stream);
 
 /* Multi-head self-attention core - heads.py:222-237.  qkv [B*N, 3I] (q|k|v, head-major columns),
  * o [B*N, I], lse2 fp32 [B,H,N] = log2-domain log-sum-exp of the scaled scores (saved for backward). */

@@ -95,6 +95,8 @@ SIGNATURES = {
     "avf_layer_lowp_bytes": (_sz, [C.POINTER(LayerCfg)]),
     "avf_layernorm_bwd_mx8": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp]),
     "avf_attn_fwd_mx8": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
+    "avf_attn_bwd_emits_mx8": (_int, [_int, _int]),
+    "avf_attn_bwd_mx8": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     "avf_attn_fwd_masked": (_int, [_int, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     "avf_attn_bwd_masked": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     "avf_layer_workspace_bytes": (_sz, [C.POINTER(LayerCfg)]),

@@ -292,6 +292,15 @@ extern "C" int avf_attn_fwd_mx8(const void* qkv, void* o, float* lse2, void* o_q
   return attn_fwd_bf16((const bf16*)qkv, (bf16*)o, lse2, batch, tokens, heads, dim_head, (hipStream_t)stream, false, o_q,
                        o_scales);
 }
+extern "C" int avf_attn_bwd_emits_mx8(int tokens, int dim_head) { return attn_bwd_emits_mx8(tokens, dim_head, true) ? 1 : 0; }
+extern "C" int avf_attn_bwd_mx8(const void* qkv, const void* o, const void* d_o, const float* lse2, void* dqkv, void* dqkv_q,
+                                void* dqkv_scales, int batch, int tokens, int heads, int dim_head, void* stream) {
+  AVF_REQUIRE(qkv && o && d_o && lse2 && dqkv && dqkv_q && dqkv_scales, "attn_bwd_mx8: null pointer");
+  AVF_REQUIRE(attn_bwd_emits_mx8(tokens, dim_head, true),
+              "attn_bwd_mx8: only the merged backward kernel writes the image (tokens=%d dim_head=%d)", tokens, dim_head);
+  return attn_bwd_bf16((const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse2, (bf16*)dqkv, nullptr, batch, tokens, heads,
+                       dim_head, (hipStream_t)stream, true, nullptr, nullptr, dqkv_q, dqkv_scales);
+}
 extern "C" int avf_quant_mx8(int dtype, const void* x, int64_t rows, int64_t cols, void* q, void* scales, void* stream) {
   AVF_REQUIRE(x && q && scales, "quant_mx8: null pointer");
   return quant_mx8(x, dtype, cols, rows, cols, q, cols, scales, (hipStream_t)stream);

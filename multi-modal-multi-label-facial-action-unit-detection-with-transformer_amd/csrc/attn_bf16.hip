@@ -1477,8 +1477,12 @@ int attn_fwd_bf16(const bf16* qkv, bf16* o, float* lse2, int B, int N, int H, in
   return check_launch("attn_fwd_bf16_kernel");
 }
 
+bool attn_bwd_emits_mx8(int N, int dh, bool q_prescaled) { return attn_bwd_merged_ok(N, dh, q_prescaled); }
+
 int attn_bwd_bf16(const bf16* qkv, const bf16* o, const bf16* d_o, const float* lse2, bf16* dqkv, float* delta, int B,
-                  int N, int H, int dh, hipStream_t s, bool q_prescaled, float* nlse, const void* keep) {
+                  int N, int H, int dh, hipStream_t s, bool q_prescaled, float* nlse, const void* keep, void* dq_q, void* dq_s) {
+  AVF_REQUIRE(!dq_q || (attn_bwd_emits_mx8(N, dh, q_prescaled) && !keep),
+              "attn_bwd_bf16: the MX-FP8 image of dqkv exists on the merged kernel only (N=%d dh=%d)", N, dh);
   AVF_REQUIRE(!keep || attn_masked_bf16_ok(N, dh, q_prescaled),
               "attn_bwd_bf16: the token mask runs on the MFMA kernels for dim_head 64, N <= 512, pre-scaled q");
   AVF_REQUIRE(B > 0 && N > 0 && H > 0, "attn_bwd_bf16: bad shape");
@@ -1490,7 +1494,7 @@ int attn_bwd_bf16(const bf16* qkv, const bf16* o, const bf16* d_o, const float* 
     shape_log("attn_bwd,%s,%d,%d,%d,%d,%d,%.0f,%.0f", attn_bwd_merged_ok(N, dh, q_prescaled) ? "attn_bwd_m4_kernel" : "attn_dq+attn_dkv",
               B * H, B, N, H * dh, -1, 10.0 * B * H * (double)N * N * dh, 2.0 * 8.0 * B * N * H * dh);
   if (keep) return attn_bwd_merged(&ts, qkv, o, d_o, lse2, dqkv, B, N, H, s, keep);  // (the merged kernel at every N <= 512)
-  if (attn_bwd_merged_ok(N, dh, q_prescaled)) return attn_bwd_merged(&ts, qkv, o, d_o, lse2, dqkv, B, N, H, s);
+  if (attn_bwd_merged_ok(N, dh, q_prescaled)) return attn_bwd_merged(&ts, qkv, o, d_o, lse2, dqkv, B, N, H, s, nullptr, dq_q, dq_s);
   if (use_resident(N, dh)) {  // delta comes out of the dQ kernel
     const int W = res_waves(N);
     const size_t smem = (size_t)((N + 31) & ~31) * 128 * 2, smem_kv = smem + (size_t)((N + 63) & ~63) * 8;

@@ -133,13 +133,29 @@ struct MLayout {
 // MASKED: the token mask of heads.py:225-232 (keep[b][n] != 0 keeps token n), as attn_fwd_res_kernel<.., MASKED> applied it:
 // a kept query gives dropped keys P = 0; a dropped query attended uniformly (P = 1/N on every real key: its lse2 is
 // log2 N exactly) and no gradient flows through its scores - dS = 0, so only dV sees the row.
-template <int KB, bool RAGGED, bool MASKED = false>
+// MXO: also write the MX-FP8 image of dqkv (e4m3 bytes [B N][3 I] + one E8M0 byte per 32 columns) - the A operand of the
+// dqkv -> dh1 GEMM in the fp8 mode.  A 32-block of dK / dV is the 16 registers of a lane and of lane + 32; a 32-block of dQ
+// stays inside one wave because the dQ job of this form gives a wave one query tile and 32 columns (not two tiles and 16).  The image is that
+// of the bf16 values as STORED.
+template <int KB, bool RAGGED, bool MASKED = false, bool MXO = false>
 __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                           const bf16* __restrict__ d_o, const float* __restrict__ lse2,
                                                           bf16* __restrict__ dqkv, int N, int H,
-                                                          const uint8_t* __restrict__ keep = nullptr) {
+                                                          const uint8_t* __restrict__ keep = nullptr,
+                                                          uint8_t* __restrict__ dq_q = nullptr,
+                                                          uint8_t* __restrict__ dq_s = nullptr) {
   constexpr int DH = 64;
   constexpr int NKB = 4 * KB;  // key blocks of the head (padded ones included)
+#ifdef AVF_MXO_NO_DQ
+  constexpr bool MXQ = false;
+#else
+  constexpr bool MXQ = MXO;
+#endif
+#ifdef AVF_MXO_NO_DKV
+  constexpr bool MXK = false;
+#else
+  constexpr bool MXK = MXO;
+#endif
   extern __shared__ __attribute__((aligned(16))) char m_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -181,12 +197,16 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
   // (b) 16x16x32 operands of the dQ job, k-order of a 32-key block: element j of lane group G <-> key 4 G + (j&3) + 16 (j>>2):
   //     rows 4 G + qq and + 16.  A = K^T: columns d = 16 w + 4 p of the K image.  B = dS^T: query columns 16 qt + 4 p of a
   //     T image (64-byte rows; 8-byte slot 4 qt + p).
-  int off_kq[2], off_tq[2][2];
+  //     MXQ (the fp8 image of dQ is written too): a wave owns ONE query tile (w & 1) and a whole 32-column block (w >> 1) -
+  //     two A fragments (columns 32 (w >> 1) + 16 ct), one B fragment - so that a block's maximum stays inside the wave
+  int off_kq[2], off_kq2[2], off_tq[2][2];
   {
     const int rk = 4 * G + qq;
-    const int ch = 2 * wave + (p >> 1), byte = (p & 1) * 8;
+    const int ch = (MXQ ? 4 * (wave >> 1) : 2 * wave) + (p >> 1), byte = (p & 1) * 8;
     off_kq[0] = rk * 128 + ((ch ^ m_swz(rk)) << 4) + byte;
     off_kq[1] = (rk + 16) * 128 + ((ch ^ m_swz(rk + 16)) << 4) + byte;
+    off_kq2[0] = rk * 128 + (((ch + 2) ^ m_swz(rk)) << 4) + byte;
+    off_kq2[1] = (rk + 16) * 128 + (((ch + 2) ^ m_swz(rk + 16)) << 4) + byte;
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       off_tq[qt][0] = rk * 64 + (((4 * qt + p) ^ m_txor(rk)) << 3);
@@ -416,9 +436,10 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
     const char* kb = kimg + kopq;
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     m_u32x4_t pkn[2], dkn[2];
+    const int tq0 = MXQ ? (wave & 1) : 0;  // (MXQ: t1 carries the second A fragment, not a second query tile)
     bf16x8_t ka = m_tr_frag(kb + off_kq[0], kb + off_kq[1]);
-    bf16x8_t t0 = m_tr_frag(tb + off_tq[0][0], tb + off_tq[0][1]);
-    bf16x8_t t1 = m_tr_frag(tb + off_tq[1][0], tb + off_tq[1][1]);
+    bf16x8_t t0 = m_tr_frag(tb + off_tq[tq0][0], tb + off_tq[tq0][1]);
+    bf16x8_t t1 = MXQ ? m_tr_frag(kb + off_kq2[0], kb + off_kq2[1]) : m_tr_frag(tb + off_tq[1][0], tb + off_tq[1][1]);
 #pragma unroll
     for (int kbk = 0; kbk < NKB; ++kbk) {
       AVF_FENCE();
@@ -427,11 +448,11 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
         const char* kn = kb + (kbk + 1) * 4096;
         const char* tn = tb + (kbk + 1) * 2048;
         kan = m_tr_frag(kn + off_kq[0], kn + off_kq[1]);
-        t0n = m_tr_frag(tn + off_tq[0][0], tn + off_tq[0][1]);
-        t1n = m_tr_frag(tn + off_tq[1][0], tn + off_tq[1][1]);
+        t0n = m_tr_frag(tn + off_tq[tq0][0], tn + off_tq[tq0][1]);
+        t1n = MXQ ? m_tr_frag(kn + off_kq2[0], kn + off_kq2[1]) : m_tr_frag(tn + off_tq[1][0], tn + off_tq[1][1]);
       }
       acc0 = AVF_MFMA16(ka, t0, acc0);
-      acc1 = AVF_MFMA16(ka, t1, acc1);
+      acc1 = MXQ ? AVF_MFMA16(t1, t0, acc1) : AVF_MFMA16(ka, t1, acc1);
       if constexpr (WITHB) {  // chunk c rides behind the MFMAs of key block floor(c NKB / 8)
 #pragma unroll
         for (int c = 0; c < 8; ++c)
@@ -444,13 +465,47 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
       pk[0] = pkn[0]; pk[1] = pkn[1]; dk[0] = dkn[0]; dk[1] = dkn[1];
     }
     // rows leave from the accumulators: lane (query li of tile qt, group G) holds columns 16 w + 4 G .. + 3
+    if constexpr (MXQ) {  // ... of query tile w & 1: columns 32 (w >> 1) + 16 ct + 4 G .. + 3, ct = 0 (acc0), 1 (acc1)
+      const int q = 32 * sp + 16 * (wave & 1) + li;
+      const int colb = h * DH + 32 * (wave >> 1);
+      uint32_t sw[2][2];
+      float t = 0.f;
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      const int q = 32 * sp + 16 * qt + li;
-      const f32x4_t a = qt ? acc1 : acc0;
-      if (q < N)
-        store4<bf16>(dqkv + ((int64_t)b * N + q) * ld + h * DH + 16 * wave + 4 * G,
-                     make_float4(a[0] * qscale, a[1] * qscale, a[2] * qscale, a[3] * qscale));
+      for (int ct = 0; ct < 2; ++ct) {
+        const f32x4_t a = ct ? acc1 : acc0;
+        sw[ct][0] = pack_bf16x2(a[0] * qscale, a[1] * qscale);
+        sw[ct][1] = pack_bf16x2(a[2] * qscale, a[3] * qscale);
+        t = fmaxf(t, fmaxf(fmaxf(fabsf(__uint_as_float(sw[ct][0] << 16)), fabsf(__uint_as_float(sw[ct][0] & 0xffff0000u))),
+                           fmaxf(fabsf(__uint_as_float(sw[ct][1] << 16)), fabsf(__uint_as_float(sw[ct][1] & 0xffff0000u)))));
+      }
+      {  // the row's 32 columns: lanes li, li + 16, li + 32, li + 48
+        const auto x = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+        t = fmaxf(__uint_as_float(x[0]), __uint_as_float(x[1]));
+        const auto y = __builtin_amdgcn_permlane16_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+        t = fmaxf(__uint_as_float(y[0]), __uint_as_float(y[1]));
+      }
+      float inv;
+      const uint32_t sb = mx8_scale_byte(t, &inv);
+      if (q < N) {
+        const int64_t row = (int64_t)b * N + q;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          *reinterpret_cast<uint2*>(dqkv + row * ld + colb + 16 * ct + 4 * G) = make_uint2(sw[ct][0], sw[ct][1]);
+          const float v4[4] = {__uint_as_float(sw[ct][0] << 16), __uint_as_float(sw[ct][0] & 0xffff0000u),
+                               __uint_as_float(sw[ct][1] << 16), __uint_as_float(sw[ct][1] & 0xffff0000u)};
+          *reinterpret_cast<uint32_t*>(dq_q + row * ld + colb + 16 * ct + 4 * G) = mx8_pack4(v4, inv);
+        }
+        if (G == 0) dq_s[row * (ld >> 5) + (colb >> 5)] = (uint8_t)sb;
+      }
+    } else {
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        const int q = 32 * sp + 16 * qt + li;
+        const f32x4_t a = qt ? acc1 : acc0;
+        if (q < N)
+          store4<bf16>(dqkv + ((int64_t)b * N + q) * ld + h * DH + 16 * wave + 4 * G,
+                       make_float4(a[0] * qscale, a[1] * qscale, a[2] * qscale, a[3] * qscale));
+      }
     }
   };
 
@@ -572,25 +627,64 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
                                              dvacc[j][db][4 * g + 3]));
         }
     }
+    if constexpr (MXK) {  // (outside the key < N branch: the lane pair (r, hf) trades words with every lane active)
+      const int64_t row = (int64_t)b * N + (key < N ? key : N - 1);
+#pragma unroll
+      for (int which = 0; which < 2; ++which)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          // the values as stored: one v_cvt_pk_bf16_f32 per pair, widened again
+          float v[16];
+          float t = 0.f;
+#pragma unroll
+          for (int i = 0; i < 16; i += 2) {
+            const float r0 = which ? dvacc[j][db][i] : dkacc[j][db][i] * kscale;
+            const float r1 = which ? dvacc[j][db][i + 1] : dkacc[j][db][i + 1] * kscale;
+            const uint32_t w = pack_bf16x2(r0, r1);
+            v[i] = __uint_as_float(w << 16);
+            v[i + 1] = __uint_as_float(w & 0xffff0000u);
+            t = fmaxf(t, fmaxf(fabsf(v[i]), fabsf(v[i + 1])));
+          }
+          const auto x = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+          t = fmaxf(__uint_as_float(x[0]), __uint_as_float(x[1]));
+          float inv;
+          const uint32_t sb = mx8_scale_byte(t, &inv);
+          uint32_t w[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float v4[4] = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+            w[g] = mx8_pack4(v4, inv);  // columns 8 g + 4 hf .. + 3 of the block
+          }
+          // lane (r, 0) collects columns 0 .. 15 of the block, lane (r, 1) columns 16 .. 31: one 16-byte store each instead of
+          // four 4-byte ones to 64 different rows per instruction (which cost 34 us at B = 64, N = 512)
+          const auto s02 = __builtin_amdgcn_permlane32_swap(w[0], w[2], false, false);
+          const auto s13 = __builtin_amdgcn_permlane32_swap(w[1], w[3], false, false);
+          const int col = (which ? 2 * I : I) + h * DH + 32 * db;
+          if (key < N) {
+            *reinterpret_cast<uint4*>(dq_q + row * ld + col + 16 * hf) = make_uint4(s02[0], s02[1], s13[0], s13[1]);
+            if (hf == 0) dq_s[row * (ld >> 5) + (col >> 5)] = (uint8_t)sb;
+          }
+        }
+    }
   }
   AVF_PHASE_MARK(6);
   AVF_PHASE_FLUSH();
 }
 
-template <int KB, bool RAGGED, bool MASKED = false>
+template <int KB, bool RAGGED, bool MASKED = false, bool MXO = false>
 int m4_launch(const TimingScope* ts, const bf16* qkv, const bf16* o, const bf16* d_o, const float* lse2, bf16* dqkv, int B,
-              int N, int H, hipStream_t s, const uint8_t* keep = nullptr) {
+              int N, int H, hipStream_t s, const uint8_t* keep = nullptr, uint8_t* dq_q = nullptr, uint8_t* dq_s = nullptr) {
   static PerDeviceOnce once;
   const MLayout L(KB, (N + 31) >> 5);
   if (once.need()) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_m4_kernel<KB, RAGGED, MASKED>,
+    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_m4_kernel<KB, RAGGED, MASKED, MXO>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     AVF_REQUIRE(e == hipSuccess, "attn_bwd_m4: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
     once.mark();
   }
   AVF_REQUIRE(L.total <= 160 * 1024, "attn_bwd_m4: %d bytes of LDS", L.total);
-  launch_in_scope(ts, attn_bwd_m4_kernel<KB, RAGGED, MASKED>, dim3(B * H), dim3(256), (uint32_t)L.total, s, qkv, o, d_o, lse2, dqkv,
-                  N, H, keep);
+  launch_in_scope(ts, attn_bwd_m4_kernel<KB, RAGGED, MASKED, MXO>, dim3(B * H), dim3(256), (uint32_t)L.total, s, qkv, o, d_o, lse2,
+                  dqkv, N, H, keep, dq_q, dq_s);
   return check_launch("attn_bwd_m4_kernel");
 }
 
@@ -614,7 +708,9 @@ bool attn_bwd_merged_ok(int N, int dh, bool q_prescaled) {
 }
 
 int attn_bwd_merged(const TimingScope* ts, const bf16* qkv, const bf16* o, const bf16* d_o, const float* lse2, bf16* dqkv,
-                    int B, int N, int H, hipStream_t s, const void* keep) {
+                    int B, int N, int H, hipStream_t s, const void* keep, void* dq_q, void* dq_s) {
+  AVF_REQUIRE(!dq_q || (dq_s && !keep && ((uintptr_t)dq_q & 3) == 0 && (3 * H * 64) % 32 == 0),
+              "attn_bwd_merged: the MX-FP8 image of dqkv needs its scale buffer, no token mask and 4-byte alignment");
   AVF_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)o & 15) == 0 && ((uintptr_t)d_o & 15) == 0 &&
                   ((uintptr_t)dqkv & 15) == 0,
               "attn_bwd_merged: misaligned pointers");
@@ -633,8 +729,14 @@ int attn_bwd_merged(const TimingScope* ts, const bf16* qkv, const bf16* o, const
     AVF_REQUIRE(false, "attn_bwd_merged: N=%d out of range", N);
   }
   const bool ragged = N != 4 * KB * 32;
-#define AVF_M4(K) return ragged ? m4_launch<K, true>(ts, qkv, o, d_o, lse2, dqkv, B, N, H, s) \
-                                : m4_launch<K, false>(ts, qkv, o, d_o, lse2, dqkv, B, N, H, s)
+#define AVF_M4(K)                                                                                                          \
+  do {                                                                                                                     \
+    if (dq_q)                                                                                                              \
+      return ragged ? m4_launch<K, true, false, true>(ts, qkv, o, d_o, lse2, dqkv, B, N, H, s, nullptr, (uint8_t*)dq_q, (uint8_t*)dq_s) \
+                    : m4_launch<K, false, false, true>(ts, qkv, o, d_o, lse2, dqkv, B, N, H, s, nullptr, (uint8_t*)dq_q, (uint8_t*)dq_s); \
+    return ragged ? m4_launch<K, true>(ts, qkv, o, d_o, lse2, dqkv, B, N, H, s)                                            \
+                  : m4_launch<K, false>(ts, qkv, o, d_o, lse2, dqkv, B, N, H, s);                                          \
+  } while (0)
   switch (KB) {
     case 1: AVF_M4(1);
     case 2: AVF_M4(2);

@@ -523,7 +523,9 @@ bool attn_masked_bf16_ok(int N, int dh, bool q_prescaled);  // head-resident for
 bool attn_fwd_emits_mx8(int N, int dh);  // mx_q / mx_s: MX-FP8 image of o, written by the head-resident kernel only
 int attn_bwd_bf16(const bf16* qkv, const bf16* o, const bf16* d_o, const float* lse2, bf16* dqkv, float* delta,
                   int B, int N, int H, int dh, hipStream_t s, bool q_prescaled = false, float* nlse = nullptr,
-                  const void* keep = nullptr);
+                  const void* keep = nullptr, void* dq_q = nullptr, void* dq_s = nullptr);
+// dq_q / dq_s: MX-FP8 image of dqkv ([B N][3 I] e4m3 + [B N][3 I / 32] E8M0), written by the merged kernel only
+bool attn_bwd_emits_mx8(int N, int dh, bool q_prescaled);
 int attn_delta(int dtype, const void* o, const void* d_o, float* delta, int B, int N, int H, int dh, hipStream_t s);
 // merged dQ + dK/dV kernel (attn_bwd_merged.hip): dim_head 64, pre-scaled q, N <= 512
 // mlp_fused.hip: the FeedForward sublayer as one kernel per direction (bf16 operands; R % 64 == 0, D in {256, 512, 768}, M % 128 == 0)
@@ -534,6 +536,6 @@ int mlp_fused_bwd(const void* dy, const void* w2_t, const void* w1_t, const void
                   int64_t R, int D, int M, hipStream_t s);
 bool attn_bwd_merged_ok(int N, int dh, bool q_prescaled);
 int attn_bwd_merged(const TimingScope* ts, const bf16* qkv, const bf16* o, const bf16* d_o, const float* lse2, bf16* dqkv,
-                    int B, int N, int H, hipStream_t s, const void* keep = nullptr);
+                    int B, int N, int H, hipStream_t s, const void* keep = nullptr, void* dq_q = nullptr, void* dq_s = nullptr);
 
 }  // namespace avf

@@ -202,6 +202,7 @@ struct LowP {
   void *wqkv_q, *wqkv_s, *w1_q, *w1_s, *w2_q, *w2_s;  // mx8_fwd only
   void *wo_q, *wo_s;                                  // mx8_fwd: out-projection (used when the attention kernel emits the image of o)
   void *w2t_q, *w2t_s, *w1t_q, *w1t_s, *wot_q, *wot_s;  // mx8_bwd: images of the transposed weights (K = out features)
+  void *wqkvt_q, *wqkvt_s;                               // mx8_bwd: image of Wqkv^T [D, 3I] (dqkv -> dh1, K = 3I)
   void *wqkv_ln, *w1_ln;                // ln_fuse: gamma-scaled images of Wqkv (query rows also carry the softmax scale) and W1
   float *s_qkv, *c_qkv, *s_1, *c_1;     // ln_fuse: their s / c vectors
 };
@@ -228,9 +229,11 @@ size_t carve_lowp(const Dims& d, void* base, LowP* l) {
     t.w2t_q = c.take((size_t)d.D * d.M);      t.w2t_s = c.take((size_t)d.D * d.M / 32);
     t.w1t_q = c.take((size_t)d.D * d.M);      t.w1t_s = c.take((size_t)d.D * d.M / 32);
     t.wot_q = c.take((size_t)d.D * d.I);      t.wot_s = c.take((size_t)d.D * d.I / 32);
+    t.wqkvt_q = c.take((size_t)3 * d.I * d.D); t.wqkvt_s = c.take((size_t)3 * d.I * d.D / 32);
   } else {
     t.wqkv_q = t.wqkv_s = t.w1_q = t.w1_s = t.w2_q = t.w2_s = nullptr;
     t.wo_q = t.wo_s = t.w2t_q = t.w2t_s = t.w1t_q = t.w1t_s = t.wot_q = t.wot_s = nullptr;
+    t.wqkvt_q = t.wqkvt_s = nullptr;
   }
   if (d.lnf) {
     t.wqkv_ln = c.take((size_t)3 * d.I * d.D * 2);
@@ -269,6 +272,7 @@ struct Work {
   void *hq, *hs, *gq, *gs;  // mx8_fwd only: MX-FP8 images of the LayerNorm output and of gelu(u), forward scratch
   void *oq, *os;            // mx8_fwd: image of the attention output (forward scratch)
   void *duq, *dus, *mq, *ms, *gyq, *gys;  // mx8_bwd: images of du, of dx_mid, and of dx_out when the caller brought none
+  void *dqq, *dqs;                        // mx8_bwd: image of dqkv (written by the merged attention backward)
   float *gy_m, *gm_m;       // fp32 mode with live dropout: masked copies of dx_out / dx_mid (what the Linears behind sites 2 / 0 see)
   float* small_part;        // short-sequence backward: per-clip partial rows (pb1 [B][M] | pln2 [B][3D] | pln1 [B][3D])
   float *ln_part_a, *ln_part_b;  // ln_fuse: per-row partial statistics [R][D/32][2] of x_in (LN1) and of x_mid (LN2)
@@ -320,8 +324,10 @@ size_t carve_work(const Dims& d, void* base, Work* w) {
     t.duq = c.take(d.R * d.M); t.dus = c.take(d.R * d.M / 32);
     t.mq = c.take(d.R * d.D);  t.ms = c.take(d.R * d.D / 32);
     t.gyq = c.take(d.R * d.D); t.gys = c.take(d.R * d.D / 32);
+    t.dqq = c.take(d.R * 3 * d.I); t.dqs = c.take(d.R * 3 * d.I / 32);
   } else {
     t.duq = t.dus = t.mq = t.ms = t.gyq = t.gys = nullptr;
+    t.dqq = t.dqs = nullptr;
   }
   const bool f32_drop = d.dt == AVF_F32 && d.p > 0.f;
   t.gy_m = (float*)c.take(f32_drop ? d.R * d.D * 4 : 0);
@@ -516,7 +522,7 @@ extern "C" int avf_stack_quant_weights_mx8(const avf_layer_cfg* cfg, int layers,
   AVF_TRY(make_dims(cfg, &d));
   AVF_REQUIRE(d.mx, "stack_quant_weights_mx8: cfg.mx8_fwd is not set");
   AVF_REQUIRE(layers > 0 && layers <= 64 && lowp, "stack_quant_weights_mx8: bad arguments");
-  MxQuantJob jobs[64 * 7];
+  MxQuantJob jobs[64 * 8];
   int n = 0;
   for (int i = 0; i < layers; ++i) {
     AVF_REQUIRE(lowp[i], "stack_quant_weights_mx8: null image buffer (layer %d)", i);
@@ -530,6 +536,7 @@ extern "C" int avf_stack_quant_weights_mx8(const avf_layer_cfg* cfg, int layers,
       jobs[n++] = MxQuantJob{l.w2_t, l.w2t_q, l.w2t_s, d.M, d.D};
       jobs[n++] = MxQuantJob{l.w1_t, l.w1t_q, l.w1t_s, d.D, d.M};
       jobs[n++] = MxQuantJob{l.wo_t, l.wot_q, l.wot_s, d.I, d.D};
+      if ((3 * d.I) % 128 == 0) jobs[n++] = MxQuantJob{l.wqkv_t, l.wqkvt_q, l.wqkvt_s, d.D, 3 * d.I};
     }
   }
   return quant_mx8_multi(jobs, n, (hipStream_t)stream);
@@ -828,6 +835,14 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
                          nullptr));
   else
     AVF_TRY(linear_dx(d, gm, d.D, p->w_out, l.wo_t, d.I, w.d_o, AVF_EPI_NONE, nullptr, s));
+  // dqkv -> dh1 on MX-FP8 operands, the image of dqkv written by the merged attention backward:
+  // built and bit-exact, but the image costs the attention kernel 18 us at B = 64, N = 512 (50 us before its stores were
+  // made 16 bytes wide and dQ's 32-blocks wave-local) while the K = 1536 GEMM, already at 0.87 PFLOP/s on bf16 operands,
+  // gains ~9 us: C5 5.06 ms per step with it against 4.93 without - OFF unless AVF_MX8_DQKV=1.
+  const char* dq_env = getenv("AVF_MX8_DQKV");  // (read per call: a test flips it inside one process)
+  const int dq_mx_on = (dq_env && *dq_env) ? atoi(dq_env) : 0;
+  const bool dq_mx = d.mxb && dq_mx_on && !d.keep && (3 * d.I) % 128 == 0 && d.D % 128 == 0 &&
+                     attn_bwd_emits_mx8(d.N, d.dh, attn_q_prescale_on());
   if (d.keep && lo && !d.mx && attn_masked_bf16_ok(d.N, d.dh, attn_q_prescale_on()))  // (as the forward chose)
     AVF_TRY(attn_bwd_bf16((const bf16*)sv.qkv, (const bf16*)sv.o, (const bf16*)w.d_o, sv.lse2, (bf16*)w.dqkv, w.delta,
                           d.B, d.N, d.H, d.dh, s, true, w.delta + (size_t)d.B * d.H * d.N, d.keep));
@@ -836,11 +851,16 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
                          lo && attn_q_prescale_on()));
   else if (lo)
     AVF_TRY(attn_bwd_bf16((const bf16*)sv.qkv, (const bf16*)sv.o, (const bf16*)w.d_o, sv.lse2, (bf16*)w.dqkv, w.delta,
-                          d.B, d.N, d.H, d.dh, s, attn_q_prescale_on(), w.delta + (size_t)d.B * d.H * d.N));
+                          d.B, d.N, d.H, d.dh, s, attn_q_prescale_on(), w.delta + (size_t)d.B * d.H * d.N, nullptr,
+                          dq_mx ? w.dqq : nullptr, dq_mx ? w.dqs : nullptr));
   else
     AVF_TRY(attn_bwd_f32((const float*)sv.qkv, (const float*)sv.o, (const float*)w.d_o, sv.lse2, (float*)w.dqkv,
                          w.delta, d.B, d.N, d.H, d.dh, s));
-  AVF_TRY(linear_dx(d, w.dqkv, 3 * d.I, p->w_qkv, l.wqkv_t, d.D, w.dh, AVF_EPI_NONE, nullptr, s));
+  if (dq_mx)  // dh1 = dqkv Wqkv on MX-FP8 operands: the image of dqkv left the attention backward's epilogue
+    AVF_TRY(linear_dx_mx(d, w.dqq, w.dqs, 3 * d.I, l.wqkvt_q, l.wqkvt_s, d.D, w.dh, AVF_EPI_NONE, nullptr, s, nullptr, nullptr,
+                         kNoDrop, nullptr));
+  else
+    AVF_TRY(linear_dx(d, w.dqkv, 3 * d.I, p->w_qkv, l.wqkv_t, d.D, w.dh, AVF_EPI_NONE, nullptr, s));
   // dw_overlap: the layer above may still be reading its gy - the buffer this layer's LN1' writes dx_in_lo into - and the
   // scratch copy the layer below will use: join its weight-gradient launch here, as late as the data allows
   AVF_TRY(side_join(side, s));

@@ -285,6 +285,20 @@ def attn_fwd_mx8(qkv: torch.Tensor, batch: int, tokens: int, heads: int, dim_hea
     return o, lse2, q, s
 
 
+def attn_bwd_mx8(qkv, o, d_o, lse2, batch: int, tokens: int, heads: int, dim_head: int):
+    """bf16 attention backward on PRE-SCALED queries -> (dqkv bf16 [B*N, 3I], its e4m3 image, the scale bytes [B*N, 3I/32]);
+    only where the merged kernel runs (avf_attn_bwd_emits_mx8)."""
+    _need_cuda(qkv, o, d_o, lse2)
+    inner = heads * dim_head
+    dev = qkv.device
+    dqkv = torch.empty((batch * tokens, 3 * inner), dtype=torch.bfloat16, device=dev)
+    q = torch.empty((batch * tokens, 3 * inner), dtype=torch.uint8, device=dev)
+    s = torch.empty((batch * tokens, 3 * inner // 32), dtype=torch.uint8, device=dev)
+    _lib.check(_lib.load().avf_attn_bwd_mx8(_ptr(qkv.contiguous()), _ptr(o.contiguous()), _ptr(d_o.contiguous()), _ptr(lse2), _ptr(dqkv),
+                                            _ptr(q), _ptr(s), batch, tokens, heads, dim_head, _stream()), "attn_bwd_mx8")
+    return dqkv, q, s
+
+
 def gemm_mx8(a_q: torch.Tensor, a_s: torch.Tensor, b_q: torch.Tensor, b_s: torch.Tensor, out_dtype=torch.float32,
              epilogue: int = EPI_NONE, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
              want_image: bool = False, aux: Optional[torch.Tensor] = None):

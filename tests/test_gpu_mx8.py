@@ -292,6 +292,56 @@ def test_attention_emits_the_image_of_its_output(ops, B, N, H):
     assert torch.equal(q.cpu(), q_ref)
 
 
+@pytest.mark.parametrize("B,N,H", [(2, 324, 8), (1, 512, 4), (2, 300, 1), (2, 385, 2)])
+def test_attention_backward_emits_the_image_of_dqkv(ops, B, N, H):
+    """round 3: the merged backward kernel writes the MX-FP8 image of dqkv (the A operand of dqkv -> dh1 in the fp8 mode):
+    dqkv itself is bit-equal to the plain call, the image is that of the stored bf16 tensor"""
+    import math
+    g = torch.Generator().manual_seed(B * 7 + N + H)
+    qkv = torch.randn(B * N, 3 * H * 64, generator=g)
+    qkv[:, :H * 64] *= math.log2(math.e) / 8.0  # pre-scaled queries, as the layer's Wqkv image produces them
+    qkv = qkv.bfloat16().cuda()
+    d_o = torch.randn(B * N, H * 64, generator=g).bfloat16().cuda()
+    o, lse2 = ops.attn_fwd(qkv, B, N, H, 64, q_prescaled=True)[:2]
+    dqkv, q, s = ops.attn_bwd_mx8(qkv, o, d_o, lse2, B, N, H, 64)
+    ref = ops.attn_bwd(qkv, o, d_o, lse2, B, N, H, 64, q_prescaled=True)
+    assert torch.equal(dqkv, ref)
+    q_ref, s_ref = oracle.mx8_quant(dqkv.float().cpu())
+    assert torch.equal(s.cpu(), s_ref)
+    assert torch.equal(q.cpu(), q_ref)
+
+
+def test_dqkv_to_dh1_on_fp8_operands_tracks_the_bf16_gemm(monkeypatch):
+    """AVF_MX8_DQKV=1 (off by default: DESIGN.md section 17, item 5): the last bf16 dX GEMM of the fp8 mode on MX-FP8 operands"""
+    import avformer_amd as A
+    torch.manual_seed(21)
+    t = A.Transformer(256, 2, 4, 64, 512, compute_dtype="mx8", residual_dtype="bf16").cuda()
+    x = torch.randn(2, 320, 256, device="cuda")
+
+    def run():
+        xi = x.clone().requires_grad_(True)
+        for p in t.parameters():
+            p.grad = None
+        t(xi).float().pow(2).mean().backward()
+        torch.cuda.synchronize()
+        return xi.grad.clone(), {k: p.grad.clone() for k, p in t.named_parameters()}
+
+    dx0, g0 = run()
+    monkeypatch.setenv("AVF_MX8_DQKV", "1")
+    dx1, g1 = run()
+    assert not torch.equal(dx0, dx1)  # (the switch took effect)
+    rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    assert rel(dx1, dx0) < 5e-2
+    for k in g0:
+        assert rel(g1[k], g0[k]) < 8e-2, k
+
+
+def test_attention_backward_image_needs_the_merged_kernel(ops):
+    z = torch.zeros(640, 3 * 64, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(RuntimeError, match="merged"):
+        ops.attn_bwd_mx8(z, z[:, :64].contiguous(), z[:, :64].contiguous(), torch.zeros(1, 1, 640, device="cuda"), 1, 640, 1, 64)
+
+
 def test_attention_image_needs_the_head_resident_kernel(ops):
     qkv = torch.zeros(640, 3 * 64, dtype=torch.bfloat16, device="cuda")
     with pytest.raises(RuntimeError, match="head-resident"):
