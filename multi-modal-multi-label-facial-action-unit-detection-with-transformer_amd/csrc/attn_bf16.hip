@@ -706,13 +706,22 @@ __global__ __launch_bounds__(MAXW * 64) void attn_fwd_res_kernel(const bf16* __r
       const int q = q0 + qb * 16 + li;
       const float l = ls[qb][0];
       const float inv = 1.0f / l;
-      if (q < N) {
-        bf16* orow = o + ((int64_t)b * N + q) * I + h * DH;
+      {
+        // lane groups lg, lg + 1 trade the words of column blocks d, d + 1 (v_permlane16_swap, all lanes active): an even
+        // group then holds 8 consecutive columns of block d, an odd one 8 of block d + 1 - 16-byte stores
+        bf16* orow = o + ((int64_t)b * N + (q < N ? q : N - 1)) * I + h * DH;
 #pragma unroll
-        for (int d = 0; d < DB; ++d)
-          store4<bf16>(orow + d * 16 + 4 * lg,
-                       make_float4(ot[d][qb][0] * inv, ot[d][qb][1] * inv, ot[d][qb][2] * inv, ot[d][qb][3] * inv));
-        if (lg == 0) lse2[(int64_t)bh * N + q] = m[qb] + log2f(l);
+        for (int d = 0; d < DB; d += 2) {
+          const uint32_t a0 = pack_bf16x2(ot[d][qb][0] * inv, ot[d][qb][1] * inv), a1 = pack_bf16x2(ot[d][qb][2] * inv, ot[d][qb][3] * inv);
+          const uint32_t b0 = pack_bf16x2(ot[d + 1][qb][0] * inv, ot[d + 1][qb][1] * inv),
+                         b1 = pack_bf16x2(ot[d + 1][qb][2] * inv, ot[d + 1][qb][3] * inv);
+          const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+          const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+          if (q < N)
+            *reinterpret_cast<uint4*>(orow + ((lg & 1) ? (d + 1) * 16 + 4 * (lg - 1) : d * 16 + 4 * lg)) =
+                make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        }
+        if (q < N && lg == 0) lse2[(int64_t)bh * N + q] = m[qb] + log2f(l);
       }
       if (oq) {  // wave-uniform: MX-FP8 image of the output rows (A operand of the out-projection in the fp8 mode); a
                  // 32-block of the head's 64 columns is two 16-column blocks x the 4 lane groups x 4 registers

@@ -498,14 +498,16 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
         if (G == 0) dq_s[row * (ld >> 5) + (colb >> 5)] = (uint8_t)sb;
       }
     } else {
-#pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
-        const int q = 32 * sp + 16 * qt + li;
-        const f32x4_t a = qt ? acc1 : acc0;
-        if (q < N)
-          store4<bf16>(dqkv + ((int64_t)b * N + q) * ld + h * DH + 16 * wave + 4 * G,
-                       make_float4(a[0] * qscale, a[1] * qscale, a[2] * qscale, a[3] * qscale));
-      }
+      // lane groups G, G + 1 trade words (v_permlane16_swap): an even group then holds 8 consecutive columns of query tile 0,
+      // an odd one 8 of tile 1 - one 16-byte store per lane and slice instead of two 8-byte ones
+      const uint32_t a0 = pack_bf16x2(acc0[0] * qscale, acc0[1] * qscale), a1 = pack_bf16x2(acc0[2] * qscale, acc0[3] * qscale);
+      const uint32_t b0 = pack_bf16x2(acc1[0] * qscale, acc1[1] * qscale), b1 = pack_bf16x2(acc1[2] * qscale, acc1[3] * qscale);
+      const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+      const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+      const int q = 32 * sp + 16 * (G & 1) + li;
+      if (q < N)
+        *reinterpret_cast<uint4*>(dqkv + ((int64_t)b * N + q) * ld + h * DH + 16 * wave + 4 * (G & ~1)) =
+            make_uint4(s0[0], s1[0], s0[1], s1[1]);
     }
   };
 
@@ -613,20 +615,36 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
 #pragma unroll
   for (int j = 0; j < KB; ++j) {
     const int key = 32 * (kb0 + j) + r;
-    if (key < N) {
-      bf16* outk = dqkv + ((int64_t)b * N + key) * ld + I + h * DH;
-      bf16* outv = outk + I;
+    // A lane holds columns 8 g + 4 hf .. + 3 (g = 0..3) of each 32-column block of its key row: the lane pair (r, 0), (r, 1)
+    // trades words (v_permlane32_swap, every lane active: outside the key < N branch) so that lane (r, 0) stores columns
+    // 0 .. 15 and lane (r, 1) columns 16 .. 31 as 16-byte pieces - half as many store instructions, each twice as wide, to
+    // the 64 different rows a wave-instruction touches here
 #pragma unroll
-      for (int db = 0; db < 2; ++db)
+    for (int which = 0; which < 2; ++which)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        uint32_t w[4][2];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int d = 32 * db + 8 * g + 4 * hf;
-          store4<bf16>(outk + d, make_float4(dkacc[j][db][4 * g] * kscale, dkacc[j][db][4 * g + 1] * kscale,
-                                             dkacc[j][db][4 * g + 2] * kscale, dkacc[j][db][4 * g + 3] * kscale));
-          store4<bf16>(outv + d, make_float4(dvacc[j][db][4 * g], dvacc[j][db][4 * g + 1], dvacc[j][db][4 * g + 2],
-                                             dvacc[j][db][4 * g + 3]));
+          if (which) {
+            w[g][0] = pack_bf16x2(dvacc[j][db][4 * g], dvacc[j][db][4 * g + 1]);
+            w[g][1] = pack_bf16x2(dvacc[j][db][4 * g + 2], dvacc[j][db][4 * g + 3]);
+          } else {
+            w[g][0] = pack_bf16x2(dkacc[j][db][4 * g] * kscale, dkacc[j][db][4 * g + 1] * kscale);
+            w[g][1] = pack_bf16x2(dkacc[j][db][4 * g + 2] * kscale, dkacc[j][db][4 * g + 3] * kscale);
+          }
         }
-    }
+        const auto a0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[2][0], false, false);
+        const auto a1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[2][1], false, false);
+        const auto b0 = __builtin_amdgcn_permlane32_swap(w[1][0], w[3][0], false, false);
+        const auto b1 = __builtin_amdgcn_permlane32_swap(w[1][1], w[3][1], false, false);
+        if (key < N) {
+          bf16* out = dqkv + ((int64_t)b * N + key) * ld + (which ? 2 * I : I) + h * DH + 32 * db + 16 * hf;
+          // lane (r, 0): [g0 own | g0 partner | g1 own | g1 partner]; lane (r, 1): [g2 partner | g2 own | g3 partner | g3 own]
+          *reinterpret_cast<uint4*>(out) = make_uint4(a0[0], a1[0], a0[1], a1[1]);
+          *reinterpret_cast<uint4*>(out + 8) = make_uint4(b0[0], b1[0], b0[1], b1[1]);
+        }
+      }
     if constexpr (MXK) {  // (outside the key < N branch: the lane pair (r, hf) trades words with every lane active)
       const int64_t row = (int64_t)b * N + (key < N ? key : N - 1);
 #pragma unroll
