@@ -116,6 +116,29 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
       if (half * 2 + ii >= MI) continue;  // odd MI: the last pair has one row block
       mm[ii] = m_base + (half * 2 + ii) * 16 + li;
       const int mc = mm[ii] < p.M ? mm[ii] : p.M - 1;
+      // 2-byte rows (bf16 residual stream, saved pre-activation): one 16-byte load per lane and block PAIR instead of two
+      // 8-byte ones - an even lane group reads 8 consecutive columns of block j (its own 4 and its right neighbour's), an odd
+      // one 8 of block j + 1 (its left neighbour's 4 and its own); v_permlane16_swap hands each lane its own columns of both
+      // blocks (the mirror image of store_pair16).  Wave-uniform condition.
+      const bool wide_ex = (NI & 1) == 0 && sizeof(CT) == 2 && (EPI == AVF_EPI_BIAS_RES || EPI == AVF_EPI_DGELU) && p.wide == 1 &&  // (AVF_NT_WIDE=2: wide stores only)
+                           (p.N & 7) == 0 && (((EPI == AVF_EPI_BIAS_RES) ? p.ldres : p.ldaux) & 7) == 0 &&
+                           (((uintptr_t)((EPI == AVF_EPI_BIAS_RES) ? p.residual : (const void*)p.aux)) & 15) == 0;
+      if (wide_ex) {
+        const bf16* src = (EPI == AVF_EPI_BIAS_RES) ? (const bf16*)p.residual : (const bf16*)p.aux;
+        const int64_t ldx = (EPI == AVF_EPI_BIAS_RES) ? p.ldres : p.ldaux;
+#pragma unroll
+        for (int j = 0; j < NI; j += 2) {
+          int cw = (lg & 1) ? nn[j + 1] - 4 : nn[j];
+          cw = cw + 8 <= p.N ? cw : 0;
+          const uint4 raw = *reinterpret_cast<const uint4*>(src + (int64_t)mc * ldx + cw);
+          const auto s0 = __builtin_amdgcn_permlane16_swap(raw.x, raw.z, false, false);
+          const auto s1 = __builtin_amdgcn_permlane16_swap(raw.y, raw.w, false, false);
+          ex[ii][j] = make_float4(__uint_as_float(s0[0] << 16), __uint_as_float(s0[0] & 0xffff0000u),
+                                  __uint_as_float(s1[0] << 16), __uint_as_float(s1[0] & 0xffff0000u));
+          ex[ii][j + 1] = make_float4(__uint_as_float(s0[1] << 16), __uint_as_float(s0[1] & 0xffff0000u),
+                                      __uint_as_float(s1[1] << 16), __uint_as_float(s1[1] & 0xffff0000u));
+        }
+      } else {
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         if (EPI == AVF_EPI_BIAS_RES) {
@@ -123,6 +146,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
           else ex[ii][j] = *reinterpret_cast<const float4*>((const float*)p.residual + (int64_t)mc * p.ldres + nc[j]);
         }
         else if (EPI == AVF_EPI_DGELU) ex[ii][j] = load4<CT>((const CT*)p.aux + (int64_t)mc * p.ldaux + nc[j]);
+      }
       }
     }
 #pragma unroll
