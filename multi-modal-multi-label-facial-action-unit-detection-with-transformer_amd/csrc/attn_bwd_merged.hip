@@ -708,7 +708,9 @@ int m4_launch(const TimingScope* ts, const bf16* qkv, const bf16* o, const bf16*
 
 }  // namespace
 
-// merged backward: dim_head 64, pre-scaled q, N <= 512.  It is the default from three key blocks per wave up (N >= 257):
+// merged backward: dim_head 64, pre-scaled q, N <= 512 - the default at every such N since its epilogue stores went to 16 bytes
+// (back to back, B = 32: N = 128 11.6 us against 18.9 for the two head-resident kernels, 196: 23.1 / 24.2, 256: 26.3 / 29.3; TFormer's
+// 17 tokens: 0.438 -> 0.428 ms per step).  History of the threshold (AVF_ATTN_MERGED_MIN_N), from three key blocks per wave up (N >= 257):
 // back to back in the harness it wins at N = 512 (B = 32 / 64: 77.3 / 155 us against 80.1 / 160.2 us) and loses at N = 324
 // (46.2 against 44.2 us), but IN THE STEP the single launch - which reads q, k, v, dO once, not twice - is the faster one there
 // too: C2 (N = 324) 2.107 / 2.113 ms per step against 2.141 / 2.129 with the two kernels (same box, alternating runs).
@@ -720,7 +722,7 @@ bool attn_bwd_merged_ok(int N, int dh, bool q_prescaled) {
   }();
   static const int min_n = [] {
     const char* e = getenv("AVF_ATTN_MERGED_MIN_N");
-    return (e && *e) ? atoi(e) : 257;
+    return (e && *e) ? atoi(e) : 1;
   }();
   return allow && q_prescaled && dh == 64 && N <= 512 && N >= min_n;
 }
