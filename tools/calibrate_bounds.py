@@ -2,10 +2,11 @@
 """tests/golden/lowp_measured.json from a calibration run of the GPU tests.
 
     AVF_RECORD_ERRORS=gpurun_out/errors.json python -m pytest tests -m gpu -q        (on the MI355X box)
-    python tools/calibrate_bounds.py gpurun_out/errors.json [--merge] [--allow-regress "<reason>"]
+    python tools/calibrate_bounds.py gpurun_out/errors.json [--merge | --keep-raised | --new-only] [--allow-regress "<reason>"]
 
 Every low-precision assertion in tests/ (gpu_util.check*) is then held to 3x the value recorded here (and to its
-stated cap).  --merge keeps entries of the existing file that the run did not touch.
+stated cap).  --merge keeps entries of the existing file that the run did not touch; --keep-raised (implies --merge) records
+new tags and lower values only and leaves every entry whose new measurement is higher untouched - no bound gets looser; --new-only records tags the file does not hold yet and nothing else.
 
 The file is FROZEN against regressions: a tag whose new measurement is HIGHER than the recorded one is a looser bound, and
 a kernel regression that lands just before a re-calibration would be baked in.  Without --allow-regress the tool refuses
@@ -38,14 +39,24 @@ def main(argv=None, out_path=None):
             return 2
         reason = argv[i + 1]
         del argv[i:i + 2]
-    merge = "--merge" in argv
+    keep_raised = "--keep-raised" in argv  # take new tags and LOWER values only; a higher measurement leaves the record as it is
+    new_only = "--new-only" in argv        # take new tags only: every recorded value stays (nothing gets looser OR tighter)
+    merge = "--merge" in argv or keep_raised or new_only
     src = [a for a in argv if not a.startswith("--")][0]
     new = json.load(open(src))
     doc = {}
     if os.path.exists(out_path):
         doc = json.load(open(out_path))
     old = doc.get("measured", {})
+    if new_only:
+        skipped = sum(1 for k in new if k in old)
+        new = {k: v for k, v in new.items() if k not in old}
+        print(f"--new-only: {skipped} already recorded tag(s) left as they are")
     up = raised_tags(old, new)
+    if keep_raised and up:
+        print(f"--keep-raised: {len(up)} higher measurement(s) ignored (their recorded values stay)")
+        new = {k: v for k, v in new.items() if k not in up}
+        up = {}
     if up and reason is None:
         print(f"REFUSED: {len(up)} recorded value(s) would be RAISED (looser bounds).  Fix the regression, or re-run with "
               f"--allow-regress \"<reason>\":", file=sys.stderr)
