@@ -6,8 +6,8 @@ naturally because every op is per-clip (LayerNorm, attention within a clip, per-
 
 Overlap: each ``Transformer`` calls a hook right after a layer's backward has been enqueued (reverse layer
 order) with that layer's flat fp32 gradient bucket (11 tensors, 2.1 M floats at d=512).  The buckets of a stack
-are consecutive slices of one allocation; the wrapper collects ``bucket_layers`` adjacent ones (default 2:
-16.8 MB at d=512) and launches ONE asynchronous all-reduce for the merged range: the process group runs it on its own
+are consecutive slices of one allocation; the wrapper collects adjacent ones up to ``bucket_bytes`` (default 16 MiB: two layers,
+16.8 MB, at d=512) and launches ONE asynchronous all-reduce for the merged range: the process group runs it on its own
 communication stream, ordered after the producing kernels, so it runs under the backward of the earlier layers - half the collectives
 of a per-layer scheme (each costs the host ~0.1 ms and the links a latency-bound ring).  ``finish()`` reduces the
 few parameters outside the transformer stacks in one extra bucket and makes the compute stream wait for
@@ -40,13 +40,19 @@ class _GlobalMeanFn(torch.autograd.Function):
 
 class DataParallel:
     def __init__(self, model: torch.nn.Module, process_group=None, broadcast_parameters: bool = True,
-                 bucket_layers: int = 2):
+                 bucket_layers: Optional[int] = None, bucket_bytes: int = 16 << 20):
         if not dist.is_initialized():
             raise RuntimeError("DataParallel needs torch.distributed to be initialised (one process per GPU)")
         self.model = model
         self.group = process_group
         self.world = dist.get_world_size(process_group)
-        self.bucket_layers = max(1, int(bucket_layers))
+        # A collective is launched once the held layers amount to ``bucket_bytes`` (default 16 MiB: two layers of 8.4 MB at
+        # d = 512, one of 18.9 MB at d = 768, a whole 12-token head stack at once): a ring all-reduce over the 7 x 153 GB/s
+        # xGMI links moves 2 (n - 1) / n of the bucket per GPU, ~0.1 ms for 16 MiB at 8 GPUs - several times the ~30-50 us
+        # latency floor of a collective, yet small enough that the LAST bucket (the bottom layers, whose reduction nothing
+        # overlaps) stays a fraction of a step.  ``bucket_layers`` (a layer count) overrides the byte rule.
+        self.bucket_layers = None if bucket_layers is None else max(1, int(bucket_layers))
+        self.bucket_bytes = max(1, int(bucket_bytes))
         self._stacks = [m for m in model.modules() if hasattr(m, "set_grad_hook") and hasattr(m, "flat_parameters")]
         self._owned = set()
         for st in self._stacks:
@@ -77,7 +83,9 @@ class DataParallel:
     # -- called from Transformer backward, once per layer ------------------------------------------
     def _on_layer_grads(self, layer: int, flat: torch.Tensor):
         self._held.append((layer, flat))
-        if len(self._held) >= self.bucket_layers or layer == 0:
+        full = (len(self._held) >= self.bucket_layers) if self.bucket_layers is not None else \
+            (sum(f.numel() * f.element_size() for _, f in self._held) >= self.bucket_bytes)
+        if full or layer == 0:
             works = self._flush()
             return lambda: [w.wait() for w in works]
         return self._flush_and_wait  # accumulation path: launch what is held now, make the current stream wait
