@@ -56,12 +56,21 @@ __device__ __forceinline__ int nt_off(int r, int c) { return r * 128 + ((c ^ (r 
 // packed dwords; v_permlane16_swap trades the (j+1) words of the even lane groups for the j words of the odd ones, after
 // which a lane owns EIGHT consecutive columns (even groups: block j, columns 4 lg .. 4 lg + 7; odd groups: block j+1,
 // columns 4 (lg-1) .. 4 (lg-1) + 7): one 16-byte store where the plain path issues two 8-byte ones to other rows' segments.
+template <bool NT = false>
 __device__ __forceinline__ void store_pair16(bf16* row, int n_j, int n_j1, int lg, uint32_t a0, uint32_t a1, uint32_t b0,
                                              uint32_t b1, bool row_ok, int N) {
   const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
   const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
   const int col = (lg & 1) ? n_j1 - 4 : n_j;
-  if (row_ok && col < N) *reinterpret_cast<uint4*>(row + col) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+  if (row_ok && col < N) {
+    if constexpr (NT) {  // written now, read again only in backward: keep it out of the caches the next kernels work from
+      typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));
+      const u32x4_nt v = {s0[0], s1[0], s0[1], s1[1]};
+      __builtin_nontemporal_store(v, reinterpret_cast<u32x4_nt*>(row + col));
+    } else {
+      *reinterpret_cast<uint4*>(row + col) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+    }
+  }
 }
 // the same for one dword per block (4 e4m3 bytes): one 8-byte store
 __device__ __forceinline__ void store_pair8(uint8_t* row, int n_j, int n_j1, int lg, uint32_t a, uint32_t b, bool row_ok, int N) {
@@ -120,7 +129,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
       // 8-byte ones - an even lane group reads 8 consecutive columns of block j (its own 4 and its right neighbour's), an odd
       // one 8 of block j + 1 (its left neighbour's 4 and its own); v_permlane16_swap hands each lane its own columns of both
       // blocks (the mirror image of store_pair16).  Wave-uniform condition.
-      const bool wide_ex = (NI & 1) == 0 && sizeof(CT) == 2 && (EPI == AVF_EPI_BIAS_RES || EPI == AVF_EPI_DGELU) && p.wide == 1 &&  // (AVF_NT_WIDE=2: wide stores only)
+      const bool wide_ex = (NI & 1) == 0 && sizeof(CT) == 2 && (EPI == AVF_EPI_BIAS_RES || EPI == AVF_EPI_DGELU) && p.wide && p.wide != 2 &&  // (AVF_NT_WIDE=2: wide stores only)
                            (p.N & 7) == 0 && (((EPI == AVF_EPI_BIAS_RES) ? p.ldres : p.ldaux) & 7) == 0 &&
                            (((uintptr_t)((EPI == AVF_EPI_BIAS_RES) ? p.residual : (const void*)p.aux)) & 15) == 0;
       if (wide_ex) {
@@ -240,6 +249,14 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
         if (EPI == AVF_EPI_BIAS_GELU && wide_aux) {
 #pragma unroll
           for (int j = 0; j < NI; j += 2)
+            // the saved pre-activation is read again in backward only: non-temporal stores keep it out of the caches the
+            // next kernels work from (C2 2.078 -> 2.063 ms per step, C3 2.757 -> 2.747, same box; AVF_NT_WIDE=3: plain stores.
+            // The same hint on its LOAD in the dGELU epilogue changed nothing; on the folded weight gradients it cost 0.8 %:
+            // the optimizer then reads them from HBM instead of the Infinity Cache)
+            if (p.wide != 3)
+              store_pair16<true>((bf16*)p.aux + (int64_t)mm[ii] * p.ldaux, nn[j], nn[j + 1], lg, aw[j][0], aw[j][1], aw[j + 1][0],
+                                 aw[j + 1][1], mok, p.N);
+            else
             store_pair16((bf16*)p.aux + (int64_t)mm[ii] * p.ldaux, nn[j], nn[j + 1], lg, aw[j][0], aw[j][1], aw[j + 1][0],
                          aw[j + 1][1], mok, p.N);
         }
