@@ -591,7 +591,8 @@ __global__ __launch_bounds__(256) void ln_bwd_row8_kernel(const bf16* __restrict
                                                           bf16* __restrict__ dx_lo, float* __restrict__ partial, int64_t rows,
                                                           int D, int want_colsum, bf16* __restrict__ h_out,
                                                           const float* __restrict__ beta, uint8_t* __restrict__ dxq = nullptr,
-                                                          uint8_t* __restrict__ dxs = nullptr) {
+                                                          uint8_t* __restrict__ dxs = nullptr, float* __restrict__ dx = nullptr) {
+  // dx (optional, wave-uniform): the fp32 copy of the row gradient (the bottom layer hands it to the caller)
   static_assert((LNR_ROWS_PER_BLOCK / 4) % RU == 0, "a wave's rows come in whole batches of RU");
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [4 waves][3][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -679,6 +680,10 @@ __global__ __launch_bounds__(256) void ln_bwd_row8_kernel(const bf16* __restrict
         if (HOUT) v[k] = fmaf(xh, gm[i][k], bt[i][k]);
       }
       *reinterpret_cast<uint4*>(dx_lo + (row0 + r) * D + c) = pack8(o);
+      if (dx) {
+        *reinterpret_cast<float4*>(dx + (row0 + r) * D + c) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(dx + (row0 + r) * D + c + 4) = make_float4(o[4], o[5], o[6], o[7]);
+      }
       if (dxq) {  // wave-uniform: MX-FP8 image of the same values (D % 32 == 0: the four lanes of a block are live together)
         const MxBlock mb = mx8_encode(o);
         *reinterpret_cast<uint2*>(dxq + (row0 + r) * D + c) = mb.q;
@@ -742,7 +747,7 @@ int layernorm_bwd(const void* dy, int dy_dtype, const void* xv, const float* gam
   int nb;
   const bool fast = (dim % 4 == 0) && dim <= 1536 && (dy_dtype == AVF_F32 || dy_dtype == AVF_BF16);
   if (fast) {
-    const bool row8 = x_dtype == AVF_BF16 && dy_dtype == AVF_BF16 && (!dres || dres_dtype == AVF_BF16) && !dx && dx_lo &&
+    const bool row8 = x_dtype == AVF_BF16 && dy_dtype == AVF_BF16 && (!dres || dres_dtype == AVF_BF16) && dx_lo &&
                       !drop.thresh16 && (!mx_q || dim % 32 == 0) && dim % 8 == 0 && ln_row8_on();
     const int rpb = row8 ? LNR_ROWS_PER_BLOCK : lnr_rows_per_block(rows);
     nb = (int)ceil_div(rows, rpb);
@@ -783,11 +788,11 @@ int layernorm_bwd(const void* dy, int dy_dtype, const void* xv, const float* gam
     if (h_out)                                                                                                               \
       launch_in_scope(&ts, ln_bwd_row8_kernel<NVV, RU, true>, dim3(nb), dim3(256), (uint32_t)lds, s, (const bf16*)dy,         \
                       (const bf16*)xv, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx_lo, partial, rows, dim, wc, (bf16*)h_out, beta, \
-                      (uint8_t*)mx_q, (uint8_t*)mx_s);                                                                       \
+                      (uint8_t*)mx_q, (uint8_t*)mx_s, dx);                                                                   \
     else                                                                                                                     \
       launch_in_scope(&ts, ln_bwd_row8_kernel<NVV, RU, false>, dim3(nb), dim3(256), (uint32_t)lds, s, (const bf16*)dy,        \
                       (const bf16*)xv, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx_lo, partial, rows, dim, wc, (bf16*)nullptr, \
-                      (const float*)nullptr, (uint8_t*)mx_q, (uint8_t*)mx_s);                                                \
+                      (const float*)nullptr, (uint8_t*)mx_q, (uint8_t*)mx_s, dx);                                            \
   } while (0)
       switch ((dim + 511) / 512) {  // rows in flight per wave: what the register file allows at two waves per SIMD or more
         case 1: LAUNCH_R8(1, 4); break;
