@@ -107,6 +107,15 @@ __device__ __forceinline__ float m_dot8(const uint4& x, const uint4& y) {
   return acc;
 }
 
+// sum over the 8 lanes 8 k .. 8 k + 7, valid in lane 8 k: two quad steps and row_shl:4 on the VALU (three dependent
+// ds_bpermute round trips sat at the bottom of every slice, in front of its barrier)
+__device__ __forceinline__ float m_sum8(float v) {
+  v += AVF_DPP_F32(v, 0xB1);
+  v += AVF_DPP_F32(v, 0x4E);
+  v += AVF_DPP_F32(v, 0x104);
+  return v;
+}
+
 __device__ __forceinline__ f32x16_t m_zero16() {
   f32x16_t z;
 #pragma unroll
@@ -259,9 +268,7 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
       const uint4 gv = *reinterpret_cast<const uint4*>(gbase + (int64_t)drow * I + dch * 8);
       part = m_dot8(ov, gv);
     }
-    part += __shfl_xor(part, 1, 64);
-    part += __shfl_xor(part, 2, 64);
-    part += __shfl_xor(part, 4, 64);
+    part = m_sum8(part);
     if (dch == 0) NDs[drow] = -part;
   }
   // MASKED: is this lane's key of block j a kept token (padded keys: no); the query flags of a slice as a bit mask,
@@ -597,9 +604,7 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
       // onext is logical chunk dch of the row: its partner sits in physical slot dch ^ swz(row)
       const uint4 gv = *reinterpret_cast<const uint4*>(gn + (drow & 31) * 128 + ((dch ^ m_swz(drow & 31)) << 4));
       float part = m_dot8(onext, gv);
-      part += __shfl_xor(part, 1, 64);
-      part += __shfl_xor(part, 2, 64);
-      part += __shfl_xor(part, 4, 64);
+      part = m_sum8(part);
       if (dch == 0) NDs[32 * (s + 1) + drow] = (32 * (s + 1) + drow < N) ? -part : 0.f;
     }
     __syncthreads();
