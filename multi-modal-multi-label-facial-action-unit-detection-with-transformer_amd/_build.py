@@ -18,8 +18,15 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 EXTRA_FLAGS = {"attn_bwd_merged.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
-def lib_path() -> str:
+def built_lib_path() -> str:
+    """where build() puts the library"""
     return os.path.join(LIBDIR, LIBNAME)
+
+
+def lib_path() -> str:
+    """what _lib.load() opens.  AVF_LIB_PATH: another build of the library (tuning aid: A/B of two builds inside one GPU-box
+    call, e.g. a copy of the previous build kept as lib/ab_base.so)"""
+    return os.environ.get("AVF_LIB_PATH") or built_lib_path()
 
 
 def _hipcc() -> str:
@@ -74,7 +81,7 @@ def _build_locked(force: bool, verbose: bool) -> str:
         with concurrent.futures.ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(compile_one, jobs))
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
-    out = lib_path()
+    out = built_lib_path()
     if force or jobs or _stale(out, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -575,6 +575,18 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
     AVF_PHASE_MARK(4);
     phase_c(std::integral_constant<int, 0>{});
     AVF_PHASE_MARK(7);
+    // (here, not at the bottom of the slice in front of its barrier: the DMA issued at the top has long landed, and the
+    //  dozen VALU instructions run beside the matrix pipe instead of on the slice's critical path)
+    if (more) {
+      // delta of the next slice: its dO rows 8 w .. 8 w + 7 were brought in by THIS wave (own vmcnt suffices)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const char* gn = ring + ((s + 1) & 1) * 8192 + 4096;
+      // onext is logical chunk dch of the row: its partner sits in physical slot dch ^ swz(row)
+      const uint4 gv = *reinterpret_cast<const uint4*>(gn + (drow & 31) * 128 + ((dch ^ m_swz(drow & 31)) << 4));
+      float part = m_dot8(onext, gv);
+      part = m_sum8(part);
+      if (dch == 0) NDs[32 * (s + 1) + drow] = (32 * (s + 1) + drow < N) ? -part : 0.f;
+    }
     if constexpr (KB > 1) {
       prefetch_c();
       AVF_FENCE();
@@ -597,16 +609,6 @@ __global__ __launch_bounds__(256) void attn_bwd_m4_kernel(const bf16* __restrict
       phase_c(std::integral_constant<int, 3>{});
     }
     AVF_PHASE_MARK(7);
-    if (more) {
-      // delta of the next slice: its dO rows 8 w .. 8 w + 7 were brought in by THIS wave (own vmcnt suffices)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const char* gn = ring + ((s + 1) & 1) * 8192 + 4096;
-      // onext is logical chunk dch of the row: its partner sits in physical slot dch ^ swz(row)
-      const uint4 gv = *reinterpret_cast<const uint4*>(gn + (drow & 31) * 128 + ((dch ^ m_swz(drow & 31)) << 4));
-      float part = m_dot8(onext, gv);
-      part = m_sum8(part);
-      if (dch == 0) NDs[32 * (s + 1) + drow] = (32 * (s + 1) + drow < N) ? -part : 0.f;
-    }
     __syncthreads();
     AVF_PHASE_MARK(5);
   }
