@@ -154,6 +154,20 @@ int avf_gemm(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K,
              const void* B, int64_t ldb, void* C, int64_t ldc, int c_dtype, int epilogue, const float* bias,
              const float* residual, int64_t ldres, void* aux, int64_t ldaux, void* workspace, void* stream);
 
+/* Weight-stationary persistent NT GEMM (csrc/gemm_ws.hip): C[M,N] = epilogue(A[M,512] W[N,512]^T), the nn.Linear forward /
+ * dX GEMMs of /root/reference/models/heads.py:191,195,212,215 at dim == 512.  W travels as its FRAGMENT-MAJOR image
+ * (avf_pack_weight_ws of the row-major bf16 image, avf_pack_weight_ws_bytes(rows, cols) bytes; rows % 256 == 0, cols == 512):
+ * each of the 8 wavefronts of a persistent workgroup keeps 32 weight rows in registers for the whole launch, only A streams.
+ * Same epilogues, argument meaning and bit-for-bit the results of avf_gemm(AVF_BF16, 0, 1, ...); colsum (optional, with
+ * workspace >= avf_colsum_workspace_bytes(M, N)): column sums of the stored C.  Errors if the shape does not qualify
+ * (M < 2048, K != 512, N % 256 != 0). */
+int avf_pack_weight_ws_ok(int64_t rows, int64_t cols);
+size_t avf_pack_weight_ws_bytes(int64_t rows, int64_t cols);
+int avf_pack_weight_ws(const void* w_bf16, int64_t ldw, int64_t rows, int64_t cols, void* out, void* stream);
+int avf_gemm_nt_ws(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B_packed, void* C, int64_t ldc,
+                   int c_dtype, int epilogue, const float* bias, const void* residual, int64_t ldres, void* aux, int64_t ldaux,
+                   void* workspace, float* colsum, void* stream);
+
 /* The weight gradients of one layer as ONE grouped launch (autograd of nn.Linear, heads.py:191,195,212,215): up to four
  * C_i[M_i,N_i] (fp32, dense) = A_i[K,M_i]^T * B_i[K,N_i] (bf16, token-major, dense: lda = M_i, ldb = N_i) that share the
  * reduction length K (the B*N token rows); K % 64 == 0, M_i % 8 == 0, N_i % 8 == 0.  Split-K partial slabs live in

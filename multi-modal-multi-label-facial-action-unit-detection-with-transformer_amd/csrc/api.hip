@@ -231,6 +231,28 @@ extern "C" int avf_gemm(int dtype, int transA, int transB, int64_t M, int64_t N,
   return gemm(a, (hipStream_t)stream);
 }
 
+// ---- weight-stationary persistent NT GEMM (gemm_ws.hip) ----
+extern "C" int avf_pack_weight_ws_ok(int64_t rows, int64_t cols) { return pack_ws_ok(rows, cols) ? 1 : 0; }
+extern "C" size_t avf_pack_weight_ws_bytes(int64_t rows, int64_t cols) { return pack_ws_ok(rows, cols) ? pack_ws_bytes(rows, cols) : 0; }
+extern "C" int avf_pack_weight_ws(const void* w_bf16, int64_t ldw, int64_t rows, int64_t cols, void* out, void* stream) {
+  return pack_ws(w_bf16, ldw, rows, cols, out, (hipStream_t)stream);
+}
+extern "C" int avf_gemm_nt_ws(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B_packed, void* C,
+                              int64_t ldc, int c_dtype, int epilogue, const float* bias, const void* residual, int64_t ldres,
+                              void* aux, int64_t ldaux, void* workspace, float* colsum, void* stream) {
+  AVF_REQUIRE(A && B_packed && C, "gemm_nt_ws: null pointer");
+  GemmArgs a;
+  a.dtype = AVF_BF16; a.transA = 0; a.transB = 1;
+  a.M = M; a.N = N; a.K = K;
+  a.A = A; a.lda = lda; a.B = nullptr; a.ldb = K; a.C = C; a.ldc = ldc;
+  a.c_dtype = c_dtype; a.epilogue = epilogue; a.bias = bias; a.residual = residual; a.ldres = ldres;
+  a.aux = aux; a.ldaux = ldaux; a.workspace = workspace; a.colsum = colsum; a.drop = kNoDrop; a.defer_fold = nullptr;
+  a.Bp = B_packed;
+  AVF_REQUIRE(gemm_bf16_nt_ws_ok(a), "gemm_nt_ws: the weight-stationary kernel takes K == 512, N %% 256 == 0, M >= 2048, 16-byte "
+              "aligned operands (M=%lld N=%lld K=%lld)", (long long)M, (long long)N, (long long)K);
+  return gemm_bf16_nt(a, (hipStream_t)stream);
+}
+
 static int fill_tn_group(TnGroupArgs* g, int count, int64_t K, const void* const* A, const void* const* B, float* const* C,
                          const int64_t* M, const int64_t* N) {
   AVF_REQUIRE(count >= 1 && count <= 4 && M && N, "gemm_tn_group: 1..4 problems");

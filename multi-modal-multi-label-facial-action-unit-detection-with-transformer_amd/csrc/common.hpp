@@ -430,7 +430,28 @@ struct GemmArgs {
   float* ln_rstd = nullptr;
   float ln_eps = 0.f;
   float* rs_out = nullptr;         // producer (BIAS_RES, bf16 C, N % 32 == 0): per-row partial statistics of C [M][N / 32][2]
+  // bf16 NT only, optional: the fragment-major image of B (pack_ws; K == 512, N % 256 == 0) - the GEMM then runs on the
+  // weight-stationary persistent kernel (gemm_ws.hip) when the shape qualifies
+  const void* Bp = nullptr;
 };
+// weight-stationary persistent NT GEMM (gemm_ws.hip)
+// byte offset of element (n, k) of a weight [N][512] in its fragment-major image: 1 KiB pieces (panel of 256 rows, wave's 32
+// rows, 16-row block j, k-step s of 32), inside a piece lane (li = n % 16, lg = (k % 32) / 8) owns 16 bytes = 8 consecutive k
+__host__ __device__ __forceinline__ size_t pack_ws_off(int n, int k) {
+  const size_t piece = (size_t)((((n >> 8) * 8 + ((n >> 5) & 7)) * 2 + ((n >> 4) & 1)) * 16 + (k >> 5));
+  return piece * 1024 + (size_t)((((k >> 3) & 3) * 16 + (n & 15)) * 16 + (k & 7) * 2);
+}
+// the fragment-major images a layer keeps behind its bf16 weight images (null where the shape does not qualify):
+// Wqkv [3I, D], Wo [D, I], W1 [M, D] (forward) and W2^T [M, D], Wo^T [I, D] (the dX GEMMs with a 512-deep reduction)
+struct LowpWs {
+  void *wqkv_p, *wo_p, *w1_p, *w2t_p, *wot_p;
+};
+int lowp_ws_images(const avf_layer_cfg* cfg, void* lowp, LowpWs* out);
+size_t pack_ws_bytes(int64_t N, int64_t K);
+bool pack_ws_ok(int64_t N, int64_t K);
+int pack_ws(const void* w_bf16, int64_t ldw, int64_t N, int64_t K, void* out, hipStream_t s);
+bool gemm_bf16_nt_ws_ok(const GemmArgs& a);
+int gemm_bf16_nt_ws(const GemmArgs& a, hipStream_t s, int* part_rows_out);
 // partial statistics (sum, sum of squares per group of 32 columns) of the rows of x [rows][dim]: the input of a
 // LayerNorm-folded GEMM whose producer is not a residual GEMM (the first layer of a stack)
 int row_stats(const void* x, int x_dtype, int64_t rows, int dim, float* part, hipStream_t s);

@@ -890,6 +890,15 @@ int gemm_bf16_nt(const GemmArgs& a, hipStream_t s) {
   AVF_REQUIRE(grid.y < 65536, "gemm_bf16_nt: M too large for grid");
   const bool cf32 = a.c_dtype == AVF_F32;
   AVF_REQUIRE(cf32 || a.c_dtype == AVF_BF16, "gemm_bf16_nt: bad c_dtype");
+  if (gemm_bf16_nt_ws_ok(a)) {  // K = 512 with a fragment-major weight image: the weight-stationary persistent kernel
+    int ws_rows = 0;
+    AVF_TRY(gemm_bf16_nt_ws(a, s, &ws_rows));
+    if (a.colsum) {
+      if (a.defer_fold) *a.defer_fold = FoldJob{(float*)a.workspace, ws_rows, (int)a.N, (int)a.N, a.colsum, nullptr, nullptr};
+      else AVF_TRY(fold_partials((float*)a.workspace, ws_rows, (int)a.N, a.colsum, s));
+    }
+    return 0;
+  }
   const bool dma = (a.K % TK == 0);
   int part_rows = (int)grid.y * 2;  // register-staged kernel: 2 wave rows per 128-row tile
   p.cs_partial = nullptr;

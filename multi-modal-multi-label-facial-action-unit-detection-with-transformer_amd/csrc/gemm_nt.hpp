@@ -79,6 +79,57 @@ __device__ __forceinline__ void store_pair8(uint8_t* row, int n_j, int n_j1, int
   if (row_ok && col < N) *reinterpret_cast<uint2*>(row + col) = make_uint2(s[0], s[1]);
 }
 
+// Operands of the epilogue fetched AHEAD of it (the persistent kernel of gemm_ws.hip issues these loads before a tile's MFMAs
+// and consumes them behind them): the bias of the lane's columns and, per row block, the residual / saved pre-activation -
+// raw 16-byte pieces of 2-byte rows in the paired layout of nt_epilogue's wide path, or fp32 rows.  nt_epi_prefetch() mirrors
+// the address arithmetic of nt_epilogue (template flag PRE there).
+template <int MI, int NI>
+struct NtPre {
+  float4 bj[NI];
+  uint4 raw[MI][(NI + 1) / 2];
+  float4 exf[MI][NI];
+};
+template <int EPI, typename CT, int MI, int NI>
+__device__ __forceinline__ void nt_epi_prefetch(const NtParams& p, int m_base, int n_base, int li, int lg, NtPre<MI, NI>& pre) {
+  int nn[NI], nc[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    nn[j] = n_base + j * 16 + 4 * lg;
+    nc[j] = nn[j] < p.N ? nn[j] : 0;
+    pre.bj[j] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nc[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // the caller has checked the conditions of nt_epilogue's wide path (2-byte rows: p.wide == 1, N % 8 == 0, leading dimension
+  // % 8 == 0, 16-byte aligned base)
+  if constexpr (EPI == AVF_EPI_BIAS_RES || EPI == AVF_EPI_DGELU) {
+    if constexpr (sizeof(CT) == 2) {
+      static_assert((NI & 1) == 0, "paired column blocks");
+      const bf16* src = (EPI == AVF_EPI_BIAS_RES) ? (const bf16*)p.residual : (const bf16*)p.aux;
+      const int64_t ldx = (EPI == AVF_EPI_BIAS_RES) ? p.ldres : p.ldaux;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int mm = m_base + i * 16 + li;
+        const int mc = mm < p.M ? mm : p.M - 1;
+#pragma unroll
+        for (int j = 0; j < NI; j += 2) {
+          int cw = (lg & 1) ? nn[j + 1] - 4 : nn[j];
+          cw = cw + 8 <= p.N ? cw : 0;
+          pre.raw[i][j >> 1] = *reinterpret_cast<const uint4*>(src + (int64_t)mc * ldx + cw);
+        }
+      }
+    } else {
+      static_assert(EPI == AVF_EPI_BIAS_RES, "fp32 C: the residual epilogue only");
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int mm = m_base + i * 16 + li;
+        const int mc = mm < p.M ? mm : p.M - 1;
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          pre.exf[i][j] = *reinterpret_cast<const float4*>((const float*)p.residual + (int64_t)mc * p.ldres + nc[j]);
+      }
+    }
+  }
+}
+
 // Shared epilogue.  A lane holds C[m = m_base + 16 i + li][n = n_base + 16 j + 4 lg + 0..3] in acc[i][j].
 // All global reads of the epilogue (bias, fp32 residual, saved pre-activation) are issued up front from CLAMPED
 // addresses - no branch sits between them, so their latencies overlap instead of serialising - and only the
@@ -89,9 +140,10 @@ __device__ __forceinline__ void store_pair8(uint8_t* row, int n_j, int n_j1, int
 #ifndef AVF_LNF_DBG
 #define AVF_LNF_DBG 0  // diagnostic builds: 1 = no prologue loads (constant statistics), 2 = also the plain epilogue
 #endif
-template <int EPI, typename CT, int MI, int NI, bool LNF_ = false>
+template <int EPI, typename CT, int MI, int NI, bool LNF_ = false, bool PRE = false>
 __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI][NI], int m_base, int n_base, int li,
-                                            int lg, int part_row, const float2* lnst = nullptr) {
+                                            int lg, int part_row, const float2* lnst = nullptr,
+                                            const NtPre<MI, NI>* pre = nullptr) {
   constexpr bool LNF = LNF_ && AVF_LNF_DBG != 2;
   int nn[NI], nc[NI];
   float4 bj[NI], sj[NI];
@@ -103,7 +155,8 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
       bj[j] = *reinterpret_cast<const float4*>(p.ln_c + nc[j]);
       sj[j] = *reinterpret_cast<const float4*>(p.ln_s + nc[j]);
     } else {
-      bj[j] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nc[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (PRE) bj[j] = pre->bj[j];
+      else bj[j] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nc[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
   const bool emit_rs = EPI == AVF_EPI_BIAS_RES && sizeof(CT) == 2 && (NI & 1) == 0 && p.rs_out != nullptr;  // wave-uniform
@@ -129,9 +182,10 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
       // 8-byte ones - an even lane group reads 8 consecutive columns of block j (its own 4 and its right neighbour's), an odd
       // one 8 of block j + 1 (its left neighbour's 4 and its own); v_permlane16_swap hands each lane its own columns of both
       // blocks (the mirror image of store_pair16).  Wave-uniform condition.
-      const bool wide_ex = (NI & 1) == 0 && sizeof(CT) == 2 && (EPI == AVF_EPI_BIAS_RES || EPI == AVF_EPI_DGELU) && p.wide && p.wide != 2 &&  // (AVF_NT_WIDE=2: wide stores only)
-                           (p.N & 7) == 0 && (((EPI == AVF_EPI_BIAS_RES) ? p.ldres : p.ldaux) & 7) == 0 &&
-                           (((uintptr_t)((EPI == AVF_EPI_BIAS_RES) ? p.residual : (const void*)p.aux)) & 15) == 0;
+      const bool wide_ex = (PRE && sizeof(CT) == 2 && (EPI == AVF_EPI_BIAS_RES || EPI == AVF_EPI_DGELU)) ||  // PRE: the caller checked
+                           ((NI & 1) == 0 && sizeof(CT) == 2 && (EPI == AVF_EPI_BIAS_RES || EPI == AVF_EPI_DGELU) && p.wide && p.wide != 2 &&  // (AVF_NT_WIDE=2: wide stores only)
+                            (p.N & 7) == 0 && (((EPI == AVF_EPI_BIAS_RES) ? p.ldres : p.ldaux) & 7) == 0 &&
+                            (((uintptr_t)((EPI == AVF_EPI_BIAS_RES) ? p.residual : (const void*)p.aux)) & 15) == 0);
       if (wide_ex) {
         const bf16* src = (EPI == AVF_EPI_BIAS_RES) ? (const bf16*)p.residual : (const bf16*)p.aux;
         const int64_t ldx = (EPI == AVF_EPI_BIAS_RES) ? p.ldres : p.ldaux;
@@ -139,7 +193,9 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
         for (int j = 0; j < NI; j += 2) {
           int cw = (lg & 1) ? nn[j + 1] - 4 : nn[j];
           cw = cw + 8 <= p.N ? cw : 0;
-          const uint4 raw = *reinterpret_cast<const uint4*>(src + (int64_t)mc * ldx + cw);
+          uint4 raw;
+          if constexpr (PRE) raw = pre->raw[half * 2 + ii][j >> 1];
+          else raw = *reinterpret_cast<const uint4*>(src + (int64_t)mc * ldx + cw);
           const auto s0 = __builtin_amdgcn_permlane16_swap(raw.x, raw.z, false, false);
           const auto s1 = __builtin_amdgcn_permlane16_swap(raw.y, raw.w, false, false);
           ex[ii][j] = make_float4(__uint_as_float(s0[0] << 16), __uint_as_float(s0[0] & 0xffff0000u),
@@ -152,6 +208,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
       for (int j = 0; j < NI; ++j) {
         if (EPI == AVF_EPI_BIAS_RES) {
           if (sizeof(CT) == 2) ex[ii][j] = load4<bf16>((const bf16*)p.residual + (int64_t)mc * p.ldres + nc[j]);
+          else if constexpr (PRE) ex[ii][j] = pre->exf[half * 2 + ii][j];
           else ex[ii][j] = *reinterpret_cast<const float4*>((const float*)p.residual + (int64_t)mc * p.ldres + nc[j]);
         }
         else if (EPI == AVF_EPI_DGELU) ex[ii][j] = load4<CT>((const CT*)p.aux + (int64_t)mc * p.ldaux + nc[j]);
@@ -299,6 +356,156 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
               make_float4(cs[j][0], cs[j][1], cs[j][2], cs[j][3]);
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// Lean epilogue: the fast path of nt_epilogue with every option fixed at COMPILE time - the general one decides dropout,
+// MX image, column edge, store width and column sums with wave-uniform run-time branches, and its ~550 executed
+// instructions per 16 values and lane (2200 cycles of one wave's issue, 3700 beside a partner streaming MFMAs: phase stamps of
+// gemm_ws.hip) cost more than the 64 MFMAs that produce those values.  Same arithmetic, same order, same
+// bits.  Preconditions, checked by the host (nt_lean_ok): no dropout, no MX image, no LayerNorm fold / row statistics; the
+// wave tile lies inside N; 2-byte C: N % 8 == 0, every leading dimension % 8 == 0, 16-byte aligned bases (16-byte paired
+// stores and loads, p.wide == 1).  CS: column sums of the stored values into cs_partial[part_row].  PRE: bias / residual /
+// saved pre-activation were fetched by nt_epi_prefetch.  FULL: every row of the tile is inside M (no row predicate).
+// ------------------------------------------------------------------------------------------
+template <int EPI, typename CT, int MI, int NI, bool CS, bool PRE, bool FULL>
+__device__ __forceinline__ void nt_epilogue_lean_body(const NtParams& p, f32x4_t (&acc)[MI][NI], int m_base, int n_base, int li,
+                                                      int lg, int part_row, const NtPre<MI, NI>* pre) {
+  static_assert(sizeof(CT) == 4 || (NI & 1) == 0, "2-byte outputs are stored in column-block pairs");
+  const int n0 = n_base + 4 * lg;                    // this lane's 4 columns of block 0 (block j: + 16 j)
+  const int cp0 = n0 + ((lg & 1) ? 12 : 0);          // its 8 columns of the block pair (0, 1) after the lane-pair exchange
+  float4 bj[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    if constexpr (PRE) bj[j] = pre->bj[j];
+    else bj[j] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n0 + 16 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float cs[NI][4];
+#pragma unroll
+  for (int j = 0; j < NI; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cs[j][r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = m_base + 16 * i + li;
+    const bool mok = FULL || m < p.M;
+    const int mc = mok ? m : p.M - 1;
+    float4 ex[NI];
+    if constexpr (EPI == AVF_EPI_BIAS_RES || EPI == AVF_EPI_DGELU) {
+      if constexpr (sizeof(CT) == 2) {
+        const bf16* src = (EPI == AVF_EPI_BIAS_RES) ? (const bf16*)p.residual : (const bf16*)p.aux;
+        const int64_t ldx = (EPI == AVF_EPI_BIAS_RES) ? p.ldres : p.ldaux;
+#pragma unroll
+        for (int j = 0; j < NI; j += 2) {
+          uint4 raw;
+          if constexpr (PRE) raw = pre->raw[i][j >> 1];
+          else raw = *reinterpret_cast<const uint4*>(src + (int64_t)mc * ldx + cp0 + 16 * j);
+          const auto s0 = __builtin_amdgcn_permlane16_swap(raw.x, raw.z, false, false);
+          const auto s1 = __builtin_amdgcn_permlane16_swap(raw.y, raw.w, false, false);
+          ex[j] = make_float4(__uint_as_float(s0[0] << 16), __uint_as_float(s0[0] & 0xffff0000u), __uint_as_float(s1[0] << 16),
+                              __uint_as_float(s1[0] & 0xffff0000u));
+          ex[j + 1] = make_float4(__uint_as_float(s0[1] << 16), __uint_as_float(s0[1] & 0xffff0000u), __uint_as_float(s1[1] << 16),
+                                  __uint_as_float(s1[1] & 0xffff0000u));
+        }
+      } else {
+        static_assert(EPI == AVF_EPI_BIAS_RES, "fp32 C: the residual epilogue only");
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          if constexpr (PRE) ex[j] = pre->exf[i][j];
+          else ex[j] = *reinterpret_cast<const float4*>((const float*)p.residual + (int64_t)mc * p.ldres + n0 + 16 * j);
+        }
+      }
+    }
+    uint32_t cw[NI][2], aw[NI][2];
+    float4 vf[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      float v[4];
+      v[0] = acc[i][j][0] + bj[j].x; v[1] = acc[i][j][1] + bj[j].y; v[2] = acc[i][j][2] + bj[j].z; v[3] = acc[i][j][3] + bj[j].w;
+      if constexpr (EPI == AVF_EPI_BIAS_RES) {
+        v[0] += ex[j].x; v[1] += ex[j].y; v[2] += ex[j].z; v[3] += ex[j].w;
+      } else if constexpr (EPI == AVF_EPI_BIAS_GELU) {
+        if constexpr (sizeof(CT) == 2) {
+          aw[j][0] = pack_bf16x2(v[0], v[1]); aw[j][1] = pack_bf16x2(v[2], v[3]);
+        } else if (mok) {
+          store4<CT>((CT*)p.aux + (int64_t)m * p.ldaux + n0 + 16 * j, make_float4(v[0], v[1], v[2], v[3]));
+        }
+        v[0] = gelu_tanh_fast(v[0]); v[1] = gelu_tanh_fast(v[1]); v[2] = gelu_tanh_fast(v[2]); v[3] = gelu_tanh_fast(v[3]);
+      } else if constexpr (EPI == AVF_EPI_DGELU) {
+        v[0] *= dgelu_tanh_fast(ex[j].x); v[1] *= dgelu_tanh_fast(ex[j].y);
+        v[2] *= dgelu_tanh_fast(ex[j].z); v[3] *= dgelu_tanh_fast(ex[j].w);
+      }
+      if constexpr (sizeof(CT) == 2) {
+        cw[j][0] = pack_bf16x2(v[0], v[1]); cw[j][1] = pack_bf16x2(v[2], v[3]);
+      } else {
+        vf[j] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+      if constexpr (CS) {
+        if (mok) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cs[j][r] += v[r];
+        }
+      }
+    }
+    if constexpr (sizeof(CT) == 2) {
+      // lane pairs trade words (store_pair16): every lane stores 8 consecutive columns of one block
+      uint4 sc[NI / 2], sa[NI / 2];
+#pragma unroll
+      for (int j = 0; j < NI; j += 2) {
+        const auto s0 = __builtin_amdgcn_permlane16_swap(cw[j][0], cw[j + 1][0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(cw[j][1], cw[j + 1][1], false, false);
+        sc[j >> 1] = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        if constexpr (EPI == AVF_EPI_BIAS_GELU) {
+          const auto t0 = __builtin_amdgcn_permlane16_swap(aw[j][0], aw[j + 1][0], false, false);
+          const auto t1 = __builtin_amdgcn_permlane16_swap(aw[j][1], aw[j + 1][1], false, false);
+          sa[j >> 1] = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+        }
+      }
+      if (mok) {
+        bf16* crow = (bf16*)p.C + (int64_t)m * p.ldc + cp0;
+#pragma unroll
+        for (int j = 0; j < NI; j += 2) *reinterpret_cast<uint4*>(crow + 16 * j) = sc[j >> 1];
+        if constexpr (EPI == AVF_EPI_BIAS_GELU) {
+          // the saved pre-activation is read again in backward only: non-temporal (as nt_epilogue; p.wide == 3: plain)
+          typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));
+          bf16* arow = (bf16*)p.aux + (int64_t)m * p.ldaux + cp0;
+#pragma unroll
+          for (int j = 0; j < NI; j += 2) {
+            const u32x4_nt v4 = {sa[j >> 1].x, sa[j >> 1].y, sa[j >> 1].z, sa[j >> 1].w};
+            __builtin_nontemporal_store(v4, reinterpret_cast<u32x4_nt*>(arow + 16 * j));
+          }
+        }
+      }
+    } else if (mok) {
+      float* crow = (float*)p.C + (int64_t)m * p.ldc + n0;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) *reinterpret_cast<float4*>(crow + 16 * j) = vf[j];
+    }
+  }
+  if constexpr (CS) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t = cs[j][r];  // the same DPP tree as nt_epilogue: identical bits
+        t += AVF_DPP_F32(t, 0xB1);
+        t += AVF_DPP_F32(t, 0x4E);
+        t += AVF_DPP_F32(t, 0x124);
+        t += AVF_DPP_F32(t, 0x128);
+        cs[j][r] = t;
+      }
+    if (li == 0) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        *reinterpret_cast<float4*>(p.cs_partial + (int64_t)part_row * p.N + n0 + 16 * j) = make_float4(cs[j][0], cs[j][1], cs[j][2], cs[j][3]);
+    }
+  }
+}
+template <int EPI, typename CT, int MI, int NI, bool CS, bool PRE>
+__device__ __forceinline__ void nt_epilogue_lean(const NtParams& p, f32x4_t (&acc)[MI][NI], int m_base, int n_base, int li, int lg,
+                                                 int part_row, const NtPre<MI, NI>* pre = nullptr) {
+  if (m_base + 16 * MI <= p.M) nt_epilogue_lean_body<EPI, CT, MI, NI, CS, PRE, true>(p, acc, m_base, n_base, li, lg, part_row, pre);
+  else nt_epilogue_lean_body<EPI, CT, MI, NI, CS, PRE, false>(p, acc, m_base, n_base, li, lg, part_row, pre);
 }
 
 typedef __attribute__((address_space(1))) const void gptr_t;

@@ -205,6 +205,7 @@ struct LowP {
   void *wqkvt_q, *wqkvt_s;                               // mx8_bwd: image of Wqkv^T [D, 3I] (dqkv -> dh1, K = 3I)
   void *wqkv_ln, *w1_ln;                // ln_fuse: gamma-scaled images of Wqkv (query rows also carry the softmax scale) and W1
   float *s_qkv, *c_qkv, *s_1, *c_1;     // ln_fuse: their s / c vectors
+  LowpWs ws;                            // fragment-major images for the weight-stationary GEMM (gemm_ws.hip), null if unfit
 };
 size_t carve_lowp(const Dims& d, void* base, LowP* l) {
   if (d.dt != AVF_BF16) {
@@ -244,6 +245,13 @@ size_t carve_lowp(const Dims& d, void* base, LowP* l) {
     t.wqkv_ln = t.w1_ln = nullptr;
     t.s_qkv = t.c_qkv = t.s_1 = t.c_1 = nullptr;
   }
+  // LAST (avf_*_adam_step finds the eight bf16 images by their offsets from the front): the fragment-major images
+  t.ws.wqkv_p = pack_ws_ok(3 * d.I, d.D) ? c.take(pack_ws_bytes(3 * d.I, d.D)) : nullptr;
+  t.ws.wo_p = pack_ws_ok(d.D, d.I) ? c.take(pack_ws_bytes(d.D, d.I)) : nullptr;
+  t.ws.w1_p = pack_ws_ok(d.M, d.D) ? c.take(pack_ws_bytes(d.M, d.D)) : nullptr;
+  t.ws.w2t_p = pack_ws_ok(d.M, d.D) ? c.take(pack_ws_bytes(d.M, d.D)) : nullptr;
+  t.ws.wot_p = pack_ws_ok(d.I, d.D) ? c.take(pack_ws_bytes(d.I, d.D)) : nullptr;
+  if (!base) t.ws = LowpWs{nullptr, nullptr, nullptr, nullptr, nullptr};
   if (l) *l = t;
   return c.off;
 }
@@ -343,7 +351,8 @@ size_t carve_work(const Dims& d, void* base, Work* w) {
 // C[R, out] = A[R, in] * W[out, in]^T  (nn.Linear forward)
 int linear_fwd(const Dims& d, const void* A, int in, const void* W, int out, void* C, int c_dtype, int epi,
                const float* bias, const void* res, void* aux, hipStream_t s, const DropCfg& drop = kNoDrop,
-               float* rs_out = nullptr) {  // rs_out: partial row statistics of the stored C (ln_fuse)
+               float* rs_out = nullptr,     // rs_out: partial row statistics of the stored C (ln_fuse)
+               const void* Wp = nullptr) {  // Wp: fragment-major image of W (weight-stationary kernel, gemm_ws.hip)
   GemmArgs a;
   a.dtype = d.dt; a.transA = 0; a.transB = 1;
   a.M = d.R; a.N = out; a.K = in;
@@ -352,6 +361,7 @@ int linear_fwd(const Dims& d, const void* A, int in, const void* W, int out, voi
   a.bias = bias; a.residual = res; a.ldres = out; a.aux = aux; a.ldaux = out; a.workspace = nullptr; a.colsum = nullptr;
   a.drop = drop; a.defer_fold = nullptr;
   a.rs_out = rs_out;
+  a.Bp = Wp;
   return gemm(a, s);
 }
 
@@ -389,7 +399,7 @@ int linear_fwd_mx(const Dims& d, const void* Aq, const void* As, int in, const v
 // colsum (bf16 mode only, optional): column sums of the produced dX, fused in the GEMM epilogue (ws = partials)
 int linear_dx(const Dims& d, const void* dY, int out, const void* W_f32, const void* Wt_lo, int in, void* dX, int epi,
               void* aux, hipStream_t s, float* colsum_out = nullptr, void* ws = nullptr,
-              const DropCfg& drop = kNoDrop, FoldJob* defer = nullptr) {
+              const DropCfg& drop = kNoDrop, FoldJob* defer = nullptr, const void* Wtp = nullptr) {  // Wtp: as Wp of linear_fwd
   GemmArgs a;
   a.dtype = d.dt; a.transA = 0;
   a.M = d.R; a.N = in; a.K = out;
@@ -399,6 +409,7 @@ int linear_dx(const Dims& d, const void* dY, int out, const void* W_f32, const v
   a.C = dX; a.ldc = in; a.c_dtype = d.dt; a.epilogue = epi;
   a.bias = nullptr; a.residual = nullptr; a.ldres = 0; a.aux = aux; a.ldaux = in; a.workspace = ws; a.colsum = colsum_out;
   a.drop = drop; a.defer_fold = defer;
+  a.Bp = d.dt == AVF_BF16 ? Wtp : nullptr;
   return gemm(a, s);
 }
 
@@ -434,6 +445,15 @@ int linear_dw(const Dims& d, const void* dY, int out, const void* X, int in, flo
 size_t gemm_ws(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K) {
   if (dtype == AVF_BF16 && transA == 1 && transB == 0) return gemm_bf16_tn_ws(M, N, K);
   if (dtype == AVF_F32) return gemm_f32_ws(M, N, K);
+  return 0;
+}
+
+int lowp_ws_images(const avf_layer_cfg* cfg, void* lowp, LowpWs* out) {
+  Dims d;
+  AVF_TRY(make_dims(cfg, &d));
+  LowP l;
+  carve_lowp(d, lowp, &l);
+  *out = l.ws;
   return 0;
 }
 
@@ -493,7 +513,14 @@ extern "C" int avf_layer_prepare_weights(const avf_layer_cfg* cfg, const avf_lay
   b.d[1] = PrepDesc{p->w_out, (bf16*)l.wo, (bf16*)l.wo_t, d.D, d.I, 1.0f, 0};
   b.d[2] = PrepDesc{p->w1, (bf16*)l.w1, (bf16*)l.w1_t, d.M, d.D, 1.0f, 0};
   b.d[3] = PrepDesc{p->w2, (bf16*)l.w2, (bf16*)l.w2_t, d.D, d.M, 1.0f, 0};
-  return prep_weights_multi(b, 4, s);
+  AVF_TRY(prep_weights_multi(b, 4, s));
+  // fragment-major images for the weight-stationary GEMM (the optimizer step rewrites them itself: optim.hip)
+  if (l.ws.wqkv_p) AVF_TRY(pack_ws(l.wqkv, d.D, 3 * d.I, d.D, l.ws.wqkv_p, s));
+  if (l.ws.wo_p) AVF_TRY(pack_ws(l.wo, d.I, d.D, d.I, l.ws.wo_p, s));
+  if (l.ws.w1_p) AVF_TRY(pack_ws(l.w1, d.D, d.M, d.D, l.ws.w1_p, s));
+  if (l.ws.w2t_p) AVF_TRY(pack_ws(l.w2_t, d.D, d.M, d.D, l.ws.w2t_p, s));
+  if (l.ws.wot_p) AVF_TRY(pack_ws(l.wo_t, d.D, d.I, d.D, l.ws.wot_p, s));
+  return 0;
 }
 
 extern "C" int avf_stack_ln_fold(const avf_layer_cfg* cfg, int layers, const avf_layer_params* const* params,
@@ -586,7 +613,7 @@ extern "C" int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p
       AVF_TRY(linear_fwd_mx(d, w.oq, w.os, d.I, l.wo_q, l.wo_s, d.D, sv.x_mid, d.xdt, AVF_EPI_BIAS_RES, p->b_out, x_in, nullptr,
                             s, dr0));
     else
-      AVF_TRY(linear_fwd(d, sv.o, d.I, wo, d.D, sv.x_mid, d.xdt, AVF_EPI_BIAS_RES, p->b_out, x_in, nullptr, s, dr0));
+      AVF_TRY(linear_fwd(d, sv.o, d.I, wo, d.D, sv.x_mid, d.xdt, AVF_EPI_BIAS_RES, p->b_out, x_in, nullptr, s, dr0, nullptr, l.ws.wo_p));
     AVF_TRY(layernorm_fwd(sv.x_mid, p->ln2_w, p->ln2_b, sv.h2, d.dt, sv.mean2, sv.rstd2, d.R, d.D, cfg->ln_eps, s, w.hq, w.hs, d.xdt));
     AVF_TRY(linear_fwd_mx(d, w.hq, w.hs, d.D, l.w1_q, l.w1_s, d.M, sv.g, d.dt, AVF_EPI_BIAS_GELU, p->b1, nullptr, sv.u, s, dr1,
                           w.gq, w.gs));
@@ -620,7 +647,8 @@ extern "C" int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p
     return 0;
   }
   AVF_TRY(layernorm_fwd(x_in, p->ln1_w, p->ln1_b, sv.h1, d.dt, sv.mean1, sv.rstd1, d.R, d.D, cfg->ln_eps, s, nullptr, nullptr, d.xdt));
-  AVF_TRY(linear_fwd(d, sv.h1, d.D, wqkv, 3 * d.I, sv.qkv, d.dt, AVF_EPI_NONE, nullptr, nullptr, nullptr, s));
+  AVF_TRY(linear_fwd(d, sv.h1, d.D, wqkv, 3 * d.I, sv.qkv, d.dt, AVF_EPI_NONE, nullptr, nullptr, nullptr, s, kNoDrop, nullptr,
+                     l.ws.wqkv_p));
   // token mask (heads.py:225-232): on the MFMA kernels where they carry it (bf16, dim_head 64, up to 512 tokens), else on
   // the fp32-arithmetic ones
   const bool mask_mfma = d.keep && lo && attn_masked_bf16_ok(d.N, d.dh, attn_q_prescale_on());
@@ -631,11 +659,11 @@ extern "C" int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   else AVF_TRY(attn_fwd_f32((const float*)sv.qkv, (float*)sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s));
   const DropCfg dr0 = make_drop(d.p0, d.seed, d.layer, 0, d.seed_dev), dr1 = make_drop(d.p, d.seed, d.layer, 1, d.seed_dev),
                 dr2 = make_drop(d.p, d.seed, d.layer, 2, d.seed_dev);
-  AVF_TRY(linear_fwd(d, sv.o, d.I, wo, d.D, sv.x_mid, d.xdt, AVF_EPI_BIAS_RES, p->b_out, x_in, nullptr, s, dr0));
+  AVF_TRY(linear_fwd(d, sv.o, d.I, wo, d.D, sv.x_mid, d.xdt, AVF_EPI_BIAS_RES, p->b_out, x_in, nullptr, s, dr0, nullptr, l.ws.wo_p));
   AVF_TRY(layernorm_fwd(sv.x_mid, p->ln2_w, p->ln2_b, sv.h2, d.dt, sv.mean2, sv.rstd2, d.R, d.D, cfg->ln_eps, s, nullptr, nullptr, d.xdt));
   if (lo && d.p == 0.f && mlp_fused_on() && mlp_fused_ok(d.R, d.D, d.M))  // FeedForward as one launch (mlp_fused.hip)
     return mlp_fused_fwd(sv.h2, w1, p->b1, w2, p->b2, sv.x_mid, d.xdt, x_out, sv.u, sv.g, d.R, d.D, d.M, s);
-  AVF_TRY(linear_fwd(d, sv.h2, d.D, w1, d.M, sv.g, d.dt, AVF_EPI_BIAS_GELU, p->b1, nullptr, sv.u, s, dr1));
+  AVF_TRY(linear_fwd(d, sv.h2, d.D, w1, d.M, sv.g, d.dt, AVF_EPI_BIAS_GELU, p->b1, nullptr, sv.u, s, dr1, nullptr, l.ws.w1_p));
   AVF_TRY(linear_fwd(d, sv.g, d.M, w2, d.D, x_out, d.xdt, AVF_EPI_BIAS_RES, p->b2, sv.x_mid, nullptr, s, dr2));
   return 0;
 }
@@ -808,7 +836,7 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
     else AVF_TRY(fold_job(fj, s));
   } else if (lo) {  // db1 = colsum(du) fused into the dGELU GEMM epilogue
     AVF_TRY(linear_dx(d, gy, d.D, p->w2, l.w2_t, d.M, w.du, AVF_EPI_DGELU, sv.u, s, g->b1, w.cs_ws, dr1,
-                      grouped ? &folds.job[0] : nullptr));
+                      grouped ? &folds.job[0] : nullptr, l.ws.w2t_p));
   } else {
     AVF_TRY(linear_dx(d, gy, d.D, p->w2, l.w2_t, d.M, w.du, AVF_EPI_DGELU, sv.u, s, nullptr, nullptr, dr1));
     AVF_TRY(colsum(w.du, d.dt, d.R, d.M, d.M, g->b1, w.cs_ws, s));
@@ -834,7 +862,8 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
     AVF_TRY(linear_dx_mx(d, w.mq, w.ms, d.D, l.wot_q, l.wot_s, d.I, w.d_o, AVF_EPI_NONE, nullptr, s, nullptr, nullptr, kNoDrop,
                          nullptr));
   else
-    AVF_TRY(linear_dx(d, gm, d.D, p->w_out, l.wo_t, d.I, w.d_o, AVF_EPI_NONE, nullptr, s));
+    AVF_TRY(linear_dx(d, gm, d.D, p->w_out, l.wo_t, d.I, w.d_o, AVF_EPI_NONE, nullptr, s, nullptr, nullptr, kNoDrop, nullptr,
+                      l.ws.wot_p));
   // dqkv -> dh1 on MX-FP8 operands, the image of dqkv written by the merged attention backward:
   // built and bit-exact, but the image costs the attention kernel 18 us at B = 64, N = 512 (50 us before its stores were
   // made 16 bytes wide and dQ's 32-blocks wave-local) while the K = 1536 GEMM, already at 0.87 PFLOP/s on bf16 operands,

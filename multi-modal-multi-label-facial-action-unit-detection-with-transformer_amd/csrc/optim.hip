@@ -32,6 +32,8 @@ struct AdamDesc {
   float* v;
   bf16* lo;  // row-major bf16 copy [R, C] (nullable)
   bf16* t;   // transposed bf16 copy [C, R] (nullable)
+  bf16* lo_p;  // fragment-major image of `lo` (C == 512; common.hpp pack_ws_off) (nullable)
+  bf16* t_p;   // fragment-major image of `t` (R == 512) (nullable)
   int R, C;
   float lo_scale;      // rows < lo_scaled_rows of `lo` (only) are written multiplied by this: the query rows of Wqkv carry
   int lo_scaled_rows;  // the softmax scale (attn_q_prescale)
@@ -127,6 +129,9 @@ __global__ __launch_bounds__(256) void adam_layer_kernel(AdamBatch b) {
         if (d.lo) {
           const float sc = r < d.lo_scaled_rows ? d.lo_scale : 1.0f;
           store4<bf16>(d.lo + o, make_float4(p.x * sc, p.y * sc, p.z * sc, p.w * sc));
+          if (d.lo_p)  // the same values in the fragment-major image (8 bytes of a lane's 16-byte operand piece)
+            store4<bf16>(reinterpret_cast<bf16*>(reinterpret_cast<char*>(d.lo_p) + pack_ws_off(r, c)),
+                         make_float4(p.x * sc, p.y * sc, p.z * sc, p.w * sc));
         }
       }
       tile[ty + 16 * i][tx * 4 + 0] = p.x; tile[ty + 16 * i][tx * 4 + 1] = p.y;
@@ -139,9 +144,11 @@ __global__ __launch_bounds__(256) void adam_layer_kernel(AdamBatch b) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int rr = rg + 4 * q;
-        if (r0 + rr < d.R)
-          store4<bf16>(d.t + (int64_t)(c0 + cc) * d.R + r0 + rr,
-                       make_float4(tile[rr][cc], tile[rr + 1][cc], tile[rr + 2][cc], tile[rr + 3][cc]));
+        if (r0 + rr < d.R) {
+          const float4 tv = make_float4(tile[rr][cc], tile[rr + 1][cc], tile[rr + 2][cc], tile[rr + 3][cc]);
+          store4<bf16>(d.t + (int64_t)(c0 + cc) * d.R + r0 + rr, tv);
+          if (d.t_p) store4<bf16>(reinterpret_cast<bf16*>(reinterpret_cast<char*>(d.t_p) + pack_ws_off(c0 + cc, r0 + rr)), tv);
+        }
       }
     }
     return;
@@ -193,24 +200,29 @@ int adam_add_layer(AdamBatch& b, int& n, int& tiles, const avf_layer_cfg* cfg, c
       }
     // (with cfg->mx8_fwd the MX-FP8 images follow the bf16 ones; the caller re-derives them from these: transformer.py)
     // (with cfg->ln_fuse the gamma-scaled images and their s / c vectors follow likewise: avf_stack_ln_fold)
-    AVF_REQUIRE((cfg->mx8_fwd || (cfg->ln_fuse & 1)) ? off < avf_layer_lowp_bytes(cfg) : off == avf_layer_lowp_bytes(cfg),
-                "layer_adam_step: lowp layout mismatch (%zu vs %zu)", off, avf_layer_lowp_bytes(cfg));
+    AVF_REQUIRE(off <= avf_layer_lowp_bytes(cfg), "layer_adam_step: lowp layout mismatch (%zu vs %zu)", off,
+                avf_layer_lowp_bytes(cfg));
   }
+  // fragment-major images behind them (weight-stationary GEMM): rewritten by the same launch
+  LowpWs wsi = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (cfg->dtype == AVF_BF16) AVF_TRY(lowp_ws_images(cfg, lowp, &wsi));
   const int first = n;
   auto add = [&](const float* pp, float* gg, float* mm, float* vv, bf16* lo, bf16* t, int R, int C, float lo_scale = 1.0f,
-                 int lo_scaled_rows = 0) {
+                 int lo_scaled_rows = 0, void* lo_p = nullptr, void* t_p = nullptr) {
     if (!pp || (!gg && !lo && !t)) return;  // absent tensor, or nothing to do for it
     AdamDesc& d = b.d[n++];
     d.p = const_cast<float*>(pp); d.g = gg; d.m = mm; d.v = vv; d.lo = lo; d.t = t; d.R = R; d.C = C;
+    d.lo_p = lo ? (bf16*)lo_p : nullptr; d.t_p = t ? (bf16*)t_p : nullptr;
     d.lo_scale = lo_scale; d.lo_scaled_rows = lo_scaled_rows;
     d.tile0 = tiles;
     d.tiles_c = R == 1 ? 1 : (C + 63) / 64;
     tiles += R == 1 ? (C + 4095) / 4096 : ((R + 63) / 64) * d.tiles_c;
   };
-  add(p->w_qkv, g->w_qkv, exp_avg->w_qkv, exp_avg_sq->w_qkv, img[0], img[1], 3 * I, D, attn_q_prescale(cfg->dim_head), I);
-  add(p->w_out, g->w_out, exp_avg->w_out, exp_avg_sq->w_out, img[2], img[3], D, I);
-  add(p->w1, g->w1, exp_avg->w1, exp_avg_sq->w1, img[4], img[5], M, D);
-  add(p->w2, g->w2, exp_avg->w2, exp_avg_sq->w2, img[6], img[7], D, M);
+  add(p->w_qkv, g->w_qkv, exp_avg->w_qkv, exp_avg_sq->w_qkv, img[0], img[1], 3 * I, D, attn_q_prescale(cfg->dim_head), I,
+      wsi.wqkv_p, nullptr);
+  add(p->w_out, g->w_out, exp_avg->w_out, exp_avg_sq->w_out, img[2], img[3], D, I, 1.0f, 0, wsi.wo_p, wsi.wot_p);
+  add(p->w1, g->w1, exp_avg->w1, exp_avg_sq->w1, img[4], img[5], M, D, 1.0f, 0, wsi.w1_p, nullptr);
+  add(p->w2, g->w2, exp_avg->w2, exp_avg_sq->w2, img[6], img[7], D, M, 1.0f, 0, nullptr, wsi.w2t_p);
   add(p->ln1_w, g->ln1_w, exp_avg->ln1_w, exp_avg_sq->ln1_w, nullptr, nullptr, 1, D);
   add(p->ln1_b, g->ln1_b, exp_avg->ln1_b, exp_avg_sq->ln1_b, nullptr, nullptr, 1, D);
   add(p->b_out, g->b_out, exp_avg->b_out, exp_avg_sq->b_out, nullptr, nullptr, 1, D);

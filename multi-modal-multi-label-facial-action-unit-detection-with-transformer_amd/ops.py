@@ -165,6 +165,50 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool 
     return c
 
 
+def pack_ws(w: torch.Tensor) -> torch.Tensor:
+    """Fragment-major image of a bf16 weight [rows % 256 == 0, 512] for gemm_ws (avf_pack_weight_ws)."""
+    _need_cuda(w)
+    lib = _lib.load()
+    w = _rows2d(w)
+    assert w.dtype == torch.bfloat16
+    rows, cols = w.shape
+    n = lib.avf_pack_weight_ws_bytes(rows, cols)
+    if n == 0:
+        raise ValueError(f"pack_ws: needs rows % 256 == 0 and cols == 512, got {tuple(w.shape)}")
+    out = torch.empty(n // 2, dtype=torch.bfloat16, device=w.device)
+    _lib.check(lib.avf_pack_weight_ws(_ptr(w), w.stride(0), rows, cols, _ptr(out), _stream()), "pack_weight_ws")
+    return out
+
+
+def gemm_ws(a: torch.Tensor, w_packed: torch.Tensor, n_out: int, out_dtype=None, epilogue: int = EPI_NONE,
+            bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, aux: Optional[torch.Tensor] = None,
+            want_colsum: bool = False):
+    """C = epilogue(A W^T) on the weight-stationary persistent kernel (avf_gemm_nt_ws); w_packed = pack_ws(W[n_out, 512]).
+    Returns C (and the saved pre-activation for EPI_BIAS_GELU; and the column sums of C with want_colsum)."""
+    _need_cuda(a, w_packed, bias, residual, aux)
+    lib = _lib.load()
+    a = _rows2d(a)
+    M, K = a.shape
+    cdt = torch_dtype(out_dtype) if out_dtype is not None else a.dtype
+    c = torch.empty((M, n_out), dtype=cdt, device=a.device)
+    made_aux = None
+    if epilogue == EPI_BIAS_GELU and aux is None:
+        made_aux = aux = torch.empty((M, n_out), dtype=cdt, device=a.device)
+    cs = torch.empty(n_out, dtype=torch.float32, device=a.device) if want_colsum else None
+    ws = _bytes(lib.avf_colsum_workspace_bytes(M, n_out) + (M // 32 + 8) * n_out * 4, a.device) if want_colsum else None
+    if residual is not None:
+        residual = residual.contiguous()
+    _lib.check(lib.avf_gemm_nt_ws(M, n_out, K, _ptr(a), a.stride(0), _ptr(w_packed), _ptr(c), c.stride(0), avf_dtype(cdt),
+                                  epilogue, _ptr(bias), _ptr(residual), n_out, _ptr(aux), n_out, _ptr(ws), _ptr(cs), _stream()),
+               "gemm_nt_ws")
+    res = (c,)
+    if made_aux is not None:
+        res += (made_aux,)
+    if want_colsum:
+        res += (cs,)
+    return res[0] if len(res) == 1 else res
+
+
 def gemm_tn_group(pairs):
     """[(A_i [K, M_i] bf16, B_i [K, N_i] bf16), ...] (up to 4, same K) -> [C_i [M_i, N_i] fp32 = A_i^T B_i]: the grouped
     weight-gradient launch of a layer's backward (avf_gemm_tn_group)."""
