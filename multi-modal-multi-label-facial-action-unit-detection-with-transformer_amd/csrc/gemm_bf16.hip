@@ -103,7 +103,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(NtParams p) {
 // flight while the current one feeds the MFMAs; one barrier per K-step.  Block ids are remapped so that the
 // workgroups dealt to one XCD (ids congruent mod 8) cover a contiguous range of tiles and share A panels in its L2.
 // ------------------------------------------------------------------------------------------
-template <int EPI, typename CT, int WM, int WN, int MI, int NI, int NS, bool LNF = false>
+// LEAN: 0 = the general epilogue (run-time options), 1 = nt_epilogue_lean (every option fixed at compile time; the host has
+// checked nt_lean_ok), 2 = the same with column sums
+template <int EPI, typename CT, int WM, int WN, int MI, int NI, int NS, bool LNF = false, int LEAN = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(NtParams p, int tiles_n, int nwg) {
   constexpr int WTM = 16 * MI, WTN = 16 * NI;  // per-wave output tile
   constexpr int BMT = WTM * WM, BNT = WTN * WN, NW = WM * WN;
@@ -266,18 +268,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(NtParam
     cur = (cur + 1 == NS) ? 0 : cur + 1;
   }
 
-  nt_epilogue<EPI, CT, MI, NI, LNF>(p, acc, m0 + wm * WTM, n0 + wn * WTN, li, lg,
-                                    p.cs_partial ? (wg / tiles_n) * WM + wm : -1, lnst + wm * WTM);
+  if constexpr (LEAN != 0)
+    nt_epilogue_lean<EPI, CT, MI, NI, LEAN == 2, false>(p, acc, m0 + wm * WTM, n0 + wn * WTN, li, lg, (wg / tiles_n) * WM + wm);
+  else
+    nt_epilogue<EPI, CT, MI, NI, LNF>(p, acc, m0 + wm * WTM, n0 + wn * WTN, li, lg,
+                                      p.cs_partial ? (wg / tiles_n) * WM + wm : -1, lnst + wm * WTM);
 }
 
-template <int EPI, typename CT, int WM, int WN, int MI, int NI, int NS, bool LNF = false>
+template <int EPI, typename CT, int WM, int WN, int MI, int NI, int NS, bool LNF = false, int LEAN = 0>
 int launch_nt_glds(const NtParams& p, hipStream_t s, int* part_rows, TimingScope* ts) {
   constexpr int BMT = 16 * MI * WM, BNT = 16 * NI * WN;
   constexpr int SMEM = NS * (BMT + BNT) * 128 + (LNF ? BMT * 8 : 0);
   static_assert(NS >= 2 && NS <= 8 && SMEM <= 160 * 1024, "stage count / LDS budget");
   static PerDeviceOnce raised;
   if (SMEM > 64 * 1024 && raised.need()) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_glds_kernel<EPI, CT, WM, WN, MI, NI, NS, LNF>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_glds_kernel<EPI, CT, WM, WN, MI, NI, NS, LNF, LEAN>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     AVF_REQUIRE(e == hipSuccess, "gemm_bf16_nt: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
     raised.mark();
@@ -288,12 +293,12 @@ int launch_nt_glds(const NtParams& p, hipStream_t s, int* part_rows, TimingScope
   if (shape_log_on()) {
     const double csz = sizeof(CT);
     const double epi_b = (EPI == AVF_EPI_BIAS_RES || EPI == AVF_EPI_BIAS_GELU || EPI == AVF_EPI_DGELU) ? csz * p.M * p.N : 0.0;
-    shape_log("gemm_bf16_nt,gemm_bf16_nt_glds_kernel<%d, %s, %d, %d, %d, %d, %d, %s>,%d,%d,%d,%d,%d,%.0f,%.0f", EPI,
-              sizeof(CT) == 4 ? "float" : "bf16", WM, WN, MI, NI, NS, LNF ? "true" : "false", nwg, p.M, p.N, p.K,
+    shape_log("gemm_bf16_nt,gemm_bf16_nt_glds_kernel<%d, %s, %d, %d, %d, %d, %d, %s, %d>,%d,%d,%d,%d,%d,%.0f,%.0f", EPI,
+              sizeof(CT) == 4 ? "float" : "bf16", WM, WN, MI, NI, NS, LNF ? "true" : "false", LEAN, nwg, p.M, p.N, p.K,
               EPI + (LNF ? 10 : 0), 2.0 * p.M * p.N * p.K,
               2.0 * ((double)p.M * p.K + (double)p.N * p.K) + csz * p.M * p.N + epi_b);
   }
-  launch_in_scope(ts, gemm_bf16_nt_glds_kernel<EPI, CT, WM, WN, MI, NI, NS, LNF>, dim3(nwg), dim3(WM * WN * 64), SMEM, s, p,
+  launch_in_scope(ts, gemm_bf16_nt_glds_kernel<EPI, CT, WM, WN, MI, NI, NS, LNF, LEAN>, dim3(nwg), dim3(WM * WN * 64), SMEM, s, p,
                   tiles_n, nwg);
   return 0;
 }
@@ -305,7 +310,20 @@ int launch_nt_glds_any(const NtParams& p, hipStream_t s, int* part_rows, TimingS
     return launch_nt_glds<EPI, CT, 2, 4, 4, 2, 2, true>(p, s, part_rows, ts);
   } else {
     // (the row-statistics epilogue of the LayerNorm fold needs column-block pairs: not on the small-M tile)
-    switch (p.rs_out ? pick_nt_tile(p.M, p.N, p.K) : pick_nt_tile_bf16(p.M, p.N, p.K)) {
+    const int tile = p.rs_out ? pick_nt_tile(p.M, p.N, p.K) : pick_nt_tile_bf16(p.M, p.N, p.K);
+    // the two 8-wave tiles with the lean epilogue when nothing asks for the general one's options
+    if ((tile == 2 || tile == 5) && nt_lean_ok<EPI, CT>(p, 128)) {
+      constexpr bool csv = EPI == AVF_EPI_DGELU;  // column sums ride on the dGELU epilogue only
+      if (p.cs_partial == nullptr) {
+        if (tile == 5) return launch_nt_glds<EPI, CT, 2, 4, 3, 2, 2, false, 1>(p, s, part_rows, ts);
+        return launch_nt_glds<EPI, CT, 2, 4, 4, 2, 2, false, 1>(p, s, part_rows, ts);
+      }
+      if constexpr (csv) {
+        if (tile == 5) return launch_nt_glds<EPI, CT, 2, 4, 3, 2, 2, false, 2>(p, s, part_rows, ts);
+        return launch_nt_glds<EPI, CT, 2, 4, 4, 2, 2, false, 2>(p, s, part_rows, ts);
+      }
+    }
+    switch (tile) {
       case 6: return launch_nt_glds<EPI, CT, 1, 4, 2, 1, 6>(p, s, part_rows, ts);  // 72 KiB: two workgroups per CU
       case 0: return launch_nt_glds<EPI, CT, 2, 2, 4, 4, 2>(p, s, part_rows, ts);
       case 1: return launch_nt_glds<EPI, CT, 2, 2, 2, 4, 2>(p, s, part_rows, ts);

@@ -116,15 +116,15 @@ __device__ __forceinline__ void nt_epi_prefetch(const NtParams& p, int m_base, i
           pre.raw[i][j >> 1] = *reinterpret_cast<const uint4*>(src + (int64_t)mc * ldx + cw);
         }
       }
-    } else {
-      static_assert(EPI == AVF_EPI_BIAS_RES, "fp32 C: the residual epilogue only");
+    } else {  // fp32 C: fp32 residual / saved pre-activation rows
+      const float* src = (EPI == AVF_EPI_BIAS_RES) ? (const float*)p.residual : (const float*)p.aux;
+      const int64_t ldx = (EPI == AVF_EPI_BIAS_RES) ? p.ldres : p.ldaux;
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const int mm = m_base + i * 16 + li;
         const int mc = mm < p.M ? mm : p.M - 1;
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
-          pre.exf[i][j] = *reinterpret_cast<const float4*>((const float*)p.residual + (int64_t)mc * p.ldres + nc[j]);
+        for (int j = 0; j < NI; ++j) pre.exf[i][j] = *reinterpret_cast<const float4*>(src + (int64_t)mc * ldx + nc[j]);
       }
     }
   }
@@ -407,12 +407,13 @@ __device__ __forceinline__ void nt_epilogue_lean_body(const NtParams& p, f32x4_t
           ex[j + 1] = make_float4(__uint_as_float(s0[1] << 16), __uint_as_float(s0[1] & 0xffff0000u), __uint_as_float(s1[1] << 16),
                                   __uint_as_float(s1[1] & 0xffff0000u));
         }
-      } else {
-        static_assert(EPI == AVF_EPI_BIAS_RES, "fp32 C: the residual epilogue only");
+      } else {  // fp32 C: fp32 residual / saved pre-activation rows
+        const float* src = (EPI == AVF_EPI_BIAS_RES) ? (const float*)p.residual : (const float*)p.aux;
+        const int64_t ldx = (EPI == AVF_EPI_BIAS_RES) ? p.ldres : p.ldaux;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           if constexpr (PRE) ex[j] = pre->exf[i][j];
-          else ex[j] = *reinterpret_cast<const float4*>((const float*)p.residual + (int64_t)mc * p.ldres + n0 + 16 * j);
+          else ex[j] = *reinterpret_cast<const float4*>(src + (int64_t)mc * ldx + n0 + 16 * j);
         }
       }
     }
@@ -569,6 +570,30 @@ __device__ __forceinline__ void lds_read_words(uint32_t* dst, uint32_t addr, std
 // (3- and 4-stage rings, 256x128 / 256x256 / 192x128 tiles, 64x64 tiles and a persistent tile loop were all measured slower
 //  on this path's shapes - M = 10k..16k, N = 512..1536, K = 512..1536 - and removed: the waves wait ~55 % of their
 //  cycles (SQ_WAIT_ANY) on LDS/barrier latency, which more resident waves hide better than deeper DMA rings)
+int nt_lean_on() {
+  static const int on = [] {
+    const char* e = getenv("AVF_NT_LEAN");  // A/B aid: 0 = the general epilogue everywhere in the tiled kernels
+    return (e && *e) ? atoi(e) : 1;
+  }();
+  return on;
+}
+int nt_wide_stores();
+// the preconditions of nt_epilogue_lean for a block tile of bn columns (host side)
+template <int EPI, typename CT>
+bool nt_lean_ok(const NtParams& p, int bn) {
+  if (!nt_lean_on() || p.drop.thresh16 || p.mxq || p.rs_out || p.ln_part || p.N % bn != 0) return false;
+  if (p.cs_partial && EPI != AVF_EPI_DGELU) return false;
+  if (sizeof(CT) == 2) {
+    if (nt_wide_stores() != 1 || p.wide != 1 || (p.N & 7) || (p.ldc & 7) || ((uintptr_t)p.C & 15)) return false;
+    if (EPI == AVF_EPI_BIAS_RES && ((p.ldres & 7) || ((uintptr_t)p.residual & 15))) return false;
+    if ((EPI == AVF_EPI_BIAS_GELU || EPI == AVF_EPI_DGELU) && ((p.ldaux & 7) || ((uintptr_t)p.aux & 15))) return false;
+  } else {
+    if ((p.ldc & 3) || ((uintptr_t)p.C & 15)) return false;
+    if (EPI == AVF_EPI_BIAS_RES && ((p.ldres & 3) || ((uintptr_t)p.residual & 15))) return false;
+    if ((EPI == AVF_EPI_BIAS_GELU || EPI == AVF_EPI_DGELU) && ((p.ldaux & 3) || ((uintptr_t)p.aux & 15))) return false;
+  }
+  return true;
+}
 int nt_wide_stores() {
   static const int on = [] {
     const char* e = getenv("AVF_NT_WIDE");  // tuning aid: 0 = the plain per-block stores

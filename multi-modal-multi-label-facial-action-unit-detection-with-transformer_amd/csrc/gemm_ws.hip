@@ -36,6 +36,9 @@ constexpr int WS_KS = WS_K / 32;   // MFMA k-steps per tile
 #ifndef AVF_WS_STAMPS
 #define AVF_WS_STAMPS 0
 #endif
+#ifndef AVF_WS_EPI_PRIO
+#define AVF_WS_EPI_PRIO 2
+#endif
 #ifndef AVF_WS_DMA_LATE
 #define AVF_WS_DMA_LATE 1
 #endif
@@ -44,7 +47,7 @@ constexpr int WS_KS = WS_K / 32;   // MFMA k-steps per tile
 #endif
 constexpr int WS_NSTAMP = 64;
 #if AVF_WS_STAMPS
-__device__ unsigned long long g_ws_stamps[1024 * 2 * WS_NSTAMP];
+__device__ unsigned long long g_ws_stamps[512 * 8 * WS_NSTAMP];
 #define WS_STAMP(i)                                                                              \
   do {                                                                                           \
     if (stamp_on && (i) < WS_NSTAMP) stamp_lds[(i)] = (unsigned long long)__builtin_amdgcn_s_memtime(); \
@@ -96,8 +99,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_ws_kernel(NtParams p, const 
   if (nt <= 0) return;
   const int n0 = panel * WS_BN + wave * 32;
 #if AVF_WS_STAMPS
-  const bool stamp_on = (wave & 3) == 0 && lane == 0;
-  unsigned long long* stamp_lds = reinterpret_cast<unsigned long long*>(dsm + NSLOT * SLOT) + (wave >> 2) * WS_NSTAMP;
+  const bool stamp_on = lane == 0;
+  unsigned long long* stamp_lds = reinterpret_cast<unsigned long long*>(dsm + NSLOT * SLOT) + wave * WS_NSTAMP;
   if (stamp_on)
     for (int i = 0; i < WS_NSTAMP; ++i) stamp_lds[i] = 0;
   WS_STAMP(0);
@@ -126,23 +129,35 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_ws_kernel(NtParams p, const 
 #pragma unroll
   for (int i = 0; i < NSLOT - 1; ++i)
     if (i < nt) dma_tile(t0 + i, lds0 + i * SLOT);
-  // this wave's weight fragments (coalesced: 64 lanes x 16 B per instruction), behind the first tiles' DMA in the queue
+  // this wave's weight fragments (coalesced: 64 lanes x 16 B per instruction), behind the first tiles' DMA in the queue.
+  // The 256 KiB of a workgroup's panel come out of the XCD's L2 at the rate all its CUs share (3.5 us when the eight waves of
+  // every CU ask at once), so the two wave halves take TURNS: waves 0..3 load first and run tile 0 while waves 4..7 - which
+  // trail them by half a period for the whole launch anyway - load theirs.
+  const bool late = wave >= 4;  // wave-uniform
   bf16x8_t wr[NI][WS_KS];
-  {
-    const bf16x8_t* src = reinterpret_cast<const bf16x8_t*>(wp) + ((size_t)(panel * 8 + wave) * NI * WS_KS) * 64 + lane;
+  const bf16x8_t* wsrc = reinterpret_cast<const bf16x8_t*>(wp) + ((size_t)(panel * 8 + wave) * NI * WS_KS) * 64 + lane;
+  if (!late) {
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
-      for (int s = 0; s < WS_KS; ++s) wr[j][s] = src[(j * WS_KS + s) * 64];
+      for (int s = 0; s < WS_KS; ++s) wr[j][s] = wsrc[(j * WS_KS + s) * 64];
+    // ONE compiler-visible vmcnt(0): the weights (and, the queue being in order, the first tiles) have landed.  As a builtin
+    // the wait-count pass knows it: without it hipcc waits for each weight register at its first use INSIDE the tile loop,
+    // where a counted vmcnt(3..23) in front of the MFMAs also waits for the DMA issued at the top of the iteration
+    WS_STAMP(1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
+    WS_STAMP(2);
+  } else {
+    wait_vmcnt<0>();  // own pieces of the first tiles
+    __builtin_amdgcn_s_barrier();
+    WS_STAMP(1);
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int s = 0; s < WS_KS; ++s) wr[j][s] = wsrc[(j * WS_KS + s) * 64];
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    WS_STAMP(2);
   }
-  // ONE compiler-visible vmcnt(0): the weights (and, the queue being in order, the first tiles) have landed.  As a builtin the
-  // wait-count pass knows it: without it hipcc waits for each weight register at its first use INSIDE the tile loop, where a
-  // counted vmcnt(3..23) in front of the MFMAs also waits for the DMA issued at the top of the iteration
-  WS_STAMP(1);
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
-  WS_STAMP(2);
-  const bool late = wave >= 4;  // wave-uniform
-  if (late) __builtin_amdgcn_s_barrier();
 
   f32x4_t acc[MI][NI];
   uint32_t rd_slot = 0, wr_slot = (NSLOT - 1) * SLOT;
@@ -211,6 +226,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_ws_kernel(NtParams p, const 
     WS_STAMP(8 + 6 * t);
     if (late && t + 1 < nt) __builtin_amdgcn_s_barrier();
     WS_STAMP(9 + 6 * t);
+    // the epilogue's vector instructions outrank the SIMD partner's MFMA stream: a wave in its epilogue is on the workgroup's
+    // critical path (2480 cycles beside a partner issuing MFMAs against 1450 alone), the matrix pipe has slack
+    __builtin_amdgcn_s_setprio(AVF_WS_EPI_PRIO);
     if constexpr ((AVF_WS_DBG & 2) != 0) {
       NtParams p2 = p;
       p2.M = 0;  // every store predicated off
@@ -218,13 +236,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_ws_kernel(NtParams p, const 
     } else {
       nt_epilogue_lean<EPI, CT, MI, NI, CS, true>(p, acc, (t0 + t) * BM, n0, li, lg, t0 + t, &pre);
     }
+    __builtin_amdgcn_s_setprio(0);
     rd_slot = rd_slot + SLOT == NSLOT * SLOT ? 0 : rd_slot + SLOT;
     wr_slot = wr_slot + SLOT == NSLOT * SLOT ? 0 : wr_slot + SLOT;
   }
 #if AVF_WS_STAMPS
   WS_STAMP(3);
-  if (stamp_on && blockIdx.x < 1024)
-    for (int i = 0; i < WS_NSTAMP; ++i) g_ws_stamps[(blockIdx.x * 2 + (wave >> 2)) * WS_NSTAMP + i] = stamp_lds[i];
+  if (stamp_on && blockIdx.x < 512)
+    for (int i = 0; i < WS_NSTAMP; ++i) g_ws_stamps[(blockIdx.x * 8 + wave) * WS_NSTAMP + i] = stamp_lds[i];
 #endif
 }
 
@@ -252,7 +271,7 @@ int ws_grid() {
 template <int EPI, typename CT, int MI, int NSLOT, bool CS>
 int launch_ws(const NtParams& p, const void* bp, hipStream_t s, int* part_rows, TimingScope* ts) {
   constexpr int BM = 16 * MI;
-  constexpr int SMEM = NSLOT * BM * 1024 + (AVF_WS_STAMPS ? 2 * WS_NSTAMP * 8 : 0);
+  constexpr int SMEM = NSLOT * BM * 1024 + (AVF_WS_STAMPS ? 8 * WS_NSTAMP * 8 : 0);
   static_assert(SMEM <= 160 * 1024, "LDS budget");
   static PerDeviceOnce raised;
   if (SMEM > 64 * 1024 && raised.need()) {

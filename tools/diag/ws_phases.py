@@ -40,18 +40,19 @@ def main():
     torch.cuda.synchronize()
     NS = 64
     nwg = 256
-    buf = (C.c_uint64 * (nwg * 2 * NS))()
+    NWV = 8
+    buf = (C.c_uint64 * (nwg * NWV * NS))()
     fn = lib.avf_ws_stamps_read
     fn.restype = C.c_int
     fn.argtypes = [C.c_void_p, C.c_size_t]
     assert fn(buf, C.sizeof(buf)) == 0
-    st = [[[buf[(g * 2 + h) * NS + i] for i in range(NS)] for h in range(2)] for g in range(nwg)]
+    st = [[[buf[(g * NWV + h) * NS + i] for i in range(NS)] for h in range(NWV)] for g in range(nwg)]
     live = [g for g in range(nwg) if st[g][0][0] != 0]
     ntile = max(sum(1 for t in range(10) if st[g][0][4 + 6 * t] != 0) for g in live)
     full = [g for g in live if st[g][0][4 + 6 * (ntile - 1)] != 0]
     print(f"M={M} N={N} epi={args.epi}: {len(live)} live workgroups, up to {ntile} tiles ({len(full)} workgroups with that many)")
     med = lambda xs: int(statistics.median(xs))
-    for h, nm in ((0, "wave 0 (early)"), (1, "wave 4 (late) ")):
+    for h, nm in [(w, f"wave {w} ({'early' if w < 4 else 'late'})") for w in range(NWV)]:
         d = lambda i, j: med([st[g][h][j] - st[g][h][i] for g in full])
         print(f"{nm}: total {d(0, 3)}  issue(DMA+W) {d(0, 1)}  W/tile0 arrival {d(1, 2)}  to first tile top {d(2, 4)}")
         for t in range(ntile):
@@ -59,6 +60,13 @@ def main():
             nxt = (4 + 6 * (t + 1)) if t + 1 < ntile else 3
             print(f"   tile {t}: barrier {d(b, b + 1):6d}  dma-issue {d(b + 1, b + 2):5d}  mfma {d(b + 2, b + 3):6d}  vmcnt {d(b + 3, b + 4):6d}"
                   f"  late-barrier {d(b + 4, b + 5):6d}  epilogue {d(b + 5, nxt):6d}   | period {d(b, nxt):6d}")
+    # arrival order at the tile barriers: per tile, when each wave reaches its barrier relative to the first arriver (median)
+    for t in range(1, ntile):
+        arr = []
+        for w in range(NWV):
+            idx = (4 + 6 * t) if w < 4 else (8 + 6 * (t - 1))  # early waves: top of tile t; late waves: behind the MFMAs of t - 1
+            arr.append(med([st[g][w][idx] - min(st[g][v][(4 + 6 * t) if v < 4 else (8 + 6 * (t - 1))] for v in range(NWV)) for g in full]))
+        print(f"   barrier {t}: arrival after the first wave:", arr)
     # skew of the workgroups: start and end relative to the first start
     s0 = min(st[g][0][0] for g in live)
     print("workgroup start (min/med/max):", min(st[g][0][0] - s0 for g in live), med([st[g][0][0] - s0 for g in live]),
