@@ -205,6 +205,24 @@ class Region:
 
         self.step = step
 
+        def fwd_bwd():
+            model.zero_grad(set_to_none=True)  # (drops the .grad views; the flat gradient buckets are overwritten, not cleared)
+            loss = model.get_au_loss(model(batch), labels)
+            loss.backward()
+            if dp is not None:
+                dp.finish()
+            return loss
+
+        self.fwd_bwd = fwd_bwd if opt is not None else None
+
+    def agree(self, flag: bool) -> bool:
+        """`flag` on one rank; under data parallelism: true on EVERY rank if it is true on any (one tiny all-reduce)"""
+        if not self.use_dist:
+            return bool(flag)
+        t = self.torch.tensor([1.0 if flag else 0.0], device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return t.item() > 0.5
+
     def fence(self):
         self.torch.cuda.synchronize()
         if self.use_dist:
@@ -219,16 +237,20 @@ class Region:
         # the caching allocator may still be growing after W steps of a large configuration (C4: 59 device allocations over
         # the first ~10 steps, each a multi-millisecond hipMalloc that would land inside the timed region): keep stepping,
         # untimed, until two consecutive steps allocate nothing new (at most 12 more)
+        # Every step issues collectives under data parallelism, so the decision to take another one must be the SAME on every
+        # rank (a rank that left such a loop on its own clock / its own allocator counter would meet its peers' all-reduces
+        # with a barrier): the local verdict is MAX-reduced over the ranks before it is acted on (self.agree).
         quiet, extra = 0, 0
         while quiet < 2 and extra < 12:
             before = torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0)
             self.step()
             extra += 1
-            quiet = quiet + 1 if torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0) == before else 0
+            grew = torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0) != before
+            quiet = 0 if self.agree(grew) else quiet + 1
         # ... and until the device has been busy for SETTLE_S seconds, so that the clock / power state the timed steps see is
         # the steady one of this workload and not whatever the few warm-up steps left (a 20-step region is 45 ms long)
         t_settle = time.perf_counter()
-        while time.perf_counter() - t_settle < SETTLE_S:
+        while self.agree(time.perf_counter() - t_settle < SETTLE_S):
             for _ in range(5):
                 self.step()
                 extra += 1
@@ -294,6 +316,21 @@ class Region:
         if self.use_dist:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         dt = t.item()
+        # forward + loss + backward (+ the gradient all-reduces) alone - what the metric names; the step above also clears the
+        # gradients and applies Adam.  Eager launches, same fences (the step is GPU-bound either way: `eager_ms_per_step`).
+        self.fwd_bwd_ms = None
+        if getattr(self, "fwd_bwd", None) is not None:
+            for _ in range(3):
+                self.fwd_bwd()
+            self.fence()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                self.fwd_bwd()
+            self.fence()
+            tfb = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=self.dev)
+            if self.use_dist:
+                self.dist.all_reduce(tfb, op=self.dist.ReduceOp.MAX)
+            self.fwd_bwd_ms = tfb.item() / steps * 1e3
         self.steps = steps
         self.ms = dt / steps * 1e3
         self.clips_per_s = self.B * self.world * steps / dt
@@ -324,6 +361,45 @@ class Region:
                                       if v["ms"] > 0 and v["flops"] > 0 else None),
                 "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None}
             for k, v in tm.items() if v["launches"] > 0}
+
+
+def dp_report(torch, dist, region, dev, world):
+    """What the data-parallel step did on the wire, for the record of a multi-GPU run: the ranks every rank saw, the
+    collectives of one step and their sizes, and the time of the same all-reduces issued ALONE (back to back, nothing to
+    overlap with) - an upper bound of the communication time per step; the overlap is the difference to `ms_per_step`."""
+    ones = torch.ones(1, device=dev)
+    dist.all_reduce(ones)
+    seen = int(round(ones.item()))
+    mism = torch.tensor([0.0 if seen == world else 1.0], device=dev)
+    dist.all_reduce(mism, op=dist.ReduceOp.MAX)
+    if mism.item() > 0.5:
+        raise SystemExit(f"bench.py: a rank saw {seen} ranks in the process group, expected {world}")
+    dp = region.dp
+    dp.stats_reset()
+    region.step()
+    torch.cuda.synchronize()
+    st = dp.stats()
+    sizes = st["bucket_bytes"]
+    bufs = [torch.zeros(max(1, b // 4), device=dev) for b in sizes]
+    for b in bufs:
+        dist.all_reduce(b)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        for b in bufs:
+            dist.all_reduce(b)  # synchronous form: the calling stream waits for the group's stream, so the events bracket it
+    e1.record()
+    torch.cuda.synchronize()
+    alone = torch.tensor([e0.elapsed_time(e1) / reps], device=dev)
+    dist.all_reduce(alone, op=dist.ReduceOp.MAX)
+    return {"rccl_ranks": seen, "backend": dist.get_backend(), "gradient_collectives_per_step": st["collectives"],
+            "loss_collectives_per_step": st["loss_collectives"], "bucket_bytes": sizes,
+            "gradient_bytes_per_step": int(sum(sizes)), "bucket_rule_bytes": dp.bucket_bytes,
+            "allreduce_alone_ms_per_step": round(alone.item(), 4),
+            "note": "allreduce_alone = the step's gradient all-reduces issued back to back with nothing to overlap (max over "
+                    "ranks); ms_per_step minus the one-rank ms_per_step is what the collectives cost beside the backward"}
 
 
 def main():
@@ -423,7 +499,12 @@ def main():
         # the same step launched eagerly from Python (None when `value` itself is the eager number)
         "eager_ms_per_step": None if main_r.eager_ms is None else round(main_r.eager_ms, 4),
         "eager_clips_per_s": None if main_r.eager_ms is None else round(B * world / (main_r.eager_ms * 1e-3), 2),
+        # forward + AULoss + backward (+ all-reduce) only, eager launches: the part of the step the metric names
+        "fwd_bwd_ms_per_step": None if main_r.fwd_bwd_ms is None else round(main_r.fwd_bwd_ms, 4),
+        "fwd_bwd_clips_per_s": None if main_r.fwd_bwd_ms is None else round(B * world / (main_r.fwd_bwd_ms * 1e-3), 2),
     }
+    if use_dist:
+        result["data_parallel"] = dp_report(torch, dist, main_r, dev, world)
     c3_r = f32_r = r32_r = None
     if not args.no_extra and args.dtype != "f32" and args.residual == "bf16":
         # the same workload with the fp32 forward residual stream (the round-1/2 default): reported beside `value`

@@ -269,7 +269,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(NtParam
   }
 
   if constexpr (LEAN != 0)
-    nt_epilogue_lean<EPI, CT, MI, NI, LEAN == 2, false>(p, acc, m0 + wm * WTM, n0 + wn * WTN, li, lg, (wg / tiles_n) * WM + wm);
+    nt_epilogue_lean<EPI, CT, MI, NI, LEAN == 2 ? 1 : 0, false>(p, acc, m0 + wm * WTM, n0 + wn * WTN, li, lg, (wg / tiles_n) * WM + wm);
   else
     nt_epilogue<EPI, CT, MI, NI, LNF>(p, acc, m0 + wm * WTM, n0 + wn * WTN, li, lg,
                                       p.cs_partial ? (wg / tiles_n) * WM + wm : -1, lnst + wm * WTM);

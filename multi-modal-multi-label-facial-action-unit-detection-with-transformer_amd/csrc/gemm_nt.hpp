@@ -368,9 +368,33 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
 // stores and loads, p.wide == 1).  CS: column sums of the stored values into cs_partial[part_row].  PRE: bias / residual /
 // saved pre-activation were fetched by nt_epi_prefetch.  FULL: every row of the tile is inside M (no row predicate).
 // ------------------------------------------------------------------------------------------
-template <int EPI, typename CT, int MI, int NI, bool CS, bool PRE, bool FULL>
+// the column sums of a wave tile, summed over the lanes that share a column (the 16 lanes of a DPP row) and stored as one
+// partial row: the same DPP tree as nt_epilogue
+template <int NI>
+__device__ __forceinline__ void nt_cs_flush(const NtParams& p, float (&cs)[NI][4], int part_row, int n_base, int li, int lg) {
+  const int n0 = n_base + 4 * lg;
+#pragma unroll
+  for (int j = 0; j < NI; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float t = cs[j][r];
+      t += AVF_DPP_F32(t, 0xB1);
+      t += AVF_DPP_F32(t, 0x4E);
+      t += AVF_DPP_F32(t, 0x124);
+      t += AVF_DPP_F32(t, 0x128);
+      cs[j][r] = t;
+    }
+  if (li == 0) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+      *reinterpret_cast<float4*>(p.cs_partial + (int64_t)part_row * p.N + n0 + 16 * j) = make_float4(cs[j][0], cs[j][1], cs[j][2], cs[j][3]);
+  }
+}
+// CS: 0 = no column sums; 1 = summed and stored per call (row part_row of cs_partial); 2 = added into the caller's per-lane
+// accumulators cs_acc (a persistent kernel sums every tile it owns in registers and calls nt_cs_flush once)
+template <int EPI, typename CT, int MI, int NI, int CS, bool PRE, bool FULL>
 __device__ __forceinline__ void nt_epilogue_lean_body(const NtParams& p, f32x4_t (&acc)[MI][NI], int m_base, int n_base, int li,
-                                                      int lg, int part_row, const NtPre<MI, NI>* pre) {
+                                                      int lg, int part_row, const NtPre<MI, NI>* pre, float (*cs_acc)[4]) {
   static_assert(sizeof(CT) == 4 || (NI & 1) == 0, "2-byte outputs are stored in column-block pairs");
   const int n0 = n_base + 4 * lg;                    // this lane's 4 columns of block 0 (block j: + 16 j)
   const int cp0 = n0 + ((lg & 1) ? 12 : 0);          // its 8 columns of the block pair (0, 1) after the lane-pair exchange
@@ -441,10 +465,15 @@ __device__ __forceinline__ void nt_epilogue_lean_body(const NtParams& p, f32x4_t
       } else {
         vf[j] = make_float4(v[0], v[1], v[2], v[3]);
       }
-      if constexpr (CS) {
+      if constexpr (CS == 1) {
         if (mok) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) cs[j][r] += v[r];
+        }
+      } else if constexpr (CS == 2) {
+        if (mok) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cs_acc[j][r] += v[r];
         }
       }
     }
@@ -483,30 +512,15 @@ __device__ __forceinline__ void nt_epilogue_lean_body(const NtParams& p, f32x4_t
       for (int j = 0; j < NI; ++j) *reinterpret_cast<float4*>(crow + 16 * j) = vf[j];
     }
   }
-  if constexpr (CS) {
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float t = cs[j][r];  // the same DPP tree as nt_epilogue: identical bits
-        t += AVF_DPP_F32(t, 0xB1);
-        t += AVF_DPP_F32(t, 0x4E);
-        t += AVF_DPP_F32(t, 0x124);
-        t += AVF_DPP_F32(t, 0x128);
-        cs[j][r] = t;
-      }
-    if (li == 0) {
-#pragma unroll
-      for (int j = 0; j < NI; ++j)
-        *reinterpret_cast<float4*>(p.cs_partial + (int64_t)part_row * p.N + n0 + 16 * j) = make_float4(cs[j][0], cs[j][1], cs[j][2], cs[j][3]);
-    }
-  }
+  if constexpr (CS == 1) nt_cs_flush<NI>(p, cs, part_row, n_base, li, lg);
 }
-template <int EPI, typename CT, int MI, int NI, bool CS, bool PRE>
+template <int EPI, typename CT, int MI, int NI, int CS, bool PRE>
 __device__ __forceinline__ void nt_epilogue_lean(const NtParams& p, f32x4_t (&acc)[MI][NI], int m_base, int n_base, int li, int lg,
-                                                 int part_row, const NtPre<MI, NI>* pre = nullptr) {
-  if (m_base + 16 * MI <= p.M) nt_epilogue_lean_body<EPI, CT, MI, NI, CS, PRE, true>(p, acc, m_base, n_base, li, lg, part_row, pre);
-  else nt_epilogue_lean_body<EPI, CT, MI, NI, CS, PRE, false>(p, acc, m_base, n_base, li, lg, part_row, pre);
+                                                 int part_row, const NtPre<MI, NI>* pre = nullptr, float (*cs_acc)[4] = nullptr) {
+  if (m_base + 16 * MI <= p.M)
+    nt_epilogue_lean_body<EPI, CT, MI, NI, CS, PRE, true>(p, acc, m_base, n_base, li, lg, part_row, pre, cs_acc);
+  else
+    nt_epilogue_lean_body<EPI, CT, MI, NI, CS, PRE, false>(p, acc, m_base, n_base, li, lg, part_row, pre, cs_acc);
 }
 
 typedef __attribute__((address_space(1))) const void gptr_t;

@@ -160,6 +160,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_ws_kernel(NtParams p, const 
   }
 
   f32x4_t acc[MI][NI];
+  // CS: the column sums of ALL the tiles this wave owns, per lane; one DPP reduction and one partial row per workgroup
+  // group at the end (row `grp` of cs_partial) instead of one per tile
+  float cs_acc[NI][4];
+#pragma unroll
+  for (int j = 0; j < NI; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cs_acc[j][r] = 0.f;
   uint32_t rd_slot = 0, wr_slot = (NSLOT - 1) * SLOT;
   for (int t = 0; t < nt; ++t) {
     WS_STAMP(4 + 6 * t);
@@ -232,14 +239,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_ws_kernel(NtParams p, const 
     if constexpr ((AVF_WS_DBG & 2) != 0) {
       NtParams p2 = p;
       p2.M = 0;  // every store predicated off
-      nt_epilogue_lean<EPI, CT, MI, NI, false, true>(p2, acc, (t0 + t) * BM, n0, li, lg, -1, &pre);
+      nt_epilogue_lean<EPI, CT, MI, NI, 0, true>(p2, acc, (t0 + t) * BM, n0, li, lg, -1, &pre);
     } else {
-      nt_epilogue_lean<EPI, CT, MI, NI, CS, true>(p, acc, (t0 + t) * BM, n0, li, lg, t0 + t, &pre);
+      nt_epilogue_lean<EPI, CT, MI, NI, CS ? 2 : 0, true>(p, acc, (t0 + t) * BM, n0, li, lg, -1, &pre, cs_acc);
     }
     __builtin_amdgcn_s_setprio(0);
     rd_slot = rd_slot + SLOT == NSLOT * SLOT ? 0 : rd_slot + SLOT;
     wr_slot = wr_slot + SLOT == NSLOT * SLOT ? 0 : wr_slot + SLOT;
   }
+  if constexpr (CS) nt_cs_flush<NI>(p, cs_acc, grp, n0, li, lg);
 #if AVF_WS_STAMPS
   WS_STAMP(3);
   if (stamp_on && blockIdx.x < 512)
@@ -286,7 +294,7 @@ int launch_ws(const NtParams& p, const void* bp, hipStream_t s, int* part_rows, 
   int G = nwg / P;
   if (G > T) G = T;
   AVF_REQUIRE(G >= 1, "gemm_bf16_nt_ws: more column panels (%d) than persistent workgroups (%d)", P, nwg);
-  *part_rows = T;
+  *part_rows = CS ? G : T;  // column sums: one partial row per workgroup group
   if (shape_log_on()) {
     const double csz = sizeof(CT);
     const double epi_b = (EPI == AVF_EPI_BIAS_RES || EPI == AVF_EPI_BIAS_GELU || EPI == AVF_EPI_DGELU) ? csz * p.M * p.N : 0.0;

@@ -60,6 +60,7 @@ class DataParallel:
             self._owned.update(id(p) for p in st.flat_parameters())
         self._rest_params = [p for p in model.parameters() if id(p) not in self._owned]
         self._cuda = any(p.is_cuda for p in model.parameters())
+        self._stats = {"collectives": 0, "loss_collectives": 0, "bucket_bytes": []}
         self._pending: List = []
         self._held: List = []  # (layer, flat) handed over but not launched yet
         # losses that are ratios over the kept rows (AULoss, loss.py:85-102) reduce numerator and denominator over the ranks
@@ -118,7 +119,16 @@ class DataParallel:
         self._held = []
         return [self._launch(t) for t in self._merge(flats)]
 
+    def stats_reset(self):
+        self._stats = {"collectives": 0, "loss_collectives": 0, "bucket_bytes": []}
+
+    def stats(self):
+        """collectives issued since stats_reset(): gradient all-reduces (count, bytes of each) and loss reductions"""
+        return {k: (list(v) if isinstance(v, list) else v) for k, v in self._stats.items()}
+
     def _launch(self, flat: torch.Tensor):
+        self._stats["collectives"] += 1
+        self._stats["bucket_bytes"].append(flat.numel() * flat.element_size())
         if self._cuda:
             # Issued from the compute stream with async_op=True: the process group makes ITS communication stream wait for
             # what the compute stream has enqueued so far (the producing backward kernels), runs the collective there and
@@ -137,6 +147,7 @@ class DataParallel:
         equals the single-process loss on the concatenated batch for any split of the ignored rows over the ranks"""
         # on the GPU the "blocking" all-reduce only makes the current stream wait for the group's communication stream (no host
         # block), so it is recorded by a hipGraph capture like the gradient collectives (graphs.GraphedTrainStep(dp=...))
+        self._stats["loss_collectives"] += 1
         return _GlobalMeanFn.apply(local_sum, local_count, self.world, self.group)
 
     # -- called once per step, after loss.backward() and before optimizer.step() -------------------

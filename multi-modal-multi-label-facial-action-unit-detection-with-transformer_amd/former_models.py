@@ -59,6 +59,18 @@ def _fc_head(in_features):
 class _FormerTask(nn.Module, _TaskLossMixin):
     num_channels = 3
 
+    def _config(self, modality, task):
+        """``config_modality`` (sformer.py:384-391, same in vformer / tformer): RGB + mask -> the last 4 channels of the
+        clip, mask only -> the last one, otherwise the 3 RGB channels (the caller's stem must take that many: the reference
+        rebuilds ``conv1`` there, which belongs to the backbone this package does not ship).  Tasks: AU and EX logits come out
+        of these entries as in the reference; its VA branch (``VA_former`` on the frame feature, sformer.py:378-380) is not
+        built - refuse it instead of silently returning the fc head's columns."""
+        if 'M' in modality:
+            self.num_channels = 4 if 'V' in modality else 1
+        if task == 'VA':
+            raise NotImplementedError("task='VA' of the *former registry entries (VA_former head) is outside the hot path this "
+                                      "package builds (SURVEY.md section 8); use task='AU' or 'EX'")
+
     def _select(self, x):
         clip = x['clip']
         if clip.dim() == 5 and self.has_backbone:             # [B, C, T, H, W] -> [B, T, C, H, W] (sformer.py:374-377)
@@ -73,9 +85,13 @@ class SpatialFormerModel(_FormerTask):
         super().__init__()
         self.has_backbone = backbone is not None
         self.base_model = ResFormerShell(backbone, dropout=0.2, compute_dtype=compute_dtype)
+        self._config(modality, task)
         self.task, self.modes = task, ["clip"]
         self.fc = _fc_head(512)
         self.au_head = AU_former(dropout=0.2, compute_dtype=compute_dtype)
+        # DEVIATION, on purpose: the reference's SpatialFormer trains AU with DiceAULoss (multi-label Dice + 5 x weighted BCE,
+        # sformer.py:362, loss.py:149-176); this entry uses the AULoss of the path SURVEY.md section 8 scopes (loss.py:63-103,
+        # what avformer / vformer / tformer use).  INTEGRATION.md section 4 says so.
         self.loss_AU = AULoss()
 
     def forward(self, x):
@@ -109,6 +125,7 @@ class VisualFormerModel(_FormerTask):
         super().__init__()
         self.has_backbone = backbone is not None
         self.video_model = _VideoModel(backbone, 512, False, compute_dtype)
+        self._config(modality, task)
         self.task, self.modes = task, ["clip"]
         self.fc = _fc_head(512)
         self.loss_AU = AULoss()
@@ -125,6 +142,7 @@ class SpatialTemporalFormerModel(_FormerTask):
         super().__init__()
         self.has_backbone = backbone is not None
         self.video_model = _VideoModel(backbone, 128 * 12, True, compute_dtype)
+        self._config(modality, task)
         self.task, self.modes = task, ["clip"]
         self.au_head = tformer_AU_head(dropout=0.2, compute_dtype=compute_dtype)
         self.fc = _fc_head(128 * 12)

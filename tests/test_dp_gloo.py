@@ -88,6 +88,8 @@ def _worker(rank, world, port, out, bucket_layers=2):
         for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
             worst = max(worst, (p.grad - q.grad).abs().max().item() / (q.grad.abs().max().item() + 1e-12))
         same_w = all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), ref.state_dict().values()))
+        st = dp.stats()  # the counters bench.py reports for a multi-GPU run
+        assert st["collectives"] == len(launched) and len(st["bucket_bytes"]) == len(launched) and min(st["bucket_bytes"]) > 0
         out.put((rank, worst, same_w, len(dp._pending), len(launched)))
     finally:
         dist.destroy_process_group()

@@ -1,0 +1,134 @@
+"""Weight-stationary persistent NT GEMM (csrc/gemm_ws.hip) and the lean epilogue (gemm_nt.hpp): the K = 512 GEMMs of
+/root/reference/models/heads.py:191,195,212,215 (nn.Linear forward / dX at dim 512).
+
+The persistent kernel must return bit for bit what the tiled kernel returns (same epilogue arithmetic, same k order of the fp32
+accumulation), for every epilogue, both output types, ragged row counts and every ring depth; both are held to an fp64
+restatement; the fragment-major weight image is a pure permutation; the column sums of the dGELU form equal the sums of the
+stored values."""
+import os
+
+import pytest
+import torch
+
+import avformer_amd as A
+from gpu_util import check
+
+pytestmark = pytest.mark.gpu
+ops = A.ops
+bf = torch.bfloat16
+
+
+def _inputs(M, N, epi, od, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    a = torch.randn(M, 512, device="cuda", generator=g).to(bf)
+    w = (torch.randn(N, 512, device="cuda", generator=g) / 512 ** 0.5).to(bf)
+    bias = torch.randn(N, device="cuda", generator=g) if epi in (ops.EPI_BIAS_RES, ops.EPI_BIAS_GELU) else None
+    res = torch.randn(M, N, device="cuda", generator=g).to(od) if epi == ops.EPI_BIAS_RES else None
+    aux = torch.randn(M, N, device="cuda", generator=g).to(od) if epi == ops.EPI_DGELU else None
+    return a, w, bias, res, aux
+
+
+def _gelu(u):
+    return 0.5 * u * (1.0 + torch.tanh(0.7978845608028654 * (u + 0.044715 * u ** 3)))
+
+
+def _dgelu(u):
+    t = torch.tanh(0.7978845608028654 * (u + 0.044715 * u ** 3))
+    return 0.5 * (1 + t) + 0.5 * u * (1 - t * t) * 0.7978845608028654 * (1 + 3 * 0.044715 * u * u)
+
+
+def _ref64(a, w, bias, res, aux, epi):
+    c = a.double() @ w.double().t()
+    if bias is not None:
+        c = c + bias.double()
+    if epi == ops.EPI_BIAS_RES:
+        return (c + res.double(),)
+    if epi == ops.EPI_BIAS_GELU:
+        return (_gelu(c), c)
+    if epi == ops.EPI_DGELU:
+        return (c * _dgelu(aux.double()),)
+    return (c,)
+
+
+def test_packed_image_is_a_permutation_of_the_weight():
+    w = torch.arange(1024 * 512, device="cuda", dtype=torch.float32).remainder(251.0).to(bf).view(1024, 512)
+    wp = ops.pack_ws(w)
+    assert wp.numel() == w.numel()
+    # chunk (panel, wave, j, s, lane) = W[256 panel + 32 wave + 16 j + (lane & 15)][32 s + 8 (lane >> 4) .. + 7]
+    v = wp.view(4, 8, 2, 16, 4, 16, 8)  # panel, wave, j, s, lg, li, k8
+    back = v.permute(0, 1, 2, 5, 3, 4, 6).reshape(1024, 512)  # -> (panel, wave, j, li) rows x (s, lg, k8) columns
+    assert torch.equal(back, w)
+    with pytest.raises(ValueError):
+        ops.pack_ws(torch.zeros(100, 512, device="cuda", dtype=bf))
+
+
+@pytest.mark.parametrize("epi_name", ["none", "res", "gelu", "dgelu"])
+@pytest.mark.parametrize("out", ["bf16", "f32"])
+@pytest.mark.parametrize("M,N", [(16384, 512), (10368, 1024), (4099, 1536), (2048, 256)])
+def test_persistent_kernel_equals_the_tiled_kernel_bit_for_bit(epi_name, out, M, N):
+    epi = {"none": ops.EPI_NONE, "res": ops.EPI_BIAS_RES, "gelu": ops.EPI_BIAS_GELU, "dgelu": ops.EPI_DGELU}[epi_name]
+    od = bf if out == "bf16" else torch.float32
+    if epi == ops.EPI_DGELU and out == "f32":
+        pytest.skip("the layer never asks for an fp32 dGELU product; the persistent kernel refuses it")
+    a, w, bias, res, aux = _inputs(M, N, epi, od, seed=M + N)
+    r0 = ops.gemm(a, w, out_dtype=od, epilogue=epi, bias=bias, residual=res, aux=aux)
+    r1 = ops.gemm_ws(a, ops.pack_ws(w), N, out_dtype=od, epilogue=epi, bias=bias, residual=res, aux=aux)
+    r0 = r0 if isinstance(r0, tuple) else (r0,)
+    r1 = r1 if isinstance(r1, tuple) else (r1,)
+    assert len(r0) == len(r1)
+    for x, y in zip(r0, r1):
+        assert torch.equal(x, y), float((x.float() - y.float()).abs().max())
+    ref = _ref64(a, w, bias, res, aux, epi)
+    for i, (y, r) in enumerate(zip(r1, ref)):
+        err = float((y.double() - r).norm() / r.norm())
+        check(f"ws_{epi_name}_{out}_{M}x{N}_{i}", err, 1e-2 if out == "bf16" else 2e-5)
+
+
+def test_column_sums_of_the_dgelu_form():
+    M, N = 10368, 1024
+    a, w, _, _, aux = _inputs(M, N, ops.EPI_DGELU, bf, seed=5)
+    c, cs = ops.gemm_ws(a, ops.pack_ws(w), N, out_dtype=bf, epilogue=ops.EPI_DGELU, aux=aux, want_colsum=True)
+    ref = _ref64(a, w, None, None, aux, ops.EPI_DGELU)[0]
+    # the sums are taken of the fp32 values BEFORE their rounding to bf16 (as the tiled kernel's), in fp32
+    err = float((cs.double() - ref.sum(0)).abs().max() / ref.abs().sum(0).max())
+    assert err < 2e-5, err
+    assert torch.equal(c, ops.gemm(a, w, out_dtype=bf, epilogue=ops.EPI_DGELU, aux=aux))
+
+
+def test_unfit_shapes_are_refused_and_the_layer_falls_back():
+    a = torch.randn(1024, 512, device="cuda").to(bf)  # fewer than 2048 rows
+    w = torch.randn(512, 512, device="cuda").to(bf)
+    with pytest.raises(RuntimeError, match="weight-stationary"):
+        ops.gemm_ws(a, ops.pack_ws(w), 512)
+
+
+def test_stack_with_and_without_the_persistent_kernel(tmp_path):
+    """AVF_NT_WS is read once per process: two child processes run the same 2-layer stack (forward + backward) with the
+    persistent kernel on and off.  Every tensor is bit-identical except the gradient of net.0's bias, whose column sums go
+    through per-tile (tiled kernel) or per-workgroup (persistent kernel) fp32 partial sums."""
+    import subprocess
+    import sys
+    code = (
+        "import os, torch, avformer_amd as A\n"
+        "torch.manual_seed(3)\n"
+        "m = A.Transformer(512, 2, 8, 64, 1024, compute_dtype='bf16', residual_dtype='bf16').cuda()\n"
+        "x = torch.randn(8, 324, 512, device='cuda', requires_grad=True)\n"
+        "y = m(x); y.float().pow(2).mean().backward()\n"
+        "d = {'y': y.detach().float().cpu(), 'dx': x.grad.cpu()}\n"
+        "d.update({n: p.grad.cpu() for n, p in m.named_parameters()})\n"
+        "torch.save(d, os.environ['AVF_TEST_OUT'])\n")
+    outs = []
+    for ws in ("1", "0"):
+        path = str(tmp_path / f"ws{ws}.pt")
+        env = dict(os.environ, AVF_NT_WS=ws, AVF_TEST_OUT=path)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(torch.load(path))
+    on, off = outs
+    assert on.keys() == off.keys()
+    for k in on:
+        if k.endswith("net.0.bias"):
+            assert torch.allclose(on[k], off[k], rtol=1e-4, atol=1e-6), k
+        else:
+            assert torch.equal(on[k], off[k]), k

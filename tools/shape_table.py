@@ -1,14 +1,19 @@
 #!/usr/bin/env python3
-"""Per-shape kernel table for profiles/ (VERDICT r02, weak item 6c): one row per distinct (kernel template, grid) of the hot
-path with its operand shape, launches, mean duration from a rocprofv3 kernel trace, TFLOP/s, fraction of the bf16 MFMA roof,
-algorithmic bytes and - when the FETCH_SIZE / WRITE_SIZE passes are given - measured HBM bytes per launch.
+"""Per-shape kernel table for profiles/: one row per distinct hot-path launch (kernel template, grid, operand shape, epilogue)
+with its launches, mean duration from a rocprofv3 kernel trace, TFLOP/s, fraction of the bf16 MFMA roof, algorithmic bytes and -
+when the FETCH_SIZE / WRITE_SIZE passes are given - measured HBM bytes per launch OF THAT SHAPE.
 
   python tools/shape_table.py <kernel_trace.csv> <shape_log.csv> <out.csv> [fetch_counter_collection.csv write_counter_collection.csv]
 
 <kernel_trace.csv>: rocprofv3 --kernel-trace --output-format csv (one row per dispatch).  <shape_log.csv>: written by the library
-under AVF_SHAPE_LOG=<file> during an EAGER run of the same workload (python bench.py --launch eager ...): lines
-"class,kernel template,grid (workgroups),M,N,K,epilogue,flops,bytes".  Kernels are joined on (template name, workgroups);
-shapes that share both (same tile grid, different K) are told apart by the order of their first appearance within a step.
+under AVF_SHAPE_LOG=<file> during ONE eager step of the same workload (python bench.py --steps 1 --warmup 0 --launch eager ...):
+lines "class,kernel template,grid (workgroups),M,N,K,epilogue,flops,bytes" in launch order.
+
+Join (round 4; the round-3 tool joined by kernel NAME, which gave every shape of a template the template's mean): the shape log
+is the launch sequence of one step; the hot-path dispatches of the trace (and of each PMC pass), in time / dispatch order, repeat
+that sequence step after step, so every dispatch is matched to its log entry by POSITION with the kernel name as a check (a
+dispatch the current entry does not accept moves the pointer on).  An attention call that dispatches to several kernels
+(dQ + dK/dV, delta) is one entry: its duration and traffic are the sums over its kernels.
 HBM bytes: (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts half of wide reads; MI355X_MICROARCH.md, HBM)."""
 import collections
 import csv
@@ -16,6 +21,7 @@ import re
 import sys
 
 PEAK_TFLOPS = 2500.0
+HOT = ("gemm_bf16_nt", "gemm_bf16_tn_group", "gemm_mx8_nt", "attn_")
 
 
 def short(n):
@@ -24,96 +30,120 @@ def short(n):
     return n.split("(")[0].strip()
 
 
-def main():
-    trace, shapes, out = sys.argv[1:4]
-    pmc = sys.argv[4:6] if len(sys.argv) >= 6 else None
-    # ---- shape log: (template, wgs) -> ordered list of distinct (M, N, K, epi, flops, bytes)
-    by_key = collections.OrderedDict()
-    for line in open(shapes):
+def norm(t):
+    return t.replace(" ", "")
+
+
+class Entry:
+    def __init__(self, cls, tmpl, wgs, M, N, K, epi, flops, byts):
+        self.cls, self.tmpl, self.wgs, self.M, self.N, self.K, self.epi, self.flops, self.byts = cls, tmpl, wgs, M, N, K, epi, flops, byts
+        self.multi = tmpl.startswith("attn")
+
+    def key(self):
+        return (self.cls, self.tmpl, self.wgs, self.M, self.N, self.K, self.epi)
+
+    def accepts(self, name, wgs):
+        if self.multi:
+            if self.tmpl == "attn_fwd":
+                return name.startswith("attn_fwd")
+            return name.startswith(("attn_dq", "attn_dkv", "attn_bwd", "attn_delta"))
+        if norm(self.tmpl) == norm(name):
+            # (the grouped weight-gradient launch pads its grid for the XCD-aware block order: name only)
+            return wgs == self.wgs or self.tmpl.startswith("gemm_bf16_tn_group")
+        # fold / helper launches are not logged; a template logged without arguments matches by prefix
+        return "<" not in self.tmpl and name.startswith(self.tmpl) and wgs == self.wgs
+
+
+def read_log(path):
+    seq = []
+    for line in open(path):
         f = line.strip().split(",")
         if len(f) < 9:
             continue
-        # the template name itself contains commas: class, <template...>, wgs, M, N, K, epi, flops, bytes
         cls, rest = f[0], f[1:]
         flops, byts = float(rest[-2]), float(rest[-1])
         epi, K, N, M, wgs = rest[-3], rest[-4], rest[-5], rest[-6], int(rest[-7])
-        tmpl = ",".join(rest[:-7])
-        key = (tmpl, wgs)
-        ent = (cls, M, N, K, epi, flops, byts)
-        by_key.setdefault(key, [])
-        if ent not in by_key[key]:
-            by_key[key].append(ent)
-    # ---- trace: group dispatches by (template, wgs)
-    durs = collections.defaultdict(list)
+        seq.append(Entry(cls, ",".join(rest[:-7]), wgs, M, N, K, epi, flops, byts))
+    return seq
+
+
+def walk(seq, dispatches):
+    """dispatches: iterable of (name, workgroups, payload) in launch order -> list of (entry index, call number, name, payload);
+    a call = one pass of the pointer over an entry (the kernels of a multi-kernel attention call share a call number)"""
+    out, ptr, call, open_multi, skipped = [], 0, 0, False, 0
+    n = len(seq)
+    for name, wgs, payload in dispatches:
+        if not name.startswith(HOT):
+            continue
+        tries = 0
+        while tries <= n:
+            e = seq[ptr % n]
+            if e.accepts(name, wgs):
+                out.append((ptr % n, call, name, payload))
+                if e.multi:
+                    open_multi = True
+                else:
+                    ptr += 1
+                    call += 1
+                break
+            if open_multi:
+                open_multi = False
+            ptr += 1
+            call += 1
+            tries += 1
+        else:
+            skipped += 1
+    return out, skipped
+
+
+def main():
+    trace, shapes, out = sys.argv[1:4]
+    pmc = sys.argv[4:6] if len(sys.argv) >= 6 else None
+    seq = read_log(shapes)
+    if not seq:
+        sys.exit("empty shape log")
+    disp = []
     for r in csv.DictReader(open(trace)):
         name = short(r["Kernel_Name"])
         wg = int(r["Workgroup_Size_X"]) * int(r.get("Workgroup_Size_Y", 1) or 1) * int(r.get("Workgroup_Size_Z", 1) or 1)
         grid = int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1)
-        durs[(name, grid // max(wg, 1))].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
-    # ---- optional PMC passes
+        disp.append((int(r["Start_Timestamp"]), name, grid // max(wg, 1), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    disp.sort()
+    matched, skipped = walk(seq, [(n, w, d) for _, n, w, d in disp])
+    # per entry KEY (the six layers of a stack log the same entry six times): per call the summed duration of its kernels
+    per_call = collections.OrderedDict()
+    names = collections.defaultdict(list)
+    for idx, call, name, d in matched:
+        k = seq[idx].key()
+        per_call.setdefault(k, collections.OrderedDict())
+        per_call[k][call] = per_call[k].get(call, 0) + d
+        if name not in names[k]:
+            names[k].append(name)
     hbm = {}
     if pmc:
-        acc = collections.defaultdict(lambda: [0, 0.0, 0, 0.0])
-        for path, cname, slot in ((pmc[0], "FETCH_SIZE", 0), (pmc[1], "WRITE_SIZE", 2)):
-            for r in csv.DictReader(open(path)):
-                if r["Counter_Name"] != cname:
-                    continue
+        for path, cname, mult in ((pmc[0], "FETCH_SIZE", 2.0), (pmc[1], "WRITE_SIZE", 1.0)):
+            rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == cname]
+            rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+            ds = []
+            for r in rows:
                 wg = int(r.get("Workgroup_Size", 0) or 0) or 1
-                key = (short(r["Kernel_Name"]), int(r["Grid_Size"]) // wg)
-                acc[key][slot] += 1
-                acc[key][slot + 1] += float(r["Counter_Value"])
-        for k, (nf, f, nw, w) in acc.items():
-            hbm[k] = (2.0 * (f / nf if nf else 0.0) + (w / nw if nw else 0.0)) * 1024.0
-    def norm(t):
-        return t.replace(" ", "")
-
-    def lookup(name, wgs):
-        for (tmpl, w2), e in by_key.items():
-            if w2 != wgs:
-                continue
-            if norm(tmpl) == norm(name) or ("<" not in tmpl and name.startswith(tmpl)) or name.startswith(tmpl):
-                return e
-        return None
-
+                ds.append((short(r["Kernel_Name"]), int(r["Grid_Size"]) // wg, float(r["Counter_Value"])))
+            m, _ = walk(seq, ds)
+            acc = collections.defaultdict(lambda: collections.OrderedDict())
+            for idx, call, _, v in m:
+                k = seq[idx].key()
+                acc[k][call] = acc[k].get(call, 0.0) + v
+            for k, calls in acc.items():
+                hbm[k] = hbm.get(k, 0.0) + mult * (sum(calls.values()) / len(calls)) * 1024.0
     rows = []
-    for (name, wgs), lst in durs.items():
-        ents = lookup(name, wgs)
-        lst.sort()
-        n = len(lst)
-        if not ents:
-            continue
-        # several shapes on one (template, grid): launches alternate in a fixed per-step order -> split round-robin
-        k = len(ents)
-        for i, (cls, M, N, K, epi, flops, byts) in enumerate(ents):
-            sub = [d for j, (_, d) in enumerate(lst) if j % k == i]
-            if not sub:
-                continue
-            us = sum(sub) / len(sub) / 1e3
-            tf = flops / (us * 1e-6) / 1e12 if flops > 0 else 0.0
-            rows.append([cls, name, wgs, M, N, K, epi, len(sub), round(us, 2), round(tf, 1), round(tf / PEAK_TFLOPS, 4),
-                         round(byts / 1e6, 2), "" if (name, wgs) not in hbm else round(hbm[(name, wgs)] / 1e6, 2),
-                         round(byts / (us * 1e-6) / 1e9, 1)])
-    # attention launches are logged per CALL ("attn_fwd", "attn_dq+attn_dkv"), whatever kernel(s) the call dispatches to (head-
-    # resident, merged or the two-kernel / streaming forms, whose grids differ from the logged B*H): kernels not matched above
-    # are joined by name prefix, a call's row = the sum of the mean durations of its kernels
-    matched = {r[1] for r in rows}
-    for (tmpl, wgs), ents in by_key.items():
-        if not tmpl.startswith("attn"):
-            continue
-        parts = tmpl.split("+")
-        ks = [(name, w) for (name, w) in durs if name not in matched and any(name.startswith(pp) for pp in parts)]
-        if tmpl == "attn_dq+attn_dkv":
-            ks += [(name, w) for (name, w) in durs if name not in matched and name.startswith("attn_bwd") and (name, w) not in ks]
-        if not ks:
-            continue
-        cls, M, N, K, epi, flops, byts = ents[0]
-        us = sum(sum(d for _, d in durs[k]) / len(durs[k]) for k in ks) / 1e3
-        n = min(len(durs[k]) for k in ks)
-        tf = flops / (us * 1e-6) / 1e12
-        hb = sum(hbm.get(k, 0.0) for k in ks)
-        rows.append([cls, " + ".join(k[0] for k in ks), "/".join(str(k[1]) for k in ks), M, N, K, epi, n, round(us, 2), round(tf, 1),
-                     round(tf / PEAK_TFLOPS, 4), round(byts / 1e6, 2), round(hb / 1e6, 2) if hb else "", round(byts / (us * 1e-6) / 1e9, 1)])
-        matched.update(k[0] for k in ks)
+    info = {e.key(): e for e in seq}
+    for k, calls in per_call.items():
+        e = info[k]
+        us = sum(calls.values()) / len(calls) / 1e3
+        tf = e.flops / (us * 1e-6) / 1e12 if e.flops > 0 else 0.0
+        rows.append([e.cls, " + ".join(names[k]), e.wgs, e.M, e.N, e.K, e.epi, len(calls), round(us, 2), round(tf, 1),
+                     round(tf / PEAK_TFLOPS, 4), round(e.byts / 1e6, 2), round(hbm[k] / 1e6, 2) if k in hbm else "",
+                     round(e.byts / (us * 1e-6) / 1e9, 1)])
     rows.sort(key=lambda r: -r[7] * r[8])
     with open(out, "w", newline="") as fh:
         w = csv.writer(fh)
@@ -122,6 +152,8 @@ def main():
         w.writerows(rows)
     for r in rows:
         print(",".join(str(v) for v in r))
+    if skipped:
+        print(f"# {skipped} hot-path dispatches matched no log entry", file=sys.stderr)
 
 
 if __name__ == "__main__":
