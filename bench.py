@@ -320,6 +320,12 @@ class Region:
         # gradients and applies Adam.  Eager launches, same fences (the step is GPU-bound either way: `eager_ms_per_step`).
         self.fwd_bwd_ms = None
         if getattr(self, "fwd_bwd", None) is not None:
+            # no optimizer step between these forwards: the stacks keep their bf16 weight images (cache_weights) instead of
+            # re-deriving them per forward as they must when nothing vouches for the masters being unchanged
+            stacks = [m for m in self.model.modules() if hasattr(m, "cache_weights")]
+            keep = [m.cache_weights for m in stacks]
+            for m in stacks:
+                m.cache_weights = True
             for _ in range(3):
                 self.fwd_bwd()
             self.fence()
@@ -331,6 +337,9 @@ class Region:
             if self.use_dist:
                 self.dist.all_reduce(tfb, op=self.dist.ReduceOp.MAX)
             self.fwd_bwd_ms = tfb.item() / steps * 1e3
+            for m, k in zip(stacks, keep):
+                m.cache_weights = k
+                m.refresh_weights()
         self.steps = steps
         self.ms = dt / steps * 1e3
         self.clips_per_s = self.B * self.world * steps / dt

@@ -654,6 +654,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_tn_group_big_kernel(TnGroup g) 
     const int lo = (int)((int64_t)g.total_tiles * grp / g.xcd_groups), hi = (int)((int64_t)g.total_tiles * (grp + 1) / g.xcd_groups);
     tile = lo + j;
     if (tile >= hi) return;  // (whole workgroup: uniform)
+  } else if (g.xcd_groups < 0) {
+    // any split count (S = 3 at d = 768: round 3 ran that shape tile-major - every XCD fetched every panel, 1.6 GB measured for
+    // 0.32 GB of operands and slabs): the S * tiles work items in split-major order, XCD x takes the x-th eighth of them -
+    // a contiguous run of tiles of one K-range (two at a seam), so a panel is fetched by one XCD (two at a seam)
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int W = g.S * g.total_tiles;
+    const int lo = (int)((int64_t)W * xcd / 8), hi = (int)((int64_t)W * (xcd + 1) / 8);
+    const int w = lo + j;
+    if (w >= hi) return;  // (whole workgroup: uniform)
+    split = w / g.total_tiles;
+    tile = w - split * g.total_tiles;
   } else {
     tile = blockIdx.x / g.S;
     split = blockIdx.x - tile * g.S;
@@ -1104,6 +1115,15 @@ int gemm_bf16_tn_group(const TnGroupArgs& a, hipStream_t s, const FoldList* extr
       int per = 0;  // tiles of the largest group
       for (int grp = 0; grp < g.xcd_groups; ++grp) {
         const int n = (int)((int64_t)tiles * (grp + 1) / g.xcd_groups - (int64_t)tiles * grp / g.xcd_groups);
+        per = n > per ? n : per;
+      }
+      nblocks = 8 * per;
+    } else if (xcd_order) {
+      g.xcd_groups = -1;
+      const int W = tiles * g.S;
+      int per = 0;
+      for (int x = 0; x < 8; ++x) {
+        const int n = (int)((int64_t)W * (x + 1) / 8 - (int64_t)W * x / 8);
         per = n > per ? n : per;
       }
       nblocks = 8 * per;

@@ -36,7 +36,9 @@ __device__ __forceinline__ void glds4(const void* g, char* l) {
   __builtin_amdgcn_global_load_lds((gptr_t*)g, (lptr_t*)l, 4, 0, 0);
 }
 
-template <int EPI, typename CT, int WM, int WN, int MI, int NI>
+// LEAN (bit flags): 0 = the general epilogue; 1 = nt_epilogue_lean (gemm_nt.hpp; the host has checked nt_lean_ok), + 2 = with
+// column sums, + 4 = with the MX-FP8 image of C
+template <int EPI, typename CT, int WM, int WN, int MI, int NI, int LEAN = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_mx8_nt_kernel(Mx8Params q, int tiles_n, int nwg) {
   const NtParams& p = q.nt;
   constexpr int WTM = 16 * MI, WTN = 16 * NI;
@@ -158,18 +160,22 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mx8_nt_kernel(Mx8Params q, 
     cur ^= 1;
   }
 
-  nt_epilogue<EPI, CT, MI, NI>(p, acc, m0 + wm * WTM, n0 + wn * WTN, li, lg,
-                               p.cs_partial ? (wg / tiles_n) * WM + wm : -1);
+  if constexpr (LEAN != 0)
+    nt_epilogue_lean<EPI, CT, MI, NI, (LEAN & 2) ? 1 : 0, false, (LEAN & 4) != 0>(p, acc, m0 + wm * WTM, n0 + wn * WTN, li, lg,
+                                                                                (wg / tiles_n) * WM + wm);
+  else
+    nt_epilogue<EPI, CT, MI, NI>(p, acc, m0 + wm * WTM, n0 + wn * WTN, li, lg,
+                                 p.cs_partial ? (wg / tiles_n) * WM + wm : -1);
 }
 
-template <int EPI, typename CT, int WM, int WN, int MI, int NI>
+template <int EPI, typename CT, int WM, int WN, int MI, int NI, int LEAN = 0>
 int launch_mx8(const Mx8Params& q, hipStream_t s, int* part_rows, TimingScope* ts) {
   constexpr int BMT = 16 * MI * WM, BNT = 16 * NI * WN;
   constexpr int SMEM = 2 * ((BMT + BNT) * 128 + ((BMT + BNT + 63) / 64) * 256);
   static_assert(SMEM <= 160 * 1024, "LDS budget");
   static PerDeviceOnce raised;
   if (SMEM > 64 * 1024 && raised.need()) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_mx8_nt_kernel<EPI, CT, WM, WN, MI, NI>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_mx8_nt_kernel<EPI, CT, WM, WN, MI, NI, LEAN>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     AVF_REQUIRE(e == hipSuccess, "gemm_mx8_nt: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
     raised.mark();
@@ -177,13 +183,34 @@ int launch_mx8(const Mx8Params& q, hipStream_t s, int* part_rows, TimingScope* t
   const int tiles_m = (q.nt.M + BMT - 1) / BMT, tiles_n = (q.nt.N + BNT - 1) / BNT;
   const int nwg = tiles_m * tiles_n;
   *part_rows = tiles_m * WM;
-  launch_in_scope(ts, gemm_mx8_nt_kernel<EPI, CT, WM, WN, MI, NI>, dim3(nwg), dim3(WM * WN * 64), SMEM, s, q, tiles_n, nwg);
+  launch_in_scope(ts, gemm_mx8_nt_kernel<EPI, CT, WM, WN, MI, NI, LEAN>, dim3(nwg), dim3(WM * WN * 64), SMEM, s, q, tiles_n, nwg);
   return 0;
 }
 
 template <int EPI, typename CT>
 int launch_mx8_any(const Mx8Params& q, hipStream_t s, int* part_rows, TimingScope* ts) {
-  switch (pick_nt_tile(q.nt.M, q.nt.N, q.nt.K / 2)) {  // K/2: the same LDS bytes per row as a bf16 problem of that depth
+  const int tile = pick_nt_tile(q.nt.M, q.nt.N, q.nt.K / 2);  // K/2: the same LDS bytes per row as a bf16 problem of that depth
+  // the two 8-wave tiles with the lean epilogue (options fixed at compile time) when nothing asks for the general one's
+  if ((tile == 2 || tile == 5) && nt_lean_ok<EPI, CT>(q.nt, 128, /*mx_ok=*/true)) {
+    constexpr bool can_mx = EPI == AVF_EPI_BIAS_GELU || EPI == AVF_EPI_DGELU;
+    constexpr bool can_cs = EPI == AVF_EPI_DGELU;
+    const bool mx = q.nt.mxq != nullptr, cs = q.nt.cs_partial != nullptr;
+#define AVF_MX8_LEAN(F)                                                                 \
+    do {                                                                                \
+      if (tile == 5) return launch_mx8<EPI, CT, 2, 4, 3, 2, F>(q, s, part_rows, ts);    \
+      return launch_mx8<EPI, CT, 2, 4, 4, 2, F>(q, s, part_rows, ts);                   \
+    } while (0)
+    if (!mx && !cs) AVF_MX8_LEAN(1);
+    if constexpr (can_mx) {
+      if (mx && !cs) AVF_MX8_LEAN(5);
+    }
+    if constexpr (can_cs) {
+      if (!mx && cs) AVF_MX8_LEAN(3);
+      if (mx && cs) AVF_MX8_LEAN(7);
+    }
+#undef AVF_MX8_LEAN
+  }
+  switch (tile) {
     case 0: return launch_mx8<EPI, CT, 2, 2, 4, 4>(q, s, part_rows, ts);
     case 1: return launch_mx8<EPI, CT, 2, 2, 2, 4>(q, s, part_rows, ts);
     case 3: return launch_mx8<EPI, CT, 2, 2, 3, 4>(q, s, part_rows, ts);

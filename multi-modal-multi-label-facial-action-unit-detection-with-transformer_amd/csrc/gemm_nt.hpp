@@ -392,7 +392,10 @@ __device__ __forceinline__ void nt_cs_flush(const NtParams& p, float (&cs)[NI][4
 }
 // CS: 0 = no column sums; 1 = summed and stored per call (row part_row of cs_partial); 2 = added into the caller's per-lane
 // accumulators cs_acc (a persistent kernel sums every tile it owns in registers and calls nt_cs_flush once)
-template <int EPI, typename CT, int MI, int NI, int CS, bool PRE, bool FULL>
+// MXO: also emit the MX-FP8 image of the values as computed (fp32, before their rounding to CT) into p.mxq / p.mxs - a 32-block
+// is the column-block pair (j, j + 1) x the four lane groups x 4 registers; the block maximum crosses the lane groups on the
+// VALU (v_permlane32_swap / v_permlane16_swap) where nt_epilogue takes two LDS round trips (__shfl_xor)
+template <int EPI, typename CT, int MI, int NI, int CS, bool PRE, bool FULL, bool MXO = false>
 __device__ __forceinline__ void nt_epilogue_lean_body(const NtParams& p, f32x4_t (&acc)[MI][NI], int m_base, int n_base, int li,
                                                       int lg, int part_row, const NtPre<MI, NI>* pre, float (*cs_acc)[4]) {
   static_assert(sizeof(CT) == 4 || (NI & 1) == 0, "2-byte outputs are stored in column-block pairs");
@@ -443,6 +446,7 @@ __device__ __forceinline__ void nt_epilogue_lean_body(const NtParams& p, f32x4_t
     }
     uint32_t cw[NI][2], aw[NI][2];
     float4 vf[NI];
+    float mxv[MXO ? NI : 1][4];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       float v[4];
@@ -464,6 +468,10 @@ __device__ __forceinline__ void nt_epilogue_lean_body(const NtParams& p, f32x4_t
         cw[j][0] = pack_bf16x2(v[0], v[1]); cw[j][1] = pack_bf16x2(v[2], v[3]);
       } else {
         vf[j] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+      if constexpr (MXO) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mxv[j][r] = v[r];
       }
       if constexpr (CS == 1) {
         if (mok) {
@@ -511,16 +519,38 @@ __device__ __forceinline__ void nt_epilogue_lean_body(const NtParams& p, f32x4_t
 #pragma unroll
       for (int j = 0; j < NI; ++j) *reinterpret_cast<float4*>(crow + 16 * j) = vf[j];
     }
+    if constexpr (MXO) {
+      static_assert((NI & 1) == 0, "MX-FP8 image: 32-blocks are column-block pairs");
+#pragma unroll
+      for (int j = 0; j < NI; j += 2) {
+        float am = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) am = fmaxf(am, fmaxf(fabsf(mxv[j][r]), fabsf(mxv[j + 1][r])));
+        {  // maximum over the lanes li, li + 16, li + 32, li + 48 (exact: the order does not matter)
+          const auto a32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(am), __float_as_uint(am), false, false);
+          am = fmaxf(__uint_as_float(a32[0]), __uint_as_float(a32[1]));
+          const auto a16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(am), __float_as_uint(am), false, false);
+          am = fmaxf(__uint_as_float(a16[0]), __uint_as_float(a16[1]));
+        }
+        float inv;
+        const uint32_t sb = mx8_scale_byte(am, &inv);
+        const auto sq = __builtin_amdgcn_permlane16_swap(mx8_pack4(mxv[j], inv), mx8_pack4(mxv[j + 1], inv), false, false);
+        if (mok) {
+          *reinterpret_cast<uint2*>(p.mxq + (int64_t)m * p.N + cp0 + 16 * j) = make_uint2(sq[0], sq[1]);
+          if (lg == 0) p.mxs[(int64_t)m * (p.N >> 5) + ((n_base + 16 * j) >> 5)] = (uint8_t)sb;
+        }
+      }
+    }
   }
   if constexpr (CS == 1) nt_cs_flush<NI>(p, cs, part_row, n_base, li, lg);
 }
-template <int EPI, typename CT, int MI, int NI, int CS, bool PRE>
+template <int EPI, typename CT, int MI, int NI, int CS, bool PRE, bool MXO = false>
 __device__ __forceinline__ void nt_epilogue_lean(const NtParams& p, f32x4_t (&acc)[MI][NI], int m_base, int n_base, int li, int lg,
                                                  int part_row, const NtPre<MI, NI>* pre = nullptr, float (*cs_acc)[4] = nullptr) {
   if (m_base + 16 * MI <= p.M)
-    nt_epilogue_lean_body<EPI, CT, MI, NI, CS, PRE, true>(p, acc, m_base, n_base, li, lg, part_row, pre, cs_acc);
+    nt_epilogue_lean_body<EPI, CT, MI, NI, CS, PRE, true, MXO>(p, acc, m_base, n_base, li, lg, part_row, pre, cs_acc);
   else
-    nt_epilogue_lean_body<EPI, CT, MI, NI, CS, PRE, false>(p, acc, m_base, n_base, li, lg, part_row, pre, cs_acc);
+    nt_epilogue_lean_body<EPI, CT, MI, NI, CS, PRE, false, MXO>(p, acc, m_base, n_base, li, lg, part_row, pre, cs_acc);
 }
 
 typedef __attribute__((address_space(1))) const void gptr_t;
@@ -594,8 +624,10 @@ int nt_lean_on() {
 int nt_wide_stores();
 // the preconditions of nt_epilogue_lean for a block tile of bn columns (host side)
 template <int EPI, typename CT>
-bool nt_lean_ok(const NtParams& p, int bn) {
-  if (!nt_lean_on() || p.drop.thresh16 || p.mxq || p.rs_out || p.ln_part || p.N % bn != 0) return false;
+bool nt_lean_ok(const NtParams& p, int bn, bool mx_ok = false) {
+  if (!nt_lean_on() || p.drop.thresh16 || p.rs_out || p.ln_part || p.N % bn != 0) return false;
+  if (p.mxq && !(mx_ok && (EPI == AVF_EPI_BIAS_GELU || EPI == AVF_EPI_DGELU) && p.mxs && p.N % 32 == 0 && ((uintptr_t)p.mxq & 7) == 0))
+    return false;
   if (p.cs_partial && EPI != AVF_EPI_DGELU) return false;
   if (sizeof(CT) == 2) {
     if (nt_wide_stores() != 1 || p.wide != 1 || (p.N & 7) || (p.ldc & 7) || ((uintptr_t)p.C & 15)) return false;

@@ -36,7 +36,7 @@ def run(env_extra, steps, extra):
         raise RuntimeError(f"bench.py printed no JSON line:\n{r.stdout[-2000:]}\n{r.stderr[-2000:]}")
     d = json.loads(line[-1])
     ns = d.get("north_star_shape") or {}
-    return {"c2_ms": d["ms_per_step"], "c3_ms": ns.get("ms_per_step"), "value": d["value"]}
+    return {"c2_ms": d["ms_per_step"], "c3_ms": ns.get("ms_per_step"), "value": d["value"]}  # (c2_ms = the main workload's)
 
 
 def parse_env(items):
@@ -57,8 +57,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--note", default="")
-    ap.add_argument("bench_args", nargs="*")
-    args = ap.parse_args()
+    args, rest = ap.parse_known_args()  # everything this tool does not know goes to bench.py (e.g. --config c5 --dtype mx8)
+    args.bench_args = rest
     ea, eb = parse_env(args.a_env), parse_env(args.b_env)
     if args.a_lib:
         ea["AVF_LIB_PATH"] = os.path.abspath(args.a_lib)
