@@ -80,22 +80,6 @@ typedef struct avf_layer_cfg {
                           query gives dropped keys zero weight; no gradient flows through a filled score.  bf16 layers with
                           dim_head 64 and <= 512 tokens apply it inside the MFMA attention kernels (head-resident forward, merged
                           backward); every other case runs the attention core on the fp32-arithmetic kernels (correct, not tuned). */
-  int32_t ln_fuse;     /* bit 0 (needs resid_bf16, no mx8_fwd, no key_mask, dim % 64 == 0): PreNorm's LayerNorm (heads.py:178-185) is
-                          folded into the GEMM behind it - to_qkv and net.0 read the raw bf16 residual stream against gamma-scaled
-                          weight images (refresh them with avf_stack_ln_fold whenever weights, gamma, beta or b1 changed) and finish
-                          rstd (acc - mean s) + c in their epilogues; the normalised rows are not written in forward (avf_layer_bwd
-                          rebuilds them for its weight-gradient GEMM), the residual GEMM epilogues emit the row statistics.
-                          avf_layer_fwd then needs the workspace.  bit 1: the partial row statistics of x_in are already in the
-                          workspace - set it for a layer whose x_in is the x_out of the preceding avf_layer_fwd call with the SAME
-                          workspace and shapes (the layers of a stack above the first).                                  */
-  int32_t dw_overlap;  /* avf_layer_bwd, bf16 grouped weight-gradient path: the grouped dW launch (+ its fold) of a layer with
-                          layer_index > 0 goes to a low-priority side HIP stream owned by the library (ordered by events, recorded
-                          into a hipGraph capture like any other work) and runs UNDER the gradient chain of the next call, which
-                          must be the layer below with the SAME workspace; that call joins it before its last kernel.  The layer
-                          with layer_index 0 launches in-stream, so a stack walked top-down to layer 0 leaves nothing pending
-                          (avf_stack_join joins by hand).  The workspace holds two copies of the scratch (layer parity):
-                          avf_layer_workspace_bytes doubles.  A layer's weight gradients are complete on `stream` only after the
-                          NEXT avf_layer_bwd call (or avf_stack_join) returned.                                              */
 } avf_layer_cfg;
 
 /* fp32 master parameters of one layer, in state_dict order:
@@ -187,11 +171,6 @@ int avf_gemm_tn_group(int count, int64_t K, const void* const* A, const void* co
  * bf16 images, one launch (cfg.mx8_fwd = 1);
  * lowp[i] = the avf_layer_lowp_bytes buffer of layer i, after avf_layer_prepare_weights / the library Adam wrote it */
 int avf_stack_quant_weights_mx8(const avf_layer_cfg* cfg, int layers, void* const* lowp, void* stream);
-/* cfg.ln_fuse: the gamma-scaled images of to_qkv / net.0 and their s / c vectors (heads.py:178-185 folded into heads.py:212,191)
- * for every layer of a stack in one launch; params[i] / lowp[i]: the fp32 masters and the weight-image buffer of layer i
- * (avf_layer_lowp_bytes with the same cfg).  Call whenever a weight, a LayerNorm gamma / beta or b1 changed.            */
-int avf_stack_ln_fold(const avf_layer_cfg* cfg, int layers, const avf_layer_params* const* params, void* const* lowp,
-                      void* stream);
 int avf_quant_mx8(int dtype, const void* x, int64_t rows, int64_t cols, void* q, void* scales, void* stream);
 int avf_gemm_mx8_nt(int64_t M, int64_t N, int64_t K, const void* a_q, const void* a_scales, const void* b_q,
                     const void* b_scales, void* C, int64_t ldc, int c_dtype, int epilogue, const float* bias,
@@ -315,23 +294,6 @@ size_t avf_layer_lowp_bytes(const avf_layer_cfg* cfg);      /* bf16 weight copie
 size_t avf_layer_workspace_bytes(const avf_layer_cfg* cfg); /* scratch, reusable across layers      */
 size_t avf_layer_grad_stream_bytes(const avf_layer_cfg* cfg); /* bytes of one dx_out_lo / dx_in_lo buffer of avf_layer_bwd:
                                                                  R*D bf16, plus the MX-FP8 image behind it when cfg.mx8_bwd */
-/* ---- FeedForward sublayer (heads.py:188-199) as one launch per direction (csrc/mlp_fused.hip) ----
- * bf16 operands; rows % 64 == 0, dim in {256, 512, 768}, mlp_dim % 128 == 0 (avf_mlp_fused_ok says).
- * forward:  u = h W1^T + b1 (saved), g = gelu(u) (saved), x_out = g W2^T + b2 + x_mid;  x_dtype: type of x_mid / x_out.
- * backward: du = (dy W2) o gelu'(u), dh = du W1; w2_t = W2^T [mlp_dim, dim], w1_t = W1^T [dim, mlp_dim] (the images
- *           avf_layer_prepare_weights keeps); colsum_partial [avf_mlp_fused_bwd_partial_rows(rows)][mlp_dim] fp32: summed over
- *           its rows it is db1.                                                                                             */
-int avf_mlp_fused_ok(int64_t rows, int dim, int mlp_dim);
-int avf_mlp_fused_fwd(const void* h, const void* w1, const float* b1, const void* w2, const float* b2, const void* x_mid,
-                      int x_dtype, void* x_out, void* u, void* g, int64_t rows, int dim, int mlp_dim, void* stream);
-size_t avf_mlp_fused_bwd_partial_rows(int64_t rows);
-int avf_mlp_fused_bwd(const void* dy, const void* w2_t, const void* w1_t, const void* u, void* du, void* dh,
-                      float* colsum_partial, int64_t rows, int dim, int mlp_dim, void* stream);
-
-/* cfg.dw_overlap: make `stream` wait for a weight-gradient launch still pending on the side stream of `workspace`
- * (no-op when there is none) */
-int avf_stack_join(void* workspace, void* stream);
-
 /* refresh the bf16 weight copies from the fp32 masters (no-op in AVF_F32 mode) */
 int avf_layer_prepare_weights(const avf_layer_cfg* cfg, const avf_layer_params* p, void* lowp, void* stream);
 

@@ -27,8 +27,7 @@ class LayerCfg(C.Structure):
                 ("dim_head", C.c_int32), ("mlp_dim", C.c_int32), ("dtype", C.c_int32), ("project_out", C.c_int32),
                 ("ln_eps", C.c_float), ("dropout_p", C.c_float), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32),
                 ("layer_index", C.c_int32), ("seed_dev", C.c_void_p), ("grad_stream_bf16", C.c_int32), ("mx8_fwd", C.c_int32),
-                ("resid_bf16", C.c_int32), ("mx8_bwd", C.c_int32), ("dx_out_mx8", C.c_int32), ("key_mask", C.c_void_p),
-                ("ln_fuse", C.c_int32), ("dw_overlap", C.c_int32)]
+                ("resid_bf16", C.c_int32), ("mx8_bwd", C.c_int32), ("dx_out_mx8", C.c_int32), ("key_mask", C.c_void_p)]
 
 
 PARAM_FIELDS = ("ln1_w", "ln1_b", "w_qkv", "w_out", "b_out", "ln2_w", "ln2_b", "w1", "b1", "w2", "b2")
@@ -63,12 +62,6 @@ SIGNATURES = {
     "avf_gemm_tn_group_workspace_bytes": (_sz, [_int, _i64, _vp, _vp]),
     "avf_gemm_tn_group": (_int, [_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "avf_stack_quant_weights_mx8": (_int, [_vp, _int, _vp, _vp]),
-    "avf_stack_ln_fold": (_int, [_vp, _int, _vp, _vp, _vp]),
-    "avf_stack_join": (_int, [_vp, _vp]),
-    "avf_mlp_fused_ok": (_int, [_i64, _int, _int]),
-    "avf_mlp_fused_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _i64, _int, _int, _vp]),
-    "avf_mlp_fused_bwd_partial_rows": (_sz, [_i64]),
-    "avf_mlp_fused_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp]),
     "avf_quant_mx8": (_int, [_int, _vp, _i64, _i64, _vp, _vp, _vp]),
     "avf_gemm_mx8_nt": (_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _i64, _vp, _i64,
                                _vp, _vp, _vp]),

@@ -330,8 +330,7 @@ int layernorm_bwd(const void* dy, int dy_dtype, const void* x, const float* gamm
                   const float* rstd, const void* dres, float* dx, void* dx_lo, float* dgamma, float* dbeta,
                   float* dcolsum, void* ws, int64_t rows, int dim, hipStream_t s, const DropCfg& drop = kNoDrop,
                   FoldJob* defer_fold = nullptr, int dres_dtype = AVF_F32, int x_dtype = AVF_F32, void* mx_q = nullptr,
-                  void* mx_s = nullptr,  // mx_q / mx_s: also the MX-FP8 image of the values written to dx_lo
-                  void* h_out = nullptr, const float* beta = nullptr);  // h_out (bf16 x only): also xhat * gamma + beta
+                  void* mx_s = nullptr);  // mx_q / mx_s: also the MX-FP8 image of the values written to dx_lo
 size_t colsum_ws(int64_t rows, int cols);
 int colsum(const void* in, int in_dtype, int64_t rows, int cols, int64_t ld, float* out, void* ws, hipStream_t s);
 int cast_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t s, const DropCfg& drop = kNoDrop);
@@ -422,14 +421,6 @@ struct GemmArgs {
   float* colsum;  // optional: column sums of the stored C (bf16 NT only; partials go to workspace)
   DropCfg drop;   // bf16 NT only: BIAS_RES masks (acc+bias) before the residual, BIAS_GELU masks gelu(u), DGELU masks acc
   FoldJob* defer_fold;  // with colsum: do not launch the fold, describe it here instead
-  // LayerNorm folded into a bf16 NT GEMM (gemm_nt.hpp NtParams; K % 64 == 0, K % 32 == 0): all null / 0 when unused
-  const float* ln_part = nullptr;  // consumer: per-row partial statistics of A [M][K / 32][2]
-  const float* ln_s = nullptr;     //           [N] sums of the gamma-scaled weight image rows
-  const float* ln_c = nullptr;     //           [N] beta . W (+ bias); `bias` must be null
-  float* ln_mean = nullptr;        //           [M] out
-  float* ln_rstd = nullptr;
-  float ln_eps = 0.f;
-  float* rs_out = nullptr;         // producer (BIAS_RES, bf16 C, N % 32 == 0): per-row partial statistics of C [M][N / 32][2]
   // bf16 NT only, optional: the fragment-major image of B (pack_ws; K == 512, N % 256 == 0) - the GEMM then runs on the
   // weight-stationary persistent kernel (gemm_ws.hip) when the shape qualifies
   const void* Bp = nullptr;
@@ -452,23 +443,6 @@ bool pack_ws_ok(int64_t N, int64_t K);
 int pack_ws(const void* w_bf16, int64_t ldw, int64_t N, int64_t K, void* out, hipStream_t s);
 bool gemm_bf16_nt_ws_ok(const GemmArgs& a);
 int gemm_bf16_nt_ws(const GemmArgs& a, hipStream_t s, int* part_rows_out);
-// partial statistics (sum, sum of squares per group of 32 columns) of the rows of x [rows][dim]: the input of a
-// LayerNorm-folded GEMM whose producer is not a residual GEMM (the first layer of a stack)
-int row_stats(const void* x, int x_dtype, int64_t rows, int dim, float* part, hipStream_t s);
-// gamma-scaled weight images and the s / c vectors of the LayerNorm-folded GEMMs, any number of jobs in one launch
-struct LnFoldJob {
-  const float* w;      // fp32 master [rows][dim]
-  const float* gamma;  // [dim]
-  const float* beta;   // [dim]
-  const float* bias;   // [rows] or null
-  bf16* w_ln;          // out [rows][dim]: bf16(row_scale * gamma[k] * w[n][k])
-  float* s;            // out [rows]: sum_k of the stored image row
-  float* c;            // out [rows]: row_scale * sum_k beta[k] w[n][k] + bias[n]
-  int rows, dim;
-  float lo_scale;      // the first lo_scaled_rows rows carry this factor (query rows of Wqkv: the softmax scale)
-  int lo_scaled_rows;
-};
-int ln_fold_weights(const LnFoldJob* jobs, int count, hipStream_t s);
 size_t gemm_ws(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K);
 int gemm(const GemmArgs& a, hipStream_t s);
 int gemm_f32(const GemmArgs& a, hipStream_t s);
@@ -549,12 +523,6 @@ int attn_bwd_bf16(const bf16* qkv, const bf16* o, const bf16* d_o, const float* 
 bool attn_bwd_emits_mx8(int N, int dh, bool q_prescaled);
 int attn_delta(int dtype, const void* o, const void* d_o, float* delta, int B, int N, int H, int dh, hipStream_t s);
 // merged dQ + dK/dV kernel (attn_bwd_merged.hip): dim_head 64, pre-scaled q, N <= 512
-// mlp_fused.hip: the FeedForward sublayer as one kernel per direction (bf16 operands; R % 64 == 0, D in {256, 512, 768}, M % 128 == 0)
-bool mlp_fused_ok(int64_t R, int D, int M);
-int mlp_fused_fwd(const void* h, const void* w1, const float* b1, const void* w2, const float* b2, const void* x_mid, int x_dtype,
-                  void* x_out, void* u, void* g, int64_t R, int D, int M, hipStream_t s);
-int mlp_fused_bwd(const void* dy, const void* w2_t, const void* w1_t, const void* u, void* du, void* dh, float* cs_partial,
-                  int64_t R, int D, int M, hipStream_t s);
 bool attn_bwd_merged_ok(int N, int dh, bool q_prescaled);
 int attn_bwd_merged(const TimingScope* ts, const bf16* qkv, const bf16* o, const bf16* d_o, const float* lse2, bf16* dqkv,
                     int B, int N, int H, hipStream_t s, const void* keep = nullptr, void* dq_q = nullptr, void* dq_s = nullptr);

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(NtParams p) {
 // ------------------------------------------------------------------------------------------
 // LEAN: 0 = the general epilogue (run-time options), 1 = nt_epilogue_lean (every option fixed at compile time; the host has
 // checked nt_lean_ok), 2 = the same with column sums
-template <int EPI, typename CT, int WM, int WN, int MI, int NI, int NS, bool LNF = false, int LEAN = 0>
+template <int EPI, typename CT, int WM, int WN, int MI, int NI, int NS, int LEAN = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(NtParams p, int tiles_n, int nwg) {
   constexpr int WTM = 16 * MI, WTN = 16 * NI;  // per-wave output tile
   constexpr int BMT = WTM * WM, BNT = WTN * WN, NW = WM * WN;
@@ -174,49 +174,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(NtParam
 #pragma unroll
   for (int i = 0; i < NS - 1; ++i)
     if (i < nt) stage(i, i * TK);
-  // LNF: while the first tiles are in flight, the (mean, rstd) of this workgroup's rows from the per-32-column partials
-  // of the A rows (fixed summation order: deterministic); the table sits behind the stages, the K-loop's barriers order
-  // it before the epilogue reads it
-  float2* lnst = reinterpret_cast<float2*>(dsm + NS * STAGE);
-  if constexpr (LNF && AVF_LNF_DBG >= 1) {  // diagnostic build: constant statistics, no prologue loads
-    if (tid < BMT) lnst[tid] = make_float2(0.f, 1.f);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
-  if constexpr (LNF && AVF_LNF_DBG == 0) {
-    constexpr int TPR = (NW * 64 / BMT) >= 4 ? 4 : ((NW * 64 / BMT) >= 2 ? 2 : 1);
-    if (tid < BMT * TPR) {
-      const int row = tid / TPR, sub = tid % TPR;
-      const int m = m0 + row < p.M ? m0 + row : p.M - 1;
-      const float2* pp = reinterpret_cast<const float2*>(p.ln_part) + (int64_t)m * p.ln_np;
-      float s1 = 0.f, s2 = 0.f;
-      for (int i = sub; i < p.ln_np; i += TPR) {
-        const float2 v = pp[i];
-        s1 += v.x;
-        s2 += v.y;
-      }
-      // neighbours inside a quad through DPP (quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E): no LDS round trip
-      if (TPR >= 2) {
-        s1 += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(s1), 0xB1, 0xF, 0xF, true));
-        s2 += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(s2), 0xB1, 0xF, 0xF, true));
-      }
-      if (TPR >= 4) {
-        s1 += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(s1), 0x4E, 0xF, 0xF, true));
-        s2 += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(s2), 0x4E, 0xF, 0xF, true));
-      }
-      const float invk = 1.0f / (float)p.K;
-      const float mu = s1 * invk;
-      const float var = fmaxf(s2 * invk - mu * mu, 0.f);
-      const float rs = 1.0f / sqrtf(var + p.ln_eps);
-      if (sub == 0) {
-        lnst[row] = make_float2(mu, rs);
-        if (n0 == 0 && m0 + row < p.M) {
-          p.ln_mean[m0 + row] = mu;
-          p.ln_rstd[m0 + row] = rs;
-        }
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
   int cur = 0;
   for (int t = 0; t < nt; ++t) {
     const int ahead = (nt - 1 - t) < (NS - 2) ? (nt - 1 - t) : (NS - 2);  // tiles issued after tile t
@@ -271,18 +228,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(NtParam
   if constexpr (LEAN != 0)
     nt_epilogue_lean<EPI, CT, MI, NI, LEAN == 2 ? 1 : 0, false>(p, acc, m0 + wm * WTM, n0 + wn * WTN, li, lg, (wg / tiles_n) * WM + wm);
   else
-    nt_epilogue<EPI, CT, MI, NI, LNF>(p, acc, m0 + wm * WTM, n0 + wn * WTN, li, lg,
-                                      p.cs_partial ? (wg / tiles_n) * WM + wm : -1, lnst + wm * WTM);
+    nt_epilogue<EPI, CT, MI, NI>(p, acc, m0 + wm * WTM, n0 + wn * WTN, li, lg, p.cs_partial ? (wg / tiles_n) * WM + wm : -1);
 }
 
-template <int EPI, typename CT, int WM, int WN, int MI, int NI, int NS, bool LNF = false, int LEAN = 0>
+template <int EPI, typename CT, int WM, int WN, int MI, int NI, int NS, int LEAN = 0>
 int launch_nt_glds(const NtParams& p, hipStream_t s, int* part_rows, TimingScope* ts) {
   constexpr int BMT = 16 * MI * WM, BNT = 16 * NI * WN;
-  constexpr int SMEM = NS * (BMT + BNT) * 128 + (LNF ? BMT * 8 : 0);
+  constexpr int SMEM = NS * (BMT + BNT) * 128;
   static_assert(NS >= 2 && NS <= 8 && SMEM <= 160 * 1024, "stage count / LDS budget");
   static PerDeviceOnce raised;
   if (SMEM > 64 * 1024 && raised.need()) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_glds_kernel<EPI, CT, WM, WN, MI, NI, NS, LNF, LEAN>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_glds_kernel<EPI, CT, WM, WN, MI, NI, NS, LEAN>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     AVF_REQUIRE(e == hipSuccess, "gemm_bf16_nt: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
     raised.mark();
@@ -293,44 +249,38 @@ int launch_nt_glds(const NtParams& p, hipStream_t s, int* part_rows, TimingScope
   if (shape_log_on()) {
     const double csz = sizeof(CT);
     const double epi_b = (EPI == AVF_EPI_BIAS_RES || EPI == AVF_EPI_BIAS_GELU || EPI == AVF_EPI_DGELU) ? csz * p.M * p.N : 0.0;
-    shape_log("gemm_bf16_nt,gemm_bf16_nt_glds_kernel<%d, %s, %d, %d, %d, %d, %d, %s, %d>,%d,%d,%d,%d,%d,%.0f,%.0f", EPI,
-              sizeof(CT) == 4 ? "float" : "bf16", WM, WN, MI, NI, NS, LNF ? "true" : "false", LEAN, nwg, p.M, p.N, p.K,
-              EPI + (LNF ? 10 : 0), 2.0 * p.M * p.N * p.K,
+    shape_log("gemm_bf16_nt,gemm_bf16_nt_glds_kernel<%d, %s, %d, %d, %d, %d, %d, %d>,%d,%d,%d,%d,%d,%.0f,%.0f", EPI,
+              sizeof(CT) == 4 ? "float" : "bf16", WM, WN, MI, NI, NS, LEAN, nwg, p.M, p.N, p.K,
+              EPI, 2.0 * p.M * p.N * p.K,
               2.0 * ((double)p.M * p.K + (double)p.N * p.K) + csz * p.M * p.N + epi_b);
   }
-  launch_in_scope(ts, gemm_bf16_nt_glds_kernel<EPI, CT, WM, WN, MI, NI, NS, LNF, LEAN>, dim3(nwg), dim3(WM * WN * 64), SMEM, s, p,
+  launch_in_scope(ts, gemm_bf16_nt_glds_kernel<EPI, CT, WM, WN, MI, NI, NS, LEAN>, dim3(nwg), dim3(WM * WN * 64), SMEM, s, p,
                   tiles_n, nwg);
   return 0;
 }
 
-template <int EPI, typename CT, bool LNF = false>
+template <int EPI, typename CT>
 int launch_nt_glds_any(const NtParams& p, hipStream_t s, int* part_rows, TimingScope* ts) {
-  if constexpr (LNF) {  // the LayerNorm-folded forms exist on the two 8-wave tiles (what the layer's shapes select)
-    if (pick_nt_tile(p.M, p.N, p.K) == 5) return launch_nt_glds<EPI, CT, 2, 4, 3, 2, 2, true>(p, s, part_rows, ts);
-    return launch_nt_glds<EPI, CT, 2, 4, 4, 2, 2, true>(p, s, part_rows, ts);
-  } else {
-    // (the row-statistics epilogue of the LayerNorm fold needs column-block pairs: not on the small-M tile)
-    const int tile = p.rs_out ? pick_nt_tile(p.M, p.N, p.K) : pick_nt_tile_bf16(p.M, p.N, p.K);
-    // the two 8-wave tiles with the lean epilogue when nothing asks for the general one's options
-    if ((tile == 2 || tile == 5) && nt_lean_ok<EPI, CT>(p, 128)) {
-      constexpr bool csv = EPI == AVF_EPI_DGELU;  // column sums ride on the dGELU epilogue only
-      if (p.cs_partial == nullptr) {
-        if (tile == 5) return launch_nt_glds<EPI, CT, 2, 4, 3, 2, 2, false, 1>(p, s, part_rows, ts);
-        return launch_nt_glds<EPI, CT, 2, 4, 4, 2, 2, false, 1>(p, s, part_rows, ts);
-      }
-      if constexpr (csv) {
-        if (tile == 5) return launch_nt_glds<EPI, CT, 2, 4, 3, 2, 2, false, 2>(p, s, part_rows, ts);
-        return launch_nt_glds<EPI, CT, 2, 4, 4, 2, 2, false, 2>(p, s, part_rows, ts);
-      }
+  const int tile = pick_nt_tile_bf16(p.M, p.N, p.K);
+  // the two 8-wave tiles with the lean epilogue when nothing asks for the general one's options
+  if ((tile == 2 || tile == 5) && nt_lean_ok<EPI, CT>(p, 128)) {
+    constexpr bool csv = EPI == AVF_EPI_DGELU;  // column sums ride on the dGELU epilogue only
+    if (p.cs_partial == nullptr) {
+      if (tile == 5) return launch_nt_glds<EPI, CT, 2, 4, 3, 2, 2, 1>(p, s, part_rows, ts);
+      return launch_nt_glds<EPI, CT, 2, 4, 4, 2, 2, 1>(p, s, part_rows, ts);
     }
-    switch (tile) {
-      case 6: return launch_nt_glds<EPI, CT, 1, 4, 2, 1, 6>(p, s, part_rows, ts);  // 72 KiB: two workgroups per CU
-      case 0: return launch_nt_glds<EPI, CT, 2, 2, 4, 4, 2>(p, s, part_rows, ts);
-      case 1: return launch_nt_glds<EPI, CT, 2, 2, 2, 4, 2>(p, s, part_rows, ts);
-      case 3: return launch_nt_glds<EPI, CT, 2, 2, 3, 4, 2>(p, s, part_rows, ts);
-      case 5: return launch_nt_glds<EPI, CT, 2, 4, 3, 2, 2>(p, s, part_rows, ts);
-      default: return launch_nt_glds<EPI, CT, 2, 4, 4, 2, 2>(p, s, part_rows, ts);
+    if constexpr (csv) {
+      if (tile == 5) return launch_nt_glds<EPI, CT, 2, 4, 3, 2, 2, 2>(p, s, part_rows, ts);
+      return launch_nt_glds<EPI, CT, 2, 4, 4, 2, 2, 2>(p, s, part_rows, ts);
     }
+  }
+  switch (tile) {
+    case 6: return launch_nt_glds<EPI, CT, 1, 4, 2, 1, 6>(p, s, part_rows, ts);  // 72 KiB: two workgroups per CU
+    case 0: return launch_nt_glds<EPI, CT, 2, 2, 4, 4, 2>(p, s, part_rows, ts);
+    case 1: return launch_nt_glds<EPI, CT, 2, 2, 2, 4, 2>(p, s, part_rows, ts);
+    case 3: return launch_nt_glds<EPI, CT, 2, 2, 3, 4, 2>(p, s, part_rows, ts);
+    case 5: return launch_nt_glds<EPI, CT, 2, 4, 3, 2, 2>(p, s, part_rows, ts);
+    default: return launch_nt_glds<EPI, CT, 2, 4, 4, 2, 2>(p, s, part_rows, ts);
   }
 }
 
@@ -904,17 +854,6 @@ int gemm_bf16_nt(const GemmArgs& a, hipStream_t s) {
   p.wide = nt_wide_stores();
   AVF_REQUIRE(!a.drop.thresh16 || a.epilogue != AVF_EPI_NONE, "gemm_bf16_nt: dropout needs a fused epilogue");
   p.M = (int)a.M; p.N = (int)a.N; p.K = (int)a.K;
-  p.ln_part = a.ln_part; p.ln_np = (int)(a.K / 32); p.ln_s = a.ln_s; p.ln_c = a.ln_c; p.ln_mean = a.ln_mean;
-  p.ln_rstd = a.ln_rstd; p.ln_eps = a.ln_eps; p.rs_out = a.rs_out;
-  const bool lnf = a.ln_part != nullptr;
-  if (lnf) {
-    AVF_REQUIRE(a.ln_s && a.ln_c && a.ln_mean && a.ln_rstd && !a.bias && a.K % TK == 0 && a.c_dtype == AVF_BF16 &&
-                    (a.epilogue == AVF_EPI_NONE || a.epilogue == AVF_EPI_BIAS_GELU) && a.N % 4 == 0 && !a.colsum,
-                "gemm_bf16_nt: LayerNorm-folded form needs s / c / mean / rstd, no bias, K %% 64 == 0, a bf16 C and the NONE or "
-                "BIAS_GELU epilogue");
-  }
-  AVF_REQUIRE(!a.rs_out || (a.epilogue == AVF_EPI_BIAS_RES && a.c_dtype == AVF_BF16 && a.N % 32 == 0 && a.K % TK == 0),
-              "gemm_bf16_nt: row statistics of C need BIAS_RES, a bf16 C, N %% 32 == 0 and K %% 64 == 0");
   dim3 grid((unsigned)ceil_div(a.N, TB), (unsigned)ceil_div(a.M, TB));
   AVF_REQUIRE(grid.y < 65536, "gemm_bf16_nt: M too large for grid");
   const bool cf32 = a.c_dtype == AVF_F32;
@@ -937,7 +876,7 @@ int gemm_bf16_nt(const GemmArgs& a, hipStream_t s) {
     // the partial rows the chosen tile will write must fit the workspace - checked BEFORE anything is enqueued
     int planned = part_rows;
     if (dma) {
-      const int t = (lnf || a.rs_out) ? pick_nt_tile(a.M, a.N, a.K) : pick_nt_tile_bf16(a.M, a.N, a.K);
+      const int t = pick_nt_tile_bf16(a.M, a.N, a.K);
       const int bmt = (t == 0 || t == 2) ? 128 : (t == 1 ? 64 : (t == 6 ? 32 : 96));
       planned = (int)ceil_div(a.M, bmt) * (t == 6 ? 1 : 2);  // two wave rows per block tile (the small-M tile: one)
     }
@@ -952,14 +891,6 @@ int gemm_bf16_nt(const GemmArgs& a, hipStream_t s) {
     } else if (cf32) launch_in_scope(&ts, gemm_bf16_nt_kernel<E, float>, grid, dim3(256), 0, s, p); \
     else launch_in_scope(&ts, gemm_bf16_nt_kernel<E, bf16>, grid, dim3(256), 0, s, p); \
   } while (0)
-  if (lnf) {
-    if (a.epilogue == AVF_EPI_NONE) AVF_TRY((launch_nt_glds_any<AVF_EPI_NONE, bf16, true>(p, s, &part_rows, &ts)));
-    else {
-      AVF_REQUIRE(a.aux && a.ldaux % 4 == 0, "gemm_bf16_nt: aux missing");
-      AVF_TRY((launch_nt_glds_any<AVF_EPI_BIAS_GELU, bf16, true>(p, s, &part_rows, &ts)));
-    }
-    return check_launch("gemm_bf16_nt_glds_kernel<LNF>");
-  }
   switch (a.epilogue) {
     case AVF_EPI_NONE: LAUNCH(AVF_EPI_NONE); break;
     case AVF_EPI_BIAS_RES:

@@ -34,19 +34,6 @@ struct NtParams {
   uint8_t* mxq;       // optional (BIAS_GELU / DGELU, N % 32 == 0): MX-FP8 image of the stored C, [M][N] e4m3 bytes ...
   uint8_t* mxs;       // ... and [M][N/32] E8M0 scale bytes - the A operand of the next GEMM in the fp8 mode
   int M, N, K;
-  // LayerNorm folded into this GEMM (LNF kernels): A is the RAW bf16 residual stream, B the
-  // gamma-scaled weight image W'[n][k] = gamma[k] W[n][k]; the epilogue finishes  rstd (acc - mean s[n]) + c[n]  with
-  // s[n] = sum_k W'[n][k] (of the bf16 image: the cancellation against mean is then exact) and c[n] = beta . W[n] + bias[n]
-  const float* ln_part = nullptr;  // [M][ln_np][2]: per row, (sum, sum of squares) of the A row over groups of 32 columns
-  int ln_np = 0;                   // = K / 32
-  const float* ln_s = nullptr;     // [N]
-  const float* ln_c = nullptr;     // [N]
-  float* ln_mean = nullptr;        // [M] out: the row statistics, written by the workgroups of the first column tile
-  float* ln_rstd = nullptr;        //          (backward reads them)
-  float ln_eps = 0.f;
-  // row statistics of the STORED C values (BIAS_RES with a 2-byte C: the bf16 residual stream), for the LayerNorm-folded
-  // GEMM that consumes C next: [M][N / 32][2] (sum, sum of squares) per group of 32 columns
-  float* rs_out = nullptr;
 };
 
 // 16-byte chunk c (0..7) of tile row r lives at chunk slot c ^ (r & 7): conflict-free ds_read_b128
@@ -136,30 +123,18 @@ __device__ __forceinline__ void nt_epi_prefetch(const NtParams& p, int m_base, i
 // stores are predicated on the tile edge.
 // part_row >= 0: also emit the column sums of this wave's 64 rows into cs_partial[part_row][n] (plain stores;
 // a fold kernel adds the tiles_m*WM partial rows) - fuses the bias gradient "db = sum_rows dY" into the GEMM.
-// LNF: LayerNorm folded in (see NtParams): lnst = this wave's rows of the workgroup's (mean, rstd) table in LDS.
-#ifndef AVF_LNF_DBG
-#define AVF_LNF_DBG 0  // diagnostic builds: 1 = no prologue loads (constant statistics), 2 = also the plain epilogue
-#endif
-template <int EPI, typename CT, int MI, int NI, bool LNF_ = false, bool PRE = false>
+template <int EPI, typename CT, int MI, int NI, bool PRE = false>
 __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI][NI], int m_base, int n_base, int li,
-                                            int lg, int part_row, const float2* lnst = nullptr,
-                                            const NtPre<MI, NI>* pre = nullptr) {
-  constexpr bool LNF = LNF_ && AVF_LNF_DBG != 2;
+                                            int lg, int part_row, const NtPre<MI, NI>* pre = nullptr) {
   int nn[NI], nc[NI];
-  float4 bj[NI], sj[NI];
+  float4 bj[NI];
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     nn[j] = n_base + j * 16 + 4 * lg;
     nc[j] = nn[j] < p.N ? nn[j] : 0;
-    if constexpr (LNF) {
-      bj[j] = *reinterpret_cast<const float4*>(p.ln_c + nc[j]);
-      sj[j] = *reinterpret_cast<const float4*>(p.ln_s + nc[j]);
-    } else {
-      if constexpr (PRE) bj[j] = pre->bj[j];
-      else bj[j] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nc[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    if constexpr (PRE) bj[j] = pre->bj[j];
+    else bj[j] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nc[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  const bool emit_rs = EPI == AVF_EPI_BIAS_RES && sizeof(CT) == 2 && (NI & 1) == 0 && p.rs_out != nullptr;  // wave-uniform
   const uint64_t dkey = p.drop.thresh16 ? drop_key(p.drop) : 0;
   // 2-byte outputs: lane pairs trade words so that every store is 16 bytes (wave-uniform conditions)
   const bool wide_c = (NI & 1) == 0 && sizeof(CT) == 2 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && p.wide;
@@ -222,20 +197,10 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
       const bool mok = mm[ii] < p.M;
       float mxv[NI][4];
       uint32_t cw[NI][2], aw[NI][2];  // packed bf16 words of C / aux when a lane pair shares its stores (store_pair16)
-      float2 st = make_float2(0.f, 1.f);
-      if constexpr (LNF) st = lnst[i * 16 + li];
-      float rs1[NI / 2 > 0 ? NI / 2 : 1], rs2[NI / 2 > 0 ? NI / 2 : 1];  // row statistics per 32-column group
-#pragma unroll
-      for (int jp = 0; jp < (NI / 2 > 0 ? NI / 2 : 1); ++jp) rs1[jp] = rs2[jp] = 0.f;
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         float v[4];
-        if constexpr (LNF) {
-          v[0] = fmaf(st.y, acc[i][j][0] - st.x * sj[j].x, bj[j].x); v[1] = fmaf(st.y, acc[i][j][1] - st.x * sj[j].y, bj[j].y);
-          v[2] = fmaf(st.y, acc[i][j][2] - st.x * sj[j].z, bj[j].z); v[3] = fmaf(st.y, acc[i][j][3] - st.x * sj[j].w, bj[j].w);
-        } else {
-          v[0] = acc[i][j][0] + bj[j].x; v[1] = acc[i][j][1] + bj[j].y; v[2] = acc[i][j][2] + bj[j].z; v[3] = acc[i][j][3] + bj[j].w;
-        }
+        v[0] = acc[i][j][0] + bj[j].x; v[1] = acc[i][j][1] + bj[j].y; v[2] = acc[i][j][2] + bj[j].z; v[3] = acc[i][j][3] + bj[j].w;
         const bool ok = mok && nn[j] < p.N;
         float4 df = make_float4(1.f, 1.f, 1.f, 1.f);
         if (p.drop.thresh16) df = drop_factor4(p.drop, dkey, (uint64_t)mm[ii] * p.N + nn[j]);  // wave-uniform branch
@@ -254,13 +219,6 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
           v[0] *= df.x * dgelu_tanh_fast(ex[ii][j].x); v[1] *= df.y * dgelu_tanh_fast(ex[ii][j].y);
           v[2] *= df.z * dgelu_tanh_fast(ex[ii][j].z); v[3] *= df.w * dgelu_tanh_fast(ex[ii][j].w);
         }
-        if (emit_rs && ok) {  // statistics of the values as STORED (bf16-rounded): what the consuming GEMM multiplies
-          const uint32_t w0 = pack_bf16x2(v[0], v[1]), w1 = pack_bf16x2(v[2], v[3]);
-          const float q0 = __uint_as_float(w0 << 16), q1 = __uint_as_float(w0 & 0xffff0000u);
-          const float q2 = __uint_as_float(w1 << 16), q3 = __uint_as_float(w1 & 0xffff0000u);
-          rs1[j >> 1] += (q0 + q1) + (q2 + q3);
-          rs2[j >> 1] += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
-        }
         if (wide_c) {
           cw[j][0] = pack_bf16x2(v[0], v[1]); cw[j][1] = pack_bf16x2(v[2], v[3]);
         } else if (ok) {
@@ -273,27 +231,6 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
         if ((EPI == AVF_EPI_BIAS_GELU || EPI == AVF_EPI_DGELU) && (NI & 1) == 0) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) mxv[j][r] = v[r];
-        }
-      }
-      if (emit_rs) {  // a row's 32 columns of a group live in the four lane groups li, li + 16, li + 32, li + 48
-#pragma unroll
-        for (int jp = 0; jp < NI / 2; ++jp) {
-          // sum over the lanes li, li + 16, li + 32, li + 48 on the VALU (v_permlane{32,16}_swap; a __shfl_xor is an LDS
-          // round trip, four dependent ones per row block cost the epilogue ~1 us)
-          float a = rs1[jp], b = rs2[jp];
-          {
-            const auto a32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(a), false, false);
-            const auto b32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(b), __float_as_uint(b), false, false);
-            a = __uint_as_float(a32[0]) + __uint_as_float(a32[1]);
-            b = __uint_as_float(b32[0]) + __uint_as_float(b32[1]);
-            const auto a16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(a), false, false);
-            const auto b16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(b), __float_as_uint(b), false, false);
-            a = __uint_as_float(a16[0]) + __uint_as_float(a16[1]);
-            b = __uint_as_float(b16[0]) + __uint_as_float(b16[1]);
-          }
-          const int grp = (n_base + 32 * jp) >> 5;
-          if (lg == 0 && mok && n_base + 32 * jp < p.N)
-            *reinterpret_cast<float2*>(p.rs_out + ((int64_t)mm[ii] * (p.N >> 5) + grp) * 2) = make_float2(a, b);
         }
       }
       if ((NI & 1) == 0) {
@@ -625,7 +562,7 @@ int nt_wide_stores();
 // the preconditions of nt_epilogue_lean for a block tile of bn columns (host side)
 template <int EPI, typename CT>
 bool nt_lean_ok(const NtParams& p, int bn, bool mx_ok = false) {
-  if (!nt_lean_on() || p.drop.thresh16 || p.rs_out || p.ln_part || p.N % bn != 0) return false;
+  if (!nt_lean_on() || p.drop.thresh16 || p.N % bn != 0) return false;
   if (p.mxq && !(mx_ok && (EPI == AVF_EPI_BIAS_GELU || EPI == AVF_EPI_DGELU) && p.mxs && p.N % 32 == 0 && ((uintptr_t)p.mxq & 7) == 0))
     return false;
   if (p.cs_partial && EPI != AVF_EPI_DGELU) return false;

@@ -350,7 +350,6 @@ int pack_ws(const void* w_bf16, int64_t ldw, int64_t N, int64_t K, void* out, hi
 bool gemm_bf16_nt_ws_ok(const GemmArgs& a) {
   if (!ws_enabled() || !a.Bp) return false;
   if (!pack_ws_ok(a.N, a.K) || a.M < 2048) return false;
-  if (a.ln_part || a.rs_out) return false;
   if (a.lda % 8 || a.ldc % 8 || ((uintptr_t)a.A & 15) || ((uintptr_t)a.C & 15) || ((uintptr_t)a.Bp & 15)) return false;
   // the epilogue's prefetch takes nt_epilogue's wide path for 2-byte residual / pre-activation rows unconditionally
   if (nt_wide_stores() != 1) return false;

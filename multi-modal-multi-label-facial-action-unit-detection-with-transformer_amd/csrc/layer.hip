@@ -21,72 +21,6 @@ namespace avf {
 
 namespace {
 
-// ---- cfg.dw_overlap: the grouped weight-gradient launch of a layer on a side stream -------------------------------
-// One record per workspace (= per stack): a low-priority non-blocking stream and two events.  The calls only enqueue
-// (event record / stream wait), so a hipGraph capture of the calling stream pulls the side stream into the capture and
-// the replayed graph carries the same fork / join edges.  The stream and events are created on first use - do a step
-// outside a capture first (a capture forbids nothing here, but a stream created inside one would outlive its graph idle).
-struct SideState {
-  void* ws;
-  int dev;
-  hipStream_t side;
-  hipEvent_t chain_done, group_done;
-  bool pending;
-};
-std::mutex g_side_mu;
-std::vector<SideState*> g_side;
-
-SideState* side_state(void* ws, bool create) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  std::lock_guard<std::mutex> lk(g_side_mu);
-  for (SideState* t : g_side)
-    if (t->ws == ws && t->dev == dev) return t;
-  if (!create) return nullptr;
-  SideState* t = nullptr;
-  if (g_side.size() >= 64) {  // workspaces come and go with their stacks: recycle a record with nothing pending
-    for (SideState* o : g_side)
-      if (!o->pending && o->dev == dev) { t = o; break; }
-    if (!t) return nullptr;
-    t->ws = ws;
-    return t;
-  }
-  t = new SideState();
-  t->ws = ws;
-  t->dev = dev;
-  t->pending = false;
-  int least = 0, greatest = 0;
-  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
-  if (const char* e = getenv("AVF_DW_PRIO")) {  // tuning aid: 0 = default priority, 1 = highest
-    if (atoi(e) == 0) least = 0;
-    else if (atoi(e) == 1) least = greatest;
-  }
-  if (hipStreamCreateWithPriority(&t->side, hipStreamNonBlocking, least) != hipSuccess ||
-      hipEventCreateWithFlags(&t->chain_done, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&t->group_done, hipEventDisableTiming) != hipSuccess) {
-    delete t;
-    return nullptr;
-  }
-  g_side.push_back(t);
-  return t;
-}
-
-int mlp_fused_on() {
-  static const int on = [] {
-    const char* e = getenv("AVF_MLP_FUSED");  // the FeedForward sublayer as one launch per direction
-    return (e && *e) ? atoi(e) : 0;
-  }();
-  return on;
-}
-
-int side_join(SideState* t, hipStream_t s) {
-  if (t && t->pending) {
-    AVF_REQUIRE(hipStreamWaitEvent(s, t->group_done, 0) == hipSuccess, "layer_bwd: hipStreamWaitEvent failed");
-    t->pending = false;
-  }
-  return 0;
-}
-
 struct Dims {
   int64_t R;  // rows = batch * tokens
   int D, H, dh, I, M, B, N;
@@ -104,8 +38,6 @@ struct Dims {
   const void* keep;  // optional token mask [B, N] bytes (1 = kept), heads.py:225-232: attention then runs on the fp32-arithmetic kernels
   bool mxb;   // backward dX GEMMs fed by LayerNorm backward / the dGELU epilogue take MX-FP8 operands too (config 5)
   bool gy_mx; // the caller's dx_out_lo buffer already carries the MX-FP8 image behind the bf16 one
-  bool lnf;   // LayerNorm forward folded into the to_qkv / net.0 GEMMs (cfg.ln_fuse bit 0)
-  bool ln1_ready;  // ... and the partial row statistics of x_in already sit in the workspace (bit 1: the previous layer's call)
 };
 
 // bf16 gradient-stream buffers in the mx8_bwd mode: [R, D] bf16 | [R, D] e4m3 | [R, D / 32] E8M0, each part 256-aligned
@@ -149,11 +81,6 @@ int make_dims(const avf_layer_cfg* c, Dims* d) {
   d->xdt = d->rs16 ? AVF_BF16 : AVF_F32;
   AVF_REQUIRE(!d->rs16 || (c->dtype == AVF_BF16 && c->dim % 8 == 0 && c->dim <= 1536),
               "layer: resid_bf16 needs the bf16 path, dim %% 8 == 0 and dim <= 1536 (dim=%d)", c->dim);
-  d->lnf = (c->ln_fuse & 1) != 0;
-  d->ln1_ready = d->lnf && (c->ln_fuse & 2) != 0;
-  AVF_REQUIRE(!d->lnf || (d->rs16 && !d->mx && !c->key_mask && c->dim % 64 == 0 && (c->heads * c->dim_head) % 4 == 0 &&
-                          c->mlp_dim % 4 == 0),
-              "layer: ln_fuse needs resid_bf16, no mx8, no key mask and dim %% 64 == 0 (dim=%d)", c->dim);
   if (c->dtype == AVF_BF16) {
     AVF_REQUIRE(d->D % 8 == 0 && d->I % 8 == 0 && d->M % 8 == 0, "layer(bf16): dim, inner and mlp_dim must be multiples of 8");
     AVF_REQUIRE(d->dh == 32 || d->dh == 64, "layer(bf16): dim_head must be 32 or 64 (got %d)", d->dh);
@@ -203,8 +130,6 @@ struct LowP {
   void *wo_q, *wo_s;                                  // mx8_fwd: out-projection (used when the attention kernel emits the image of o)
   void *w2t_q, *w2t_s, *w1t_q, *w1t_s, *wot_q, *wot_s;  // mx8_bwd: images of the transposed weights (K = out features)
   void *wqkvt_q, *wqkvt_s;                               // mx8_bwd: image of Wqkv^T [D, 3I] (dqkv -> dh1, K = 3I)
-  void *wqkv_ln, *w1_ln;                // ln_fuse: gamma-scaled images of Wqkv (query rows also carry the softmax scale) and W1
-  float *s_qkv, *c_qkv, *s_1, *c_1;     // ln_fuse: their s / c vectors
   LowpWs ws;                            // fragment-major images for the weight-stationary GEMM (gemm_ws.hip), null if unfit
 };
 size_t carve_lowp(const Dims& d, void* base, LowP* l) {
@@ -235,15 +160,6 @@ size_t carve_lowp(const Dims& d, void* base, LowP* l) {
     t.wqkv_q = t.wqkv_s = t.w1_q = t.w1_s = t.w2_q = t.w2_s = nullptr;
     t.wo_q = t.wo_s = t.w2t_q = t.w2t_s = t.w1t_q = t.w1t_s = t.wot_q = t.wot_s = nullptr;
     t.wqkvt_q = t.wqkvt_s = nullptr;
-  }
-  if (d.lnf) {
-    t.wqkv_ln = c.take((size_t)3 * d.I * d.D * 2);
-    t.w1_ln = c.take((size_t)d.M * d.D * 2);
-    t.s_qkv = (float*)c.take((size_t)3 * d.I * 4); t.c_qkv = (float*)c.take((size_t)3 * d.I * 4);
-    t.s_1 = (float*)c.take((size_t)d.M * 4);       t.c_1 = (float*)c.take((size_t)d.M * 4);
-  } else {
-    t.wqkv_ln = t.w1_ln = nullptr;
-    t.s_qkv = t.c_qkv = t.s_1 = t.c_1 = nullptr;
   }
   // LAST (avf_*_adam_step finds the eight bf16 images by their offsets from the front): the fragment-major images
   t.ws.wqkv_p = pack_ws_ok(3 * d.I, d.D) ? c.take(pack_ws_bytes(3 * d.I, d.D)) : nullptr;
@@ -283,7 +199,6 @@ struct Work {
   void *dqq, *dqs;                        // mx8_bwd: image of dqkv (written by the merged attention backward)
   float *gy_m, *gm_m;       // fp32 mode with live dropout: masked copies of dx_out / dx_mid (what the Linears behind sites 2 / 0 see)
   float* small_part;        // short-sequence backward: per-clip partial rows (pb1 [B][M] | pln2 [B][3D] | pln1 [B][3D])
-  float *ln_part_a, *ln_part_b;  // ln_fuse: per-row partial statistics [R][D/32][2] of x_in (LN1) and of x_mid (LN2)
 };
 size_t carve_work(const Dims& d, void* base, Work* w) {
   Carver c(base);
@@ -340,10 +255,6 @@ size_t carve_work(const Dims& d, void* base, Work* w) {
   const bool f32_drop = d.dt == AVF_F32 && d.p > 0.f;
   t.gy_m = (float*)c.take(f32_drop ? d.R * d.D * 4 : 0);
   t.gm_m = (float*)c.take(f32_drop ? d.R * d.D * 4 : 0);
-  // LAST, so that every layer of a stack (same shapes, same flags) finds the two tables at the same place in the shared
-  // workspace: layer l's net.3 epilogue leaves the statistics of ITS output where layer l+1's to_qkv GEMM looks for them
-  t.ln_part_a = (float*)c.take(d.lnf ? (size_t)d.R * (d.D / 32) * 8 : 0);
-  t.ln_part_b = (float*)c.take(d.lnf ? (size_t)d.R * (d.D / 32) * 8 : 0);
   if (w) *w = t;
   return c.off;
 }
@@ -351,7 +262,6 @@ size_t carve_work(const Dims& d, void* base, Work* w) {
 // C[R, out] = A[R, in] * W[out, in]^T  (nn.Linear forward)
 int linear_fwd(const Dims& d, const void* A, int in, const void* W, int out, void* C, int c_dtype, int epi,
                const float* bias, const void* res, void* aux, hipStream_t s, const DropCfg& drop = kNoDrop,
-               float* rs_out = nullptr,     // rs_out: partial row statistics of the stored C (ln_fuse)
                const void* Wp = nullptr) {  // Wp: fragment-major image of W (weight-stationary kernel, gemm_ws.hip)
   GemmArgs a;
   a.dtype = d.dt; a.transA = 0; a.transB = 1;
@@ -360,24 +270,7 @@ int linear_fwd(const Dims& d, const void* A, int in, const void* W, int out, voi
   a.C = C; a.ldc = out; a.c_dtype = c_dtype; a.epilogue = epi;
   a.bias = bias; a.residual = res; a.ldres = out; a.aux = aux; a.ldaux = out; a.workspace = nullptr; a.colsum = nullptr;
   a.drop = drop; a.defer_fold = nullptr;
-  a.rs_out = rs_out;
   a.Bp = Wp;
-  return gemm(a, s);
-}
-
-// C = LayerNorm(X) W^T (+ b) with the LayerNorm folded into the GEMM: X is the raw bf16 residual stream, W_ln the gamma-scaled
-// image, part the partial row statistics of X; the row statistics land in mean / rstd (PreNorm, heads.py:178-185)
-int linear_fwd_ln(const Dims& d, const void* X, int in, const void* W_ln, const float* sv, const float* cv, const float* part,
-                  int out, void* C, int epi, void* aux, float* mean, float* rstd, float eps, hipStream_t s,
-                  const DropCfg& drop = kNoDrop) {
-  GemmArgs a;
-  a.dtype = AVF_BF16; a.transA = 0; a.transB = 1;
-  a.M = d.R; a.N = out; a.K = in;
-  a.A = X; a.lda = in; a.B = W_ln; a.ldb = in;
-  a.C = C; a.ldc = out; a.c_dtype = AVF_BF16; a.epilogue = epi;
-  a.bias = nullptr; a.residual = nullptr; a.ldres = 0; a.aux = aux; a.ldaux = out; a.workspace = nullptr; a.colsum = nullptr;
-  a.drop = drop; a.defer_fold = nullptr;
-  a.ln_part = part; a.ln_s = sv; a.ln_c = cv; a.ln_mean = mean; a.ln_rstd = rstd; a.ln_eps = eps;
   return gemm(a, s);
 }
 
@@ -489,12 +382,7 @@ extern "C" size_t avf_layer_grad_stream_bytes(const avf_layer_cfg* cfg) {
 extern "C" size_t avf_layer_workspace_bytes(const avf_layer_cfg* cfg) {
   Dims d;
   if (make_dims(cfg, &d)) return 0;
-  const size_t one = align_up(carve_work(d, nullptr, nullptr), 256);
-  return cfg->dw_overlap ? 2 * one : one;  // dw_overlap: one copy of the scratch per layer parity
-}
-
-extern "C" int avf_stack_join(void* workspace, void* stream) {
-  return side_join(side_state(workspace, false), (hipStream_t)stream);
+  return align_up(carve_work(d, nullptr, nullptr), 256);
 }
 
 extern "C" int avf_layer_prepare_weights(const avf_layer_cfg* cfg, const avf_layer_params* p, void* lowp,
@@ -521,27 +409,6 @@ extern "C" int avf_layer_prepare_weights(const avf_layer_cfg* cfg, const avf_lay
   if (l.ws.w2t_p) AVF_TRY(pack_ws(l.w2_t, d.D, d.M, d.D, l.ws.w2t_p, s));
   if (l.ws.wot_p) AVF_TRY(pack_ws(l.wo_t, d.D, d.I, d.D, l.ws.wot_p, s));
   return 0;
-}
-
-extern "C" int avf_stack_ln_fold(const avf_layer_cfg* cfg, int layers, const avf_layer_params* const* params,
-                                 void* const* lowp, void* stream) {
-  Dims d;
-  AVF_TRY(make_dims(cfg, &d));
-  AVF_REQUIRE(d.lnf, "stack_ln_fold: cfg.ln_fuse is not set");
-  AVF_REQUIRE(layers > 0 && layers <= 64 && params && lowp, "stack_ln_fold: bad arguments");
-  LnFoldJob jobs[64 * 2];
-  int n = 0;
-  for (int i = 0; i < layers; ++i) {
-    AVF_REQUIRE(params[i] && lowp[i], "stack_ln_fold: null pointer (layer %d)", i);
-    LowP l;
-    carve_lowp(d, lowp[i], &l);
-    const avf_layer_params* p = params[i];
-    // to_qkv has no bias (heads.py:212); its query rows carry the softmax scale like the plain image (attn_q_prescale)
-    jobs[n++] = LnFoldJob{p->w_qkv, p->ln1_w, p->ln1_b, nullptr, (bf16*)l.wqkv_ln, l.s_qkv, l.c_qkv, 3 * d.I, d.D,
-                          attn_q_prescale(d.dh), d.I};
-    jobs[n++] = LnFoldJob{p->w1, p->ln2_w, p->ln2_b, p->b1, (bf16*)l.w1_ln, l.s_1, l.c_1, d.M, d.D, 1.0f, 0};
-  }
-  return ln_fold_weights(jobs, n, (hipStream_t)stream);
 }
 
 extern "C" int avf_stack_quant_weights_mx8(const avf_layer_cfg* cfg, int layers, void* const* lowp, void* stream) {
@@ -613,7 +480,7 @@ extern "C" int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p
       AVF_TRY(linear_fwd_mx(d, w.oq, w.os, d.I, l.wo_q, l.wo_s, d.D, sv.x_mid, d.xdt, AVF_EPI_BIAS_RES, p->b_out, x_in, nullptr,
                             s, dr0));
     else
-      AVF_TRY(linear_fwd(d, sv.o, d.I, wo, d.D, sv.x_mid, d.xdt, AVF_EPI_BIAS_RES, p->b_out, x_in, nullptr, s, dr0, nullptr, l.ws.wo_p));
+      AVF_TRY(linear_fwd(d, sv.o, d.I, wo, d.D, sv.x_mid, d.xdt, AVF_EPI_BIAS_RES, p->b_out, x_in, nullptr, s, dr0, l.ws.wo_p));
     AVF_TRY(layernorm_fwd(sv.x_mid, p->ln2_w, p->ln2_b, sv.h2, d.dt, sv.mean2, sv.rstd2, d.R, d.D, cfg->ln_eps, s, w.hq, w.hs, d.xdt));
     AVF_TRY(linear_fwd_mx(d, w.hq, w.hs, d.D, l.w1_q, l.w1_s, d.M, sv.g, d.dt, AVF_EPI_BIAS_GELU, p->b1, nullptr, sv.u, s, dr1,
                           w.gq, w.gs));
@@ -628,27 +495,8 @@ extern "C" int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p
                            make_drop(d.p0, d.seed, d.layer, 0, d.seed_dev), make_drop(d.p, d.seed, d.layer, 1, d.seed_dev),
                            make_drop(d.p, d.seed, d.layer, 2, d.seed_dev), s);
   }
-  if (d.lnf) {
-    // LayerNorm folded into the two GEMMs behind it: h1 / h2 are not written (backward's LayerNorm kernels rebuild them for
-    // the weight-gradient GEMM); the residual GEMM epilogues leave the row statistics of what they store
-    AVF_REQUIRE(workspace, "layer_fwd(ln_fuse): workspace missing");
-    Work w;
-    carve_work(d, workspace, &w);
-    const DropCfg dr0 = make_drop(d.p0, d.seed, d.layer, 0, d.seed_dev), dr1 = make_drop(d.p, d.seed, d.layer, 1, d.seed_dev),
-                  dr2 = make_drop(d.p, d.seed, d.layer, 2, d.seed_dev);
-    if (!d.ln1_ready) AVF_TRY(row_stats(x_in, AVF_BF16, d.R, d.D, w.ln_part_a, s));
-    AVF_TRY(linear_fwd_ln(d, x_in, d.D, l.wqkv_ln, l.s_qkv, l.c_qkv, w.ln_part_a, 3 * d.I, sv.qkv, AVF_EPI_NONE, nullptr,
-                          sv.mean1, sv.rstd1, cfg->ln_eps, s));
-    AVF_TRY(attn_fwd_bf16((const bf16*)sv.qkv, (bf16*)sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s, attn_q_prescale_on()));
-    AVF_TRY(linear_fwd(d, sv.o, d.I, wo, d.D, sv.x_mid, d.xdt, AVF_EPI_BIAS_RES, p->b_out, x_in, nullptr, s, dr0, w.ln_part_b));
-    AVF_TRY(linear_fwd_ln(d, sv.x_mid, d.D, l.w1_ln, l.s_1, l.c_1, w.ln_part_b, d.M, sv.g, AVF_EPI_BIAS_GELU, sv.u, sv.mean2,
-                          sv.rstd2, cfg->ln_eps, s, dr1));
-    AVF_TRY(linear_fwd(d, sv.g, d.M, w2, d.D, x_out, d.xdt, AVF_EPI_BIAS_RES, p->b2, sv.x_mid, nullptr, s, dr2, w.ln_part_a));
-    return 0;
-  }
   AVF_TRY(layernorm_fwd(x_in, p->ln1_w, p->ln1_b, sv.h1, d.dt, sv.mean1, sv.rstd1, d.R, d.D, cfg->ln_eps, s, nullptr, nullptr, d.xdt));
-  AVF_TRY(linear_fwd(d, sv.h1, d.D, wqkv, 3 * d.I, sv.qkv, d.dt, AVF_EPI_NONE, nullptr, nullptr, nullptr, s, kNoDrop, nullptr,
-                     l.ws.wqkv_p));
+  AVF_TRY(linear_fwd(d, sv.h1, d.D, wqkv, 3 * d.I, sv.qkv, d.dt, AVF_EPI_NONE, nullptr, nullptr, nullptr, s, kNoDrop, l.ws.wqkv_p));
   // token mask (heads.py:225-232): on the MFMA kernels where they carry it (bf16, dim_head 64, up to 512 tokens), else on
   // the fp32-arithmetic ones
   const bool mask_mfma = d.keep && lo && attn_masked_bf16_ok(d.N, d.dh, attn_q_prescale_on());
@@ -659,11 +507,9 @@ extern "C" int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   else AVF_TRY(attn_fwd_f32((const float*)sv.qkv, (float*)sv.o, sv.lse2, d.B, d.N, d.H, d.dh, s));
   const DropCfg dr0 = make_drop(d.p0, d.seed, d.layer, 0, d.seed_dev), dr1 = make_drop(d.p, d.seed, d.layer, 1, d.seed_dev),
                 dr2 = make_drop(d.p, d.seed, d.layer, 2, d.seed_dev);
-  AVF_TRY(linear_fwd(d, sv.o, d.I, wo, d.D, sv.x_mid, d.xdt, AVF_EPI_BIAS_RES, p->b_out, x_in, nullptr, s, dr0, nullptr, l.ws.wo_p));
+  AVF_TRY(linear_fwd(d, sv.o, d.I, wo, d.D, sv.x_mid, d.xdt, AVF_EPI_BIAS_RES, p->b_out, x_in, nullptr, s, dr0, l.ws.wo_p));
   AVF_TRY(layernorm_fwd(sv.x_mid, p->ln2_w, p->ln2_b, sv.h2, d.dt, sv.mean2, sv.rstd2, d.R, d.D, cfg->ln_eps, s, nullptr, nullptr, d.xdt));
-  if (lo && d.p == 0.f && mlp_fused_on() && mlp_fused_ok(d.R, d.D, d.M))  // FeedForward as one launch (mlp_fused.hip)
-    return mlp_fused_fwd(sv.h2, w1, p->b1, w2, p->b2, sv.x_mid, d.xdt, x_out, sv.u, sv.g, d.R, d.D, d.M, s);
-  AVF_TRY(linear_fwd(d, sv.h2, d.D, w1, d.M, sv.g, d.dt, AVF_EPI_BIAS_GELU, p->b1, nullptr, sv.u, s, dr1, nullptr, l.ws.w1_p));
+  AVF_TRY(linear_fwd(d, sv.h2, d.D, w1, d.M, sv.g, d.dt, AVF_EPI_BIAS_GELU, p->b1, nullptr, sv.u, s, dr1, l.ws.w1_p));
   AVF_TRY(linear_fwd(d, sv.g, d.M, w2, d.D, x_out, d.xdt, AVF_EPI_BIAS_RES, p->b2, sv.x_mid, nullptr, s, dr2));
   return 0;
 }
@@ -686,12 +532,8 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   LowP l;
   carve_lowp(d, (void*)lowp, &l);
   const bool lo = d.dt == AVF_BF16;
-  // dw_overlap: odd layers use the second copy of the scratch, so the chain of the layer below cannot overwrite what this
-  // layer's weight-gradient launch is still reading on the side stream
-  const bool ovl = cfg->dw_overlap && lo;
   Work w;
-  carve_work(d, (char*)workspace + ((ovl && (d.layer & 1)) ? align_up(carve_work(d, nullptr, nullptr), 256) : 0), &w);
-  SideState* side = ovl ? side_state(workspace, true) : nullptr;
+  carve_work(d, workspace, &w);
 
   // gradient of the layer output in the compute dtype (GEMM operand)
   // dropout: the Linears behind a dropout site see the masked, rescaled gradient (the residual stream does not)
@@ -729,15 +571,12 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   TnGroupArgs grp = dw_group(d, gy, sv.g, w.du, sv.h2, gm, sv.o, w.dqkv, sv.h1, g);
   grp.workspace = w.gemm_ws;
   const bool grouped = lo && gemm_bf16_tn_group_ok(grp);
-  // (ln_fuse: h1 / h2 are rebuilt by this call's LayerNorm backward kernels - the weight-gradient GEMMs that read them run
-  //  after those: the grouped launch at the end, or the separate dW1 / dWqkv calls right behind LN2' / LN1')
   FoldList folds;
   memset(&folds, 0, sizeof(folds));
   folds.count = 3;
 
   // the grouped dW launch and its fold are shared with the general path
   if (small_bwd) {
-    AVF_TRY(side_join(side, s));  // (this path launches everything in-stream)
     float* pb1 = w.small_part;
     float* pln2 = pb1 + (size_t)d.B * d.M;
     float* pln1 = pln2 + (size_t)d.B * 3 * d.D;
@@ -824,16 +663,9 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
       ins = (char*)dx_in_lo + grad_s_off(d.R, d.D);
     }
   }
-  const bool fused_mlp = lo && !d.mxb && d.p == 0.f && mlp_fused_on() && mlp_fused_ok(d.R, d.D, d.M);
-  // (its column-sum partials, [R / 32][M] floats, fit the dGELU GEMM's: gemm_nt_colsum_ws)
   if (d.mxb) {
     AVF_TRY(linear_dx_mx(d, gyq, gys, d.D, l.w2t_q, l.w2t_s, d.M, w.du, AVF_EPI_DGELU, sv.u, s, g->b1, w.cs_ws, dr1,
                          grouped ? &folds.job[0] : nullptr, w.duq, w.dus));
-  } else if (fused_mlp) {  // du, db1 partials and dh2 in one launch (mlp_fused.hip)
-    AVF_TRY(mlp_fused_bwd(gy, l.w2_t, l.w1_t, sv.u, w.du, w.dh, (float*)w.cs_ws, d.R, d.D, d.M, s));
-    const FoldJob fj{(const float*)w.cs_ws, (int)(2 * (d.R / 64)), d.M, d.M, g->b1, nullptr, nullptr};
-    if (grouped) folds.job[0] = fj;
-    else AVF_TRY(fold_job(fj, s));
   } else if (lo) {  // db1 = colsum(du) fused into the dGELU GEMM epilogue
     AVF_TRY(linear_dx(d, gy, d.D, p->w2, l.w2_t, d.M, w.du, AVF_EPI_DGELU, sv.u, s, g->b1, w.cs_ws, dr1,
                       grouped ? &folds.job[0] : nullptr, l.ws.w2t_p));
@@ -844,17 +676,16 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   if (d.mxb)
     AVF_TRY(linear_dx_mx(d, w.duq, w.dus, d.M, l.w1t_q, l.w1t_s, d.D, w.dh, AVF_EPI_NONE, nullptr, s, nullptr, nullptr, kNoDrop,
                          nullptr));
-  else if (!fused_mlp)
+  else
     AVF_TRY(linear_dx(d, w.du, d.M, p->w1, l.w1_t, d.D, w.dh, AVF_EPI_NONE, nullptr, s));
   if (d.gs16)  // residual gradient in: the bf16 image the GEMMs read; out: the bf16 dx_mid only
     AVF_TRY(layernorm_bwd(w.dh, d.dt, sv.x_mid, p->ln2_w, sv.mean2, sv.rstd2, gy, nullptr, w.dx_mid_lo, g->ln2_w, g->ln2_b,
-                          g->b_out, w.ln_ws, d.R, d.D, s, dr0, grouped ? &folds.job[1] : nullptr, AVF_BF16, d.xdt, w.mq, w.ms,
-                          d.lnf ? sv.h2 : nullptr, p->ln2_b));
+                          g->b_out, w.ln_ws, d.R, d.D, s, dr0, grouped ? &folds.job[1] : nullptr, AVF_BF16, d.xdt, w.mq, w.ms));
   else
     AVF_TRY(layernorm_bwd(w.dh, d.dt, sv.x_mid, p->ln2_w, sv.mean2, sv.rstd2, dx_out, w.dx_mid,
                           lo ? w.dx_mid_lo : nullptr, g->ln2_w, g->ln2_b, g->b_out, w.ln_ws, d.R, d.D, s, dr0,
-                          grouped ? &folds.job[1] : nullptr, AVF_F32, d.xdt, w.mq, w.ms, d.lnf ? sv.h2 : nullptr, p->ln2_b));
-  if (!grouped) AVF_TRY(linear_dw(d, w.du, d.M, sv.h2, d.D, g->w1, w.gemm_ws, s));  // (behind LN2': ln_fuse rebuilds h2 there)
+                          grouped ? &folds.job[1] : nullptr, AVF_F32, d.xdt, w.mq, w.ms));
+  if (!grouped) AVF_TRY(linear_dw(d, w.du, d.M, sv.h2, d.D, g->w1, w.gemm_ws, s));
   // ---- attention half ----------------------------------------------------------------------
   if (f32_drop0) AVF_TRY(mask_copy_f32(w.dx_mid, w.gm_m, d.R * d.D, s, dr0));  // to_out sees dx_mid through its site-0 mask
   if (!grouped) AVF_TRY(linear_dw(d, gm, d.D, sv.o, d.I, g->w_out, w.gemm_ws, s));
@@ -890,30 +721,19 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
                          kNoDrop, nullptr));
   else
     AVF_TRY(linear_dx(d, w.dqkv, 3 * d.I, p->w_qkv, l.wqkv_t, d.D, w.dh, AVF_EPI_NONE, nullptr, s));
-  // dw_overlap: the layer above may still be reading its gy - the buffer this layer's LN1' writes dx_in_lo into - and the
-  // scratch copy the layer below will use: join its weight-gradient launch here, as late as the data allows
-  AVF_TRY(side_join(side, s));
   // dx_in may alias dx_out, which the grouped dW2 GEMM does not read (it uses the bf16 copy gy)
   if (d.gs16)
     AVF_TRY(layernorm_bwd(w.dh, d.dt, x_in, p->ln1_w, sv.mean1, sv.rstd1, w.dx_mid_lo, dx_in, dx_in_lo, g->ln1_w, g->ln1_b,
                           dx_in_colsum, w.ln_ws1, d.R, d.D, s, dr_prev2, grouped ? &folds.job[2] : nullptr, AVF_BF16, d.xdt,
-                          inq, ins, d.lnf ? sv.h1 : nullptr, p->ln1_b));
+                          inq, ins));
   else
     AVF_TRY(layernorm_bwd(w.dh, d.dt, x_in, p->ln1_w, sv.mean1, sv.rstd1, w.dx_mid, dx_in, lo ? dx_in_lo : nullptr,
                           g->ln1_w, g->ln1_b, dx_in_colsum, w.ln_ws1, d.R, d.D, s, dr_prev2,
-                          grouped ? &folds.job[2] : nullptr, AVF_F32, d.xdt, inq, ins, d.lnf ? sv.h1 : nullptr, p->ln1_b));
-  if (!grouped) AVF_TRY(linear_dw(d, w.dqkv, 3 * d.I, sv.h1, d.D, g->w_qkv, w.gemm_ws, s));  // (behind LN1': ln_fuse rebuilds h1)
+                          grouped ? &folds.job[2] : nullptr, AVF_F32, d.xdt, inq, ins));
+  if (!grouped) AVF_TRY(linear_dw(d, w.dqkv, 3 * d.I, sv.h1, d.D, g->w_qkv, w.gemm_ws, s));
   // one launch folds the split-K slabs of the four weight gradients and the three deferred column folds
   // (db1; dgamma2/dbeta2/dbo; dgamma1/dbeta1/previous layer's db2)
-  if (grouped && side && d.layer > 0) {
-    // fork: the launch waits for this layer's chain, then runs beside the chain of the layer below (whose call joins it)
-    AVF_REQUIRE(hipEventRecord(side->chain_done, s) == hipSuccess &&
-                    hipStreamWaitEvent(side->side, side->chain_done, 0) == hipSuccess,
-                "layer_bwd: fork to the side stream failed");
-    AVF_TRY(gemm_bf16_tn_group(grp, side->side, &folds));
-    AVF_REQUIRE(hipEventRecord(side->group_done, side->side) == hipSuccess, "layer_bwd: hipEventRecord failed");
-    side->pending = true;
-  } else if (grouped) {
+  if (grouped) {
     AVF_TRY(gemm_bf16_tn_group(grp, s, &folds));
   }
   return 0;

@@ -432,26 +432,21 @@ __global__ __launch_bounds__(256) void ln_bwd_reg_kernel(const DyT* __restrict__
                                                          int64_t rows, int D, int want_colsum, DropCfg drop,
                                                          uint8_t* __restrict__ dxq = nullptr,
                                                          uint8_t* __restrict__ dxs = nullptr,
-                                                         bf16* __restrict__ h_out = nullptr,
-                                                         const float* __restrict__ beta = nullptr,
                                                          int rpb = LNR_ROWS_PER_BLOCK) {
   // rpb: rows per workgroup (16; 4 - one row per wave - for short inputs, where 16-row blocks leave most CUs empty and the
   //      four rows of a wave run one after the other)
-  // h_out (LayerNorm folded into the forward GEMM: the normalised rows were never stored): also write
-  // h = xhat * gamma + beta, the operand of this layer's weight-gradient GEMM
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [4 waves][3][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t row0 = (int64_t)blockIdx.x * rpb;
   const float invD = 1.0f / (float)D;
   const uint64_t dkey = drop.thresh16 ? drop_key(drop) : 0;
-  float4 g[NV], adg[NV], adb[NV], acs[NV], bt[NV];
+  float4 g[NV], adg[NV], adb[NV], acs[NV];
   bool act[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane * 4 + 256 * i;
     act[i] = c < D;
     g[i] = act[i] ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    bt[i] = (act[i] && h_out) ? *reinterpret_cast<const float4*>(beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     adg[i] = adb[i] = acs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   for (int rr = wave; rr < rpb; rr += 4) {
@@ -497,9 +492,6 @@ __global__ __launch_bounds__(256) void ln_bwd_reg_kernel(const DyT* __restrict__
       o.z = rs * (d[i].z * g[i].z - s1 - xh[i].z * s2) + r.z;
       o.w = rs * (d[i].w * g[i].w - s1 - xh[i].w * s2) + r.w;
       if (dx) *reinterpret_cast<float4*>(dx + row * D + c) = o;
-      if (h_out)  // wave-uniform
-        store4<bf16>(h_out + row * D + c, make_float4(fmaf(xh[i].x, g[i].x, bt[i].x), fmaf(xh[i].y, g[i].y, bt[i].y),
-                                                      fmaf(xh[i].z, g[i].z, bt[i].z), fmaf(xh[i].w, g[i].w, bt[i].w)));
       if (drop.thresh16) {  // what the Linear behind the dropout site sees: masked, rescaled
         const float4 f = drop_factor4(drop, dkey, (uint64_t)row * D + c);
         o.x *= f.x; o.y *= f.y; o.z *= f.z; o.w *= f.w;
@@ -584,28 +576,24 @@ int fold_job(const FoldJob& j, hipStream_t s) { return launch_fold(j.partial, j.
 // LayerNorm backward on the all-bf16 streams (dy, x, the incoming residual gradient and dx in bf16; no dropout, no MX image):
 // the row8 layout of ln_fwd_row8_kernel.  A workgroup owns LNR_ROWS_PER_BLOCK = 4 waves x RU rows; the per-column sums stay in
 // registers and are combined through LDS in wave order, so the partial of a block - and the folded result - is deterministic.
-template <int NV8, int RU, bool HOUT>
+template <int NV8, int RU>
 __global__ __launch_bounds__(256) void ln_bwd_row8_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, const bf16* __restrict__ dres,
                                                           bf16* __restrict__ dx_lo, float* __restrict__ partial, int64_t rows,
-                                                          int D, int want_colsum, bf16* __restrict__ h_out,
-                                                          const float* __restrict__ beta, uint8_t* __restrict__ dxq = nullptr,
+                                                          int D, int want_colsum, uint8_t* __restrict__ dxq = nullptr,
                                                           uint8_t* __restrict__ dxs = nullptr, float* __restrict__ dx = nullptr) {
   // dx (optional, wave-uniform): the fp32 copy of the row gradient (the bottom layer hands it to the caller)
   static_assert((LNR_ROWS_PER_BLOCK / 4) % RU == 0, "a wave's rows come in whole batches of RU");
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [4 waves][3][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float gm[NV8][8], bt[NV8][8];
+  float gm[NV8][8];
 #pragma unroll
   for (int i = 0; i < NV8; ++i) {
     const int c = lane * 8 + 512 * i;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) gm[i][k] = bt[i][k] = 0.f;
-    if (c < D) {
-      load8f(gamma + c, gm[i]);
-      if (HOUT) load8f(beta + c, bt[i]);
-    }
+    for (int k = 0; k < 8; ++k) gm[i][k] = 0.f;
+    if (c < D) load8f(gamma + c, gm[i]);
   }
   float adg[NV8][8], adb[NV8][8], acs[NV8][8];
 #pragma unroll
@@ -677,7 +665,6 @@ __global__ __launch_bounds__(256) void ln_bwd_row8_kernel(const bf16* __restrict
         adg[i][k] = fmaf(d[k], xh, adg[i][k]);
         adb[i][k] += d[k];
         acs[i][k] += o[k];
-        if (HOUT) v[k] = fmaf(xh, gm[i][k], bt[i][k]);
       }
       *reinterpret_cast<uint4*>(dx_lo + (row0 + r) * D + c) = pack8(o);
       if (dx) {
@@ -689,7 +676,6 @@ __global__ __launch_bounds__(256) void ln_bwd_row8_kernel(const bf16* __restrict
         *reinterpret_cast<uint2*>(dxq + (row0 + r) * D + c) = mb.q;
         if ((lane & 3) == 0) dxs[(row0 + r) * (D >> 5) + (c >> 5)] = (uint8_t)mb.scale;
       }
-      if (HOUT) *reinterpret_cast<uint4*>(h_out + (row0 + r) * D + c) = pack8(v);
     }
   }
   }  // batch
@@ -724,10 +710,8 @@ size_t layernorm_bwd_ws(int64_t rows, int dim) {
 int layernorm_bwd(const void* dy, int dy_dtype, const void* xv, const float* gamma, const float* mean,
                   const float* rstd, const void* dres, float* dx, void* dx_lo, float* dgamma, float* dbeta,
                   float* dcolsum, void* ws, int64_t rows, int dim, hipStream_t s, const DropCfg& drop,
-                  FoldJob* defer_fold, int dres_dtype, int x_dtype, void* mx_q, void* mx_s, void* h_out, const float* beta) {
+                  FoldJob* defer_fold, int dres_dtype, int x_dtype, void* mx_q, void* mx_s) {
   AVF_REQUIRE(rows > 0 && dim > 0 && ws, "layernorm_bwd: bad arguments");
-  AVF_REQUIRE(!h_out || (beta && x_dtype == AVF_BF16 && dy_dtype == AVF_BF16 && dim % 4 == 0 && dim <= 1536),
-              "layernorm_bwd: the normalised rows (h_out) are written on the bf16 residual stream only, and need beta");
   AVF_REQUIRE(!mx_q || (mx_s && dy_dtype == AVF_BF16 && dim % 32 == 0 && dim <= 1536 && ((uintptr_t)mx_q & 3) == 0),
               "layernorm_bwd: the MX-FP8 image of dx needs bf16 dy, dim %% 32 == 0 and dim <= 1536 (dim=%d)", dim);
   AVF_REQUIRE(x_dtype == AVF_F32 || (x_dtype == AVF_BF16 && dy_dtype == AVF_BF16 && dim % 4 == 0 && dim <= 1536),
@@ -741,7 +725,7 @@ int layernorm_bwd(const void* dy, int dy_dtype, const void* xv, const float* gam
   AVF_REQUIRE((size_t)3 * dim * sizeof(float) <= 64 * 1024, "layernorm_bwd: dim %d too large", dim);
   TimingScope ts(KC_LAYERNORM, 0.0,
                  (double)rows * dim * ((dy_dtype == AVF_BF16 ? 2.0 : 4.0) + (x_dtype == AVF_BF16 ? 2.0 : 4.0) + (dres ? (dres_dtype == AVF_BF16 ? 2.0 : 4.0) : 0.0) +
-                                       (dx ? 4.0 : 0.0) + (dx_lo ? 2.0 : 0.0) + (h_out ? 2.0 : 0.0)), s, /*per_kernel=*/true);
+                                       (dx ? 4.0 : 0.0) + (dx_lo ? 2.0 : 0.0)), s, /*per_kernel=*/true);
   float* partial = (float*)ws;
   const int wc = dcolsum ? 1 : 0;
   int nb;
@@ -775,24 +759,17 @@ int layernorm_bwd(const void* dy, int dy_dtype, const void* xv, const float* gam
       if (lds > 64 * 1024) {
         static PerDeviceOnce raised8;
         if (raised8.need()) {
-          hipError_t e1 = hipFuncSetAttribute((const void*)ln_bwd_row8_kernel<3, 1, false>,
+          hipError_t e1 = hipFuncSetAttribute((const void*)ln_bwd_row8_kernel<3, 1>,
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 3 * 1536 * 4);
-          hipError_t e2 = hipFuncSetAttribute((const void*)ln_bwd_row8_kernel<3, 1, true>,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 3 * 1536 * 4);
-          AVF_REQUIRE(e1 == hipSuccess && e2 == hipSuccess, "layernorm_bwd: cannot raise dynamic LDS limit");
+          AVF_REQUIRE(e1 == hipSuccess, "layernorm_bwd: cannot raise dynamic LDS limit");
           raised8.mark();
         }
       }
 #define LAUNCH_R8(NVV, RU)                                                                                                   \
   do {                                                                                                                       \
-    if (h_out)                                                                                                               \
-      launch_in_scope(&ts, ln_bwd_row8_kernel<NVV, RU, true>, dim3(nb), dim3(256), (uint32_t)lds, s, (const bf16*)dy,         \
-                      (const bf16*)xv, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx_lo, partial, rows, dim, wc, (bf16*)h_out, beta, \
-                      (uint8_t*)mx_q, (uint8_t*)mx_s, dx);                                                                   \
-    else                                                                                                                     \
-      launch_in_scope(&ts, ln_bwd_row8_kernel<NVV, RU, false>, dim3(nb), dim3(256), (uint32_t)lds, s, (const bf16*)dy,        \
-                      (const bf16*)xv, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx_lo, partial, rows, dim, wc, (bf16*)nullptr, \
-                      (const float*)nullptr, (uint8_t*)mx_q, (uint8_t*)mx_s, dx);                                            \
+    launch_in_scope(&ts, ln_bwd_row8_kernel<NVV, RU>, dim3(nb), dim3(256), (uint32_t)lds, s, (const bf16*)dy,                \
+                    (const bf16*)xv, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx_lo, partial, rows, dim, wc,              \
+                    (uint8_t*)mx_q, (uint8_t*)mx_s, dx);                                                                     \
   } while (0)
       switch ((dim + 511) / 512) {  // rows in flight per wave: what the register file allows at two waves per SIMD or more
         case 1: LAUNCH_R8(1, 4); break;
@@ -806,18 +783,18 @@ int layernorm_bwd(const void* dy, int dy_dtype, const void* xv, const float* gam
   do {                                                                                                                      \
     if (x_dtype == AVF_BF16 && dres_dtype == AVF_BF16)                                                                      \
       launch_in_scope(&ts, ln_bwd_reg_kernel<bf16, NVV, bf16, bf16>, dim3(nb), dim3(256), (uint32_t)lds, s, (const bf16*)dy,   \
-                      (const bf16*)xv, gamma, mean, rstd, (const bf16*)dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop, (uint8_t*)mx_q, (uint8_t*)mx_s, (bf16*)h_out, beta, rpb); \
+                      (const bf16*)xv, gamma, mean, rstd, (const bf16*)dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop, (uint8_t*)mx_q, (uint8_t*)mx_s, rpb); \
     else if (x_dtype == AVF_BF16)                                                                                           \
       launch_in_scope(&ts, ln_bwd_reg_kernel<bf16, NVV, float, bf16>, dim3(nb), dim3(256), (uint32_t)lds, s, (const bf16*)dy,  \
-                      (const bf16*)xv, gamma, mean, rstd, (const float*)dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop, (uint8_t*)mx_q, (uint8_t*)mx_s, (bf16*)h_out, beta, rpb); \
+                      (const bf16*)xv, gamma, mean, rstd, (const float*)dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop, (uint8_t*)mx_q, (uint8_t*)mx_s, rpb); \
     else if (dres_dtype == AVF_BF16)                                                                                        \
       launch_in_scope(&ts, ln_bwd_reg_kernel<bf16, NVV, bf16>, dim3(nb), dim3(256), (uint32_t)lds, s, (const bf16*)dy, x, gamma, \
                       mean, rstd, (const bf16*)dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop, (uint8_t*)mx_q,         \
-                      (uint8_t*)mx_s, (bf16*)nullptr, (const float*)nullptr, rpb);                                           \
+                      (uint8_t*)mx_s, rpb);                                                                                 \
     else                                                                                                                    \
       launch_in_scope(&ts, ln_bwd_reg_kernel<T, NVV, float>, dim3(nb), dim3(256), (uint32_t)lds, s, (const T*)dy, x, gamma, mean, \
                       rstd, (const float*)dres, dx, (bf16*)dx_lo, partial, rows, dim, wc, drop, (uint8_t*)mx_q,              \
-                      (uint8_t*)mx_s, (bf16*)nullptr, (const float*)nullptr, rpb);                                           \
+                      (uint8_t*)mx_s, rpb);                                                                                 \
   } while (0)
 #define LAUNCH_T(T)                                   \
   switch (nv) {                                       \

@@ -199,7 +199,6 @@ int adam_add_layer(AdamBatch& b, int& n, int& tiles, const avf_layer_cfg* cfg, c
         off += (bytes[i] + 255) & ~(size_t)255;
       }
     // (with cfg->mx8_fwd the MX-FP8 images follow the bf16 ones; the caller re-derives them from these: transformer.py)
-    // (with cfg->ln_fuse the gamma-scaled images and their s / c vectors follow likewise: avf_stack_ln_fold)
     AVF_REQUIRE(off <= avf_layer_lowp_bytes(cfg), "layer_adam_step: lowp layout mismatch (%zu vs %zu)", off,
                 avf_layer_lowp_bytes(cfg));
   }

@@ -228,43 +228,6 @@ def gemm_tn_group(pairs):
     return Cs
 
 
-def mlp_fused_ok(rows: int, dim: int, mlp_dim: int) -> bool:
-    return bool(_lib.load().avf_mlp_fused_ok(rows, dim, mlp_dim))
-
-
-def mlp_fused_fwd(h: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, x_mid: torch.Tensor):
-    """FeedForward forward (heads.py:188-199) in one launch: h [R, D] bf16 (the LayerNorm output), W1 [M, D] / W2 [D, M] bf16,
-    biases fp32, x_mid [R, D] fp32 | bf16 (the residual) -> (x_out in x_mid's type, u [R, M] bf16, g = gelu(u) [R, M] bf16)."""
-    _need_cuda(h, w1, b1, w2, b2, x_mid)
-    R, D = h.shape
-    M = w1.shape[0]
-    assert h.dtype == w1.dtype == w2.dtype == torch.bfloat16 and w1.shape == (M, D) and w2.shape == (D, M)
-    h, w1, w2, x_mid = h.contiguous(), w1.contiguous(), w2.contiguous(), x_mid.contiguous()
-    x_out = torch.empty_like(x_mid)
-    u = torch.empty((R, M), dtype=torch.bfloat16, device=h.device)
-    g = torch.empty((R, M), dtype=torch.bfloat16, device=h.device)
-    _lib.check(_lib.load().avf_mlp_fused_fwd(_ptr(h), _ptr(w1), _ptr(b1.float().contiguous()), _ptr(w2), _ptr(b2.float().contiguous()),
-                                             _ptr(x_mid), avf_dtype(x_mid.dtype), _ptr(x_out), _ptr(u), _ptr(g), R, D, M, _stream()),
-               "mlp_fused_fwd")
-    return x_out, u, g
-
-
-def mlp_fused_bwd(dy: torch.Tensor, w2_t: torch.Tensor, w1_t: torch.Tensor, u: torch.Tensor):
-    """FeedForward backward chain in one launch: dy [R, D] bf16, W2^T [M, D], W1^T [D, M] bf16, u [R, M] bf16 (saved) ->
-    (du [R, M] bf16, dh [R, D] bf16, partial column sums of du [2 R / 64, M] fp32: their sum over the rows is db1)."""
-    _need_cuda(dy, w2_t, w1_t, u)
-    R, D = dy.shape
-    M = u.shape[1]
-    assert w2_t.shape == (M, D) and w1_t.shape == (D, M)
-    lib = _lib.load()
-    du = torch.empty((R, M), dtype=torch.bfloat16, device=dy.device)
-    dh = torch.empty((R, D), dtype=torch.bfloat16, device=dy.device)
-    part = torch.empty((lib.avf_mlp_fused_bwd_partial_rows(R), M), dtype=torch.float32, device=dy.device)
-    _lib.check(lib.avf_mlp_fused_bwd(_ptr(dy.contiguous()), _ptr(w2_t.contiguous()), _ptr(w1_t.contiguous()), _ptr(u.contiguous()),
-                                     _ptr(du), _ptr(dh), _ptr(part), R, D, M, _stream()), "mlp_fused_bwd")
-    return du, dh, part
-
-
 def quant_mx8(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """[rows, cols] f32|bf16 -> (e4m3 bytes [rows, cols] uint8, E8M0 scale bytes [rows, cols/32] uint8)."""
     _need_cuda(x)

@@ -121,8 +121,7 @@ class _StackFn(torch.autograd.Function):
         ctx.keep = keep  # token mask bytes (heads.py:225-232); the layer configurations carry its device pointer
         # the L layer configurations are rebuilt only when something in them changes (shape, live dropout, seed / mask pointers)
         ckey = (B, N, mod.training, mod.dropout, None if seed_t is None else seed_t.data_ptr(),
-                None if keep is None else keep.data_ptr(), mod.compute_dtype, mod.mx8, mod.mx8_bwd, mod.resid_bf16,
-                mod.__dict__.get("ln_fuse", False), mod.__dict__.get("dw_overlap", False))
+                None if keep is None else keep.data_ptr(), mod.compute_dtype, mod.mx8, mod.mx8_bwd, mod.resid_bf16)
         chit = mod.__dict__.get("_cfg_cache")
         if chit is not None and chit[0] == ckey:
             cfgs = chit[1]
@@ -240,8 +239,6 @@ class _StackFn(torch.autograd.Function):
                                               _ptr(lo_a) if have_lo else None,
                                               _ptr(views[L - 1][B2]) if top_colsum else None, B, N, D, stream),
                        "token_mean_bwd")
-        deferred = bool(cfg.dw_overlap)
-
         def hand_over(l):
             waiter = hook(l, flats[l]) if hook is not None else None  # e.g. launch this layer's all-reduce now
             # Parameter gradients are handed over directly (views of the layer's flat buffer, no copy):
@@ -271,17 +268,7 @@ class _StackFn(torch.autograd.Function):
                        f"layer_bwd[{l}]")
             lo_a, lo_b = lo_b, lo_a
             have_lo = bf16
-            # dw_overlap: the weight gradients of layer l are complete on this stream once the call for layer l - 1 has
-            # joined the side stream (layer 0 launches in-stream) - hand a layer over one call late
-            if not deferred:
-                hand_over(l)
-            else:
-                if l < L - 1:
-                    hand_over(l + 1)
-                if l == 0:
-                    hand_over(0)
-        if deferred:
-            _lib.check(lib.avf_stack_join(_ptr(ws), stream), "stack_join")  # (nothing pending after layer 0: a no-op)
+            hand_over(l)
         _check_canaries()
         ctx.saved_bufs = None
         ctx.xs = None
@@ -327,18 +314,6 @@ class Transformer(nn.Module):
         self.resid_bf16 = rd in ("bf16", "bfloat16")
         if self.resid_bf16 and (self.compute_dtype != _lib.BF16 or dim % 8 or dim > 1536):
             raise ValueError("residual_dtype='bf16' needs compute_dtype 'bf16' / 'mx8', dim % 8 == 0 and dim <= 1536")
-        # LayerNorm forward folded into the GEMM behind it (bf16 residual stream only).  Built and
-        # measured in round 3: the 12 LayerNorm launches it removes were also absorbing the write-back drain of the residual
-        # GEMM in front of them, which moves into the folded GEMMs - level at C2 and C3 - so it is OFF unless AVF_LN_FUSE=1
-        # (or ``stack.ln_fuse = True`` where ``ln_fuse_ok``).
-        self.ln_fuse_ok = bool(self.resid_bf16 and not self.mx8 and dim % 64 == 0 and mlp_dim % 4 == 0)
-        self.ln_fuse = bool(self.ln_fuse_ok and os.environ.get("AVF_LN_FUSE", "0") == "1")
-        # backward: a layer's grouped weight-gradient launch on a low-priority side stream, under the gradient chain of the
-        # layer below (avformer_hip.h cfg.dw_overlap).  Built and measured in round 3: the launches do
-        # overlap (54 of 62 us, rocprofv3) but the step does not get shorter - the two kernels contend for the same L2 -> LDS
-        # path - and a hipGraph replay of the forked capture is 2.2x slower, so it is OFF unless AVF_DW_OVERLAP=1 (or
-        # ``stack.dw_overlap = True`` before the first step).
-        self.dw_overlap = bool(self.compute_dtype == _lib.BF16 and depth >= 2 and os.environ.get("AVF_DW_OVERLAP", "0") == "1")
         self.project_out = not (heads == 1 and dim_head == dim)
         self.layers = nn.ModuleList([_make_layer(dim, heads, dim_head, mlp_dim, dropout) for _ in range(depth)])
         if not self.project_out:
@@ -361,7 +336,7 @@ class Transformer(nn.Module):
     # per-process caches (ctypes structs, device scratch, bf16 weight images): never copied or pickled with the module
     _CACHES = {"_ws": None, "_lowp_bufs": None, "_lowp_ptrs": None, "_lowp_versions": None, "_lowp_ready": False,
                "_seed_dev": None, "_last_seed_t": None}
-    _LAZY_CACHES = ("_pstruct_cache", "_mx_ptr_array", "_flat_cache", "_cfg_cache", "_lnf_stale")  # created on first use
+    _LAZY_CACHES = ("_pstruct_cache", "_mx_ptr_array", "_flat_cache", "_cfg_cache")  # created on first use
 
     def __getstate__(self):
         d = self.__dict__.copy()
@@ -414,11 +389,7 @@ class Transformer(nn.Module):
                              int(self.project_out), 1e-5, float(p), 0, 0, layer,
                              seed_t.data_ptr() if (seed_t is not None and p != 0.0) else None,
                              int(self._grad_stream_bf16(p)), int(self.mx8), int(self.resid_bf16), int(self.mx8_bwd),
-                             int(self.mx8_bwd and layer < self.depth - 1), None if keep is None else keep.data_ptr(),
-                             # LayerNorm folded into to_qkv / net.0 (bit 0); layers above the first find the row statistics
-                             # of their input in the shared workspace, left there by the layer below (bit 1)
-                             ((1 | (2 if layer > 0 else 0)) if (self.ln_fuse and self.ln_fuse_ok and keep is None) else 0),
-                             int(bool(self.__dict__.get("dw_overlap", False)) and self.compute_dtype == _lib.BF16))
+                             int(self.mx8_bwd and layer < self.depth - 1), None if keep is None else keep.data_ptr())
 
     def _grad_stream_bf16(self, p: float) -> bool:
         """backward keeps the residual gradient between the LayerNorm backward kernels in bf16 (the GEMMs read that image
@@ -501,17 +472,6 @@ class Transformer(nn.Module):
                 self._mx_ptr_array = (C.c_void_p * self.depth)(*[b.data_ptr() for b in self._lowp_bufs])
             _lib.check(lib.avf_stack_quant_weights_mx8(C.byref(cfg), self.depth, self._mx_ptr_array, stream),
                        "stack_quant_weights_mx8")
-        if cfg.ln_fuse & 1:
-            # gamma-scaled images + s / c vectors of the LayerNorm-folded GEMMs: they follow every change of a weight, gamma,
-            # beta or b1 - one launch for the stack.  (A forward that ran without them, e.g. with a mask, leaves them stale.)
-            if changed or fresh or self.__dict__.get("_lnf_stale", True):
-                bufs = (C.c_void_p * self.depth)(*[b.data_ptr() for b in self._lowp_bufs])
-                structs = [self._param_struct(params, l) for l in range(self.depth)]
-                pps = (C.c_void_p * self.depth)(*[C.addressof(st) for st in structs])
-                _lib.check(lib.avf_stack_ln_fold(C.byref(cfg), self.depth, pps, bufs, stream), "stack_ln_fold")
-                self.__dict__["_lnf_stale"] = False
-        elif changed or fresh:
-            self.__dict__["_lnf_stale"] = True
         return self._lowp_bufs
 
     def set_seed_rank(self, rank: int):
