@@ -76,14 +76,16 @@ struct NtPre {
   uint4 raw[MI][(NI + 1) / 2];
   float4 exf[MI][NI];
 };
-template <int EPI, typename CT, int MI, int NI>
+// BIAS: also (re)load the bias (a persistent kernel loads it once and passes false afterwards: the per-tile loads are then
+// exactly MI * NI / 2 (2-byte rows) or MI * NI (fp32 rows) instructions, which its vmcnt bookkeeping counts on)
+template <int EPI, typename CT, int MI, int NI, bool BIAS = true>
 __device__ __forceinline__ void nt_epi_prefetch(const NtParams& p, int m_base, int n_base, int li, int lg, NtPre<MI, NI>& pre) {
   int nn[NI], nc[NI];
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     nn[j] = n_base + j * 16 + 4 * lg;
     nc[j] = nn[j] < p.N ? nn[j] : 0;
-    pre.bj[j] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nc[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (BIAS) pre.bj[j] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nc[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   // the caller has checked the conditions of nt_epilogue's wide path (2-byte rows: p.wide == 1, N % 8 == 0, leading dimension
   // % 8 == 0, 16-byte aligned base)

@@ -39,9 +39,6 @@ constexpr int WS_KS = WS_K / 32;   // MFMA k-steps per tile
 #ifndef AVF_WS_EPI_PRIO
 #define AVF_WS_EPI_PRIO 2
 #endif
-#ifndef AVF_WS_DMA_LATE
-#define AVF_WS_DMA_LATE 1
-#endif
 #ifndef AVF_WS_DBG
 #define AVF_WS_DBG 0  // timing experiments (WRONG results): bit 0 = no DMA after the prologue, bit 1 = no stores (epilogue sees M = 0)
 #endif
@@ -83,6 +80,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_ws_kernel(NtParams p, const 
   constexpr int SLOT = 8 * CH;           // one tile: 8 chunks
   constexpr int PPW = BM / 8;            // DMA wave-instructions per wave and tile (8 rows x 128 B each)
   static_assert(BM % 8 == 0 && 7 * CH + (MI - 1) * 2048 < 65536, "tile shape");
+  static_assert(NSLOT == 3, "the vmcnt bookkeeping below is written for two tiles of look-ahead");
   extern __shared__ __attribute__((aligned(16))) char dsm[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -100,7 +98,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_ws_kernel(NtParams p, const 
   const int n0 = panel * WS_BN + wave * 32;
 #if AVF_WS_STAMPS
   const bool stamp_on = lane == 0;
-  unsigned long long* stamp_lds = reinterpret_cast<unsigned long long*>(dsm + NSLOT * SLOT) + wave * WS_NSTAMP;
+  unsigned long long* stamp_lds = reinterpret_cast<unsigned long long*>(dsm + NSLOT * SLOT + 8 * 2 * MI * 1024) + wave * WS_NSTAMP;
   if (stamp_on)
     for (int i = 0; i < WS_NSTAMP; ++i) stamp_lds[i] = 0;
   WS_STAMP(0);
@@ -129,6 +127,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_ws_kernel(NtParams p, const 
 #pragma unroll
   for (int i = 0; i < NSLOT - 1; ++i)
     if (i < nt) dma_tile(t0 + i, lds0 + i * SLOT);
+  // (the staged epilogue operands of tile 0 ride with them: issued below, once the lambda exists - still ahead of the
+  //  weight loads whose vmcnt(0) covers everything)
   // this wave's weight fragments (coalesced: 64 lanes x 16 B per instruction), behind the first tiles' DMA in the queue.
   // The 256 KiB of a workgroup's panel come out of the XCD's L2 at the rate all its CUs share (3.5 us when the eight waves of
   // every CU ask at once), so the two wave halves take TURNS: waves 0..3 load first and run tile 0 while waves 4..7 - which
@@ -167,20 +167,46 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_ws_kernel(NtParams p, const 
   for (int j = 0; j < NI; ++j)
 #pragma unroll
     for (int r = 0; r < 4; ++r) cs_acc[j][r] = 0.f;
+  // The epilogue's operands.  The bias of the lane's columns is loaded once.  The residual / saved pre-activation rows (2-byte
+  // rows: the bf16 streams) of tile t + 1 travel by LDS-DMA into a per-wave staging buffer while tile t is being finished -
+  // requested BEHIND the DMA of tile t + 2 and read a whole period later: in the pipeline these rows are HBM-cold (the saved
+  // pre-activation was written a forward pass ago), and a register prefetch issued in front of a tile's MFMAs gave them one
+  // MFMA phase in flight (16 KiB per CU: the dGELU GEMM ran at 2.6 TB/s).  No VGPR destination, no compiler-visible load in the
+  // tile loop: the wait-count pass inserts nothing there, the kernel's own vmcnt counts every instruction.  fp32 rows (the
+  // fp32 residual stream) keep the register prefetch in front of the MFMAs.
+  constexpr bool PRE_LDS = (EPI == AVF_EPI_BIAS_RES || EPI == AVF_EPI_DGELU) && sizeof(CT) == 2;
+  constexpr int KPRE = PRE_LDS ? MI * (NI / 2) : 0;  // LDS-DMA instructions per tile and wave (16 rows x 64 B each)
+  static_assert(NI == 2, "one column-block pair per wave");
+  const uint32_t pre_lds = lds0 + NSLOT * SLOT + (uint32_t)wave * (2 * MI * 1024);
+  const int cp0 = n0 + 4 * lg + ((lg & 1) ? 12 : 0);  // nt_epilogue_lean: the lane's 8 columns of the pair after the exchange
+  auto pre_dma = [&](int tile, int buf) {
+    if constexpr (PRE_LDS) {
+      const bf16* src = (EPI == AVF_EPI_BIAS_RES) ? (const bf16*)p.residual : (const bf16*)p.aux;
+      const int64_t ldx = (EPI == AVF_EPI_BIAS_RES) ? p.ldres : p.ldaux;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        int r = tile * BM + 16 * i + li;
+        r = r < p.M ? r : p.M - 1;
+        ws_glds16(src + (int64_t)r * ldx + cp0, __builtin_amdgcn_readfirstlane(pre_lds + (uint32_t)((buf * MI + i) * 1024)));
+      }
+    }
+  };
+  pre_dma(t0, 0);  // tile 0's rows: landed by the first counted wait of the loop (older than everything it leaves in flight)
+  NtPre<MI, NI> pre;
+  nt_epi_prefetch<EPI, CT, MI, NI, true>(p, t0 * BM, n0, li, lg, pre);  // the bias (and, fp32 rows, tile 0's operands)
+  // compiler-visible, so that the wait-count pass knows the bias has landed: it would otherwise wait vmcnt(0) at the bias'
+  // first use in EVERY iteration's epilogue - behind the DMA that iteration has just issued
+  __builtin_amdgcn_s_waitcnt(0x0F70);
   uint32_t rd_slot = 0, wr_slot = (NSLOT - 1) * SLOT;
   for (int t = 0; t < nt; ++t) {
     WS_STAMP(4 + 6 * t);
     if (!late) __builtin_amdgcn_s_barrier();  // tile t landed for every wave; every wave is done reading tile t - 1
     WS_STAMP(5 + 6 * t);
-    // the epilogue's operands (bias; residual / saved pre-activation rows) are requested BEFORE the tile's DMA and MFMAs and
-    // consumed behind them: the queue is in order, so the vmcnt wait below covers them as well
-    NtPre<MI, NI> pre;
-    nt_epi_prefetch<EPI, CT, MI, NI>(p, (t0 + t) * BM, n0, li, lg, pre);
-#if !AVF_WS_DMA_LATE
-    if (t + NSLOT - 1 < nt && !(AVF_WS_DBG & 1)) dma_tile(t0 + t + NSLOT - 1, lds0 + wr_slot);
-#endif
+    if constexpr (!PRE_LDS) {
+      if (t > 0) nt_epi_prefetch<EPI, CT, MI, NI, false>(p, (t0 + t) * BM, n0, li, lg, pre);  // (covered by the wait below)
+    }
     WS_STAMP(6 + 6 * t);
-    // ---- the tile's 16 k-steps, fully unrolled; A fragments one 64-deep chunk ahead of the MFMAs ----
+    // ---- the tile's 16 k-steps, fully unrolled ----
     // three fragment buffers: the reads of chunk c + 2 are issued before the MFMAs of chunk c (an LDS read under load takes
     // longer than the 8 MFMAs of one chunk: with one chunk of look-ahead the 64 MFMAs took 2200 cycles instead of 1024)
     bf16x8_t fa[3][2][MI];
@@ -214,25 +240,32 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_ws_kernel(NtParams p, const 
               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[j][2 * c + ks], fa[c % 3][ks][i], acc[i][j], 0, 0, 0);
           }
     }
-#if AVF_WS_DMA_LATE
-    // the tile's DMA is issued BEHIND its MFMAs: an LDS-DMA in flight counts in the issuing wave's lgkmcnt as well as in its
-    // vmcnt, so a DMA issued in front of the K-loop turns every counted lgkmcnt wait of the fragment reads into a wait for the
-    // DMA (64 MFMAs: 1850 cycles with the DMA in front, 1280 with none in flight)
-    if (t + NSLOT - 1 < nt && !(AVF_WS_DBG & 1)) dma_tile(t0 + t + NSLOT - 1, lds0 + wr_slot);
-#endif
+    // the DMA of tile t + 2 is issued BEHIND the MFMAs of tile t: an LDS-DMA in flight counts in the issuing wave's lgkmcnt as
+    // well as in its vmcnt, so a DMA issued in front of the K-loop turns every counted lgkmcnt wait of the fragment reads into
+    // a wait for the DMA (64 MFMAs: 1850 cycles with the DMA in front, 1280 with none in flight)
+    const bool more2 = t + 2 < nt, more1 = t + 1 < nt;
+    if (more2 && !(AVF_WS_DBG & 1)) dma_tile(t0 + t + 2, lds0 + wr_slot);
+    if (more1) pre_dma(t0 + t + 1, (t + 1) & 1);
     WS_STAMP(7 + 6 * t);
-    // own pieces of tile t + 1 (issued NSLOT - 2 iterations ago) have landed: all but the pieces of the tiles issued since
-    if constexpr (NSLOT >= 3) {
-      const int ahead = (nt - 1 - t) < (NSLOT - 1) ? (nt - 1 - t) : (NSLOT - 1);  // tiles in flight beyond tile t: t+1 .. t+ahead
-      if (ahead >= 3) wait_vmcnt<2 * PPW>();
-      else if (ahead == 2) wait_vmcnt<PPW>();
-      else wait_vmcnt<0>();
-    } else {
-      wait_vmcnt<0>();
-    }
+    // everything OLDER than what this iteration issued has landed - this wave's pieces of tile t + 1 and the staged epilogue
+    // operands of tile t (both issued an iteration ago); the queue is in order, so the count is that of this iteration's own
+    // instructions: PPW DMA pieces and KPRE staging pieces
+    if (more2) wait_vmcnt<PPW + KPRE>();
+    else if (more1) wait_vmcnt<KPRE>();
+    else wait_vmcnt<0>();
     WS_STAMP(8 + 6 * t);
-    if (late && t + 1 < nt) __builtin_amdgcn_s_barrier();
+    if (late && more1) __builtin_amdgcn_s_barrier();
     WS_STAMP(9 + 6 * t);
+    if constexpr (PRE_LDS) {  // this wave's staged rows of tile t: the 16 bytes a lane would have loaded (lane-linear image)
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        const u32x4_t v = lds_read_b128<u32x4_t, 0>(pre_lds + (uint32_t)(((t & 1) * MI + i) * 1024) + (uint32_t)lane * 16);
+        pre.raw[i][0] = make_uint4(v[0], v[1], v[2], v[3]);
+      }
+      wait_lgkmcnt<0>();
+      __builtin_amdgcn_sched_barrier(0);
+    }
     // the epilogue's vector instructions outrank the SIMD partner's MFMA stream: a wave in its epilogue is on the workgroup's
     // critical path (2480 cycles beside a partner issuing MFMAs against 1450 alone), the matrix pipe has slack
     __builtin_amdgcn_s_setprio(AVF_WS_EPI_PRIO);
@@ -279,7 +312,8 @@ int ws_grid() {
 template <int EPI, typename CT, int MI, int NSLOT, bool CS>
 int launch_ws(const NtParams& p, const void* bp, hipStream_t s, int* part_rows, TimingScope* ts) {
   constexpr int BM = 16 * MI;
-  constexpr int SMEM = NSLOT * BM * 1024 + (AVF_WS_STAMPS ? 8 * WS_NSTAMP * 8 : 0);
+  // the A ring, the per-wave staging of the epilogue's 2-byte operand rows (two tiles), [diagnostic build: the stamps]
+  constexpr int SMEM = NSLOT * BM * 1024 + 8 * 2 * MI * 1024 + (AVF_WS_STAMPS ? 8 * WS_NSTAMP * 8 : 0);
   static_assert(SMEM <= 160 * 1024, "LDS budget");
   static PerDeviceOnce raised;
   if (SMEM > 64 * 1024 && raised.need()) {
@@ -308,20 +342,12 @@ int launch_ws(const NtParams& p, const void* bp, hipStream_t s, int* part_rows, 
 
 template <int EPI, typename CT>
 int launch_ws_any(const NtParams& p, const void* bp, hipStream_t s, int* part_rows, TimingScope* ts) {
-  static const int slots = [] {
-    const char* e = getenv("AVF_NT_WS_SLOTS");  // tuning aid: ring depth in tiles (2..4)
-    return (e && *e) ? atoi(e) : 3;
-  }();
   // column sums ride on the dGELU epilogue only (db1 of the layer's backward); other epilogues with a colsum request go to
   // the tiled kernel (gemm_bf16_nt_ws_ok)
   if constexpr (EPI == AVF_EPI_DGELU) {
     if (p.cs_partial) return launch_ws<EPI, CT, 2, 3, true>(p, bp, s, part_rows, ts);
   }
-  switch (slots) {
-    case 2: return launch_ws<EPI, CT, 2, 2, false>(p, bp, s, part_rows, ts);
-    case 4: return launch_ws<EPI, CT, 2, 4, false>(p, bp, s, part_rows, ts);
-    default: return launch_ws<EPI, CT, 2, 3, false>(p, bp, s, part_rows, ts);
-  }
+  return launch_ws<EPI, CT, 2, 3, false>(p, bp, s, part_rows, ts);
 }
 
 }  // namespace
