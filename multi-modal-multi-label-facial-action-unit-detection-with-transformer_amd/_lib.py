@@ -58,7 +58,8 @@ SIGNATURES = {
     "avf_pack_weight_ws_ok": (_int, [_i64, _i64]),
     "avf_pack_weight_ws_bytes": (_sz, [_i64, _i64]),
     "avf_pack_weight_ws": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
-    "avf_gemm_nt_ws": (_int, [_i64, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _int, _int, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    "avf_gemm_nt_ws": (_int, [_i64, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _int, _int, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp,
+                              _vp]),
     "avf_gemm_tn_group_workspace_bytes": (_sz, [_int, _i64, _vp, _vp]),
     "avf_gemm_tn_group": (_int, [_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "avf_stack_quant_weights_mx8": (_int, [_vp, _int, _vp, _vp]),

@@ -239,7 +239,7 @@ extern "C" int avf_pack_weight_ws(const void* w_bf16, int64_t ldw, int64_t rows,
 }
 extern "C" int avf_gemm_nt_ws(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B_packed, void* C,
                               int64_t ldc, int c_dtype, int epilogue, const float* bias, const void* residual, int64_t ldres,
-                              void* aux, int64_t ldaux, void* workspace, float* colsum, void* stream) {
+                              void* aux, int64_t ldaux, void* workspace, float* colsum, void* mx_q, void* mx_s, void* stream) {
   AVF_REQUIRE(A && B_packed && C, "gemm_nt_ws: null pointer");
   GemmArgs a;
   a.dtype = AVF_BF16; a.transA = 0; a.transB = 1;
@@ -248,8 +248,10 @@ extern "C" int avf_gemm_nt_ws(int64_t M, int64_t N, int64_t K, const void* A, in
   a.c_dtype = c_dtype; a.epilogue = epilogue; a.bias = bias; a.residual = residual; a.ldres = ldres;
   a.aux = aux; a.ldaux = ldaux; a.workspace = workspace; a.colsum = colsum; a.drop = kNoDrop; a.defer_fold = nullptr;
   a.Bp = B_packed;
+  a.mx_q = mx_q; a.mx_s = mx_s;
   AVF_REQUIRE(gemm_bf16_nt_ws_ok(a), "gemm_nt_ws: the weight-stationary kernel takes K == 512, N %% 256 == 0, M >= 2048, 16-byte "
-              "aligned operands (M=%lld N=%lld K=%lld)", (long long)M, (long long)N, (long long)K);
+              "aligned operands; an MX-FP8 image only with DGELU + colsum + a bf16 C (M=%lld N=%lld K=%lld)", (long long)M,
+              (long long)N, (long long)K);
   return gemm_bf16_nt(a, (hipStream_t)stream);
 }
 

@@ -424,6 +424,10 @@ struct GemmArgs {
   // bf16 NT only, optional: the fragment-major image of B (pack_ws; K == 512, N % 256 == 0) - the GEMM then runs on the
   // weight-stationary persistent kernel (gemm_ws.hip) when the shape qualifies
   const void* Bp = nullptr;
+  // ... and on that kernel only (BIAS_GELU / DGELU, N % 32 == 0): also the MX-FP8 image of C (e4m3 bytes [M][N], E8M0 scale
+  // bytes [M][N / 32]) - the fp8 mode's dGELU GEMM keeps bf16 operands there and still feeds the fp8 GEMM behind it
+  void* mx_q = nullptr;
+  void* mx_s = nullptr;
 };
 // weight-stationary persistent NT GEMM (gemm_ws.hip)
 // byte offset of element (n, k) of a weight [N][512] in its fragment-major image: 1 KiB pieces (panel of 256 rows, wave's 32

@@ -858,6 +858,8 @@ int gemm_bf16_nt(const GemmArgs& a, hipStream_t s) {
   AVF_REQUIRE(grid.y < 65536, "gemm_bf16_nt: M too large for grid");
   const bool cf32 = a.c_dtype == AVF_F32;
   AVF_REQUIRE(cf32 || a.c_dtype == AVF_BF16, "gemm_bf16_nt: bad c_dtype");
+  AVF_REQUIRE(!a.mx_q || gemm_bf16_nt_ws_ok(a), "gemm_bf16_nt: an MX-FP8 image of C exists on the weight-stationary kernel only "
+              "(ask gemm_bf16_nt_ws_ok first)");
   if (gemm_bf16_nt_ws_ok(a)) {  // K = 512 with a fragment-major weight image: the weight-stationary persistent kernel
     int ws_rows = 0;
     AVF_TRY(gemm_bf16_nt_ws(a, s, &ws_rows));

@@ -183,6 +183,14 @@ int launch_mx8(const Mx8Params& q, hipStream_t s, int* part_rows, TimingScope* t
   const int tiles_m = (q.nt.M + BMT - 1) / BMT, tiles_n = (q.nt.N + BNT - 1) / BNT;
   const int nwg = tiles_m * tiles_n;
   *part_rows = tiles_m * WM;
+  if (shape_log_on()) {
+    const NtParams& p = q.nt;
+    const double csz = sizeof(CT);
+    const double epi_b = (EPI == AVF_EPI_BIAS_RES || EPI == AVF_EPI_BIAS_GELU || EPI == AVF_EPI_DGELU) ? csz * p.M * p.N : 0.0;
+    shape_log("gemm_mx8_nt,gemm_mx8_nt_kernel<%d, %s, %d, %d, %d, %d, %d>,%d,%d,%d,%d,%d,%.0f,%.0f", EPI,
+              sizeof(CT) == 4 ? "float" : "bf16", WM, WN, MI, NI, LEAN, nwg, p.M, p.N, p.K, EPI + (p.mxq ? 10 : 0), 2.0 * p.M * p.N * p.K,
+              ((double)p.M * p.K + (double)p.N * p.K) * (1.0 + 1.0 / 32) + csz * p.M * p.N + epi_b + (p.mxq ? (double)p.M * p.N * (1.0 + 1.0 / 32) : 0.0));
+  }
   launch_in_scope(ts, gemm_mx8_nt_kernel<EPI, CT, WM, WN, MI, NI, LEAN>, dim3(nwg), dim3(WM * WN * 64), SMEM, s, q, tiles_n, nwg);
   return 0;
 }

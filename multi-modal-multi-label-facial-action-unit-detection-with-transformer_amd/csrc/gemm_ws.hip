@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void pack_ws_kernel(const bf16* __restrict__ w
   out[o] = *reinterpret_cast<const uint4*>(w + (int64_t)n * ldw + s * 32 + lg * 8);
 }
 
-template <int EPI, typename CT, int MI, int NSLOT, bool CS>
+template <int EPI, typename CT, int MI, int NSLOT, bool CS, bool MXO = false>
 __global__ __launch_bounds__(512) void gemm_bf16_nt_ws_kernel(NtParams p, const uint4* __restrict__ wp, int P, int G, int tq, int tr) {
   constexpr int NI = 2;
   constexpr int BM = 16 * MI;            // rows per tile
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_ws_kernel(NtParams p, const 
       p2.M = 0;  // every store predicated off
       nt_epilogue_lean<EPI, CT, MI, NI, 0, true>(p2, acc, (t0 + t) * BM, n0, li, lg, -1, &pre);
     } else {
-      nt_epilogue_lean<EPI, CT, MI, NI, CS ? 2 : 0, true>(p, acc, (t0 + t) * BM, n0, li, lg, -1, &pre, cs_acc);
+      nt_epilogue_lean<EPI, CT, MI, NI, CS ? 2 : 0, true, MXO>(p, acc, (t0 + t) * BM, n0, li, lg, -1, &pre, cs_acc);
     }
     __builtin_amdgcn_s_setprio(0);
     rd_slot = rd_slot + SLOT == NSLOT * SLOT ? 0 : rd_slot + SLOT;
@@ -309,7 +309,7 @@ int ws_grid() {
   return n;
 }
 
-template <int EPI, typename CT, int MI, int NSLOT, bool CS>
+template <int EPI, typename CT, int MI, int NSLOT, bool CS, bool MXO = false>
 int launch_ws(const NtParams& p, const void* bp, hipStream_t s, int* part_rows, TimingScope* ts) {
   constexpr int BM = 16 * MI;
   // the A ring, the per-wave staging of the epilogue's 2-byte operand rows (two tiles), [diagnostic build: the stamps]
@@ -317,7 +317,7 @@ int launch_ws(const NtParams& p, const void* bp, hipStream_t s, int* part_rows, 
   static_assert(SMEM <= 160 * 1024, "LDS budget");
   static PerDeviceOnce raised;
   if (SMEM > 64 * 1024 && raised.need()) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_ws_kernel<EPI, CT, MI, NSLOT, CS>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_ws_kernel<EPI, CT, MI, NSLOT, CS, MXO>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     AVF_REQUIRE(e == hipSuccess, "gemm_bf16_nt_ws: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
     raised.mark();
@@ -332,11 +332,11 @@ int launch_ws(const NtParams& p, const void* bp, hipStream_t s, int* part_rows, 
   if (shape_log_on()) {
     const double csz = sizeof(CT);
     const double epi_b = (EPI == AVF_EPI_BIAS_RES || EPI == AVF_EPI_BIAS_GELU || EPI == AVF_EPI_DGELU) ? csz * p.M * p.N : 0.0;
-    shape_log("gemm_bf16_nt,gemm_bf16_nt_ws_kernel<%d, %s, %d, %d, %s>,%d,%d,%d,%d,%d,%.0f,%.0f", EPI,
-              sizeof(CT) == 4 ? "float" : "bf16", MI, NSLOT, CS ? "true" : "false", nwg, p.M, p.N, p.K, EPI, 2.0 * p.M * p.N * p.K,
+    shape_log("gemm_bf16_nt,gemm_bf16_nt_ws_kernel<%d, %s, %d, %d, %s, %s>,%d,%d,%d,%d,%d,%.0f,%.0f", EPI,
+              sizeof(CT) == 4 ? "float" : "bf16", MI, NSLOT, CS ? "true" : "false", MXO ? "true" : "false", nwg, p.M, p.N, p.K, EPI, 2.0 * p.M * p.N * p.K,
               2.0 * ((double)p.M * p.K + (double)p.N * p.K) + csz * p.M * p.N + epi_b);
   }
-  launch_in_scope(ts, gemm_bf16_nt_ws_kernel<EPI, CT, MI, NSLOT, CS>, dim3(nwg), dim3(512), SMEM, s, p, (const uint4*)bp, P, G, T / G, T % G);
+  launch_in_scope(ts, gemm_bf16_nt_ws_kernel<EPI, CT, MI, NSLOT, CS, MXO>, dim3(nwg), dim3(512), SMEM, s, p, (const uint4*)bp, P, G, T / G, T % G);
   return 0;
 }
 
@@ -344,9 +344,11 @@ template <int EPI, typename CT>
 int launch_ws_any(const NtParams& p, const void* bp, hipStream_t s, int* part_rows, TimingScope* ts) {
   // column sums ride on the dGELU epilogue only (db1 of the layer's backward); other epilogues with a colsum request go to
   // the tiled kernel (gemm_bf16_nt_ws_ok)
-  if constexpr (EPI == AVF_EPI_DGELU) {
+  if constexpr (EPI == AVF_EPI_DGELU && sizeof(CT) == 2) {
+    if (p.cs_partial && p.mxq) return launch_ws<EPI, CT, 2, 3, true, true>(p, bp, s, part_rows, ts);  // (the fp8 mode's dGELU)
     if (p.cs_partial) return launch_ws<EPI, CT, 2, 3, true>(p, bp, s, part_rows, ts);
   }
+  AVF_REQUIRE(!p.mxq && !p.cs_partial, "gemm_bf16_nt_ws: no instantiation for this combination of options (internal error)");
   return launch_ws<EPI, CT, 2, 3, false>(p, bp, s, part_rows, ts);
 }
 
@@ -385,6 +387,9 @@ bool gemm_bf16_nt_ws_ok(const GemmArgs& a) {
   // the lean epilogue (gemm_nt.hpp) has no dropout site and sums columns on the dGELU epilogue only
   if (a.drop.thresh16) return false;
   if (a.colsum && a.epilogue != AVF_EPI_DGELU) return false;
+  // the MX-FP8 image of C: on the dGELU form with column sums only (what the fp8 mode's backward asks for)
+  if (a.mx_q && !(a.mx_s && a.epilogue == AVF_EPI_DGELU && a.colsum && a.c_dtype == AVF_BF16 && a.N % 32 == 0 && ((uintptr_t)a.mx_q & 7) == 0))
+    return false;
   if (a.c_dtype == AVF_BF16 && (a.N % 8 || a.ldc % 8)) return false;
   return a.N / WS_BN <= ws_grid();
 }
@@ -401,7 +406,7 @@ int gemm_bf16_nt_ws(const GemmArgs& a, hipStream_t s, int* part_rows_out) {
   p.C = a.C; p.ldc = a.ldc; p.bias = a.bias; p.residual = a.residual; p.ldres = a.ldres;
   p.aux = a.aux; p.ldaux = a.ldaux;
   p.drop = a.drop;
-  p.mxq = nullptr; p.mxs = nullptr;
+  p.mxq = (uint8_t*)a.mx_q; p.mxs = (uint8_t*)a.mx_s;
   p.wide = nt_wide_stores();
   p.M = (int)a.M; p.N = (int)a.N; p.K = (int)a.K;
   p.cs_partial = a.colsum ? (float*)a.workspace : nullptr;

@@ -182,9 +182,10 @@ def pack_ws(w: torch.Tensor) -> torch.Tensor:
 
 def gemm_ws(a: torch.Tensor, w_packed: torch.Tensor, n_out: int, out_dtype=None, epilogue: int = EPI_NONE,
             bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, aux: Optional[torch.Tensor] = None,
-            want_colsum: bool = False):
+            want_colsum: bool = False, want_image: bool = False):
     """C = epilogue(A W^T) on the weight-stationary persistent kernel (avf_gemm_nt_ws); w_packed = pack_ws(W[n_out, 512]).
-    Returns C (and the saved pre-activation for EPI_BIAS_GELU; and the column sums of C with want_colsum)."""
+    Returns C (and the saved pre-activation for EPI_BIAS_GELU; and the column sums of C with want_colsum; and with want_image
+    - EPI_DGELU with want_colsum - the MX-FP8 image (q, scales) of the fp32 values behind C)."""
     _need_cuda(a, w_packed, bias, residual, aux)
     lib = _lib.load()
     a = _rows2d(a)
@@ -198,14 +199,19 @@ def gemm_ws(a: torch.Tensor, w_packed: torch.Tensor, n_out: int, out_dtype=None,
     ws = _bytes(lib.avf_colsum_workspace_bytes(M, n_out) + (M // 32 + 8) * n_out * 4, a.device) if want_colsum else None
     if residual is not None:
         residual = residual.contiguous()
+    cq = torch.empty((M, n_out), dtype=torch.uint8, device=a.device) if want_image else None
+    csc = torch.empty((M, n_out // 32), dtype=torch.uint8, device=a.device) if want_image else None
     _lib.check(lib.avf_gemm_nt_ws(M, n_out, K, _ptr(a), a.stride(0), _ptr(w_packed), _ptr(c), c.stride(0), avf_dtype(cdt),
-                                  epilogue, _ptr(bias), _ptr(residual), n_out, _ptr(aux), n_out, _ptr(ws), _ptr(cs), _stream()),
+                                  epilogue, _ptr(bias), _ptr(residual), n_out, _ptr(aux), n_out, _ptr(ws), _ptr(cs), _ptr(cq),
+                                  _ptr(csc), _stream()),
                "gemm_nt_ws")
     res = (c,)
     if made_aux is not None:
         res += (made_aux,)
     if want_colsum:
         res += (cs,)
+    if want_image:
+        res += (cq, csc)
     return res[0] if len(res) == 1 else res
 
 

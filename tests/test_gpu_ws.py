@@ -95,6 +95,25 @@ def test_column_sums_of_the_dgelu_form():
     assert torch.equal(c, ops.gemm(a, w, out_dtype=bf, epilogue=ops.EPI_DGELU, aux=aux))
 
 
+def test_dgelu_form_emits_the_mx_fp8_image_of_its_product():
+    """the fp8 mode's dGELU GEMM runs on this kernel with bf16 operands and writes the MX-FP8 image of du for the fp8 GEMM
+    behind it.  Exact check: sparse {-1, 0, 1} operands make every accumulator a small integer and u = 30 makes gelu'(u) = 1
+    exactly, so the fp32 value behind C IS the stored bf16 value and the image must be the OCP conversion of C bit for bit."""
+    import oracle
+    M, N = 4096, 1024
+    g = torch.Generator(device="cuda").manual_seed(11)
+    a = ((torch.rand(M, 512, device="cuda", generator=g) < 1 / 16).float() * torch.randint(0, 2, (M, 512), device="cuda", generator=g).mul(2).sub(1)).to(bf)
+    w = torch.randint(-1, 2, (N, 512), device="cuda", generator=g).to(bf)
+    u = torch.full((M, N), 30.0, device="cuda").to(bf)
+    c, cs, q, sc = ops.gemm_ws(a, ops.pack_ws(w), N, out_dtype=bf, epilogue=ops.EPI_DGELU, aux=u, want_colsum=True, want_image=True)
+    ref = a.double() @ w.double().t()
+    assert torch.equal(c.double(), ref)
+    q_ref, s_ref = oracle.mx8_quant(c.float().cpu())
+    assert torch.equal(sc.cpu(), s_ref)
+    assert torch.equal(q.cpu(), q_ref)
+    assert torch.equal(cs.double(), ref.sum(0))
+
+
 def test_unfit_shapes_are_refused_and_the_layer_falls_back():
     a = torch.randn(1024, 512, device="cuda").to(bf)  # fewer than 2048 rows
     w = torch.randn(512, 512, device="cuda").to(bf)
