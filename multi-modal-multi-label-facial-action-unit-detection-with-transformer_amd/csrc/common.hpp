@@ -354,37 +354,43 @@ struct FoldList {
   FoldJob job[3];
   int count;
 };
-// 32 columns (8 quads) x 32 row groups per 256-thread block; width % 4 == 0, 16-byte aligned partials
-__device__ __forceinline__ void fold_columns_vec(const FoldJob& j, int colgroup, float4 (*red)[8]) {
-  const int cq = threadIdx.x & 7, grp = threadIdx.x >> 3;
-  const int col = colgroup * 32 + cq * 4;
-  float4 a[4];
+// 16 columns (4 quads) x 64 row groups per 256-thread block, eight 16-byte loads per thread in flight; width % 4 == 0, 16-byte
+// aligned partials.  (Round 4: 32 columns x 32 row groups with four loads in flight put 48 blocks on the 1536 columns of a
+// LayerNorm fold, each walking 1024 partial rows with 16 KiB in flight - latency-bound at ~8 GB/s per CU, 12 of the 19.5 us of
+// the layer's fold launch at C3.  Half the columns per block and twice the loads in flight: four times the bytes in flight.)
+constexpr int FOLD_COLS = 16, FOLD_RG = 64;
+__device__ __forceinline__ void fold_columns_vec(const FoldJob& j, int colgroup, float4 (*red)[FOLD_COLS / 4]) {
+  const int cq = threadIdx.x & (FOLD_COLS / 4 - 1), grp = threadIdx.x / (FOLD_COLS / 4);
+  const int col = colgroup * FOLD_COLS + cq * 4;
+  float4 a[8];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int u = 0; u < 8; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (col < j.width) {
     int b = grp;
-    for (; b + 96 < j.nb; b += 128) {
+    for (; b + 7 * FOLD_RG < j.nb; b += 8 * FOLD_RG) {
+      float4 t[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float4 t = *reinterpret_cast<const float4*>(j.partial + (int64_t)(b + 32 * u) * j.width + col);
-        a[u].x += t.x; a[u].y += t.y; a[u].z += t.z; a[u].w += t.w;
-      }
+      for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const float4*>(j.partial + (int64_t)(b + FOLD_RG * u) * j.width + col);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a[u].x += t[u].x; a[u].y += t[u].y; a[u].z += t[u].z; a[u].w += t[u].w; }
     }
-    for (; b < j.nb; b += 32) {
+    for (; b < j.nb; b += FOLD_RG) {
       const float4 t = *reinterpret_cast<const float4*>(j.partial + (int64_t)b * j.width + col);
       a[0].x += t.x; a[0].y += t.y; a[0].z += t.z; a[0].w += t.w;
     }
   }
-  red[grp][cq] = make_float4((a[0].x + a[1].x) + (a[2].x + a[3].x), (a[0].y + a[1].y) + (a[2].y + a[3].y),
-                             (a[0].z + a[1].z) + (a[2].z + a[3].z), (a[0].w + a[1].w) + (a[2].w + a[3].w));
+  red[grp][cq] = make_float4(((a[0].x + a[1].x) + (a[2].x + a[3].x)) + ((a[4].x + a[5].x) + (a[6].x + a[7].x)),
+                             ((a[0].y + a[1].y) + (a[2].y + a[3].y)) + ((a[4].y + a[5].y) + (a[6].y + a[7].y)),
+                             ((a[0].z + a[1].z) + (a[2].z + a[3].z)) + ((a[4].z + a[5].z) + (a[6].z + a[7].z)),
+                             ((a[0].w + a[1].w) + (a[2].w + a[3].w)) + ((a[4].w + a[5].w) + (a[6].w + a[7].w)));
   __syncthreads();
-  if (threadIdx.x < 32) {  // thread -> (quad, component)
+  if (threadIdx.x < FOLD_COLS) {  // thread -> (quad, component)
     const int q = threadIdx.x >> 2, comp = threadIdx.x & 3;
-    const int c = colgroup * 32 + threadIdx.x;
+    const int c = colgroup * FOLD_COLS + threadIdx.x;
     if (c < j.width) {
       float v = 0.f;
 #pragma unroll
-      for (int g2 = 0; g2 < 32; ++g2) v += reinterpret_cast<const float*>(&red[g2][q])[comp];
+      for (int g2 = 0; g2 < FOLD_RG; ++g2) v += reinterpret_cast<const float*>(&red[g2][q])[comp];
       const int which = c / j.seg, cc = c - which * j.seg;
       float* dst = which == 0 ? j.o0 : (which == 1 ? j.o1 : j.o2);
       if (dst) dst[cc] = v;

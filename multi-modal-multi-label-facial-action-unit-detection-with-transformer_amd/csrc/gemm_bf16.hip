@@ -754,9 +754,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_tn_group_big_kernel(TnGroup g) 
 template <int SS>  // SS > 0: the split count, fully unrolled (all slab loads of an element in flight); 0: runtime g.S
 __global__ __launch_bounds__(256) void fold_group_kernel(TnGroup g, int nslab, FoldList fl) {
   if ((int)blockIdx.y >= nslab) {
-    __shared__ float4 red[32][8];
+    __shared__ float4 red[FOLD_RG][FOLD_COLS / 4];
     const FoldJob& job = fl.job[blockIdx.y - nslab];
-    const int groups = (job.width + 31) / 32;
+    const int groups = (job.width + FOLD_COLS - 1) / FOLD_COLS;
     for (int cg = blockIdx.x; cg < groups; cg += gridDim.x) fold_columns_vec(job, cg, red);
     return;
   }

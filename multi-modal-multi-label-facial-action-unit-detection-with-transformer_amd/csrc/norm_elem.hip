@@ -552,18 +552,17 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restr
   }
 }
 
-// width % 4 == 0: 8 column quads (32 columns) x 32 row groups per block, 16-byte loads, 4 loads in flight
+// width % 4 == 0: FOLD_COLS columns x FOLD_RG row groups per block, 16-byte loads, 8 loads in flight (common.hpp)
 __global__ __launch_bounds__(256) void fold_partials_vec_kernel(FoldJob job) {
-  __shared__ float4 red[32][8];
+  __shared__ float4 red[FOLD_RG][FOLD_COLS / 4];
   fold_columns_vec(job, blockIdx.x, red);
 }
 
 static int launch_fold(const float* partial, int nb, int width, float* o0, float* o1, float* o2, int seg, hipStream_t s) {
-  const unsigned grid = (unsigned)ceil_div(width, 32);
   if (width % 4 == 0 && (((uintptr_t)partial) & 15) == 0)
-    fold_partials_vec_kernel<<<grid, 256, 0, s>>>(FoldJob{partial, nb, width, seg, o0, o1, o2});
+    fold_partials_vec_kernel<<<(unsigned)ceil_div(width, FOLD_COLS), 256, 0, s>>>(FoldJob{partial, nb, width, seg, o0, o1, o2});
   else
-    fold_partials_kernel<<<grid, 256, 0, s>>>(partial, nb, width, o0, o1, o2, seg);
+    fold_partials_kernel<<<(unsigned)ceil_div(width, 32), 256, 0, s>>>(partial, nb, width, o0, o1, o2, seg);
   return check_launch("fold_partials_kernel");
 }
 
