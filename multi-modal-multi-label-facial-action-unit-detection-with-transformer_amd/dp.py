@@ -28,10 +28,19 @@ class _GlobalMeanFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, s, k, world, group):
-        pack = torch.stack([s.detach().to(torch.float32), k.detach().to(torch.float32)])
+        # s and k as AULoss hands them over are the two elements of ONE float32 2-vector (ops.au_loss_sum): reduce that
+        # vector where it lies instead of stacking a copy (each tiny kernel here sits between forward and backward)
+        pack = None
+        if (s.dtype == torch.float32 and k.dtype == torch.float32 and s.dim() == 0 and k.dim() == 0
+                and s.untyped_storage().data_ptr() == k.untyped_storage().data_ptr()
+                and k.storage_offset() == s.storage_offset() + 1):
+            pack = torch.empty(0, dtype=torch.float32, device=s.device).set_(s.untyped_storage(), s.storage_offset(), (2,))
+        if pack is None:
+            pack = torch.stack([s.detach().to(torch.float32), k.detach().to(torch.float32)])
         dist.all_reduce(pack, op=dist.ReduceOp.SUM, group=group)
-        ctx.scale = float(world) / pack[1]  # a tensor: no host synchronisation (K = 0 on every rank -> NaN, as the reference)
-        return pack[0] / pack[1]
+        inv = torch.reciprocal(pack[1])  # a tensor: no host synchronisation (K = 0 on every rank -> NaN, as the reference)
+        ctx.scale = inv * float(world)
+        return pack[0] * inv
 
     @staticmethod
     def backward(ctx, g):
@@ -161,12 +170,13 @@ class DataParallel:
         for work, _ in self._pending:
             work.wait()  # CUDA: the current stream waits (no host block); gloo: blocks until done
         if bucket is not None:
-            off, srcs = 0, []
+            # the reduced gradients stay where the collective left them: every .grad becomes a view of the bucket (no copy
+            # back; the optimizers read .grad through its data pointer)
+            off = 0
             for p in rest:
                 n = p.numel()
-                srcs.append(bucket[off:off + n].view_as(p.grad))
+                p.grad = bucket[off:off + n].view_as(p)
                 off += n
-            torch._foreach_copy_([p.grad for p in rest], srcs)  # one launch for all of them
         self._pending.clear()
 
     def __call__(self, *a, **k):
