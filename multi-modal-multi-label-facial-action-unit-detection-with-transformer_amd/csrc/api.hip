@@ -247,7 +247,7 @@ extern "C" int avf_gemm_nt_ws(int64_t M, int64_t N, int64_t K, const void* A, in
   a.A = A; a.lda = lda; a.B = nullptr; a.ldb = K; a.C = C; a.ldc = ldc;
   a.c_dtype = c_dtype; a.epilogue = epilogue; a.bias = bias; a.residual = residual; a.ldres = ldres;
   a.aux = aux; a.ldaux = ldaux; a.workspace = workspace; a.colsum = colsum; a.drop = kNoDrop; a.defer_fold = nullptr;
-  a.Bp = B_packed;
+  a.Bp = B_packed; a.ws_force = 1;
   a.mx_q = mx_q; a.mx_s = mx_s;
   AVF_REQUIRE(gemm_bf16_nt_ws_ok(a), "gemm_nt_ws: the weight-stationary kernel takes K == 512, N %% 256 == 0, M >= 2048, 16-byte "
               "aligned operands; an MX-FP8 image only with DGELU + colsum + a bf16 C (M=%lld N=%lld K=%lld)", (long long)M,

@@ -430,6 +430,7 @@ struct GemmArgs {
   // bf16 NT only, optional: the fragment-major image of B (pack_ws; K == 512, N % 256 == 0) - the GEMM then runs on the
   // weight-stationary persistent kernel (gemm_ws.hip) when the shape qualifies
   const void* Bp = nullptr;
+  int ws_force = 0;  // 1: take that kernel whenever it can run the shape (avf_gemm_nt_ws); 0: where it is the faster one
   // ... and on that kernel only (BIAS_GELU / DGELU, N % 32 == 0): also the MX-FP8 image of C (e4m3 bytes [M][N], E8M0 scale
   // bytes [M][N / 32]) - the fp8 mode's dGELU GEMM keeps bf16 operands there and still feeds the fp8 GEMM behind it
   void* mx_q = nullptr;
@@ -452,6 +453,7 @@ size_t pack_ws_bytes(int64_t N, int64_t K);
 bool pack_ws_ok(int64_t N, int64_t K);
 int pack_ws(const void* w_bf16, int64_t ldw, int64_t N, int64_t K, void* out, hipStream_t s);
 bool gemm_bf16_nt_ws_ok(const GemmArgs& a);
+bool gemm_bf16_nt_ws_preferred(const GemmArgs& a);
 int gemm_bf16_nt_ws(const GemmArgs& a, hipStream_t s, int* part_rows_out);
 size_t gemm_ws(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K);
 int gemm(const GemmArgs& a, hipStream_t s);

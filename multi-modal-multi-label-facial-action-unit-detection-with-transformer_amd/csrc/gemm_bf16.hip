@@ -860,7 +860,8 @@ int gemm_bf16_nt(const GemmArgs& a, hipStream_t s) {
   AVF_REQUIRE(cf32 || a.c_dtype == AVF_BF16, "gemm_bf16_nt: bad c_dtype");
   AVF_REQUIRE(!a.mx_q || gemm_bf16_nt_ws_ok(a), "gemm_bf16_nt: an MX-FP8 image of C exists on the weight-stationary kernel only "
               "(ask gemm_bf16_nt_ws_ok first)");
-  if (gemm_bf16_nt_ws_ok(a)) {  // K = 512 with a fragment-major weight image: the weight-stationary persistent kernel
+  // K = 512 with a fragment-major weight image: the weight-stationary persistent kernel - where it is the faster one, or asked for
+  if ((a.ws_force || a.mx_q) ? gemm_bf16_nt_ws_ok(a) : gemm_bf16_nt_ws_preferred(a)) {
     int ws_rows = 0;
     AVF_TRY(gemm_bf16_nt_ws(a, s, &ws_rows));
     if (a.colsum) {

@@ -394,6 +394,32 @@ bool gemm_bf16_nt_ws_ok(const GemmArgs& a) {
   return a.N / WS_BN <= ws_grid();
 }
 
+// ... and the shapes gemm_bf16_nt() SENDS there (avf_gemm_nt_ws takes every shape the kernel can run)
+bool gemm_bf16_nt_ws_preferred(const GemmArgs& a) {
+  if (!gemm_bf16_nt_ws_ok(a)) return false;
+  {
+    static const int mask = [] {
+      const char* e = getenv("AVF_NT_WS_EPI");  // tuning aid: bit e set = epilogue e (AVF_EPI_*) may take the persistent kernel
+      return (e && *e) ? atoi(e) : 15;
+    }();
+    if (!((mask >> a.epilogue) & 1) && !a.mx_q) return false;
+  }
+  // bias + residual (the out-projection, N = dim): the persistent kernel pays its prologue (a CU's 256 KiB of weights out of
+  // L2, ~3 us) once per workgroup; with 4 row tiles per workgroup (C3: 512 tiles over 128 groups) the tiled kernel is ahead -
+  // 15.5 against 16.8 us at C3, 13.1 against 14.4 at C2, per-shape rocprof of the pipeline - so this form needs 6 tiles
+  if (a.epilogue == AVF_EPI_BIAS_RES) {
+    const int64_t P = a.N / WS_BN, T = (a.M + 31) / 32;
+    int64_t G = ws_grid() / P;
+    G = G > T ? T : G;
+    static const int min_tiles = [] {
+      const char* e = getenv("AVF_NT_WS_RES_TILES");  // tuning aid
+      return (e && *e) ? atoi(e) : 6;
+    }();
+    if (T / G < min_tiles) return false;
+  }
+  return true;
+}
+
 int gemm_bf16_nt_ws(const GemmArgs& a, hipStream_t s, int* part_rows_out) {
   AVF_REQUIRE(gemm_bf16_nt_ws_ok(a), "gemm_bf16_nt_ws: unsupported shape / arguments");
   NtParams p;
