@@ -102,6 +102,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_ws_kernel(NtParams p, const 
   if (stamp_on)
     for (int i = 0; i < WS_NSTAMP; ++i) stamp_lds[i] = 0;
   WS_STAMP(0);
+#if AVF_WS_STAMPS
+  if (stamp_on) stamp_lds[62] = (unsigned long long)__builtin_amdgcn_s_memrealtime();  // the 100 MHz constant clock: calibrates s_memtime
+#endif
 #endif
 
   // LDS-DMA pieces of a tile: piece q = wave + 8 jj covers k-chunk q / PPW, rows 8 (q % PPW) .. + 7; lane l fills row l >> 3,
@@ -283,6 +286,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_ws_kernel(NtParams p, const 
   if constexpr (CS) nt_cs_flush<NI>(p, cs_acc, grp, n0, li, lg);
 #if AVF_WS_STAMPS
   WS_STAMP(3);
+  if (stamp_on) stamp_lds[63] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
   if (stamp_on && blockIdx.x < 512)
     for (int i = 0; i < WS_NSTAMP; ++i) g_ws_stamps[(blockIdx.x * 8 + wave) * WS_NSTAMP + i] = stamp_lds[i];
 #endif

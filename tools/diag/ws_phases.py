@@ -52,6 +52,10 @@ def main():
     full = [g for g in live if st[g][0][4 + 6 * (ntile - 1)] != 0]
     print(f"M={M} N={N} epi={args.epi}: {len(live)} live workgroups, up to {ntile} tiles ({len(full)} workgroups with that many)")
     med = lambda xs: int(statistics.median(xs))
+    # stamps 62 / 63: s_memrealtime (100 MHz) beside stamps 0 / 3 (s_memtime): the rate of the cycle counter during this kernel
+    rt = [(st[g][0][3] - st[g][0][0]) / max(1, st[g][0][63] - st[g][0][62]) * 100.0 for g in live if st[g][0][63] > st[g][0][62]]
+    if rt:
+        print(f"s_memtime ticks at {statistics.median(rt):.0f} MHz during this kernel (against the 100 MHz s_memrealtime)")
     for h, nm in [(w, f"wave {w} ({'early' if w < 4 else 'late'})") for w in range(NWV)]:
         d = lambda i, j: med([st[g][h][j] - st[g][h][i] for g in full])
         print(f"{nm}: total {d(0, 3)}  issue(DMA+W) {d(0, 1)}  W/tile0 arrival {d(1, 2)}  to first tile top {d(2, 4)}")
