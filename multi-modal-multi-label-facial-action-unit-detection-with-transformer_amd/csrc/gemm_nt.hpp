@@ -334,7 +334,8 @@ __device__ __forceinline__ void nt_cs_flush(const NtParams& p, float (&cs)[NI][4
 // MXO: also emit the MX-FP8 image of the values as computed (fp32, before their rounding to CT) into p.mxq / p.mxs - a 32-block
 // is the column-block pair (j, j + 1) x the four lane groups x 4 registers; the block maximum crosses the lane groups on the
 // VALU (v_permlane32_swap / v_permlane16_swap) where nt_epilogue takes two LDS round trips (__shfl_xor)
-template <int EPI, typename CT, int MI, int NI, int CS, bool PRE, bool FULL, bool MXO = false>
+// BIAS = false: the caller vouches for p.bias == nullptr (no bias registers, no adds of zeros)
+template <int EPI, typename CT, int MI, int NI, int CS, bool PRE, bool FULL, bool MXO = false, bool BIAS = true>
 __device__ __forceinline__ void nt_epilogue_lean_body(const NtParams& p, f32x4_t (&acc)[MI][NI], int m_base, int n_base, int li,
                                                       int lg, int part_row, const NtPre<MI, NI>* pre, float (*cs_acc)[4]) {
   static_assert(sizeof(CT) == 4 || (NI & 1) == 0, "2-byte outputs are stored in column-block pairs");
@@ -343,7 +344,8 @@ __device__ __forceinline__ void nt_epilogue_lean_body(const NtParams& p, f32x4_t
   float4 bj[NI];
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
-    if constexpr (PRE) bj[j] = pre->bj[j];
+    if constexpr (!BIAS) bj[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    else if constexpr (PRE) bj[j] = pre->bj[j];
     else bj[j] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n0 + 16 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   float cs[NI][4];
@@ -356,6 +358,10 @@ __device__ __forceinline__ void nt_epilogue_lean_body(const NtParams& p, f32x4_t
     const int m = m_base + 16 * i + li;
     const bool mok = FULL || m < p.M;
     const int mc = mok ? m : p.M - 1;
+    // addresses as (wave-uniform tile offset) + (per-lane offset that does not depend on the tile): a persistent kernel's tile
+    // loop then keeps the per-lane part in a register and the 64-bit arithmetic on the scalar unit - every vector instruction
+    // of the epilogue competes with the MFMA stream for the SIMD's issue
+    const uint32_t lrow = (uint32_t)(16 * i + li);
     float4 ex[NI];
     if constexpr (EPI == AVF_EPI_BIAS_RES || EPI == AVF_EPI_DGELU) {
       if constexpr (sizeof(CT) == 2) {
@@ -365,6 +371,7 @@ __device__ __forceinline__ void nt_epilogue_lean_body(const NtParams& p, f32x4_t
         for (int j = 0; j < NI; j += 2) {
           uint4 raw;
           if constexpr (PRE) raw = pre->raw[i][j >> 1];
+          else if constexpr (FULL) raw = *reinterpret_cast<const uint4*>(src + (int64_t)m_base * ldx + (uint32_t)(lrow * (uint32_t)ldx + (uint32_t)(cp0 + 16 * j)));
           else raw = *reinterpret_cast<const uint4*>(src + (int64_t)mc * ldx + cp0 + 16 * j);
           const auto s0 = __builtin_amdgcn_permlane16_swap(raw.x, raw.z, false, false);
           const auto s1 = __builtin_amdgcn_permlane16_swap(raw.y, raw.w, false, false);
@@ -389,14 +396,19 @@ __device__ __forceinline__ void nt_epilogue_lean_body(const NtParams& p, f32x4_t
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       float v[4];
-      v[0] = acc[i][j][0] + bj[j].x; v[1] = acc[i][j][1] + bj[j].y; v[2] = acc[i][j][2] + bj[j].z; v[3] = acc[i][j][3] + bj[j].w;
+      if constexpr (BIAS) {
+        v[0] = acc[i][j][0] + bj[j].x; v[1] = acc[i][j][1] + bj[j].y; v[2] = acc[i][j][2] + bj[j].z; v[3] = acc[i][j][3] + bj[j].w;
+      } else {  // (x + 0.0f is x for every x but -0.0f, which no consumer distinguishes; the product paths pass no bias here)
+        v[0] = acc[i][j][0]; v[1] = acc[i][j][1]; v[2] = acc[i][j][2]; v[3] = acc[i][j][3];
+      }
       if constexpr (EPI == AVF_EPI_BIAS_RES) {
         v[0] += ex[j].x; v[1] += ex[j].y; v[2] += ex[j].z; v[3] += ex[j].w;
       } else if constexpr (EPI == AVF_EPI_BIAS_GELU) {
         if constexpr (sizeof(CT) == 2) {
           aw[j][0] = pack_bf16x2(v[0], v[1]); aw[j][1] = pack_bf16x2(v[2], v[3]);
         } else if (mok) {
-          store4<CT>((CT*)p.aux + (int64_t)m * p.ldaux + n0 + 16 * j, make_float4(v[0], v[1], v[2], v[3]));
+          store4<CT>((CT*)p.aux + (int64_t)m_base * p.ldaux + (uint32_t)(lrow * (uint32_t)p.ldaux + (uint32_t)(n0 + 16 * j)),
+                     make_float4(v[0], v[1], v[2], v[3]));
         }
         v[0] = gelu_tanh_fast(v[0]); v[1] = gelu_tanh_fast(v[1]); v[2] = gelu_tanh_fast(v[2]); v[3] = gelu_tanh_fast(v[3]);
       } else if constexpr (EPI == AVF_EPI_DGELU) {
@@ -439,13 +451,13 @@ __device__ __forceinline__ void nt_epilogue_lean_body(const NtParams& p, f32x4_t
         }
       }
       if (mok) {
-        bf16* crow = (bf16*)p.C + (int64_t)m * p.ldc + cp0;
+        bf16* crow = (bf16*)p.C + (int64_t)m_base * p.ldc + (uint32_t)(lrow * (uint32_t)p.ldc + (uint32_t)cp0);
 #pragma unroll
         for (int j = 0; j < NI; j += 2) *reinterpret_cast<uint4*>(crow + 16 * j) = sc[j >> 1];
         if constexpr (EPI == AVF_EPI_BIAS_GELU) {
           // the saved pre-activation is read again in backward only: non-temporal (as nt_epilogue; p.wide == 3: plain)
           typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));
-          bf16* arow = (bf16*)p.aux + (int64_t)m * p.ldaux + cp0;
+          bf16* arow = (bf16*)p.aux + (int64_t)m_base * p.ldaux + (uint32_t)(lrow * (uint32_t)p.ldaux + (uint32_t)cp0);
 #pragma unroll
           for (int j = 0; j < NI; j += 2) {
             const u32x4_nt v4 = {sa[j >> 1].x, sa[j >> 1].y, sa[j >> 1].z, sa[j >> 1].w};
@@ -454,7 +466,7 @@ __device__ __forceinline__ void nt_epilogue_lean_body(const NtParams& p, f32x4_t
         }
       }
     } else if (mok) {
-      float* crow = (float*)p.C + (int64_t)m * p.ldc + n0;
+      float* crow = (float*)p.C + (int64_t)m_base * p.ldc + (uint32_t)(lrow * (uint32_t)p.ldc + (uint32_t)n0);
 #pragma unroll
       for (int j = 0; j < NI; ++j) *reinterpret_cast<float4*>(crow + 16 * j) = vf[j];
     }
@@ -483,13 +495,13 @@ __device__ __forceinline__ void nt_epilogue_lean_body(const NtParams& p, f32x4_t
   }
   if constexpr (CS == 1) nt_cs_flush<NI>(p, cs, part_row, n_base, li, lg);
 }
-template <int EPI, typename CT, int MI, int NI, int CS, bool PRE, bool MXO = false>
+template <int EPI, typename CT, int MI, int NI, int CS, bool PRE, bool MXO = false, bool BIAS = true>
 __device__ __forceinline__ void nt_epilogue_lean(const NtParams& p, f32x4_t (&acc)[MI][NI], int m_base, int n_base, int li, int lg,
                                                  int part_row, const NtPre<MI, NI>* pre = nullptr, float (*cs_acc)[4] = nullptr) {
   if (m_base + 16 * MI <= p.M)
-    nt_epilogue_lean_body<EPI, CT, MI, NI, CS, PRE, true, MXO>(p, acc, m_base, n_base, li, lg, part_row, pre, cs_acc);
+    nt_epilogue_lean_body<EPI, CT, MI, NI, CS, PRE, true, MXO, BIAS>(p, acc, m_base, n_base, li, lg, part_row, pre, cs_acc);
   else
-    nt_epilogue_lean_body<EPI, CT, MI, NI, CS, PRE, false, MXO>(p, acc, m_base, n_base, li, lg, part_row, pre, cs_acc);
+    nt_epilogue_lean_body<EPI, CT, MI, NI, CS, PRE, false, MXO, BIAS>(p, acc, m_base, n_base, li, lg, part_row, pre, cs_acc);
 }
 
 typedef __attribute__((address_space(1))) const void gptr_t;

@@ -277,7 +277,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_ws_kernel(NtParams p, const 
       p2.M = 0;  // every store predicated off
       nt_epilogue_lean<EPI, CT, MI, NI, 0, true>(p2, acc, (t0 + t) * BM, n0, li, lg, -1, &pre);
     } else {
-      nt_epilogue_lean<EPI, CT, MI, NI, CS ? 2 : 0, true, MXO>(p, acc, (t0 + t) * BM, n0, li, lg, -1, &pre, cs_acc);
+      // (no bias on the plain and the dGELU form: gemm_bf16_nt_ws_ok)
+      nt_epilogue_lean<EPI, CT, MI, NI, CS ? 2 : 0, true, MXO, EPI != AVF_EPI_NONE && EPI != AVF_EPI_DGELU>(
+          p, acc, (t0 + t) * BM, n0, li, lg, -1, &pre, cs_acc);
     }
     __builtin_amdgcn_s_setprio(0);
     rd_slot = rd_slot + SLOT == NSLOT * SLOT ? 0 : rd_slot + SLOT;
@@ -388,6 +390,7 @@ bool gemm_bf16_nt_ws_ok(const GemmArgs& a) {
   if (a.epilogue == AVF_EPI_BIAS_RES && (a.ldres % 8 || ((uintptr_t)a.residual & 15))) return false;
   if ((a.epilogue == AVF_EPI_DGELU || a.epilogue == AVF_EPI_BIAS_GELU) && (a.ldaux % 8 || ((uintptr_t)a.aux & 15))) return false;
   if (a.epilogue == AVF_EPI_DGELU && a.c_dtype != AVF_BF16) return false;
+  if ((a.epilogue == AVF_EPI_DGELU || a.epilogue == AVF_EPI_NONE) && a.bias) return false;  // (compiled without the bias add)
   // the lean epilogue (gemm_nt.hpp) has no dropout site and sums columns on the dGELU epilogue only
   if (a.drop.thresh16) return false;
   if (a.colsum && a.epilogue != AVF_EPI_DGELU) return false;
