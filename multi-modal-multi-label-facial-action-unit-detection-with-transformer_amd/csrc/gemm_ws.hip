@@ -136,7 +136,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_ws_kernel(NtParams p, const 
   // The 256 KiB of a workgroup's panel come out of the XCD's L2 at the rate all its CUs share (3.5 us when the eight waves of
   // every CU ask at once), so the two wave halves take TURNS: waves 0..3 load first and run tile 0 while waves 4..7 - which
   // trail them by half a period for the whole launch anyway - load theirs.
-  const bool late = wave >= 4;  // wave-uniform
+  // Two schedules.  Plain stores (EPI_NONE): the two wave halves run half a period apart - waves 4..7 take the tile barrier
+  // between their MFMAs and their epilogue -, so one half's stores drain under the other half's MFMAs.  Epilogues with
+  // arithmetic (bias + residual, GELU, dGELU): every wave takes the barrier at the top of the tile, MFMA phases together and
+  // epilogues together - a wave's vector instructions get ~1 issue slot per MFMA of its SIMD partner
+  // (tools/diag/mfma_valu_overlap.hip), so an epilogue of 130 - 220 of them runs 1.7x longer beside a partner in its MFMA
+  // phase than beside one in its own epilogue (MLP1 27.9 -> 25.8 us, dGELU 25.5 -> 24.2 alone; QKV 29.6 -> 30.4 the other way)
+#ifndef AVF_WS_INPHASE
+#define AVF_WS_INPHASE (EPI != AVF_EPI_NONE)
+#endif
+  const bool late = !(AVF_WS_INPHASE) && wave >= 4;  // wave-uniform
   bf16x8_t wr[NI][WS_KS];
   const bf16x8_t* wsrc = reinterpret_cast<const bf16x8_t*>(wp) + ((size_t)(panel * 8 + wave) * NI * WS_KS) * 64 + lane;
   if (!late) {
