@@ -13,13 +13,54 @@
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
 typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4_t;
 
+#ifndef PLAIN_VALU
+#define PLAIN_VALU 0  // 1: the non-transcendental stream is v_fma_f32 kept scalar (inline asm) instead of whatever hipcc packs
+#endif
 template <bool TRANS>
 __device__ __forceinline__ void valu_block(float (&v)[8]) {  // 8 independent instructions
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     if (TRANS) v[i] = __builtin_amdgcn_exp2f(v[i]);
+    else if (PLAIN_VALU) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(1.0001f), "v"(0.5f));
     else v[i] = __builtin_fmaf(v[i], 1.0001f, 0.5f);
   }
+}
+
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16_t;
+// the same with v_mfma_f32_32x32x16_bf16 (8 passes each): 8 per iteration = the same 256 pipe cycles
+template <bool TRANS>
+__global__ __launch_bounds__(512) void split32_kernel(int mode, int iters, float* sink, unsigned long long* cyc) {
+  const int wave = threadIdx.x >> 6;
+  const bool mf = wave < 4;
+  if (mf && !(mode & 1)) return;
+  if (!mf && !(mode & 2)) return;
+  bf16x8_t a, b;
+  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * (threadIdx.x & 7)); b[i] = (__bf16)0.5f; }
+  f32x16_t acc[2];
+  for (int c = 0; c < 2; ++c)
+    for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+  float v[8];
+  for (int i = 0; i < 8; ++i) v[i] = -0.001f * (threadIdx.x + i);
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  if (mf) {
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[c], 0, 0, 0);
+    }
+  } else {
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) valu_block<TRANS>(v);
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+  for (int c = 0; c < 2; ++c) s += acc[c][0] + acc[c][5];
+  for (int i = 0; i < 8; ++i) s += v[i];
+  if (s == 12345.678f) sink[threadIdx.x] = s;
+  if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) cyc[wave] = t1 - t0;
 }
 
 // mode bit 0: MFMA waves work; bit 1: VALU waves work
@@ -113,6 +154,10 @@ int main() {
   printf("... VALU waves 64 v_exp_f32 (quarter rate)\n");
   run(split_kernel<true>, 512, 2, "VALU (exp) waves alone");
   run(split_kernel<true>, 512, 3, "both");
+  printf("... MFMA waves 8 MFMA 32x32x16 (the same 256 pipe cycles), VALU waves 64 v_fma_f32\n");
+  run(split32_kernel<false>, 512, 1, "MFMA 32x32x16 waves alone");
+  run(split32_kernel<false>, 512, 3, "both");
+  run(split32_kernel<true>, 512, 3, "both (v_exp_f32)");
   printf("one wave per SIMD issuing both streams; per iteration 16 MFMA + 64 v_fma_f32\n");
   run(inter_kernel<false, 8>, 256, 1, "MFMA only");
   run(inter_kernel<false, 8>, 256, 2, "VALU only");
