@@ -15,7 +15,11 @@ HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "gemm_nt.hpp"), 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # per-source extra flags.  attn_bwd_merged.hip: MFMA results in architectural VGPRs (the kernel pins its long-lived
 # accumulators to AGPRs itself; see the comment at m_mfma_pair_acc)
-EXTRA_FLAGS = {"attn_bwd_merged.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+# ... and no packed fp32 forms there (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32, which hipcc selects on its own): beside an MFMA
+# stream a packed instruction gets 42 % of its issue rate, a scalar one 77-88 % (tools/diag/mfma_valu_overlap.hip), and in
+# that kernel ONE wave per SIMD issues both streams.  C3: -0.8 % of the step (profiles/ab/r04_attn_bwd_unpacked.json).  The
+# feature is passed to both compilation passes; the host pass answers "not a recognized feature for this target (ignoring)".
+EXTRA_FLAGS = {"attn_bwd_merged.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]}
 
 
 def built_lib_path() -> str:
@@ -64,7 +68,7 @@ def _build_locked(force: bool, verbose: bool) -> str:
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + HEADERS):
+        if force or _stale(o, [s] + HEADERS + [os.path.abspath(__file__)]):  # (this file holds the flags)
             jobs.append((s, o))
 
     def compile_one(job):

@@ -65,9 +65,10 @@ def main():
     if args.b_lib:
         eb["AVF_LIB_PATH"] = os.path.abspath(args.b_lib)
     runs = {"A": [], "B": []}
-    for _ in range(args.rounds):
-        runs["A"].append(run(ea, args.steps, args.bench_args))
-        runs["B"].append(run(eb, args.steps, args.bench_args))
+    for i in range(args.rounds):
+        for arm, env in (("A", ea), ("B", eb)):
+            runs[arm].append(run(env, args.steps, args.bench_args))
+            print(f"round {i + 1} arm {arm}: {runs[arm][-1]}", flush=True)  # (a silent GPU-box call is taken for a hung one)
     med = lambda arm, k: statistics.median([r[k] for r in runs[arm] if r[k] is not None]) if any(r[k] is not None for r in runs[arm]) else None
     out = {"name": args.name, "note": args.note, "box": box_id(), "alternations": args.rounds, "steps": args.steps,
            "arm_A": {"env": ea, "runs": runs["A"], "median_c2_ms": med("A", "c2_ms"), "median_c3_ms": med("A", "c3_ms")},
