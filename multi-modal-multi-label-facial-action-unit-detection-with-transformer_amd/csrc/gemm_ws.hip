@@ -12,12 +12,13 @@
 //     wave multiplies the WHOLE tile by its 32 columns (one ds_read_b128 per two MFMAs).  L2 -> LDS bytes per FLOP are a
 //     quarter of the 128 x 128 tile's (1/256 against 1/64);
 //   * ONE s_barrier per tile (64 MFMAs per wave), none inside the K-loop: the K = 512 reduction of a tile is fully unrolled;
-//   * the epilogue of a tile overlaps the NEXT tile's MFMAs without double-buffered accumulators: waves 4..7 (the SIMD
-//     partners of waves 0..3) run half a period out of phase - they take the tile barrier between their MFMAs and their
-//     epilogue, waves 0..3 take it before their MFMAs.  On every SIMD one wave streams MFMAs while its partner adds bias /
-//     GELU / residual and stores.
-// The epilogue is nt_epilogue (gemm_nt.hpp) itself and the k order of the accumulation is that of the tiled kernel, so
-// results are bit-identical to gemm_bf16_nt_glds_kernel.
+//   * two schedules (AVF_WS_INPHASE, chosen by the epilogue).  Plain stores: waves 4..7 (the SIMD partners of waves 0..3)
+//     run half a period out of phase - they take the tile barrier between their MFMAs and their epilogue, waves 0..3 take
+//     it before their MFMAs - so on every SIMD one wave streams MFMAs while its partner converts and stores.  Epilogues
+//     with arithmetic (bias + residual, GELU, dGELU): every wave in phase, MFMA phases together and epilogues together (a
+//     wave's vector instructions lose most of their issue rate beside a partner's MFMA stream).
+// The epilogue is nt_epilogue_lean (gemm_nt.hpp) - the arithmetic of nt_epilogue - and the k order of the accumulation is that
+// of the tiled kernel, so results are bit-identical to gemm_bf16_nt_glds_kernel.
 #include <utility>
 
 #include "common.hpp"
