@@ -143,12 +143,17 @@ int avf_gemm(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K,
  * (avf_pack_weight_ws of the row-major bf16 image, avf_pack_weight_ws_bytes(rows, cols) bytes; rows % 256 == 0, cols == 512):
  * each of the 8 wavefronts of a persistent workgroup keeps 32 weight rows in registers for the whole launch, only A streams.
  * Same epilogues, argument meaning and bit-for-bit the results of avf_gemm(AVF_BF16, 0, 1, ...); colsum (optional, with
- * workspace >= avf_colsum_workspace_bytes(M, N)): column sums of the stored C.  mx_q / mx_s (optional; DGELU with colsum and a
+ * workspace >= avf_gemm_nt_ws_workspace_bytes(M, N) - one partial row per persistent workgroup group, NOT the
+ * avf_colsum_workspace_bytes of the standalone column sum): column sums of the stored C.  mx_q / mx_s (optional; DGELU with colsum and a
  * bf16 C, N % 32 == 0): also the MX-FP8 image of the fp32 values behind C (e4m3 [M][N], E8M0 [M][N/32]) - the fp8 mode's dGELU
  * GEMM keeps bf16 operands here and still feeds the fp8 GEMM behind it.  Errors if the shape does not qualify (M < 2048,
  * K != 512, N % 256 != 0). */
 int avf_pack_weight_ws_ok(int64_t rows, int64_t cols);
 size_t avf_pack_weight_ws_bytes(int64_t rows, int64_t cols);
+size_t avf_gemm_nt_ws_workspace_bytes(int64_t M, int64_t N);
+/* 1 when avf_gemm(AVF_BF16, 0, 1, ...) and the layer calls send this shape / epilogue to the persistent kernel (given 16-byte
+ * aligned operands and no dropout); avf_gemm_nt_ws itself takes every shape the kernel can run */
+int avf_gemm_nt_ws_dispatch(int64_t M, int64_t N, int64_t K, int epilogue, int c_dtype);
 int avf_pack_weight_ws(const void* w_bf16, int64_t ldw, int64_t rows, int64_t cols, void* out, void* stream);
 int avf_gemm_nt_ws(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B_packed, void* C, int64_t ldc,
                    int c_dtype, int epilogue, const float* bias, const void* residual, int64_t ldres, void* aux, int64_t ldaux,

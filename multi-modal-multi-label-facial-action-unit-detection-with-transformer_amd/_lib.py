@@ -57,6 +57,8 @@ SIGNATURES = {
                         _i64, _vp, _i64, _vp, _vp]),
     "avf_pack_weight_ws_ok": (_int, [_i64, _i64]),
     "avf_pack_weight_ws_bytes": (_sz, [_i64, _i64]),
+    "avf_gemm_nt_ws_workspace_bytes": (_sz, [_i64, _i64]),
+    "avf_gemm_nt_ws_dispatch": (_int, [_i64, _i64, _i64, _int, _int]),
     "avf_pack_weight_ws": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "avf_gemm_nt_ws": (_int, [_i64, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _int, _int, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp,
                               _vp]),

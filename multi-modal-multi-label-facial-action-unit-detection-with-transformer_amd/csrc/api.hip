@@ -234,6 +234,22 @@ extern "C" int avf_gemm(int dtype, int transA, int transB, int64_t M, int64_t N,
 // ---- weight-stationary persistent NT GEMM (gemm_ws.hip) ----
 extern "C" int avf_pack_weight_ws_ok(int64_t rows, int64_t cols) { return pack_ws_ok(rows, cols) ? 1 : 0; }
 extern "C" size_t avf_pack_weight_ws_bytes(int64_t rows, int64_t cols) { return pack_ws_ok(rows, cols) ? pack_ws_bytes(rows, cols) : 0; }
+extern "C" size_t avf_gemm_nt_ws_workspace_bytes(int64_t M, int64_t N) { return gemm_nt_colsum_ws(M, N); }
+// 1 when avf_gemm / the layer calls send this shape and epilogue to the persistent kernel (aligned operands, no dropout, no
+// column sums except on DGELU): what a test or a profile tool asks to know which kernel it is looking at
+extern "C" int avf_gemm_nt_ws_dispatch(int64_t M, int64_t N, int64_t K, int epilogue, int c_dtype) {
+  GemmArgs a;
+  a.dtype = AVF_BF16; a.transA = 0; a.transB = 1;
+  a.M = M; a.N = N; a.K = K;
+  void* aligned = (void*)(uintptr_t)256;  // never dereferenced: the predicates look at alignment only
+  a.A = aligned; a.lda = K; a.B = nullptr; a.ldb = K; a.C = aligned; a.ldc = N;
+  a.c_dtype = c_dtype; a.epilogue = epilogue; a.bias = (epilogue == AVF_EPI_BIAS_RES || epilogue == AVF_EPI_BIAS_GELU) ? (const float*)aligned : nullptr;
+  a.residual = epilogue == AVF_EPI_BIAS_RES ? aligned : nullptr; a.ldres = N;
+  a.aux = (epilogue == AVF_EPI_BIAS_GELU || epilogue == AVF_EPI_DGELU) ? aligned : nullptr; a.ldaux = N;
+  a.workspace = nullptr; a.colsum = nullptr; a.drop = kNoDrop; a.defer_fold = nullptr;
+  a.Bp = aligned; a.ws_force = 0; a.mx_q = nullptr; a.mx_s = nullptr;
+  return gemm_bf16_nt_ws_preferred(a) ? 1 : 0;
+}
 extern "C" int avf_pack_weight_ws(const void* w_bf16, int64_t ldw, int64_t rows, int64_t cols, void* out, void* stream) {
   return pack_ws(w_bf16, ldw, rows, cols, out, (hipStream_t)stream);
 }

@@ -1376,7 +1376,7 @@ namespace {
 // head-resident kernels: dim_head 64, the head's two operands fit in LDS; AVF_ATTN_RESIDENT=0 forces the streaming ones
 bool use_resident(int N, int dh) {
   static const int allow = [] {
-    const char* e = getenv("AVF_ATTN_RESIDENT");
+    const char* e = tuning_env("AVF_ATTN_RESIDENT");
     return (e && *e) ? atoi(e) : 1;
   }();
   return allow && dh == 64 && N <= RES_MAX_N;
@@ -1422,7 +1422,7 @@ int res_launch(const TimingScope* ts, K kernel, const char* name, int blocks, in
 // (AVF_ATTN_QS=0, a tuning aid, turns the folding off: factor 1 and the kernels that scale the scores themselves)
 bool attn_q_prescale_on() {
   static const int on = [] {
-    const char* e = getenv("AVF_ATTN_QS");
+    const char* e = tuning_env("AVF_ATTN_QS");
     return (e && *e) ? atoi(e) : 1;
   }();
   return on != 0;
@@ -1434,7 +1434,7 @@ bool attn_fwd_emits_mx8(int N, int dh) { return use_resident(N, dh); }
 
 bool attn_masked_bf16_ok(int N, int dh, bool q_prescaled) {
   static const int on = [] {
-    const char* e = getenv("AVF_ATTN_MASK_MFMA");  // A/B aid: 0 = every masked call on the fp32-arithmetic kernels
+    const char* e = tuning_env("AVF_ATTN_MASK_MFMA");  // A/B aid: 0 = every masked call on the fp32-arithmetic kernels
     return (e && *e) ? atoi(e) : 1;
   }();
   return on && q_prescaled && use_resident(N, dh) && N >= 1 && N <= 512;

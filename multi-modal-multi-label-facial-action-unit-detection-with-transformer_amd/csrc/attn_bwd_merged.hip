@@ -724,11 +724,11 @@ int m4_launch(const TimingScope* ts, const bf16* qkv, const bf16* o, const bf16*
 // AVF_ATTN_MERGED=0 turns it off, AVF_ATTN_MERGED_MIN_N moves the threshold.
 bool attn_bwd_merged_ok(int N, int dh, bool q_prescaled) {
   static const int allow = [] {
-    const char* e = getenv("AVF_ATTN_MERGED");
+    const char* e = tuning_env("AVF_ATTN_MERGED");
     return (e && *e) ? atoi(e) : 1;
   }();
   static const int min_n = [] {
-    const char* e = getenv("AVF_ATTN_MERGED_MIN_N");
+    const char* e = tuning_env("AVF_ATTN_MERGED_MIN_N");
     return (e && *e) ? atoi(e) : 1;
   }();
   return allow && q_prescaled && dh == 64 && N <= 512 && N >= min_n;

@@ -4,6 +4,7 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/avformer_hip.h"
@@ -19,6 +20,16 @@ int check_launch(const char* what);
 // <file> - tools/shape_table.py joins it with a rocprofv3 kernel trace into the per-shape table under profiles/.
 bool shape_log_on();
 void shape_log(const char* fmt, ...);
+// Every tuning / A-B switch of the library (AVF_NT_WS, AVF_NT_TILE, AVF_ATTN_MERGED, ...: INTEGRATION.md lists them) is read
+// through this: unless the process was started with AVF_TUNING=1 the switches do not exist - a product process runs ONE
+// dispatch, the one the parity tests exercised, whatever else is in its environment.
+inline const char* tuning_env(const char* name) {
+  static const bool on = [] {
+    const char* t = getenv("AVF_TUNING");
+    return t && *t && atoi(t) != 0;
+  }();
+  return on ? getenv(name) : nullptr;
+}
 
 #define AVF_REQUIRE(cond, ...)          \
   do {                                  \

@@ -784,7 +784,7 @@ __global__ __launch_bounds__(256) void fold_group_kernel(TnGroup g, int nslab, F
 
 int tn_group_splits(int total_tiles, int64_t K, int slots = 512) {
   static const int forced = [] {
-    const char* e = getenv("AVF_TN_SPLITS");  // tuning aid
+    const char* e = tuning_env("AVF_TN_SPLITS");  // tuning aid
     return (e && *e) ? atoi(e) : 0;
   }();
   if (forced > 0) return forced;
@@ -970,7 +970,7 @@ bool gemm_bf16_tn_group_ok(const TnGroupArgs& a) {
 // 256 x 128 tiles (one 8-wave workgroup per CU) when the group has enough work to fill the chip with them
 static bool tn_group_big(const TnGroupArgs& a) {
   static const int forced = [] {
-    const char* e = getenv("AVF_TN_BIG");  // tuning aid: 0 = always the 128 x 128 kernel, 1 = always the 256 x 128 one
+    const char* e = tuning_env("AVF_TN_BIG");  // tuning aid: 0 = always the 128 x 128 kernel, 1 = always the 256 x 128 one
     return (e && *e) ? atoi(e) : -1;
   }();
   if (forced >= 0) return forced != 0;
@@ -1028,7 +1028,7 @@ int gemm_bf16_tn_group(const TnGroupArgs& a, hipStream_t s, const FoldList* extr
     shape_log("gemm_bf16_tn,gemm_bf16_tn_group%s,%d,%d,%d,%lld,%d,%.0f,%.0f", big ? "_big_kernel<3>" : "_kernel", tiles * g.S,
               a.count, g.S, (long long)a.K, -1, flops, bytes);
   static const int tn_waves = [] {
-    const char* e = getenv("AVF_TN_WAVES");  // tuning aid
+    const char* e = tuning_env("AVF_TN_WAVES");  // tuning aid
     return (e && *e) ? atoi(e) : 4;  // 8 waves measured 5 % slower here (unlike the NT kernel)
   }();
   if (big) {
@@ -1039,7 +1039,7 @@ int gemm_bf16_tn_group(const TnGroupArgs& a, hipStream_t s, const FoldList* extr
       raised3.mark();
     }
     static const int xcd_order = [] {
-      const char* e = getenv("AVF_TN_XCD");  // tuning aid: 0 = tile-major block ids
+      const char* e = tuning_env("AVF_TN_XCD");  // tuning aid: 0 = tile-major block ids
       return (e && *e) ? atoi(e) : 1;
     }();
     int nblocks = tiles * g.S;

@@ -567,7 +567,7 @@ __device__ __forceinline__ void lds_read_words(uint32_t* dst, uint32_t addr, std
 //  cycles (SQ_WAIT_ANY) on LDS/barrier latency, which more resident waves hide better than deeper DMA rings)
 int nt_lean_on() {
   static const int on = [] {
-    const char* e = getenv("AVF_NT_LEAN");  // A/B aid: 0 = the general epilogue everywhere in the tiled kernels
+    const char* e = tuning_env("AVF_NT_LEAN");  // A/B aid: 0 = the general epilogue everywhere in the tiled kernels
     return (e && *e) ? atoi(e) : 1;
   }();
   return on;
@@ -593,7 +593,7 @@ bool nt_lean_ok(const NtParams& p, int bn, bool mx_ok = false) {
 }
 int nt_wide_stores() {
   static const int on = [] {
-    const char* e = getenv("AVF_NT_WIDE");  // tuning aid: 0 = the plain per-block stores
+    const char* e = tuning_env("AVF_NT_WIDE");  // tuning aid: 0 = the plain per-block stores
     return (e && *e) ? atoi(e) : 1;
   }();
   return on;
@@ -601,7 +601,7 @@ int nt_wide_stores() {
 
 int pick_nt_tile(int64_t M, int64_t N, int64_t K) {
   static const int override_tile = [] {
-    const char* e = getenv("AVF_NT_TILE");  // tuning aid: force one configuration
+    const char* e = tuning_env("AVF_NT_TILE");  // tuning aid: force one configuration
     return (e && *e) ? atoi(e) : -1;
   }();
   if (override_tile >= 0) return override_tile;
@@ -617,11 +617,11 @@ int pick_nt_tile(int64_t M, int64_t N, int64_t K) {
 // workgroups per CU): eight times the workgroups, five K-steps of a workgroup in flight at once.
 int pick_nt_tile_bf16(int64_t M, int64_t N, int64_t K) {
   static const int small_on = [] {
-    const char* e = getenv("AVF_NT_SMALL_M");  // A/B aid: 0 = the large tiles for every shape
+    const char* e = tuning_env("AVF_NT_SMALL_M");  // A/B aid: 0 = the large tiles for every shape
     return (e && *e) ? atoi(e) : 1;
   }();
   static const int forced = [] {
-    const char* e = getenv("AVF_NT_TILE");
+    const char* e = tuning_env("AVF_NT_TILE");
     return (e && *e) ? atoi(e) : -1;
   }();
   if (forced < 0 && small_on && M <= 2048 && ceil_div(M, 96) * ceil_div(N, 128) <= 160) return 6;

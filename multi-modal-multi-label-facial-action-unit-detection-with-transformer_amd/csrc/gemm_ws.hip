@@ -306,14 +306,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_ws_kernel(NtParams p, const 
 
 int ws_enabled() {
   static const int on = [] {
-    const char* e = getenv("AVF_NT_WS");  // 0: every NT GEMM on the tiled kernel (A/B aid)
+    const char* e = tuning_env("AVF_NT_WS");  // 0: every NT GEMM on the tiled kernel (A/B aid)
     return (e && *e) ? atoi(e) : 1;
   }();
   return on;
 }
 int ws_grid() {
   static const int n = [] {
-    const char* e = getenv("AVF_NT_WS_GRID");  // tuning aid: persistent workgroups (a multiple of 8)
+    const char* e = tuning_env("AVF_NT_WS_GRID");  // tuning aid: persistent workgroups (a multiple of 8)
     int v = (e && *e) ? atoi(e) : 0;
     if (v <= 0) {
       int dev = 0, cus = 256;
@@ -345,6 +345,9 @@ int launch_ws(const NtParams& p, const void* bp, hipStream_t s, int* part_rows, 
   if (G > T) G = T;
   AVF_REQUIRE(G >= 1, "gemm_bf16_nt_ws: more column panels (%d) than persistent workgroups (%d)", P, nwg);
   *part_rows = CS ? G : T;  // column sums: one partial row per workgroup group
+  // ... which must fit the caller's workspace (avf_gemm_nt_ws_workspace_bytes / gemm_nt_colsum_ws) - checked BEFORE the launch
+  AVF_REQUIRE(!CS || (size_t)G * p.N * sizeof(float) <= gemm_nt_colsum_ws(p.M, p.N),
+              "gemm_bf16_nt_ws: column-sum partials exceed their workspace (internal error)");
   if (shape_log_on()) {
     const double csz = sizeof(CT);
     const double epi_b = (EPI == AVF_EPI_BIAS_RES || EPI == AVF_EPI_BIAS_GELU || EPI == AVF_EPI_DGELU) ? csz * p.M * p.N : 0.0;
@@ -416,7 +419,7 @@ bool gemm_bf16_nt_ws_preferred(const GemmArgs& a) {
   if (!gemm_bf16_nt_ws_ok(a)) return false;
   {
     static const int mask = [] {
-      const char* e = getenv("AVF_NT_WS_EPI");  // tuning aid: bit e set = epilogue e (AVF_EPI_*) may take the persistent kernel
+      const char* e = tuning_env("AVF_NT_WS_EPI");  // tuning aid: bit e set = epilogue e (AVF_EPI_*) may take the persistent kernel
       return (e && *e) ? atoi(e) : 15;
     }();
     if (!((mask >> a.epilogue) & 1) && !a.mx_q) return false;
@@ -429,7 +432,7 @@ bool gemm_bf16_nt_ws_preferred(const GemmArgs& a) {
     int64_t G = ws_grid() / P;
     G = G > T ? T : G;
     static const int min_tiles = [] {
-      const char* e = getenv("AVF_NT_WS_RES_TILES");  // tuning aid
+      const char* e = tuning_env("AVF_NT_WS_RES_TILES");  // tuning aid
       return (e && *e) ? atoi(e) : 6;
     }();
     if (T / G < min_tiles) return false;
@@ -478,8 +481,6 @@ int gemm_bf16_nt_ws(const GemmArgs& a, hipStream_t s, int* part_rows_out) {
     default: AVF_REQUIRE(false, "gemm_bf16_nt_ws: bad epilogue %d", a.epilogue);
   }
 #undef LAUNCH_WS
-  AVF_REQUIRE((size_t)part_rows * a.N * sizeof(float) <= gemm_nt_colsum_ws(a.M, a.N) || !a.colsum,
-              "gemm_bf16_nt_ws: column-sum partials exceed their workspace (internal error)");
   *part_rows_out = part_rows;
   return check_launch("gemm_bf16_nt_ws_kernel");
 }

@@ -467,7 +467,7 @@ extern "C" int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p
                           nullptr, s, kNoDrop));
     // out-proj: its A operand is produced per head; the head-resident attention kernel writes the image from its epilogue
     static const int o_mx_on = [] {
-      const char* e = getenv("AVF_MX8_OUTPROJ");  // tuning / A-B aid: 0 = out-projection on bf16 operands
+      const char* e = tuning_env("AVF_MX8_OUTPROJ");  // tuning / A-B aid: 0 = out-projection on bf16 operands
       return (e && *e) ? atoi(e) : 1;
     }();
     const bool o_mx = o_mx_on && !d.keep && attn_fwd_emits_mx8(d.N, d.dh) && d.I % 128 == 0;
@@ -543,7 +543,7 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   // short sequences (the reference's 12-token stacks): the six dependent launches around the attention backward run as two
   // fused kernels (layer_small.hip), which also make the bf16 image of the incoming gradient when the caller gave none
   static const int small_bwd_on = [] {
-    const char* e = getenv("AVF_LAYER_SMALL_BWD");  // tuning / A-B aid
+    const char* e = tuning_env("AVF_LAYER_SMALL_BWD");  // tuning / A-B aid
     return (e && *e) ? atoi(e) : 1;
   }();
   const bool small_bwd = lo && !d.rs16 && !d.mx && !d.keep && small_bwd_on && small_layer_ok(d.dt, d.N, d.D, d.H, d.dh, d.M);
@@ -596,7 +596,7 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
       else AVF_TRY(colsum(dx_out, AVF_F32, d.R, d.D, d.D, g->b2, w.cs_ws, s));
     }
     static const int small_att_on = [] {
-      const char* e = getenv("AVF_LAYER_SMALL_ATT");  // tuning / A-B aid: 0 = per-operator attention backward
+      const char* e = tuning_env("AVF_LAYER_SMALL_ATT");  // tuning / A-B aid: 0 = per-operator attention backward
       return (e && *e) ? atoi(e) : 1;
     }();
     const bool fuse_att = small_att_on && d.H <= 16;
@@ -676,7 +676,7 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
     a.drop = dr1; a.defer_fold = grouped ? &folds.job[0] : nullptr;
     a.Bp = l.ws.w2t_p; a.mx_q = w.duq; a.mx_s = w.dus;
     static const int dgelu_ws = [] {
-      const char* e = getenv("AVF_MX8_DGELU_WS");  // A/B aid: 0 = the dGELU GEMM of the fp8 mode on MX-FP8 operands
+      const char* e = tuning_env("AVF_MX8_DGELU_WS");  // A/B aid: 0 = the dGELU GEMM of the fp8 mode on MX-FP8 operands
       return (e && *e) ? atoi(e) : 1;
     }();
     if (dgelu_ws && gemm_bf16_nt_ws_ok(a)) AVF_TRY(gemm(a, s));
@@ -716,7 +716,7 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   // built and bit-exact, but the image costs the attention kernel 18 us at B = 64, N = 512 (50 us before its stores were
   // made 16 bytes wide and dQ's 32-blocks wave-local) while the K = 1536 GEMM, already at 0.87 PFLOP/s on bf16 operands,
   // gains ~9 us: C5 5.06 ms per step with it against 4.93 without - OFF unless AVF_MX8_DQKV=1.
-  const char* dq_env = getenv("AVF_MX8_DQKV");  // (read per call: a test flips it inside one process)
+  const char* dq_env = tuning_env("AVF_MX8_DQKV");  // (read per call: a test flips it inside one process)
   const int dq_mx_on = (dq_env && *dq_env) ? atoi(dq_env) : 0;
   const bool dq_mx = d.mxb && dq_mx_on && !d.keep && (3 * d.I) % 128 == 0 && d.D % 128 == 0 &&
                      attn_bwd_emits_mx8(d.N, d.dh, attn_q_prescale_on());

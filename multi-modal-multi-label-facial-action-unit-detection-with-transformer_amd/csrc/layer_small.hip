@@ -713,7 +713,7 @@ int launch_small(const SmallArgs& a, int B, hipStream_t s) {
 // shapes the single-launch forward covers (AVF_LAYER_SMALL=0 turns it off: tuning / A-B aid)
 bool small_layer_ok(int dtype, int tokens, int dim, int heads, int dim_head, int mlp_dim) {
   static const int on = [] {
-    const char* e = getenv("AVF_LAYER_SMALL");
+    const char* e = tuning_env("AVF_LAYER_SMALL");
     return (e && *e) ? atoi(e) : 1;
   }();
   const int inner = heads * dim_head;

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void ln_fwd_reg_kernel(const InT* __restrict__
 
 static int ln_row8_on() {
   static const int on = [] {
-    const char* e = getenv("AVF_LN_ROW8");  // tuning / A-B aid: 0 = the one-row-per-wave kernels
+    const char* e = tuning_env("AVF_LN_ROW8");  // tuning / A-B aid: 0 = the one-row-per-wave kernels
     return (e && *e) ? atoi(e) : 1;
   }();
   return on;

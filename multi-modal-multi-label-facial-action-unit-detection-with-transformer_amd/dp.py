@@ -35,6 +35,10 @@ class _GlobalMeanFn(torch.autograd.Function):
                 and s.untyped_storage().data_ptr() == k.untyped_storage().data_ptr()
                 and k.storage_offset() == s.storage_offset() + 1):
             pack = torch.empty(0, dtype=torch.float32, device=s.device).set_(s.untyped_storage(), s.storage_offset(), (2,))
+            # ... which CONSUMES the inputs: after the call s and k hold the GLOBAL sum and count.  The alias is invisible to
+            # autograd, so their version counters are bumped by hand - a backward that saved the local values, or any other
+            # version-checked use, then fails loudly instead of reading the global ones
+            torch.autograd.graph.increment_version((s, k))
         if pack is None:
             pack = torch.stack([s.detach().to(torch.float32), k.detach().to(torch.float32)])
         dist.all_reduce(pack, op=dist.ReduceOp.SUM, group=group)
@@ -69,7 +73,7 @@ class DataParallel:
             self._owned.update(id(p) for p in st.flat_parameters())
         self._rest_params = [p for p in model.parameters() if id(p) not in self._owned]
         self._cuda = any(p.is_cuda for p in model.parameters())
-        self._stats = {"collectives": 0, "loss_collectives": 0, "bucket_bytes": []}
+        self.stats_reset()
         self._pending: List = []
         self._held: List = []  # (layer, flat) handed over but not launched yet
         # losses that are ratios over the kept rows (AULoss, loss.py:85-102) reduce numerator and denominator over the ranks
@@ -129,7 +133,10 @@ class DataParallel:
         return [self._launch(t) for t in self._merge(flats)]
 
     def stats_reset(self):
-        self._stats = {"collectives": 0, "loss_collectives": 0, "bucket_bytes": []}
+        # bucket_bytes: the sizes of the gradient collectives of the LAST COMPLETED step (finish() publishes the list it
+        # gathered during the step and starts a new one) - bounded however long an eager run lasts; the rest are counters
+        self._stats = {"collectives": 0, "loss_collectives": 0, "bytes_total": 0, "bucket_bytes": []}
+        self._step_bytes = []
 
     def stats(self):
         """collectives issued since stats_reset(): gradient all-reduces (count, bytes of each) and loss reductions"""
@@ -137,7 +144,9 @@ class DataParallel:
 
     def _launch(self, flat: torch.Tensor):
         self._stats["collectives"] += 1
-        self._stats["bucket_bytes"].append(flat.numel() * flat.element_size())
+        nb = flat.numel() * flat.element_size()
+        self._stats["bytes_total"] += nb
+        self._step_bytes.append(nb)
         if self._cuda:
             # Issued from the compute stream with async_op=True: the process group makes ITS communication stream wait for
             # what the compute stream has enqueued so far (the producing backward kernels), runs the collective there and
@@ -153,7 +162,9 @@ class DataParallel:
 
     def global_mean(self, local_sum: torch.Tensor, local_count: torch.Tensor) -> torch.Tensor:
         """mean over the GLOBAL batch of a per-row quantity from each rank's (sum over its kept rows, number of kept rows):
-        equals the single-process loss on the concatenated batch for any split of the ignored rows over the ranks"""
+        equals the single-process loss on the concatenated batch for any split of the ignored rows over the ranks.
+        CONSUMES its inputs when they are the two elements of one fp32 2-vector (what AULoss passes): they hold the global
+        sum / count afterwards (their autograd version counters are bumped)"""
         # on the GPU the "blocking" all-reduce only makes the current stream wait for the group's communication stream (no host
         # block), so it is recorded by a hipGraph capture like the gradient collectives (graphs.GraphedTrainStep(dp=...))
         self._stats["loss_collectives"] += 1
@@ -178,6 +189,7 @@ class DataParallel:
                 p.grad = bucket[off:off + n].view_as(p)
                 off += n
         self._pending.clear()
+        self._stats["bucket_bytes"], self._step_bytes = self._step_bytes, []
 
     def __call__(self, *a, **k):
         return self.model(*a, **k)

@@ -180,6 +180,12 @@ def pack_ws(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def gemm_ws_used(M: int, n_out: int, K: int, epilogue: int = EPI_NONE, out_dtype=torch.bfloat16) -> bool:
+    """True when ``gemm`` / the layer calls run this bf16 NT shape on the weight-stationary persistent kernel
+    (avf_gemm_nt_ws_dispatch); ``gemm_ws`` itself forces that kernel for every shape it can run."""
+    return bool(_lib.load().avf_gemm_nt_ws_dispatch(int(M), int(n_out), int(K), int(epilogue), avf_dtype(torch_dtype(out_dtype))))
+
+
 def gemm_ws(a: torch.Tensor, w_packed: torch.Tensor, n_out: int, out_dtype=None, epilogue: int = EPI_NONE,
             bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, aux: Optional[torch.Tensor] = None,
             want_colsum: bool = False, want_image: bool = False):
@@ -191,12 +197,26 @@ def gemm_ws(a: torch.Tensor, w_packed: torch.Tensor, n_out: int, out_dtype=None,
     a = _rows2d(a)
     M, K = a.shape
     cdt = torch_dtype(out_dtype) if out_dtype is not None else a.dtype
+    # the C ABI sees raw pointers: everything it cannot check is checked here
+    if a.dtype != torch.bfloat16 or w_packed.dtype != torch.bfloat16:
+        raise TypeError(f"gemm_ws: bf16 operands only (a {a.dtype}, w_packed {w_packed.dtype})")
+    if K != 512 or w_packed.numel() != n_out * 512 or not w_packed.is_contiguous():
+        raise ValueError(f"gemm_ws: a is [M, 512] and w_packed = pack_ws(W[{n_out}, 512]); got K = {K}, image of {w_packed.numel()} elements")
+    if cdt not in (torch.bfloat16, torch.float32):
+        raise TypeError(f"gemm_ws: C is bf16 or fp32, not {cdt}")
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != n_out):
+        raise TypeError("gemm_ws: bias is fp32 [n_out]")
+    for name, t in (("residual", residual), ("aux", aux)):
+        if t is not None and (t.dtype != cdt or t.numel() != M * n_out):
+            raise TypeError(f"gemm_ws: {name} is stored in C's type {cdt} as [M, n_out] (got {t.dtype}, {tuple(t.shape)})")
+    if aux is not None and not aux.is_contiguous():
+        raise ValueError("gemm_ws: aux must be contiguous")
     c = torch.empty((M, n_out), dtype=cdt, device=a.device)
     made_aux = None
     if epilogue == EPI_BIAS_GELU and aux is None:
         made_aux = aux = torch.empty((M, n_out), dtype=cdt, device=a.device)
     cs = torch.empty(n_out, dtype=torch.float32, device=a.device) if want_colsum else None
-    ws = _bytes(lib.avf_colsum_workspace_bytes(M, n_out) + (M // 32 + 8) * n_out * 4, a.device) if want_colsum else None
+    ws = _bytes(lib.avf_gemm_nt_ws_workspace_bytes(M, n_out), a.device) if want_colsum else None
     if residual is not None:
         residual = residual.contiguous()
     cq = torch.empty((M, n_out), dtype=torch.uint8, device=a.device) if want_image else None

@@ -311,24 +311,34 @@ def test_attention_backward_emits_the_image_of_dqkv(ops, B, N, H):
     assert torch.equal(q.cpu(), q_ref)
 
 
-def test_dqkv_to_dh1_on_fp8_operands_tracks_the_bf16_gemm(monkeypatch):
-    """AVF_MX8_DQKV=1 (off by default: DESIGN.md section 17, item 5): the last bf16 dX GEMM of the fp8 mode on MX-FP8 operands"""
-    import avformer_amd as A
-    torch.manual_seed(21)
-    t = A.Transformer(256, 2, 4, 64, 512, compute_dtype="mx8", residual_dtype="bf16").cuda()
-    x = torch.randn(2, 320, 256, device="cuda")
-
-    def run():
-        xi = x.clone().requires_grad_(True)
-        for p in t.parameters():
-            p.grad = None
-        t(xi).float().pow(2).mean().backward()
-        torch.cuda.synchronize()
-        return xi.grad.clone(), {k: p.grad.clone() for k, p in t.named_parameters()}
-
-    dx0, g0 = run()
-    monkeypatch.setenv("AVF_MX8_DQKV", "1")
-    dx1, g1 = run()
+def test_dqkv_to_dh1_on_fp8_operands_tracks_the_bf16_gemm(tmp_path):
+    """AVF_MX8_DQKV=1 (off by default: DESIGN.md section 17, item 5): the last bf16 dX GEMM of the fp8 mode on MX-FP8 operands.
+    A tuning switch (honoured under AVF_TUNING=1 only, read per call): both arms run in one child process started that way"""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import os, torch, avformer_amd as A\n"
+        "torch.manual_seed(21)\n"
+        "t = A.Transformer(256, 2, 4, 64, 512, compute_dtype='mx8', residual_dtype='bf16').cuda()\n"
+        "x = torch.randn(2, 320, 256, device='cuda')\n"
+        "def run():\n"
+        "    xi = x.clone().requires_grad_(True)\n"
+        "    for p in t.parameters():\n"
+        "        p.grad = None\n"
+        "    t(xi).float().pow(2).mean().backward()\n"
+        "    torch.cuda.synchronize()\n"
+        "    return xi.grad.cpu(), {k: p.grad.cpu() for k, p in t.named_parameters()}\n"
+        "a = run()\n"
+        "os.environ['AVF_MX8_DQKV'] = '1'\n"
+        "b = run()\n"
+        "torch.save((a, b), os.environ['AVF_TEST_OUT'])\n")
+    path = str(tmp_path / "dqkv.pt")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                       env=dict(os.environ, AVF_TUNING="1", AVF_TEST_OUT=path),
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    (dx0, g0), (dx1, g1) = torch.load(path)
     assert not torch.equal(dx0, dx1)  # (the switch took effect)
     rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
     assert rel(dx1, dx0) < 5e-2

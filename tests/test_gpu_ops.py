@@ -413,6 +413,6 @@ for K, shapes in [(2048, [(1000, 136), (264, 520), (8, 8)]), (192, [(256, 128)])
         torch.testing.assert_close(c.cpu(), ref, atol=2e-5 * K, rtol=1e-5)
 print("TN_BIG_OK")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, AVF_TN_BIG="1"),
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, AVF_TUNING="1", AVF_TN_BIG="1"),
                        timeout=600)
     assert r.returncode == 0 and "TN_BIG_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

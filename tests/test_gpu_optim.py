@@ -59,6 +59,38 @@ def test_fused_adam_matches_torch_adam(mode, dims):
             assert torch.equal(x, y)
 
 
+def test_fused_adam_keeps_the_fragment_major_images_in_sync():
+    """dim = 512: the Adam kernel's scattered stores (pack_ws_off, optim.hip) are the only writer of the fragment-major weight
+    images the persistent GEMM reads (gemm_ws.hip) after the first step.  After a few steps every byte of a layer's low-precision
+    buffer - row-major, transposed AND fragment-major images - must equal what a fresh avf_layer_prepare_weights derives from
+    the fp32 masters, and each fragment-major image must be pack_ws() of a bf16 rounding of its master."""
+    A, ma, _, (Tv, Ta, D) = _models("bf16", (512, 2, 8, 64, 1024, 9, 7))
+    opt = A.optim.FusedAdam(ma, lr=3e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=1e-2)
+    g = torch.Generator().manual_seed(5)
+    for _ in range(3):
+        batch = {"clip": torch.randn(3, Tv, D, generator=g).to(DEV), "audio_features": torch.randn(3, Ta, D, generator=g).to(DEV)}
+        labels = (torch.rand(3, 12, generator=g) > 0.5).float().to(DEV)
+        opt.zero_grad(set_to_none=True)
+        ma.get_au_loss(ma(batch), labels).backward()
+        opt.step()
+    st = ma.transformer
+    assert st._lowp_ready
+    kept = [b.clone() for b in st._lowp_bufs]
+    st.refresh_weights()
+    with torch.no_grad():
+        ma(batch)
+    for x, y in zip(kept, st._lowp_bufs):
+        assert torch.equal(x, y)
+    # the fragment-major image of W1 (net.0.weight [1024, 512]) is somewhere in the buffer, byte for byte
+    w1 = dict(st.named_parameters())["layers.0.1.fn.fn.net.0.weight"].detach()
+    img = A.ops.pack_ws(w1.to(torch.bfloat16).contiguous()).view(torch.uint8)
+    buf = kept[0].view(torch.uint8)
+    n = img.numel()
+    head = img[:64]
+    cand = (buf[: buf.numel() - n + 1].unfold(0, 64, 256) == head).all(1).nonzero().flatten() * 256  # (images are 256-byte aligned)
+    assert any(torch.equal(buf[int(o): int(o) + n], img) for o in cand.tolist()), "no fragment-major image of W1 in the low-precision buffer"
+
+
 def test_fused_adam_skips_weight_prep_and_state_dict_roundtrip():
     A, ma, mb, (Tv, Ta, D) = _models("bf16")
     oa = A.optim.FusedAdam(ma, lr=1e-3, weight_decay=5e-5)

@@ -123,8 +123,10 @@ def test_unfit_shapes_are_refused_and_the_layer_falls_back():
 
 def test_stack_with_and_without_the_persistent_kernel(tmp_path):
     """AVF_NT_WS is read once per process: two child processes run the same 2-layer stack (forward + backward) with the
-    persistent kernel on and off.  Every tensor is bit-identical except the gradient of net.0's bias, whose column sums go
-    through per-tile (tiled kernel) or per-workgroup (persistent kernel) fp32 partial sums."""
+    persistent kernel on and off, then one FusedAdam step - the only writer of the fragment-major weight images from then on -
+    and a second forward.  Every tensor is bit-identical except the gradient of net.0's bias, whose column sums go through
+    per-tile (tiled kernel) or per-workgroup (persistent kernel) fp32 partial sums (and what that bias feeds after the step:
+    the second forward is held to 1e-3)."""
     import subprocess
     import sys
     code = (
@@ -134,12 +136,17 @@ def test_stack_with_and_without_the_persistent_kernel(tmp_path):
         "x = torch.randn(8, 324, 512, device='cuda', requires_grad=True)\n"
         "y = m(x); y.float().pow(2).mean().backward()\n"
         "d = {'y': y.detach().float().cpu(), 'dx': x.grad.cpu()}\n"
-        "d.update({n: p.grad.cpu() for n, p in m.named_parameters()})\n"
+        "d.update({n: p.grad.clone().cpu() for n, p in m.named_parameters()})\n"
+        # ... then one library Adam step (which rewrites the weight images, the fragment-major ones included) and a forward on them
+        "opt = A.optim.FusedAdam(m, lr=1e-3)\n"
+        "opt.step()\n"
+        "with torch.no_grad():\n"
+        "    d['y_after_step'] = m(x.detach()).float().cpu()\n"
         "torch.save(d, os.environ['AVF_TEST_OUT'])\n")
     outs = []
     for ws in ("1", "0"):
         path = str(tmp_path / f"ws{ws}.pt")
-        env = dict(os.environ, AVF_NT_WS=ws, AVF_TEST_OUT=path)
+        env = dict(os.environ, AVF_TUNING="1", AVF_NT_WS=ws, AVF_TEST_OUT=path)  # (switches exist under AVF_TUNING=1 only)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env,
                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -149,5 +156,70 @@ def test_stack_with_and_without_the_persistent_kernel(tmp_path):
     for k in on:
         if k.endswith("net.0.bias"):
             assert torch.allclose(on[k], off[k], rtol=1e-4, atol=1e-6), k
+        elif k == "y_after_step":  # (Adam turns the last-bit difference of d net.0.bias into a different update of that bias)
+            assert (on[k] - off[k]).norm() <= 1e-3 * off[k].norm(), k
         else:
             assert torch.equal(on[k], off[k]), k
+
+
+# ---------------------------------------------------------------------------------------------- against the ORACLE, >= 2048 rows
+# The B = 2 oracle tests of test_gpu_configs.py have 1024 token rows and therefore run the tiled kernel; these hold the
+# PERSISTENT kernel itself to the oracle's math (oracle/reference_math.py = /root/reference/models/heads.py:164-256), so that a
+# divergence of the two kernels cannot hide behind their bit-identity tests.
+def test_stack_on_the_persistent_kernel_vs_oracle_2560_rows():
+    """d = 512, 2 layers, B = 5 x 512 tokens = 2560 rows: QKV (plain), MLP1 (bias + GELU), dGELU (+ column sums) and d_o
+    (plain) run on the persistent kernel; forward and every gradient against the oracle's autograd, both residual streams"""
+    import oracle
+    from gpu_util import check_rel, hip_transformer_run, oracle_transformer_run
+    D, L, H, dh, M, B, N = 512, 2, 8, 64, 1024, 5, 512
+    g = torch.Generator().manual_seed(2560)
+    sd = oracle.init_transformer_state(D, L, H, dh, M, generator=g)
+    for k in sd:
+        if k.endswith("norm.weight"):
+            sd[k] = 1 + 0.1 * torch.randn(D, generator=g)
+        if k.endswith("norm.bias"):
+            sd[k] = 0.1 * torch.randn(D, generator=g)
+    x = torch.randn(B, N, D, generator=g)
+    loss = lambda y: y.float().pow(2).mean()
+    y_ref, dx_ref, g_ref = oracle_transformer_run(x, sd, L, H, loss)
+    for resid, caps in (("f32", (1.5e-2, 3e-2, 4e-2)), ("bf16", (3e-2, 5e-2, 6e-2))):
+        t = A.Transformer(D, L, H, dh, M, 0.0, compute_dtype="bf16", residual_dtype=resid)
+        t.load_state_dict(sd, strict=True)
+        t = t.cuda()
+        assert ops.gemm_ws_used(B * N, 3 * H * dh, D), "this shape is expected on the persistent kernel"
+        y, dx, grads = hip_transformer_run(t, x, loss)
+        check_rel(f"ws_oracle[{resid}]:y", y, y_ref, caps[0])
+        check_rel(f"ws_oracle[{resid}]:dx", dx, dx_ref, caps[1])
+        for k, v in g_ref.items():
+            check_rel(f"ws_oracle[{resid}]:g.{k}", grads[k], v, caps[2])
+
+
+@pytest.mark.parametrize("epi", ["none", "bias_res", "bias_gelu", "dgelu"])
+def test_each_persistent_epilogue_vs_oracle_math(epi):
+    """one GEMM per epilogue on the persistent kernel (forced: avf_gemm_nt_ws), 4128 rows (ragged last tile), against the
+    oracle's own functions evaluated in fp32 on the CPU from the SAME bf16-rounded operands: what is left is the fp32
+    accumulation order and the bf16 rounding of the stored result (2^-8 relative)"""
+    import oracle
+    import torch.nn.functional as F
+    from gpu_util import check_rel
+    E = {"none": ops.EPI_NONE, "bias_res": ops.EPI_BIAS_RES, "bias_gelu": ops.EPI_BIAS_GELU, "dgelu": ops.EPI_DGELU}[epi]
+    M, N = 4128, 1024 if epi in ("bias_gelu", "dgelu") else 512
+    a, w, bias, res, aux = _inputs(M, N, E, bf, seed=11)
+    out = ops.gemm_ws(a, ops.pack_ws(w), N, out_dtype=bf, epilogue=E, bias=bias, residual=res, aux=aux,
+                      want_colsum=(epi == "dgelu"))
+    af, wf = a.float().cpu(), w.float().cpu()
+    lin = F.linear(af, wf, None if bias is None else bias.cpu())  # nn.Linear, heads.py:191,195,212,215
+    if epi == "none":
+        check_rel("ws_epi_oracle:none", out, lin, 4e-3)
+    elif epi == "bias_res":  # Residual(fn)(x) = fn(x) + x, heads.py:175
+        check_rel("ws_epi_oracle:bias_res", out, lin + res.float().cpu(), 4e-3)
+    elif epi == "bias_gelu":  # GELU of heads.py:166 (the oracle's 9-op restatement); the saved pre-activation is u itself
+        c, u = out
+        check_rel("ws_epi_oracle:bias_gelu:u", u, lin, 4e-3)
+        check_rel("ws_epi_oracle:bias_gelu:g", c, oracle.gelu_tanh(lin), 6e-3)
+    else:  # autograd of that GELU: d/du, times the incoming gradient (the GEMM's product)
+        c, cs = out
+        u = aux.float().cpu().requires_grad_(True)
+        oracle.gelu_tanh(u).backward(lin)
+        check_rel("ws_epi_oracle:dgelu", c, u.grad, 6e-3)
+        check_rel("ws_epi_oracle:dgelu:colsum", cs, c.float().sum(0), 1e-3)

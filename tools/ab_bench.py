@@ -64,6 +64,9 @@ def main():
         ea["AVF_LIB_PATH"] = os.path.abspath(args.a_lib)
     if args.b_lib:
         eb["AVF_LIB_PATH"] = os.path.abspath(args.b_lib)
+    for e in (ea, eb):  # the library honours its tuning switches under AVF_TUNING=1 only
+        if any(k.startswith("AVF_") and k != "AVF_LIB_PATH" for k in e):
+            e.setdefault("AVF_TUNING", "1")
     runs = {"A": [], "B": []}
     for i in range(args.rounds):
         for arm, env in (("A", ea), ("B", eb)):
