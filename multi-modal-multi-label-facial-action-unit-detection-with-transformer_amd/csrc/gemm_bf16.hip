@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(NtParams p) {
 // workgroups dealt to one XCD (ids congruent mod 8) cover a contiguous range of tiles and share A panels in its L2.
 // ------------------------------------------------------------------------------------------
 // LEAN: 0 = the general epilogue (run-time options), 1 = nt_epilogue_lean (every option fixed at compile time; the host has
-// checked nt_lean_ok), 2 = the same with column sums
+// checked nt_lean_ok), 2 = the same with column sums; + 4 = with the epilogue's dropout site
 template <int EPI, typename CT, int WM, int WN, int MI, int NI, int NS, int LEAN = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(NtParams p, int tiles_n, int nwg) {
   constexpr int WTM = 16 * MI, WTN = 16 * NI;  // per-wave output tile
@@ -226,7 +226,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(NtParam
   }
 
   if constexpr (LEAN != 0)
-    nt_epilogue_lean<EPI, CT, MI, NI, LEAN == 2 ? 1 : 0, false>(p, acc, m0 + wm * WTM, n0 + wn * WTN, li, lg, (wg / tiles_n) * WM + wm);
+    nt_epilogue_lean<EPI, CT, MI, NI, (LEAN & 3) == 2 ? 1 : 0, false, false, true, (LEAN & 4) != 0>(
+        p, acc, m0 + wm * WTM, n0 + wn * WTN, li, lg, (wg / tiles_n) * WM + wm, nullptr, nullptr,
+        (LEAN & 4) ? drop_key(p.drop) : 0);
   else
     nt_epilogue<EPI, CT, MI, NI>(p, acc, m0 + wm * WTM, n0 + wn * WTN, li, lg, p.cs_partial ? (wg / tiles_n) * WM + wm : -1);
 }
@@ -263,15 +265,29 @@ template <int EPI, typename CT>
 int launch_nt_glds_any(const NtParams& p, hipStream_t s, int* part_rows, TimingScope* ts) {
   const int tile = pick_nt_tile_bf16(p.M, p.N, p.K);
   // the two 8-wave tiles with the lean epilogue when nothing asks for the general one's options
-  if ((tile == 2 || tile == 5) && nt_lean_ok<EPI, CT>(p, 128)) {
+  if ((tile == 2 || tile == 5) && nt_lean_ok<EPI, CT>(p, 128, false, /*drop_ok=*/true)) {
     constexpr bool csv = EPI == AVF_EPI_DGELU;  // column sums ride on the dGELU epilogue only
-    if (p.cs_partial == nullptr) {
-      if (tile == 5) return launch_nt_glds<EPI, CT, 2, 4, 3, 2, 2, 1>(p, s, part_rows, ts);
-      return launch_nt_glds<EPI, CT, 2, 4, 4, 2, 2, 1>(p, s, part_rows, ts);
+    if constexpr (EPI != AVF_EPI_NONE) {
+      if (p.drop.thresh16) {  // the reference's real instantiations train at p = 0.2 (heads.py:277): same lean path + the mask
+        if (p.cs_partial == nullptr) {
+          if (tile == 5) return launch_nt_glds<EPI, CT, 2, 4, 3, 2, 2, 5>(p, s, part_rows, ts);
+          return launch_nt_glds<EPI, CT, 2, 4, 4, 2, 2, 5>(p, s, part_rows, ts);
+        }
+        if constexpr (csv) {
+          if (tile == 5) return launch_nt_glds<EPI, CT, 2, 4, 3, 2, 2, 6>(p, s, part_rows, ts);
+          return launch_nt_glds<EPI, CT, 2, 4, 4, 2, 2, 6>(p, s, part_rows, ts);
+        }
+      }
     }
-    if constexpr (csv) {
-      if (tile == 5) return launch_nt_glds<EPI, CT, 2, 4, 3, 2, 2, 2>(p, s, part_rows, ts);
-      return launch_nt_glds<EPI, CT, 2, 4, 4, 2, 2, 2>(p, s, part_rows, ts);
+    if (!p.drop.thresh16) {
+      if (p.cs_partial == nullptr) {
+        if (tile == 5) return launch_nt_glds<EPI, CT, 2, 4, 3, 2, 2, 1>(p, s, part_rows, ts);
+        return launch_nt_glds<EPI, CT, 2, 4, 4, 2, 2, 1>(p, s, part_rows, ts);
+      }
+      if constexpr (csv) {
+        if (tile == 5) return launch_nt_glds<EPI, CT, 2, 4, 3, 2, 2, 2>(p, s, part_rows, ts);
+        return launch_nt_glds<EPI, CT, 2, 4, 4, 2, 2, 2>(p, s, part_rows, ts);
+      }
     }
   }
   switch (tile) {

@@ -298,11 +298,11 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
 }
 
 // ------------------------------------------------------------------------------------------
-// Lean epilogue: the fast path of nt_epilogue with every option fixed at COMPILE time - the general one decides dropout,
+// Lean epilogue: the fast path of nt_epilogue with every option fixed at COMPILE time (dropout included: DROP) - the general one decides dropout,
 // MX image, column edge, store width and column sums with wave-uniform run-time branches, and its ~550 executed
 // instructions per 16 values and lane (2200 cycles of one wave's issue, 3700 beside a partner streaming MFMAs: phase stamps of
 // gemm_ws.hip) cost more than the 64 MFMAs that produce those values.  Same arithmetic, same order, same
-// bits.  Preconditions, checked by the host (nt_lean_ok): no dropout, no MX image, no LayerNorm fold / row statistics; the
+// bits.  Preconditions, checked by the host (nt_lean_ok): no MX image beside a dropout site; the
 // wave tile lies inside N; 2-byte C: N % 8 == 0, every leading dimension % 8 == 0, 16-byte aligned bases (16-byte paired
 // stores and loads, p.wide == 1).  CS: column sums of the stored values into cs_partial[part_row].  PRE: bias / residual /
 // saved pre-activation were fetched by nt_epi_prefetch.  FULL: every row of the tile is inside M (no row predicate).
@@ -335,9 +335,16 @@ __device__ __forceinline__ void nt_cs_flush(const NtParams& p, float (&cs)[NI][4
 // is the column-block pair (j, j + 1) x the four lane groups x 4 registers; the block maximum crosses the lane groups on the
 // VALU (v_permlane32_swap / v_permlane16_swap) where nt_epilogue takes two LDS round trips (__shfl_xor)
 // BIAS = false: the caller vouches for p.bias == nullptr (no bias registers, no adds of zeros)
-template <int EPI, typename CT, int MI, int NI, int CS, bool PRE, bool FULL, bool MXO = false, bool BIAS = true>
+// DROP: the dropout site of the epilogue (p.drop; nn.Dropout of heads.py:194,196,216) - the mask factors of nt_epilogue, same
+// hash of the same element index, applied at the same place of the same expression (bit-identical results): BIAS_RES masks
+// (acc + bias) before the residual, BIAS_GELU masks gelu(u) (u is saved unmasked), DGELU multiplies by mask * gelu'(u).  One
+// splitmix64 per 4 values (~40 integer instructions), where the general epilogue pays its 550 for everything else as well.
+// dkey = drop_key(p.drop), computed once per kernel by the caller.
+template <int EPI, typename CT, int MI, int NI, int CS, bool PRE, bool FULL, bool MXO = false, bool BIAS = true, bool DROP = false>
 __device__ __forceinline__ void nt_epilogue_lean_body(const NtParams& p, f32x4_t (&acc)[MI][NI], int m_base, int n_base, int li,
-                                                      int lg, int part_row, const NtPre<MI, NI>* pre, float (*cs_acc)[4]) {
+                                                      int lg, int part_row, const NtPre<MI, NI>* pre, float (*cs_acc)[4],
+                                                      uint64_t dkey = 0) {
+  static_assert(!DROP || EPI != AVF_EPI_NONE, "dropout sits in a fused epilogue");
   static_assert(sizeof(CT) == 4 || (NI & 1) == 0, "2-byte outputs are stored in column-block pairs");
   const int n0 = n_base + 4 * lg;                    // this lane's 4 columns of block 0 (block j: + 16 j)
   const int cp0 = n0 + ((lg & 1) ? 12 : 0);          // its 8 columns of the block pair (0, 1) after the lane-pair exchange
@@ -401,8 +408,14 @@ __device__ __forceinline__ void nt_epilogue_lean_body(const NtParams& p, f32x4_t
       } else {  // (x + 0.0f is x for every x but -0.0f, which no consumer distinguishes; the product paths pass no bias here)
         v[0] = acc[i][j][0]; v[1] = acc[i][j][1]; v[2] = acc[i][j][2]; v[3] = acc[i][j][3];
       }
+      float4 df;
+      if constexpr (DROP) df = drop_factor4(p.drop, dkey, (uint64_t)m * p.N + (uint64_t)(n0 + 16 * j));
       if constexpr (EPI == AVF_EPI_BIAS_RES) {
-        v[0] += ex[j].x; v[1] += ex[j].y; v[2] += ex[j].z; v[3] += ex[j].w;
+        if constexpr (DROP) {
+          v[0] = v[0] * df.x + ex[j].x; v[1] = v[1] * df.y + ex[j].y; v[2] = v[2] * df.z + ex[j].z; v[3] = v[3] * df.w + ex[j].w;
+        } else {
+          v[0] += ex[j].x; v[1] += ex[j].y; v[2] += ex[j].z; v[3] += ex[j].w;
+        }
       } else if constexpr (EPI == AVF_EPI_BIAS_GELU) {
         if constexpr (sizeof(CT) == 2) {
           aw[j][0] = pack_bf16x2(v[0], v[1]); aw[j][1] = pack_bf16x2(v[2], v[3]);
@@ -411,9 +424,17 @@ __device__ __forceinline__ void nt_epilogue_lean_body(const NtParams& p, f32x4_t
                      make_float4(v[0], v[1], v[2], v[3]));
         }
         v[0] = gelu_tanh_fast(v[0]); v[1] = gelu_tanh_fast(v[1]); v[2] = gelu_tanh_fast(v[2]); v[3] = gelu_tanh_fast(v[3]);
+        if constexpr (DROP) {
+          v[0] *= df.x; v[1] *= df.y; v[2] *= df.z; v[3] *= df.w;
+        }
       } else if constexpr (EPI == AVF_EPI_DGELU) {
-        v[0] *= dgelu_tanh_fast(ex[j].x); v[1] *= dgelu_tanh_fast(ex[j].y);
-        v[2] *= dgelu_tanh_fast(ex[j].z); v[3] *= dgelu_tanh_fast(ex[j].w);
+        if constexpr (DROP) {
+          v[0] *= df.x * dgelu_tanh_fast(ex[j].x); v[1] *= df.y * dgelu_tanh_fast(ex[j].y);
+          v[2] *= df.z * dgelu_tanh_fast(ex[j].z); v[3] *= df.w * dgelu_tanh_fast(ex[j].w);
+        } else {
+          v[0] *= dgelu_tanh_fast(ex[j].x); v[1] *= dgelu_tanh_fast(ex[j].y);
+          v[2] *= dgelu_tanh_fast(ex[j].z); v[3] *= dgelu_tanh_fast(ex[j].w);
+        }
       }
       if constexpr (sizeof(CT) == 2) {
         cw[j][0] = pack_bf16x2(v[0], v[1]); cw[j][1] = pack_bf16x2(v[2], v[3]);
@@ -495,13 +516,14 @@ __device__ __forceinline__ void nt_epilogue_lean_body(const NtParams& p, f32x4_t
   }
   if constexpr (CS == 1) nt_cs_flush<NI>(p, cs, part_row, n_base, li, lg);
 }
-template <int EPI, typename CT, int MI, int NI, int CS, bool PRE, bool MXO = false, bool BIAS = true>
+template <int EPI, typename CT, int MI, int NI, int CS, bool PRE, bool MXO = false, bool BIAS = true, bool DROP = false>
 __device__ __forceinline__ void nt_epilogue_lean(const NtParams& p, f32x4_t (&acc)[MI][NI], int m_base, int n_base, int li, int lg,
-                                                 int part_row, const NtPre<MI, NI>* pre = nullptr, float (*cs_acc)[4] = nullptr) {
+                                                 int part_row, const NtPre<MI, NI>* pre = nullptr, float (*cs_acc)[4] = nullptr,
+                                                 uint64_t dkey = 0) {
   if (m_base + 16 * MI <= p.M)
-    nt_epilogue_lean_body<EPI, CT, MI, NI, CS, PRE, true, MXO, BIAS>(p, acc, m_base, n_base, li, lg, part_row, pre, cs_acc);
+    nt_epilogue_lean_body<EPI, CT, MI, NI, CS, PRE, true, MXO, BIAS, DROP>(p, acc, m_base, n_base, li, lg, part_row, pre, cs_acc, dkey);
   else
-    nt_epilogue_lean_body<EPI, CT, MI, NI, CS, PRE, false, MXO, BIAS>(p, acc, m_base, n_base, li, lg, part_row, pre, cs_acc);
+    nt_epilogue_lean_body<EPI, CT, MI, NI, CS, PRE, false, MXO, BIAS, DROP>(p, acc, m_base, n_base, li, lg, part_row, pre, cs_acc, dkey);
 }
 
 typedef __attribute__((address_space(1))) const void gptr_t;
@@ -575,8 +597,10 @@ int nt_lean_on() {
 int nt_wide_stores();
 // the preconditions of nt_epilogue_lean for a block tile of bn columns (host side)
 template <int EPI, typename CT>
-bool nt_lean_ok(const NtParams& p, int bn, bool mx_ok = false) {
-  if (!nt_lean_on() || p.drop.thresh16 || p.N % bn != 0) return false;
+bool nt_lean_ok(const NtParams& p, int bn, bool mx_ok = false, bool drop_ok = false) {
+  if (!nt_lean_on() || p.N % bn != 0) return false;
+  // a dropout site: only where the caller has the DROP instantiation (the bf16 kernels), and only on a fused epilogue
+  if (p.drop.thresh16 && !(drop_ok && EPI != AVF_EPI_NONE && !p.mxq)) return false;
   if (p.mxq && !(mx_ok && (EPI == AVF_EPI_BIAS_GELU || EPI == AVF_EPI_DGELU) && p.mxs && p.N % 32 == 0 && ((uintptr_t)p.mxq & 7) == 0))
     return false;
   if (p.cs_partial && EPI != AVF_EPI_DGELU) return false;

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void pack_ws_kernel(const bf16* __restrict__ w
   out[o] = *reinterpret_cast<const uint4*>(w + (int64_t)n * ldw + s * 32 + lg * 8);
 }
 
-template <int EPI, typename CT, int MI, int NSLOT, bool CS, bool MXO = false>
+template <int EPI, typename CT, int MI, int NSLOT, bool CS, bool MXO = false, bool DROP = false>
 __global__ __launch_bounds__(512) void gemm_bf16_nt_ws_kernel(NtParams p, const uint4* __restrict__ wp, int P, int G, int tq, int tr) {
   constexpr int NI = 2;
   constexpr int BM = 16 * MI;            // rows per tile
@@ -210,6 +210,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_ws_kernel(NtParams p, const 
   // compiler-visible, so that the wait-count pass knows the bias has landed: it would otherwise wait vmcnt(0) at the bias'
   // first use in EVERY iteration's epilogue - behind the DMA that iteration has just issued
   __builtin_amdgcn_s_waitcnt(0x0F70);
+  // DROP: the mask key of the epilogue's dropout site, once per kernel (a scalar load when the seed lives in device memory)
+  uint64_t dkey = 0;
+  if constexpr (DROP) dkey = drop_key(p.drop);
   uint32_t rd_slot = 0, wr_slot = (NSLOT - 1) * SLOT;
   for (int t = 0; t < nt; ++t) {
     WS_STAMP(4 + 6 * t);
@@ -288,8 +291,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_ws_kernel(NtParams p, const 
       nt_epilogue_lean<EPI, CT, MI, NI, 0, true>(p2, acc, (t0 + t) * BM, n0, li, lg, -1, &pre);
     } else {
       // (no bias on the plain and the dGELU form: gemm_bf16_nt_ws_ok)
-      nt_epilogue_lean<EPI, CT, MI, NI, CS ? 2 : 0, true, MXO, EPI != AVF_EPI_NONE && EPI != AVF_EPI_DGELU>(
-          p, acc, (t0 + t) * BM, n0, li, lg, -1, &pre, cs_acc);
+      nt_epilogue_lean<EPI, CT, MI, NI, CS ? 2 : 0, true, MXO, EPI != AVF_EPI_NONE && EPI != AVF_EPI_DGELU, DROP>(
+          p, acc, (t0 + t) * BM, n0, li, lg, -1, &pre, cs_acc, dkey);
     }
     __builtin_amdgcn_s_setprio(0);
     rd_slot = rd_slot + SLOT == NSLOT * SLOT ? 0 : rd_slot + SLOT;
@@ -325,7 +328,7 @@ int ws_grid() {
   return n;
 }
 
-template <int EPI, typename CT, int MI, int NSLOT, bool CS, bool MXO = false>
+template <int EPI, typename CT, int MI, int NSLOT, bool CS, bool MXO = false, bool DROP = false>
 int launch_ws(const NtParams& p, const void* bp, hipStream_t s, int* part_rows, TimingScope* ts) {
   constexpr int BM = 16 * MI;
   // the A ring, the per-wave staging of the epilogue's 2-byte operand rows (two tiles), [diagnostic build: the stamps]
@@ -333,7 +336,7 @@ int launch_ws(const NtParams& p, const void* bp, hipStream_t s, int* part_rows, 
   static_assert(SMEM <= 160 * 1024, "LDS budget");
   static PerDeviceOnce raised;
   if (SMEM > 64 * 1024 && raised.need()) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_ws_kernel<EPI, CT, MI, NSLOT, CS, MXO>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_ws_kernel<EPI, CT, MI, NSLOT, CS, MXO, DROP>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     AVF_REQUIRE(e == hipSuccess, "gemm_bf16_nt_ws: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
     raised.mark();
@@ -351,11 +354,11 @@ int launch_ws(const NtParams& p, const void* bp, hipStream_t s, int* part_rows, 
   if (shape_log_on()) {
     const double csz = sizeof(CT);
     const double epi_b = (EPI == AVF_EPI_BIAS_RES || EPI == AVF_EPI_BIAS_GELU || EPI == AVF_EPI_DGELU) ? csz * p.M * p.N : 0.0;
-    shape_log("gemm_bf16_nt,gemm_bf16_nt_ws_kernel<%d, %s, %d, %d, %s, %s>,%d,%d,%d,%d,%d,%.0f,%.0f", EPI,
-              sizeof(CT) == 4 ? "float" : "bf16", MI, NSLOT, CS ? "true" : "false", MXO ? "true" : "false", nwg, p.M, p.N, p.K, EPI, 2.0 * p.M * p.N * p.K,
+    shape_log("gemm_bf16_nt,gemm_bf16_nt_ws_kernel<%d, %s, %d, %d, %s, %s, %s>,%d,%d,%d,%d,%d,%.0f,%.0f", EPI,
+              sizeof(CT) == 4 ? "float" : "bf16", MI, NSLOT, CS ? "true" : "false", MXO ? "true" : "false", DROP ? "true" : "false", nwg, p.M, p.N, p.K, EPI, 2.0 * p.M * p.N * p.K,
               2.0 * ((double)p.M * p.K + (double)p.N * p.K) + csz * p.M * p.N + epi_b);
   }
-  launch_in_scope(ts, gemm_bf16_nt_ws_kernel<EPI, CT, MI, NSLOT, CS, MXO>, dim3(nwg), dim3(512), SMEM, s, p, (const uint4*)bp, P, G, T / G, T % G);
+  launch_in_scope(ts, gemm_bf16_nt_ws_kernel<EPI, CT, MI, NSLOT, CS, MXO, DROP>, dim3(nwg), dim3(512), SMEM, s, p, (const uint4*)bp, P, G, T / G, T % G);
   return 0;
 }
 
@@ -363,6 +366,16 @@ template <int EPI, typename CT>
 int launch_ws_any(const NtParams& p, const void* bp, hipStream_t s, int* part_rows, TimingScope* ts) {
   // column sums ride on the dGELU epilogue only (db1 of the layer's backward); other epilogues with a colsum request go to
   // the tiled kernel (gemm_bf16_nt_ws_ok)
+  if constexpr (EPI != AVF_EPI_NONE) {
+    if (p.drop.thresh16) {  // the epilogue's dropout site (training at p > 0: heads.py:277 and every real instantiation)
+      AVF_REQUIRE(!p.mxq, "gemm_bf16_nt_ws: no MX-FP8 image beside a dropout site (internal error)");
+      if constexpr (EPI == AVF_EPI_DGELU && sizeof(CT) == 2) {
+        if (p.cs_partial) return launch_ws<EPI, CT, 2, 3, true, false, true>(p, bp, s, part_rows, ts);
+      }
+      AVF_REQUIRE(!p.cs_partial, "gemm_bf16_nt_ws: no instantiation for this combination of options (internal error)");
+      return launch_ws<EPI, CT, 2, 3, false, false, true>(p, bp, s, part_rows, ts);
+    }
+  }
   if constexpr (EPI == AVF_EPI_DGELU && sizeof(CT) == 2) {
     if (p.cs_partial && p.mxq) return launch_ws<EPI, CT, 2, 3, true, true>(p, bp, s, part_rows, ts);  // (the fp8 mode's dGELU)
     if (p.cs_partial) return launch_ws<EPI, CT, 2, 3, true>(p, bp, s, part_rows, ts);
@@ -404,8 +417,9 @@ bool gemm_bf16_nt_ws_ok(const GemmArgs& a) {
   if ((a.epilogue == AVF_EPI_DGELU || a.epilogue == AVF_EPI_BIAS_GELU) && (a.ldaux % 8 || ((uintptr_t)a.aux & 15))) return false;
   if (a.epilogue == AVF_EPI_DGELU && a.c_dtype != AVF_BF16) return false;
   if ((a.epilogue == AVF_EPI_DGELU || a.epilogue == AVF_EPI_NONE) && a.bias) return false;  // (compiled without the bias add)
-  // the lean epilogue (gemm_nt.hpp) has no dropout site and sums columns on the dGELU epilogue only
-  if (a.drop.thresh16) return false;
+  // the lean epilogue (gemm_nt.hpp) carries a dropout site on a fused epilogue only (never beside an MX-FP8 image) and sums
+  // columns on the dGELU epilogue only
+  if (a.drop.thresh16 && (a.epilogue == AVF_EPI_NONE || a.mx_q)) return false;
   if (a.colsum && a.epilogue != AVF_EPI_DGELU) return false;
   // the MX-FP8 image of C: on the dGELU form with column sums only (what the fp8 mode's backward asks for)
   if (a.mx_q && !(a.mx_s && a.epilogue == AVF_EPI_DGELU && a.colsum && a.c_dtype == AVF_BF16 && a.N % 32 == 0 && ((uintptr_t)a.mx_q & 7) == 0))

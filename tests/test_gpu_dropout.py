@@ -38,15 +38,20 @@ def test_mask_statistics():
 
 
 @pytest.mark.parametrize("cfg", [(3, 77, 128, 2, 8, 32, 256), (2, 324, 512, 2, 8, 64, 1024),
-                                 (4, 12, 128, 2, 8, 32, 256)])  # the last one takes the single-launch forward
+                                 (4, 12, 128, 2, 8, 32, 256),       # takes the single-launch forward
+                                 (8, 324, 512, 2, 8, 64, 1024),     # 2592 rows: the persistent GEMM + the lean epilogue's
+                                 (8, 324, 512, 2, 8, 64, 1024, "bf16")])  # ... dropout site (DROP), both residual streams
 def test_mask_replay_against_oracle(cfg):
     import avformer_amd as A
-    B, N, D, L, H, dh, M = cfg
+    B, N, D, L, H, dh, M = cfg[:7]
+    resid = cfg[7] if len(cfg) > 7 else "f32"
     p = 0.25
     g = torch.Generator().manual_seed(5)
     sd = oracle.init_transformer_state(D, L, H, dh, M, generator=g)
     x = torch.randn(B, N, D, generator=g)
-    t = A.Transformer(D, L, H, dh, M, dropout=p, compute_dtype="bf16")
+    t = A.Transformer(D, L, H, dh, M, dropout=p, compute_dtype="bf16", residual_dtype=resid)
+    if B * N >= 2048 and D == 512:
+        assert A.ops.gemm_ws_used(B * N, M, D, A.ops.EPI_BIAS_GELU), "expected on the persistent kernel"
     t.load_state_dict(sd)
     t = t.to(DEV).train()
     xg = x.to(DEV).requires_grad_(True)
@@ -63,10 +68,11 @@ def test_mask_replay_against_oracle(cfg):
     yr.pow(2).mean().backward()
     # masked activations differ from the unmasked forward by O(1); agreement at bf16 level proves the same masks
     tag = "dropout_replay[" + "x".join(map(str, cfg)) + "]"
-    check_rel(tag + ":y", y, yr, 1.5e-2)
-    check_rel(tag + ":dx", xg.grad, xr.grad, 3e-2)
+    caps = (1.5e-2, 3e-2, 4e-2) if resid == "f32" else (3e-2, 5e-2, 6e-2)
+    check_rel(tag + ":y", y, yr, caps[0])
+    check_rel(tag + ":dx", xg.grad, xr.grad, caps[1])
     for k, prm in t.named_parameters():
-        check_rel(f"{tag}:g.{k}", prm.grad, pr[k].grad, 4e-2)
+        check_rel(f"{tag}:g.{k}", prm.grad, pr[k].grad, caps[2])
     y_nodrop = oracle.transformer_forward(x, sd, L, H)
     assert rel_fro(yr, y_nodrop) > 0.1               # the masks really changed the result
     # a second forward draws a new seed -> different output; eval() -> deterministic, equals the p=0 math
@@ -75,7 +81,7 @@ def test_mask_replay_against_oracle(cfg):
     t.eval()
     with torch.no_grad():
         ye = t(xg)
-    check_rel(tag + ":eval_y", ye, y_nodrop, 1.5e-2)
+    check_rel(tag + ":eval_y", ye, y_nodrop, caps[0])
 
 
 @pytest.mark.parametrize("cfg", [(3, 77, 128, 2, 8, 32, 256), (2, 100, 64, 3, 2, 16, 96), (4, 12, 128, 2, 8, 32, 256)])

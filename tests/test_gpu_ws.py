@@ -121,45 +121,51 @@ def test_unfit_shapes_are_refused_and_the_layer_falls_back():
         ops.gemm_ws(a, ops.pack_ws(w), 512)
 
 
-def test_stack_with_and_without_the_persistent_kernel(tmp_path):
-    """AVF_NT_WS is read once per process: two child processes run the same 2-layer stack (forward + backward) with the
-    persistent kernel on and off, then one FusedAdam step - the only writer of the fragment-major weight images from then on -
-    and a second forward.  Every tensor is bit-identical except the gradient of net.0's bias, whose column sums go through
-    per-tile (tiled kernel) or per-workgroup (persistent kernel) fp32 partial sums (and what that bias feeds after the step:
-    the second forward is held to 1e-3)."""
+@pytest.mark.parametrize("dropout", [0.0, 0.2])
+def test_stack_with_and_without_the_persistent_kernel(tmp_path, dropout):
+    """AVF_NT_WS / AVF_NT_LEAN are read once per process (and exist under AVF_TUNING=1 only): three child processes run the same
+    2-layer stack (forward + backward) on (a) the persistent kernel + lean epilogue, (b) the tiled kernel + lean epilogue,
+    (c) the tiled kernel + the general run-time-option epilogue; then one FusedAdam step - the only writer of the
+    fragment-major weight images from then on - and a second forward.  dropout = 0.2 (the reference's heads.py:277): the
+    lean epilogue's compile-time dropout site (DROP) against the general epilogue's, same seed (torch.manual_seed), same
+    masks.  Every tensor is bit-identical except the gradient of net.0's bias, whose column sums go through per-tile (tiled
+    kernel) or per-workgroup (persistent kernel) fp32 partial sums (and what that bias feeds after the step: the second
+    forward is held to 1e-3)."""
     import subprocess
     import sys
     code = (
         "import os, torch, avformer_amd as A\n"
         "torch.manual_seed(3)\n"
-        "m = A.Transformer(512, 2, 8, 64, 1024, compute_dtype='bf16', residual_dtype='bf16').cuda()\n"
+        f"m = A.Transformer(512, 2, 8, 64, 1024, {dropout}, compute_dtype='bf16', residual_dtype='bf16').cuda().train()\n"
         "x = torch.randn(8, 324, 512, device='cuda', requires_grad=True)\n"
         "y = m(x); y.float().pow(2).mean().backward()\n"
-        "d = {'y': y.detach().float().cpu(), 'dx': x.grad.cpu()}\n"
+        "d = {'y': y.detach().float().cpu(), 'dx': x.grad.cpu(), 'seed': torch.tensor(float(m.last_seed % 65536))}\n"
         "d.update({n: p.grad.clone().cpu() for n, p in m.named_parameters()})\n"
         # ... then one library Adam step (which rewrites the weight images, the fragment-major ones included) and a forward on them
         "opt = A.optim.FusedAdam(m, lr=1e-3)\n"
         "opt.step()\n"
+        "m.eval()\n"
         "with torch.no_grad():\n"
         "    d['y_after_step'] = m(x.detach()).float().cpu()\n"
         "torch.save(d, os.environ['AVF_TEST_OUT'])\n")
     outs = []
-    for ws in ("1", "0"):
-        path = str(tmp_path / f"ws{ws}.pt")
-        env = dict(os.environ, AVF_TUNING="1", AVF_NT_WS=ws, AVF_TEST_OUT=path)  # (switches exist under AVF_TUNING=1 only)
+    for ws, lean in (("1", "1"), ("0", "1"), ("0", "0")):
+        path = str(tmp_path / f"ws{ws}{lean}.pt")
+        env = dict(os.environ, AVF_TUNING="1", AVF_NT_WS=ws, AVF_NT_LEAN=lean, AVF_TEST_OUT=path)  # (switches exist under AVF_TUNING=1 only)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env,
                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(torch.load(path))
-    on, off = outs
-    assert on.keys() == off.keys()
-    for k in on:
-        if k.endswith("net.0.bias"):
-            assert torch.allclose(on[k], off[k], rtol=1e-4, atol=1e-6), k
-        elif k == "y_after_step":  # (Adam turns the last-bit difference of d net.0.bias into a different update of that bias)
-            assert (on[k] - off[k]).norm() <= 1e-3 * off[k].norm(), k
-        else:
-            assert torch.equal(on[k], off[k]), k
+    on = outs[0]
+    for off in outs[1:]:
+        assert on.keys() == off.keys()
+        for k in on:
+            if k.endswith("net.0.bias"):
+                assert torch.allclose(on[k], off[k], rtol=1e-4, atol=1e-6), k
+            elif k == "y_after_step":  # (Adam turns the last-bit difference of d net.0.bias into a different update of that bias)
+                assert (on[k] - off[k]).norm() <= 1e-3 * off[k].norm(), k
+            else:
+                assert torch.equal(on[k], off[k]), k
 
 
 # ---------------------------------------------------------------------------------------------- against the ORACLE, >= 2048 rows
