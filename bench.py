@@ -169,7 +169,7 @@ class Region:
         torch.manual_seed(123)  # identical weights on every rank (reference default seed, opts.py:19)
         self.residual = args.residual if dtype != "f32" else "f32"
         model = A.SyntheticAVFormer(c["dim"], c["depth"], c["heads"], c["dim_head"], c["mlp_dim"], Tv, Ta, task="AU",
-                                    compute_dtype=dtype, residual_dtype=self.residual).to(dev)
+                                    compute_dtype=dtype, residual_dtype=self.residual, dropout=args.dropout).to(dev)
         g = torch.Generator().manual_seed(123 + rank)  # rank-distinct synthetic clips
         clip = torch.randn(B, Tv, c["dim"], generator=g).to(dev)
         audio = torch.randn(B, Ta, c["dim"], generator=g).to(dev)
@@ -425,6 +425,8 @@ def main():
                          "bf16 since round 3 (statistics, accumulation and the add stay fp32; tolerance: tests/test_gpu_resid16.py), "
                          "the fp32-stream step is timed beside it (`residual_f32`)")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
+    ap.add_argument("--dropout", type=float, default=0.0,
+                    help="dropout of the stack (BASELINE's configs: 0; the reference's real stacks train at 0.2, heads.py:277)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+bwd(+all-reduce) only")
@@ -502,7 +504,7 @@ def main():
                                f"mlp={c['mlp_dim']}, T_v={Tv}+T_a={Ta} tokens, B={B}/GPU",
                    "global_batch": B * world, "seq_len": Tv + Ta, "parallelism": f"dp{world}",
                    "step": "zero_grad+fwd+AULoss+bwd" + ("+allreduce" if use_dist else "") + ("+adam" if main_r.optimizer else ""),
-                   "optimizer": main_r.optimizer, "residual_stream": main_r.residual, "loss": main_r.loss},
+                   "optimizer": main_r.optimizer, "residual_stream": main_r.residual, "dropout": args.dropout, "loss": main_r.loss},
         "untimed_steps_beyond_warmup": main_r.extra_warmup,  # until the caching allocator stopped growing (Region.timed)
         "launch": main_r.launch,
         # the same step launched eagerly from Python (None when `value` itself is the eager number)

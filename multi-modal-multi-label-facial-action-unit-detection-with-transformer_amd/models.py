@@ -157,13 +157,14 @@ class SyntheticAVFormer(nn.Module, _TaskLossMixin):
     [B, T_v + T_a, dim] token sequence, mean pooling, 12 AU logits in the reference's [B,21] layout."""
 
     def __init__(self, dim=512, depth=6, heads=8, dim_head=64, mlp_dim=1024, t_video=196, t_audio=128, task='AU',
-                 compute_dtype="bf16", residual_dtype="f32"):
+                 compute_dtype="bf16", residual_dtype="f32", dropout=0.0):
         super().__init__()
         self.task = task
         self.modes = ['clip', 'audio_features']
         self.t_video, self.t_audio = t_video, t_audio
         self.pos_embedding = nn.Parameter(torch.randn(1, t_video + t_audio, dim) * 0.02)
-        self.transformer = Transformer(dim, depth, heads, dim_head, mlp_dim, 0.0, compute_dtype=compute_dtype,
+        # dropout: 0 in BASELINE's configs; the reference's real stacks train at 0.2 (heads.py:277) - bench.py --dropout times it
+        self.transformer = Transformer(dim, depth, heads, dim_head, mlp_dim, dropout, compute_dtype=compute_dtype,
                                        residual_dtype=residual_dtype)
         self.au_fc = nn.Linear(dim, 12)
         self.loss_AU = AULoss()

@@ -26,7 +26,7 @@ def box_id():
         return {"host": socket.gethostname(), "gpu": "?"}
 
 
-def run(env_extra, steps, extra):
+def run(env_extra, steps, extra):  # extra: bench.py arguments of this arm
     env = dict(os.environ)
     env.update(env_extra)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps)] + extra, capture_output=True, text=True,
@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--note", default="")
+    ap.add_argument("--a-args", default="", help="bench.py arguments of arm A only (one string, e.g. '--dropout 0')")
+    ap.add_argument("--b-args", default="")
     args, rest = ap.parse_known_args()  # everything this tool does not know goes to bench.py (e.g. --config c5 --dtype mx8)
     args.bench_args = rest
     ea, eb = parse_env(args.a_env), parse_env(args.b_env)
@@ -70,12 +72,12 @@ def main():
     runs = {"A": [], "B": []}
     for i in range(args.rounds):
         for arm, env in (("A", ea), ("B", eb)):
-            runs[arm].append(run(env, args.steps, args.bench_args))
+            runs[arm].append(run(env, args.steps, args.bench_args + (args.a_args if arm == "A" else args.b_args).split()))
             print(f"round {i + 1} arm {arm}: {runs[arm][-1]}", flush=True)  # (a silent GPU-box call is taken for a hung one)
     med = lambda arm, k: statistics.median([r[k] for r in runs[arm] if r[k] is not None]) if any(r[k] is not None for r in runs[arm]) else None
     out = {"name": args.name, "note": args.note, "box": box_id(), "alternations": args.rounds, "steps": args.steps,
-           "arm_A": {"env": ea, "runs": runs["A"], "median_c2_ms": med("A", "c2_ms"), "median_c3_ms": med("A", "c3_ms")},
-           "arm_B": {"env": eb, "runs": runs["B"], "median_c2_ms": med("B", "c2_ms"), "median_c3_ms": med("B", "c3_ms")}}
+           "arm_A": {"env": ea, "args": args.a_args, "runs": runs["A"], "median_c2_ms": med("A", "c2_ms"), "median_c3_ms": med("A", "c3_ms")},
+           "arm_B": {"env": eb, "args": args.b_args, "runs": runs["B"], "median_c2_ms": med("B", "c2_ms"), "median_c3_ms": med("B", "c3_ms")}}
     a2, b2, a3, b3 = out["arm_A"]["median_c2_ms"], out["arm_B"]["median_c2_ms"], out["arm_A"]["median_c3_ms"], out["arm_B"]["median_c3_ms"]
     out["B_over_A_c2"] = round(b2 / a2, 4) if a2 and b2 else None
     out["B_over_A_c3"] = round(b3 / a3, 4) if a3 and b3 else None
