@@ -64,7 +64,9 @@ def test_packed_image_is_a_permutation_of_the_weight():
 
 @pytest.mark.parametrize("epi_name", ["none", "res", "gelu", "dgelu"])
 @pytest.mark.parametrize("out", ["bf16", "f32"])
-@pytest.mark.parametrize("M,N", [(16384, 512), (10368, 1024), (4099, 1536), (2048, 256)])
+@pytest.mark.parametrize("M,N", [(16384, 512), (10368, 1024), (4099, 1536), (2048, 256),
+                                 # last tile ragged by 16 rows / by 24: as many groups as tiles, one tile each
+                                 (2064, 256), (2056, 256)])
 def test_persistent_kernel_equals_the_tiled_kernel_bit_for_bit(epi_name, out, M, N):
     epi = {"none": ops.EPI_NONE, "res": ops.EPI_BIAS_RES, "gelu": ops.EPI_BIAS_GELU, "dgelu": ops.EPI_DGELU}[epi_name]
     od = bf if out == "bf16" else torch.float32
