@@ -341,7 +341,7 @@ int layernorm_bwd(const void* dy, int dy_dtype, const void* x, const float* gamm
                   const float* rstd, const void* dres, float* dx, void* dx_lo, float* dgamma, float* dbeta,
                   float* dcolsum, void* ws, int64_t rows, int dim, hipStream_t s, const DropCfg& drop = kNoDrop,
                   FoldJob* defer_fold = nullptr, int dres_dtype = AVF_F32, int x_dtype = AVF_F32, void* mx_q = nullptr,
-                  void* mx_s = nullptr);  // mx_q / mx_s: also the MX-FP8 image of the values written to dx_lo
+                  void* mx_s = nullptr, void* dx_m = nullptr);  // mx_q / mx_s: also the MX-FP8 image of the values written to dx_lo
 size_t colsum_ws(int64_t rows, int cols);
 int colsum(const void* in, int in_dtype, int64_t rows, int cols, int64_t ld, float* out, void* ws, hipStream_t s);
 int cast_f32_to_bf16(const float* in, void* out, int64_t n, hipStream_t s, const DropCfg& drop = kNoDrop);

@@ -31,6 +31,8 @@ struct Dims {
   const uint64_t* seed_dev;
   int layer;
   bool gs16;  // backward keeps the residual gradient stream in bf16 (no fp32 dx between the LayerNorm backward kernels)
+  bool gsd;   // ... with LIVE dropout: every hand-off is two bf16 images, the stream (never masked) and, behind it in the same
+              // buffer, what the Linear behind the dropout site sees (masked, rescaled) - all-bf16 streams only (resid_bf16)
   bool mx;    // forward nn.Linear GEMMs fed by LayerNorm / GELU (qkv, mlp1, mlp2) take MX-FP8 operands (config 5)
   bool rs16;  // the FORWARD residual stream (x_in, x_mid, x_out) is stored in bf16 (statistics / accumulation stay fp32)
   int xdt;    // storage type of the residual stream
@@ -43,7 +45,8 @@ struct Dims {
 // bf16 gradient-stream buffers in the mx8_bwd mode: [R, D] bf16 | [R, D] e4m3 | [R, D / 32] E8M0, each part 256-aligned
 inline size_t grad_q_off(int64_t R, int D) { return align_up((size_t)R * D * 2, 256); }
 inline size_t grad_s_off(int64_t R, int D) { return grad_q_off(R, D) + align_up((size_t)R * D, 256); }
-inline size_t grad_stream_bytes(int64_t R, int D, bool mxb) {
+inline size_t grad_stream_bytes(int64_t R, int D, bool mxb, bool gsd = false) {
+  if (gsd) return 2 * grad_q_off(R, D);  // [R, D] bf16 stream | [R, D] bf16 masked image (at grad_q_off)
   return mxb ? grad_s_off(R, D) + align_up((size_t)R * D / 32, 256) : (size_t)R * D * 2;
 }
 
@@ -66,8 +69,10 @@ int make_dims(const avf_layer_cfg* c, Dims* d) {
   d->p = c->dropout_p; d->seed = ((uint64_t)c->seed_hi << 32) | c->seed_lo; d->layer = c->layer_index;
   d->seed_dev = (const uint64_t*)c->seed_dev;
   d->gs16 = c->grad_stream_bf16 != 0;
-  AVF_REQUIRE(!d->gs16 || (c->dtype == AVF_BF16 && c->dropout_p == 0.0f && c->dim <= 1536),
-              "layer: grad_stream_bf16 needs the bf16 path, dropout_p == 0 and dim <= 1536");
+  d->gsd = d->gs16 && c->dropout_p > 0.0f;
+  AVF_REQUIRE(!d->gs16 || (c->dtype == AVF_BF16 && c->dim <= 1536), "layer: grad_stream_bf16 needs the bf16 path and dim <= 1536");
+  AVF_REQUIRE(!d->gsd || (c->resid_bf16 != 0 && c->mx8_fwd == 0 && c->dim % 8 == 0),
+              "layer: grad_stream_bf16 with dropout_p > 0 needs resid_bf16 (all-bf16 streams), no mx8 and dim %% 8 == 0");
   d->mx = c->mx8_fwd != 0;
   AVF_REQUIRE(!d->mx || (c->dtype == AVF_BF16 && c->dim % 128 == 0 && c->mlp_dim % 128 == 0 && c->dim <= 1536),
               "layer: mx8_fwd needs the bf16 path with dim and mlp_dim multiples of 128 (dim=%d mlp_dim=%d)", c->dim,
@@ -197,6 +202,7 @@ struct Work {
   void *oq, *os;            // mx8_fwd: image of the attention output (forward scratch)
   void *duq, *dus, *mq, *ms, *gyq, *gys;  // mx8_bwd: images of du, of dx_mid, and of dx_out when the caller brought none
   void *dqq, *dqs;                        // mx8_bwd: image of dqkv (written by the merged attention backward)
+  void *dx_out_s, *dx_mid_m;  // gsd: the unmasked bf16 stream image of dx_out (top of the stack), the masked image of dx_mid
   float *gy_m, *gm_m;       // fp32 mode with live dropout: masked copies of dx_out / dx_mid (what the Linears behind sites 2 / 0 see)
   float* small_part;        // short-sequence backward: per-clip partial rows (pb1 [B][M] | pln2 [B][3D] | pln1 [B][3D])
 };
@@ -252,6 +258,8 @@ size_t carve_work(const Dims& d, void* base, Work* w) {
     t.duq = t.dus = t.mq = t.ms = t.gyq = t.gys = nullptr;
     t.dqq = t.dqs = nullptr;
   }
+  t.dx_out_s = c.take(d.gsd ? d.R * d.D * 2 : 0);
+  t.dx_mid_m = c.take(d.gsd ? d.R * d.D * 2 : 0);
   const bool f32_drop = d.dt == AVF_F32 && d.p > 0.f;
   t.gy_m = (float*)c.take(f32_drop ? d.R * d.D * 4 : 0);
   t.gm_m = (float*)c.take(f32_drop ? d.R * d.D * 4 : 0);
@@ -377,7 +385,7 @@ extern "C" size_t avf_layer_lowp_bytes(const avf_layer_cfg* cfg) {
 extern "C" size_t avf_layer_grad_stream_bytes(const avf_layer_cfg* cfg) {
   Dims d;
   if (make_dims(cfg, &d)) return 0;
-  return grad_stream_bytes(d.R, d.D, d.mxb);
+  return grad_stream_bytes(d.R, d.D, d.mxb, d.gsd);
 }
 extern "C" size_t avf_layer_workspace_bytes(const avf_layer_cfg* cfg) {
   Dims d;
@@ -548,16 +556,26 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   }();
   const bool small_bwd = lo && !d.rs16 && !d.mx && !d.keep && small_bwd_on && small_layer_ok(d.dt, d.N, d.D, d.H, d.dh, d.M);
   const void* gy = dx_out;
+  const void* gy_stream = nullptr;  // gsd: the unmasked bf16 stream (LayerNorm-2 backward's residual gradient); gy is the masked image
   bool own_copy = false;
   if (lo) {
-    if (dx_out_lo) gy = dx_out_lo;  // the caller's previous call already applied this layer's site-2 mask
+    if (dx_out_lo && d.gsd) {  // [stream | masked by this layer's site-2 mask] - written by the layer above's LayerNorm-1 backward
+      gy_stream = dx_out_lo;
+      gy = (const char*)dx_out_lo + grad_q_off(d.R, d.D);
+    } else if (dx_out_lo) gy = dx_out_lo;  // the caller's previous call already applied this layer's site-2 mask
     else if (small_bwd) gy = w.dx_out_lo;  // written by the fused kernel below
     else {
       AVF_TRY(cast_f32_to_bf16(dx_out, w.dx_out_lo, d.R * d.D, s, dr2));
       gy = w.dx_out_lo;
       own_copy = true;
+      if (d.gsd) {  // top of the stack: the stream image beside the masked one
+        AVF_TRY(cast_f32_to_bf16(dx_out, w.dx_out_s, d.R * d.D, s, kNoDrop));
+        gy_stream = w.dx_out_s;
+      }
     }
   }
+  AVF_REQUIRE(!d.gsd || !small_bwd, "layer_bwd: grad_stream_bf16 with dropout on a short-sequence layer (internal error)");
+  const bool gm_masked = d.gsd && d.p0 > 0.f;  // a separate masked image of dx_mid exists (site 0 behind a real to_out)
   const bool f32_drop = !lo && d.p > 0.f;
   if (f32_drop) {  // fp32 mode with live dropout: net.3 sees the gradient through its site-2 mask
     AVF_TRY(mask_copy_f32(dx_out, w.gy_m, d.R * d.D, s, dr2));
@@ -565,7 +583,8 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
     own_copy = true;
   }
   const bool f32_drop0 = f32_drop && d.p0 > 0.f;  // (no site 0 behind an nn.Identity to_out)
-  const void* gm = lo ? (const void*)w.dx_mid_lo : (f32_drop0 ? (const void*)w.gm_m : (const void*)w.dx_mid);
+  const void* gm = lo ? (gm_masked ? (const void*)w.dx_mid_m : (const void*)w.dx_mid_lo)
+                      : (f32_drop0 ? (const void*)w.gm_m : (const void*)w.dx_mid);
   // bf16 mode: the four dW GEMMs run as ONE grouped launch at the end of the layer (their operands all stay
   // alive in the workspace), when the shapes allow the LDS-DMA kernel
   TnGroupArgs grp = dw_group(d, gy, sv.g, w.du, sv.h2, gm, sv.o, w.dqkv, sv.h1, g);
@@ -695,9 +714,10 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
                          nullptr));
   else
     AVF_TRY(linear_dx(d, w.du, d.M, p->w1, l.w1_t, d.D, w.dh, AVF_EPI_NONE, nullptr, s));
-  if (d.gs16)  // residual gradient in: the bf16 image the GEMMs read; out: the bf16 dx_mid only
-    AVF_TRY(layernorm_bwd(w.dh, d.dt, sv.x_mid, p->ln2_w, sv.mean2, sv.rstd2, gy, nullptr, w.dx_mid_lo, g->ln2_w, g->ln2_b,
-                          g->b_out, w.ln_ws, d.R, d.D, s, dr0, grouped ? &folds.job[1] : nullptr, AVF_BF16, d.xdt, w.mq, w.ms));
+  if (d.gs16)  // residual gradient in: the bf16 image the GEMMs read (gsd: the unmasked stream); out: the bf16 dx_mid only
+    AVF_TRY(layernorm_bwd(w.dh, d.dt, sv.x_mid, p->ln2_w, sv.mean2, sv.rstd2, d.gsd ? gy_stream : gy, nullptr, w.dx_mid_lo,
+                          g->ln2_w, g->ln2_b, g->b_out, w.ln_ws, d.R, d.D, s, dr0, grouped ? &folds.job[1] : nullptr, AVF_BF16,
+                          d.xdt, w.mq, w.ms, gm_masked ? w.dx_mid_m : nullptr));
   else
     AVF_TRY(layernorm_bwd(w.dh, d.dt, sv.x_mid, p->ln2_w, sv.mean2, sv.rstd2, dx_out, w.dx_mid,
                           lo ? w.dx_mid_lo : nullptr, g->ln2_w, g->ln2_b, g->b_out, w.ln_ws, d.R, d.D, s, dr0,
@@ -739,10 +759,10 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   else
     AVF_TRY(linear_dx(d, w.dqkv, 3 * d.I, p->w_qkv, l.wqkv_t, d.D, w.dh, AVF_EPI_NONE, nullptr, s));
   // dx_in may alias dx_out, which the grouped dW2 GEMM does not read (it uses the bf16 copy gy)
-  if (d.gs16)
+  if (d.gs16)  // (gsd: the masked image for the layer below goes behind the stream in dx_in_lo; layer 0 has no site below it)
     AVF_TRY(layernorm_bwd(w.dh, d.dt, x_in, p->ln1_w, sv.mean1, sv.rstd1, w.dx_mid_lo, dx_in, dx_in_lo, g->ln1_w, g->ln1_b,
                           dx_in_colsum, w.ln_ws1, d.R, d.D, s, dr_prev2, grouped ? &folds.job[2] : nullptr, AVF_BF16, d.xdt,
-                          inq, ins));
+                          inq, ins, (d.gsd && dr_prev2.thresh16) ? (char*)dx_in_lo + grad_q_off(d.R, d.D) : nullptr));
   else
     AVF_TRY(layernorm_bwd(w.dh, d.dt, x_in, p->ln1_w, sv.mean1, sv.rstd1, w.dx_mid, dx_in, lo ? dx_in_lo : nullptr,
                           g->ln1_w, g->ln1_b, dx_in_colsum, w.ln_ws1, d.R, d.D, s, dr_prev2,

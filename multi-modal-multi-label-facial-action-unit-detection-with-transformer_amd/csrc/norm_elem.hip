@@ -575,14 +575,20 @@ int fold_job(const FoldJob& j, hipStream_t s) { return launch_fold(j.partial, j.
 // LayerNorm backward on the all-bf16 streams (dy, x, the incoming residual gradient and dx in bf16; no dropout, no MX image):
 // the row8 layout of ln_fwd_row8_kernel.  A workgroup owns LNR_ROWS_PER_BLOCK = 4 waves x RU rows; the per-column sums stay in
 // registers and are combined through LDS in wave order, so the partial of a block - and the folded result - is deterministic.
-template <int NV8, int RU>
+// DROP (round 5): live dropout on the all-bf16 streams.  The row gradient leaves TWICE: dx_lo = the residual-gradient stream
+// (never masked: the next LayerNorm backward's dres) and dx_m = what the Linear behind the dropout site sees (masked, rescaled:
+// the GEMM operand; the column sums - that Linear's bias gradient - are those of the MASKED values, as ln_bwd_reg_kernel's).
+template <int NV8, int RU, bool DROP = false>
 __global__ __launch_bounds__(256) void ln_bwd_row8_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, const bf16* __restrict__ dres,
                                                           bf16* __restrict__ dx_lo, float* __restrict__ partial, int64_t rows,
                                                           int D, int want_colsum, uint8_t* __restrict__ dxq = nullptr,
-                                                          uint8_t* __restrict__ dxs = nullptr, float* __restrict__ dx = nullptr) {
+                                                          uint8_t* __restrict__ dxs = nullptr, float* __restrict__ dx = nullptr,
+                                                          DropCfg drop = kNoDrop, bf16* __restrict__ dx_m = nullptr) {
   // dx (optional, wave-uniform): the fp32 copy of the row gradient (the bottom layer hands it to the caller)
+  uint64_t dkey = 0;
+  if constexpr (DROP) dkey = drop_key(drop);
   static_assert((LNR_ROWS_PER_BLOCK / 4) % RU == 0, "a wave's rows come in whole batches of RU");
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [4 waves][3][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -663,12 +669,21 @@ __global__ __launch_bounds__(256) void ln_bwd_row8_kernel(const bf16* __restrict
         o[k] = rs[r] * (d[k] * gm[i][k] - s1[r] - xh * s2[r]) + e[k];
         adg[i][k] = fmaf(d[k], xh, adg[i][k]);
         adb[i][k] += d[k];
-        acs[i][k] += o[k];
+        if constexpr (!DROP) acs[i][k] += o[k];
       }
       *reinterpret_cast<uint4*>(dx_lo + (row0 + r) * D + c) = pack8(o);
       if (dx) {
         *reinterpret_cast<float4*>(dx + (row0 + r) * D + c) = make_float4(o[0], o[1], o[2], o[3]);
         *reinterpret_cast<float4*>(dx + (row0 + r) * D + c + 4) = make_float4(o[4], o[5], o[6], o[7]);
+      }
+      if constexpr (DROP) {  // the masked image (element index = row * D + column, as every other user of this site's mask)
+        const uint64_t e0 = (uint64_t)(row0 + r) * D + c;
+        const float4 f0 = drop_factor4(drop, dkey, e0), f1 = drop_factor4(drop, dkey, e0 + 4);
+        o[0] *= f0.x; o[1] *= f0.y; o[2] *= f0.z; o[3] *= f0.w;
+        o[4] *= f1.x; o[5] *= f1.y; o[6] *= f1.z; o[7] *= f1.w;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acs[i][k] += o[k];
+        *reinterpret_cast<uint4*>(dx_m + (row0 + r) * D + c) = pack8(o);
       }
       if (dxq) {  // wave-uniform: MX-FP8 image of the same values (D % 32 == 0: the four lanes of a block are live together)
         const MxBlock mb = mx8_encode(o);
@@ -709,7 +724,11 @@ size_t layernorm_bwd_ws(int64_t rows, int dim) {
 int layernorm_bwd(const void* dy, int dy_dtype, const void* xv, const float* gamma, const float* mean,
                   const float* rstd, const void* dres, float* dx, void* dx_lo, float* dgamma, float* dbeta,
                   float* dcolsum, void* ws, int64_t rows, int dim, hipStream_t s, const DropCfg& drop,
-                  FoldJob* defer_fold, int dres_dtype, int x_dtype, void* mx_q, void* mx_s) {
+                  FoldJob* defer_fold, int dres_dtype, int x_dtype, void* mx_q, void* mx_s, void* dx_m) {
+  // dx_m (with a live `drop`, all-bf16 streams only): dx_lo is then the UNMASKED stream and dx_m the masked image (row8 DROP)
+  AVF_REQUIRE(!dx_m || (drop.thresh16 && dx_lo && dy_dtype == AVF_BF16 && x_dtype == AVF_BF16 && (!dres || dres_dtype == AVF_BF16) &&
+                        dim % 8 == 0 && dim <= 1536 && !mx_q),
+              "layernorm_bwd: a separate masked image needs live dropout on the all-bf16 streams (dim %% 8 == 0, no MX-FP8 image)");
   AVF_REQUIRE(rows > 0 && dim > 0 && ws, "layernorm_bwd: bad arguments");
   AVF_REQUIRE(!mx_q || (mx_s && dy_dtype == AVF_BF16 && dim % 32 == 0 && dim <= 1536 && ((uintptr_t)mx_q & 3) == 0),
               "layernorm_bwd: the MX-FP8 image of dx needs bf16 dy, dim %% 32 == 0 and dim <= 1536 (dim=%d)", dim);
@@ -717,8 +736,9 @@ int layernorm_bwd(const void* dy, int dy_dtype, const void* xv, const float* gam
               "layernorm_bwd: a bf16 LayerNorm input needs bf16 dy, dim %% 4 == 0 and dim <= 1536");
   const float* x = (const float*)xv;
   AVF_REQUIRE(dres_dtype == AVF_F32 || (dres_dtype == AVF_BF16 && dy_dtype == AVF_BF16 && dim % 4 == 0 && dim <= 1536 &&
-                                         !drop.thresh16 && dx_lo),
-              "layernorm_bwd: a bf16 residual gradient needs bf16 dy, a bf16 output, dim %% 4 == 0, dim <= 1536, no dropout");
+                                         (!drop.thresh16 || dx_m) && dx_lo),
+              "layernorm_bwd: a bf16 residual gradient needs bf16 dy, a bf16 output, dim %% 4 == 0, dim <= 1536, and with dropout a "
+              "separate masked image");
   AVF_REQUIRE(dx || dx_lo, "layernorm_bwd: no output");
   AVF_REQUIRE(!drop.thresh16 || (dim % 4 == 0 && dim <= 1536), "layernorm_bwd: dropout needs dim %% 4 == 0 and dim <= 1536");
   AVF_REQUIRE((size_t)3 * dim * sizeof(float) <= 64 * 1024, "layernorm_bwd: dim %d too large", dim);
@@ -731,7 +751,7 @@ int layernorm_bwd(const void* dy, int dy_dtype, const void* xv, const float* gam
   const bool fast = (dim % 4 == 0) && dim <= 1536 && (dy_dtype == AVF_F32 || dy_dtype == AVF_BF16);
   if (fast) {
     const bool row8 = x_dtype == AVF_BF16 && dy_dtype == AVF_BF16 && (!dres || dres_dtype == AVF_BF16) && dx_lo &&
-                      !drop.thresh16 && (!mx_q || dim % 32 == 0) && dim % 8 == 0 && ln_row8_on();
+                      (!drop.thresh16 || dx_m) && (!mx_q || dim % 32 == 0) && dim % 8 == 0 && (ln_row8_on() || dx_m);
     const int rpb = row8 ? LNR_ROWS_PER_BLOCK : lnr_rows_per_block(rows);
     nb = (int)ceil_div(rows, rpb);
     const size_t lds = (size_t)4 * 3 * dim * sizeof(float);
@@ -760,15 +780,22 @@ int layernorm_bwd(const void* dy, int dy_dtype, const void* xv, const float* gam
         if (raised8.need()) {
           hipError_t e1 = hipFuncSetAttribute((const void*)ln_bwd_row8_kernel<3, 1>,
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 3 * 1536 * 4);
-          AVF_REQUIRE(e1 == hipSuccess, "layernorm_bwd: cannot raise dynamic LDS limit");
+          hipError_t e2 = hipFuncSetAttribute((const void*)ln_bwd_row8_kernel<3, 1, true>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 3 * 1536 * 4);
+          AVF_REQUIRE(e1 == hipSuccess && e2 == hipSuccess, "layernorm_bwd: cannot raise dynamic LDS limit");
           raised8.mark();
         }
       }
 #define LAUNCH_R8(NVV, RU)                                                                                                   \
   do {                                                                                                                       \
-    launch_in_scope(&ts, ln_bwd_row8_kernel<NVV, RU>, dim3(nb), dim3(256), (uint32_t)lds, s, (const bf16*)dy,                \
-                    (const bf16*)xv, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx_lo, partial, rows, dim, wc,              \
-                    (uint8_t*)mx_q, (uint8_t*)mx_s, dx);                                                                     \
+    if (dx_m)                                                                                                                \
+      launch_in_scope(&ts, ln_bwd_row8_kernel<NVV, RU, true>, dim3(nb), dim3(256), (uint32_t)lds, s, (const bf16*)dy,        \
+                      (const bf16*)xv, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx_lo, partial, rows, dim, wc,            \
+                      (uint8_t*)nullptr, (uint8_t*)nullptr, dx, drop, (bf16*)dx_m);                                          \
+    else                                                                                                                     \
+      launch_in_scope(&ts, ln_bwd_row8_kernel<NVV, RU>, dim3(nb), dim3(256), (uint32_t)lds, s, (const bf16*)dy,              \
+                      (const bf16*)xv, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx_lo, partial, rows, dim, wc,            \
+                      (uint8_t*)mx_q, (uint8_t*)mx_s, dx, kNoDrop, (bf16*)nullptr);                                          \
   } while (0)
       switch ((dim + 511) / 512) {  // rows in flight per wave: what the register file allows at two waves per SIMD or more
         case 1: LAUNCH_R8(1, 4); break;

@@ -395,7 +395,10 @@ class Transformer(nn.Module):
         """backward keeps the residual gradient between the LayerNorm backward kernels in bf16 (the GEMMs read that image
         anyway): no fp32 dx write / read per sublayer.  Throughput mode without live dropout only; AVF_GRAD_STREAM=f32
         restores the fp32 stream."""
-        return (self.compute_dtype == _lib.BF16 and p == 0.0 and self.dim <= 1536 and self.dim % 4 == 0
+        # round 5: also WITH live dropout when every stream is bf16 (residual_dtype="bf16", not the fp8 mode, not the
+        # single-launch short-sequence layers): each hand-off then carries two bf16 images, the stream and its masked copy
+        drop_ok = p == 0.0 or (self.resid_bf16 and not self.mx8 and self.dim % 8 == 0)
+        return (self.compute_dtype == _lib.BF16 and drop_ok and self.dim <= 1536 and self.dim % 4 == 0
                 and os.environ.get("AVF_GRAD_STREAM", "bf16") != "f32")
 
     def _advance_seed(self, dev) -> Optional[torch.Tensor]:
