@@ -3,10 +3,10 @@
 #   bash tools/collect_profiles.sh r03        (from the repo root; raw output under gpurun_out/final)
 # Each pass is its own rocprofv3 process with the program directly after "--" (no wrappers); counters are collected
 # without any trace domain beside the kernel trace.  C2 (the bench's `value` workload): kernel stats, FETCH / WRITE traffic,
-# two SQ counter passes.  C3 (the north-star shape) and C4 (d=768, T=1024: streaming attention): kernel stats and traffic.  The reference's real head shapes: kernel stats.  C5 in the mx8 mode: kernel stats.
+# two SQ counter passes.  C3 (the north-star shape) and C4 (d=768, T=1024: streaming attention): kernel stats and traffic.  The reference's real head shapes: kernel stats.  C5 in the mx8 and in the bf16 mode: kernel stats, per-shape tables and (round 5) traffic.
 set -e -o pipefail
 export AVF_BENCH_SETTLE_S=0  # profiler passes: the trace should hold the requested steps, not the settling ones
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$PWD
 O=$R/gpurun_out/final
 mkdir -p $O
@@ -36,11 +36,17 @@ echo "real-model stats done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c5 -o s -- python $R/bench.py --config c5 --dtype mx8 --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-events --no-extra > $O/stats_c5.json 2> $O/stats_c5.err
 rm -f $O/shapes_c5.csv
 AVF_SHAPE_LOG=$O/shapes_c5.csv timeout -k 10 300 python $R/bench.py --config c5 --dtype mx8 --steps 1 --warmup 0 --launch eager --no-cpu-baseline --no-kernel-events --no-extra > /dev/null 2> $O/shapes_c5.err
-echo "c5 (mx8) stats + shape log done"
+B5="python $R/bench.py --config c5 --dtype mx8 --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-events --no-extra"
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_c5 -o f -- $B5 > /dev/null 2> $O/fetch_c5.err
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_c5 -o w -- $B5 > /dev/null 2> $O/write_c5.err
+echo "c5 (mx8) stats + shape log + traffic done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c5b -o s -- python $R/bench.py --config c5 --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-events --no-extra > $O/stats_c5b.json 2> $O/stats_c5b.err
 rm -f $O/shapes_c5b.csv
 AVF_SHAPE_LOG=$O/shapes_c5b.csv timeout -k 10 300 python $R/bench.py --config c5 --steps 1 --warmup 0 --launch eager --no-cpu-baseline --no-kernel-events --no-extra > /dev/null 2> $O/shapes_c5b.err
-echo "c5 (bf16) stats + shape log done"
+B5="python $R/bench.py --config c5 --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-events --no-extra"
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_c5b -o f -- $B5 > /dev/null 2> $O/fetch_c5b.err
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_c5b -o w -- $B5 > /dev/null 2> $O/write_c5b.err
+echo "c5 (bf16) stats + shape log + traffic done"
 cd $R
 python tools/pmc_traffic.py $O/stats_c2/s_kernel_stats.csv $O/fetch_c2/f_counter_collection.csv $O/write_c2/w_counter_collection.csv $TAG c2
 python tools/pmc_traffic.py $O/stats_c3/s_kernel_stats.csv $O/fetch_c3/f_counter_collection.csv $O/write_c3/w_counter_collection.csv ${TAG}_c3 c3
@@ -48,8 +54,8 @@ python tools/pmc_traffic.py $O/stats_c4/s_kernel_stats.csv $O/fetch_c4/f_counter
 for CFG in c2 c3 c4; do
   python tools/shape_table.py $O/stats_$CFG/s_kernel_trace.csv $O/shapes_$CFG.csv profiles/${TAG}_${CFG}_shapes.csv $O/fetch_$CFG/f_counter_collection.csv $O/write_$CFG/w_counter_collection.csv > /dev/null
 done
-python tools/shape_table.py $O/stats_c5/s_kernel_trace.csv $O/shapes_c5.csv profiles/${TAG}_c5_mx8_shapes.csv > /dev/null
-python tools/shape_table.py $O/stats_c5b/s_kernel_trace.csv $O/shapes_c5b.csv profiles/${TAG}_c5_bf16_shapes.csv > /dev/null
+python tools/shape_table.py $O/stats_c5/s_kernel_trace.csv $O/shapes_c5.csv profiles/${TAG}_c5_mx8_shapes.csv $O/fetch_c5/f_counter_collection.csv $O/write_c5/w_counter_collection.csv > /dev/null
+python tools/shape_table.py $O/stats_c5b/s_kernel_trace.csv $O/shapes_c5b.csv profiles/${TAG}_c5_bf16_shapes.csv $O/fetch_c5b/f_counter_collection.csv $O/write_c5b/w_counter_collection.csv > /dev/null
 python tools/sq_summary.py $O/sq1/q_counter_collection.csv $O/sq2/q_counter_collection.csv $TAG
 cp $O/stats_real/s_kernel_stats.csv profiles/${TAG}_real_heads_kernel_stats.csv
 cp $O/stats_c5/s_kernel_stats.csv profiles/${TAG}_c5_mx8_kernel_stats.csv
