@@ -447,7 +447,7 @@ struct GemmArgs {
   void* mx_q = nullptr;
   void* mx_s = nullptr;
 };
-// weight-stationary persistent NT GEMM (gemm_ws.hip)
+// weight-stationary persistent NT GEMM (gemm_ws.hip; DESIGN_HISTORY.md section 18)
 // byte offset of element (n, k) of a weight [N][512] in its fragment-major image: 1 KiB pieces (panel of 256 rows, wave's 32
 // rows, 16-row block j, k-step s of 32), inside a piece lane (li = n % 16, lg = (k % 32) / 8) owns 16 bytes = 8 consecutive k
 __host__ __device__ __forceinline__ size_t pack_ws_off(int n, int k) {

@@ -301,7 +301,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4_t (&acc)[MI
 // Lean epilogue: the fast path of nt_epilogue with every option fixed at COMPILE time (dropout included: DROP) - the general one decides dropout,
 // MX image, column edge, store width and column sums with wave-uniform run-time branches, and its ~550 executed
 // instructions per 16 values and lane (2200 cycles of one wave's issue, 3700 beside a partner streaming MFMAs: phase stamps of
-// gemm_ws.hip) cost more than the 64 MFMAs that produce those values.  Same arithmetic, same order, same
+// gemm_ws.hip, DESIGN_HISTORY.md section 18) cost more than the 64 MFMAs that produce those values.  Same arithmetic, same order, same
 // bits.  Preconditions, checked by the host (nt_lean_ok): no MX image beside a dropout site; the
 // wave tile lies inside N; 2-byte C: N % 8 == 0, every leading dimension % 8 == 0, 16-byte aligned bases (16-byte paired
 // stores and loads, p.wide == 1).  CS: column sums of the stored values into cs_partial[part_row].  PRE: bias / residual /
@@ -367,7 +367,7 @@ __device__ __forceinline__ void nt_epilogue_lean_body(const NtParams& p, f32x4_t
     const int mc = mok ? m : p.M - 1;
     // addresses as (wave-uniform tile offset) + (per-lane offset that does not depend on the tile): a persistent kernel's tile
     // loop then keeps the per-lane part in a register and the 64-bit arithmetic on the scalar unit - every vector instruction
-    // of the epilogue competes with the MFMA stream for the SIMD's issue
+    // of the epilogue competes with the MFMA stream for the SIMD's issue (DESIGN_HISTORY.md section 19)
     const uint32_t lrow = (uint32_t)(16 * i + li);
     float4 ex[NI];
     if constexpr (EPI == AVF_EPI_BIAS_RES || EPI == AVF_EPI_DGELU) {
@@ -551,7 +551,7 @@ __device__ __forceinline__ void wait_lgkmcnt() {
 // compiler-visible ds_read of a K-step (its wait-count pass takes the DMA for an LDS store that may alias the read), which
 // serialises the next tile's DMA with this tile's reads and MFMAs.  These reads are opaque to that pass: the kernel's own
 // vmcnt + s_barrier order them against the DMA, and the caller waits with wait_lgkmcnt<N>() + sched_barrier(0) before the
-// first use of the destination registers (the hardware does not interlock LDS returns).  DESIGN.md section 12(a).
+// first use of the destination registers (the hardware does not interlock LDS returns).  DESIGN_HISTORY.md section 12(a).
 template <typename V, int OFF>
 __device__ __forceinline__ V lds_read_b128(uint32_t addr) {
   V v;

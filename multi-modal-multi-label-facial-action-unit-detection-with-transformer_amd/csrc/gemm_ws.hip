@@ -1,4 +1,4 @@
-// gemm_ws.hip - weight-stationary persistent NT GEMM for the layer's K = 512 shapes.
+// gemm_ws.hip - weight-stationary persistent NT GEMM for the layer's K = 512 shapes (DESIGN_HISTORY.md section 18).
 //
 //   C[M, N] = epilogue(A[M, 512] * W[N, 512]^T)      nn.Linear forward / dX of heads.py:191,195,212,215 at dim = 512
 //
@@ -16,7 +16,7 @@
 //     run half a period out of phase - they take the tile barrier between their MFMAs and their epilogue, waves 0..3 take
 //     it before their MFMAs - so on every SIMD one wave streams MFMAs while its partner converts and stores.  Epilogues
 //     with arithmetic (bias + residual, GELU, dGELU): every wave in phase, MFMA phases together and epilogues together (a
-//     wave's vector instructions lose most of their issue rate beside a partner's MFMA stream).
+//     wave's vector instructions lose most of their issue rate beside a partner's MFMA stream; DESIGN_HISTORY.md section 19).
 // The epilogue is nt_epilogue_lean (gemm_nt.hpp) - the arithmetic of nt_epilogue - and the k order of the accumulation is that
 // of the tiled kernel, so results are bit-identical to gemm_bf16_nt_glds_kernel.
 #include <utility>

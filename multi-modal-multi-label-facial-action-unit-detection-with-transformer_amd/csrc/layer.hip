@@ -732,7 +732,7 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   else
     AVF_TRY(linear_dx(d, gm, d.D, p->w_out, l.wo_t, d.I, w.d_o, AVF_EPI_NONE, nullptr, s, nullptr, nullptr, kNoDrop, nullptr,
                       l.ws.wot_p));
-  // dqkv -> dh1 on MX-FP8 operands, the image of dqkv written by the merged attention backward:
+  // dqkv -> dh1 on MX-FP8 operands, the image of dqkv written by the merged attention backward (DESIGN_HISTORY.md section 17, item 5):
   // built and bit-exact, but the image costs the attention kernel 18 us at B = 64, N = 512 (50 us before its stores were
   // made 16 bytes wide and dQ's 32-blocks wave-local) while the K = 1536 GEMM, already at 0.87 PFLOP/s on bf16 operands,
   // gains ~9 us: C5 5.06 ms per step with it against 4.93 without - OFF unless AVF_MX8_DQKV=1.

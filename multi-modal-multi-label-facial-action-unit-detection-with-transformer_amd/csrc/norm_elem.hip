@@ -134,7 +134,7 @@ static int ln_row8_on() {
 // ---- the bf16 residual stream's kernels (bf16 in, bf16 out, D % 8 == 0, D <= 512 * NV8) -----------------------------
 // A lane owns 8 consecutive columns per 512 (one 16-byte access); a wave works on RU rows at once with all their loads in
 // flight before the first reduction: 4 x 4 rows per workgroup, ~10 waves per CU x RU KiB per stream in flight (the
-// one-row-per-wave form had 1 KiB per wave and ran at 2.5 TB/s).
+// one-row-per-wave form had 1 KiB per wave and ran at 2.5 TB/s; DESIGN_HISTORY.md section 14).
 __device__ __forceinline__ void unpack8(const uint4& r, float (&v)[8]) {
   v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
   v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);

@@ -312,7 +312,7 @@ def test_attention_backward_emits_the_image_of_dqkv(ops, B, N, H):
 
 
 def test_dqkv_to_dh1_on_fp8_operands_tracks_the_bf16_gemm(tmp_path):
-    """AVF_MX8_DQKV=1 (off by default: DESIGN.md section 17, item 5): the last bf16 dX GEMM of the fp8 mode on MX-FP8 operands.
+    """AVF_MX8_DQKV=1 (off by default: DESIGN_HISTORY.md section 17, item 5): the last bf16 dX GEMM of the fp8 mode on MX-FP8 operands.
     A tuning switch (honoured under AVF_TUNING=1 only, read per call): both arms run in one child process started that way"""
     import os
     import subprocess

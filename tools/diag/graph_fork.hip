@@ -1,7 +1,7 @@
 // graph_fork.hip - does a hipGraph captured from a FORKED two-stream schedule replay as fast as the eager schedule?
 //
 // Round 3 saw a captured training step that forked one launch per layer to a side stream replay 2.2x slower than the same step
-// captured on one stream.  The data-parallel step forks too (the process group's communication stream
+// captured on one stream (DESIGN_HISTORY.md section 14).  The data-parallel step forks too (the process group's communication stream
 // joins the capture through events), so the question decides the multi-rank launch default of bench.py.  This is the pattern
 // alone: a chain of L "layers" on stream A, each of NK short dependent kernels; layer l forks ONE longer kernel to stream B
 // (event record on A, wait on B) which the NEXT layer joins before its last kernel (event record on B, wait on A).

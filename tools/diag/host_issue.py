@@ -33,7 +33,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1)
-    args = argparse.Namespace(batch=0, config=a.config, residual="bf16", no_optimizer=False, torch_adam=False)
+    args = argparse.Namespace(batch=0, config=a.config, residual="bf16", no_optimizer=False, torch_adam=False, dropout=0.0)
     r = bench.Region(A, torch, dist, a.config, "bf16", args, dev, 0, 1, a.dp)
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
