@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBNAME = "libavformer_hip.so"
-SOURCES = ["api.hip", "norm_elem.hip", "gemm_f32.hip", "attn_f32.hip", "gemm_bf16.hip", "gemm_ws.hip", "gemm_mx8.hip", "attn_bf16.hip", "attn_bwd_merged.hip", "layer.hip", "optim.hip", "layer_small.hip", "heads.hip"]
+SOURCES = ["api.hip", "norm_elem.hip", "gemm_f32.hip", "attn_f32.hip", "attn_f32_mfma.hip", "gemm_bf16.hip", "gemm_ws.hip", "gemm_mx8.hip", "attn_bf16.hip", "attn_bwd_merged.hip", "layer.hip", "optim.hip", "layer_small.hip", "heads.hip"]
 HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "gemm_nt.hpp"), os.path.join(os.path.dirname(HERE), "include", "avformer_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # per-source extra flags.  attn_bwd_merged.hip: MFMA results in architectural VGPRs (the kernel pins its long-lived

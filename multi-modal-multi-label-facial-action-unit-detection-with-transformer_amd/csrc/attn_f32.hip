@@ -1,4 +1,6 @@
 // attn_f32.hip - parity-mode attention core (fp32 VALU, flash-style: never materialises [B,H,N,N]).
+// (Round 5: fp32 storage without a mask at dim_head 32 / 64 - the parity mode's own calls - runs on attn_f32_mfma.hip instead;
+//  these kernels keep the masked calls, bf16 storage and the other head widths.)
 //
 // Reference: models/heads.py:222-237 -  dots = q k^T * dh^-0.5 ; softmax(dim=-1) ; out = attn v ;
 // 'b h n d -> b n (h d)'.  No dropout on the probabilities.  The token mask of heads.py:225-232 (dead in the reference: no
@@ -305,6 +307,8 @@ int attn_fwd_vec(int dtype, const void* qkv, void* o, float* lse2, int B, int N,
   AVF_REQUIRE((int64_t)B * H < 65536, "attn_fwd_f32: batch*heads too large for grid");
   AVF_REQUIRE(dtype == AVF_F32 || dtype == AVF_BF16, "attn_fwd_f32: bad dtype %d", dtype);
   TimingScope ts(KC_ATTN_FWD, 4.0 * B * H * (double)N * N * dh, 4.0 * 4.0 * B * N * H * dh, s);
+  if (attn_f32_mfma_ok(dtype, dh, keep, H, qkv, o))  // fp32 storage, no mask, dim_head 32 / 64: the fp32 matrix pipe
+    return attn_fwd_f32_mfma((const float*)qkv, (float*)o, lse2, B, N, H, dh, s, q_prescaled);
   dim3 grid((unsigned)ceil_div(N, 64), (unsigned)(B * H));
   const uint8_t* kp = (const uint8_t*)keep;
   const int qs = q_prescaled ? 1 : 0;
@@ -333,6 +337,8 @@ int attn_bwd_vec(int dtype, const void* qkv, const void* o, const void* d_o, con
   AVF_REQUIRE(dtype == AVF_F32 || dtype == AVF_BF16, "attn_bwd_f32: bad dtype %d", dtype);
   TimingScope ts(KC_ATTN_BWD, 10.0 * B * H * (double)N * N * dh, 4.0 * 8.0 * B * N * H * dh, s);
   AVF_TRY(attn_delta(dtype, o, d_o, delta, B, N, H, dh, s));
+  if (attn_f32_mfma_ok(dtype, dh, keep, H, qkv, d_o) && ((uintptr_t)dqkv & 15) == 0)
+    return attn_bwd_f32_mfma((const float*)qkv, (const float*)d_o, lse2, delta, (float*)dqkv, B, N, H, dh, s, q_prescaled);
   dim3 grid((unsigned)ceil_div(N, 64), (unsigned)(B * H));
   const uint8_t* kp = (const uint8_t*)keep;
   const int qs = q_prescaled ? 1 : 0;

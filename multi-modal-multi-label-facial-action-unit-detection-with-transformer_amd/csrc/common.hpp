@@ -501,6 +501,11 @@ int gemm_bf16_tn_group(const TnGroupArgs& a, hipStream_t s, const FoldList* extr
 
 int attn_fwd_f32(const float* qkv, float* o, float* lse2, int B, int N, int H, int dh, hipStream_t s);
 // fp32-arithmetic attention on fp32 / bf16 storage with the optional token mask keep [B, N] (bytes, 1 = kept; heads.py:225-232)
+// parity-mode attention on the fp32 matrix pipe (attn_f32_mfma.hip): fp32 storage, no mask, dim_head 32 / 64
+bool attn_f32_mfma_ok(int dtype, int dh, const void* keep, int H, const void* qkv, const void* other);
+int attn_fwd_f32_mfma(const float* qkv, float* o, float* lse2, int B, int N, int H, int dh, hipStream_t s, bool q_prescaled);
+int attn_bwd_f32_mfma(const float* qkv, const float* d_o, const float* lse2, const float* delta, float* dqkv, int B, int N, int H,
+                      int dh, hipStream_t s, bool q_prescaled);
 int attn_fwd_vec(int dtype, const void* qkv, void* o, float* lse2, int B, int N, int H, int dh, hipStream_t s, const void* keep,
                  bool q_prescaled);
 int attn_bwd_vec(int dtype, const void* qkv, const void* o, const void* d_o, const float* lse2, void* dqkv, float* delta,
