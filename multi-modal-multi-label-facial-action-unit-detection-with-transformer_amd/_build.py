@@ -19,7 +19,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # stream a packed instruction gets 42 % of its issue rate, a scalar one 77-88 % (tools/diag/mfma_valu_overlap.hip), and in
 # that kernel ONE wave per SIMD issues both streams.  C3: -0.8 % of the step (profiles/ab/r04_attn_bwd_unpacked.json).  The
 # feature is passed to both compilation passes; the host pass answers "not a recognized feature for this target (ignoring)".
-EXTRA_FLAGS = {"attn_bwd_merged.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]}
+EXTRA_FLAGS = {"gemm_f32.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "attn_f32_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+               "attn_bwd_merged.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]}
 
 
 def built_lib_path() -> str:
