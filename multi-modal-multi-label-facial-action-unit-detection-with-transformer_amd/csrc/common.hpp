@@ -414,7 +414,8 @@ size_t gemm_nt_colsum_ws(int64_t M, int64_t N);
 int prep_weight_bf16(const float* w, void* w_lo, void* w_t_lo, int rows, int cols, hipStream_t s);
 // lo_scale / lo_scaled_rows: the first rows of the row-major image `lo` (NOT of the transposed image) are multiplied by a
 // constant - the query rows of Wqkv carry the softmax scale (see attn_q_prescale in attn_bf16.hip)
-struct PrepDesc { const float* w; bf16* lo; bf16* t; int R, C; float lo_scale; int lo_scaled_rows; };
+// lo_p / t_p (optional): the fragment-major images (pack_ws_off) of lo (C == 512) / of t (R == 512) for the weight-stationary GEMM
+struct PrepDesc { const float* w; bf16* lo; bf16* t; int R, C; float lo_scale; int lo_scaled_rows; void* lo_p = nullptr; void* t_p = nullptr; };
 struct PrepBatch { PrepDesc d[4]; };
 int prep_weights_multi(const PrepBatch& b, int count, hipStream_t s);
 

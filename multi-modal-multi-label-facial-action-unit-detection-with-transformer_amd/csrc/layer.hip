@@ -405,17 +405,13 @@ extern "C" int avf_layer_prepare_weights(const avf_layer_cfg* cfg, const avf_lay
   PrepBatch b;
   // the query rows of the forward image of Wqkv carry the softmax scale (the transposed image, which backward
   // multiplies dqkv with, does not): q' = h1 (c Wq)^T, so the attention kernels get log2-domain scores from the MFMA
-  b.d[0] = PrepDesc{p->w_qkv, (bf16*)l.wqkv, (bf16*)l.wqkv_t, 3 * d.I, d.D, attn_q_prescale(d.dh), d.I};
-  b.d[1] = PrepDesc{p->w_out, (bf16*)l.wo, (bf16*)l.wo_t, d.D, d.I, 1.0f, 0};
-  b.d[2] = PrepDesc{p->w1, (bf16*)l.w1, (bf16*)l.w1_t, d.M, d.D, 1.0f, 0};
-  b.d[3] = PrepDesc{p->w2, (bf16*)l.w2, (bf16*)l.w2_t, d.D, d.M, 1.0f, 0};
+  // ... and the fragment-major images for the weight-stationary GEMM ride in the same launch (the optimizer step rewrites all
+  // of them itself: optim.hip): of the row-major images of Wqkv, Wo, W1 and of the transposed images of W2, Wo
+  b.d[0] = PrepDesc{p->w_qkv, (bf16*)l.wqkv, (bf16*)l.wqkv_t, 3 * d.I, d.D, attn_q_prescale(d.dh), d.I, l.ws.wqkv_p, nullptr};
+  b.d[1] = PrepDesc{p->w_out, (bf16*)l.wo, (bf16*)l.wo_t, d.D, d.I, 1.0f, 0, l.ws.wo_p, l.ws.wot_p};
+  b.d[2] = PrepDesc{p->w1, (bf16*)l.w1, (bf16*)l.w1_t, d.M, d.D, 1.0f, 0, l.ws.w1_p, nullptr};
+  b.d[3] = PrepDesc{p->w2, (bf16*)l.w2, (bf16*)l.w2_t, d.D, d.M, 1.0f, 0, nullptr, l.ws.w2t_p};
   AVF_TRY(prep_weights_multi(b, 4, s));
-  // fragment-major images for the weight-stationary GEMM (the optimizer step rewrites them itself: optim.hip)
-  if (l.ws.wqkv_p) AVF_TRY(pack_ws(l.wqkv, d.D, 3 * d.I, d.D, l.ws.wqkv_p, s));
-  if (l.ws.wo_p) AVF_TRY(pack_ws(l.wo, d.I, d.D, d.I, l.ws.wo_p, s));
-  if (l.ws.w1_p) AVF_TRY(pack_ws(l.w1, d.D, d.M, d.D, l.ws.w1_p, s));
-  if (l.ws.w2t_p) AVF_TRY(pack_ws(l.w2_t, d.D, d.M, d.D, l.ws.w2t_p, s));
-  if (l.ws.wot_p) AVF_TRY(pack_ws(l.wo_t, d.D, d.I, d.D, l.ws.wot_p, s));
   return 0;
 }
 

@@ -1008,13 +1008,23 @@ __global__ __launch_bounds__(256) void prep_weights_multi_kernel(PrepBatch b) {
     int r = r0 + ty + 8 * i, c = c0 + tx;
     float v = (r < d.R && c < d.C) ? d.w[(int64_t)r * d.C + c] : 0.f;
     tile[ty + 8 * i][tx] = v;
-    if (r < d.R && c < d.C) d.lo[(int64_t)r * d.C + c] = from_f32<bf16>(r < d.lo_scaled_rows ? v * d.lo_scale : v);
+    if (r < d.R && c < d.C) {
+      const bf16 q = from_f32<bf16>(r < d.lo_scaled_rows ? v * d.lo_scale : v);
+      d.lo[(int64_t)r * d.C + c] = q;
+      // the fragment-major image of the same values (round 5: five pack_ws launches per layer before - 58 us of a 555 us
+      // TFormer step that prepares its weights in every forward)
+      if (d.lo_p) *reinterpret_cast<bf16*>(reinterpret_cast<char*>(d.lo_p) + pack_ws_off(r, c)) = q;
+    }
   }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int c = c0 + ty + 8 * i, r = r0 + tx;
-    if (c < d.C && r < d.R) d.t[(int64_t)c * d.R + r] = from_f32<bf16>(tile[tx][ty + 8 * i]);
+    if (c < d.C && r < d.R) {
+      const bf16 q = from_f32<bf16>(tile[tx][ty + 8 * i]);
+      d.t[(int64_t)c * d.R + r] = q;
+      if (d.t_p) *reinterpret_cast<bf16*>(reinterpret_cast<char*>(d.t_p) + pack_ws_off(c, r)) = q;
+    }
   }
 }
 
