@@ -132,7 +132,8 @@ int avf_prep_weight_bf16(const float* w, void* w_lo, void* w_t_lo, int rows, int
  *   transB = 0: B stored [K,N] (ldb)      transB = 1: B stored [N,K] (ldb)   (nn.Linear weight layout)
  * dtype AVF_F32: every form, any sizes.  dtype AVF_BF16: (transA=0,transB=1) "NT" with K%8==0, and
  * (transA=1,transB=0) "TN" (weight gradients, fp32 output, M%8==0, N%8==0).
- * c_dtype: storage type of C (and aux).  workspace only for bf16 TN split-K (avf_gemm_workspace_bytes). */
+ * c_dtype: storage type of C (and aux).  workspace (avf_gemm_workspace_bytes): the split-K slabs of a bf16 TN GEMM (required), of an
+ * fp32 weight-gradient-shaped or skinny GEMM (optional: without it the unsplit general kernel runs). */
 size_t avf_gemm_workspace_bytes(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K);
 int avf_gemm(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
              const void* B, int64_t ldb, void* C, int64_t ldc, int c_dtype, int epilogue, const float* bias,
