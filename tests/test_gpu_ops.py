@@ -100,6 +100,31 @@ def test_gemm_f32_forms(ops, M, N, K, ta, tb):
     _close(c, _gemm_ref(a, b, ta, tb).float(), atol=1e-4 * math.sqrt(K), rtol=1e-4)
 
 
+@pytest.mark.parametrize("M,N,K,ta,tb", [
+    (1536, 512, 4096, True, False),    # a weight gradient: 48 tiles of 128 x 128 -> split-K, both operands row-fast (TN)
+    (512, 1024, 2080, True, False),    # ... K % 32 == 0 but not a multiple of the split chunk (ragged last split)
+    (2048, 1024, 512, False, True),    # forward shape, k-fast operands (NT): 128 tiles, split 2 + fold with bias / residual
+    (2048, 1024, 768, False, False),   # dX shape: A k-fast, B row-fast (NN)
+])
+def test_gemm_f32_fast_form(ops, M, N, K, ta, tb):
+    """the fp32 kernel with 128 x 128 tiles and 16-byte accesses (gemm_f32_fast_kernel, round 5: the parity mode's weight
+    gradients), every operand orientation it takes, against fp64; with and without its split-K slabs (ops.gemm allocates the
+    workspace avf_gemm_workspace_bytes asks for, which is what selects the split)"""
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    a = torch.randn((K, M) if ta else (M, K), generator=g)
+    b = torch.randn((N, K) if tb else (K, N), generator=g)
+    ref = _gemm_ref(a, b, ta, tb)
+    c = ops.gemm(a.cuda(), b.cuda(), trans_a=ta, trans_b=tb)
+    _close(c, ref.float(), atol=1e-4 * math.sqrt(K), rtol=1e-4)
+    err = float((c.double().cpu() - ref).norm() / ref.norm())
+    assert err < 1e-6, err  # fp32 products, fp32 fmaf accumulation: the parity mode's precision class
+    if not ta:  # the fused bias + residual epilogue rides in the fold of a split launch
+        bias = torch.randn(N, generator=g)
+        res = torch.randn(M, N, generator=g)
+        c2 = ops.gemm(a.cuda(), b.cuda(), trans_a=ta, trans_b=tb, epilogue=ops.EPI_BIAS_RES, bias=bias.cuda(), residual=res.cuda())
+        _close(c2, (ref + bias.double() + res.double()).float(), atol=1e-4 * math.sqrt(K), rtol=1e-4)
+
+
 @pytest.mark.parametrize("dtype,M,N,K", [(torch.float32, 200, 136, 96), (torch.bfloat16, 200, 136, 96),
                                          (torch.bfloat16, 301, 260, 1088), (torch.bfloat16, 8200, 520, 64)])
 def test_gemm_epilogues(ops, dtype, M, N, K):
