@@ -40,7 +40,9 @@ def test_mask_statistics():
 @pytest.mark.parametrize("cfg", [(3, 77, 128, 2, 8, 32, 256), (2, 324, 512, 2, 8, 64, 1024),
                                  (4, 12, 128, 2, 8, 32, 256),       # takes the single-launch forward
                                  (8, 324, 512, 2, 8, 64, 1024),     # 2592 rows: the persistent GEMM + the lean epilogue's
-                                 (8, 324, 512, 2, 8, 64, 1024, "bf16")])  # ... dropout site (DROP), both residual streams
+                                 (8, 324, 512, 2, 8, 64, 1024, "bf16"),   # ... dropout site (DROP), both residual streams
+                                 (3, 200, 256, 4, 4, 64, 512, "bf16")])   # 4 layers: MIDDLE layers both receive and hand on the two
+                                                                          # bf16 gradient images (stream + masked) of round 5
 def test_mask_replay_against_oracle(cfg):
     import avformer_amd as A
     B, N, D, L, H, dh, M = cfg[:7]
