@@ -56,8 +56,8 @@ def test_size_queries_and_config_validation(lib):
     assert lib.avf_layer_saved_bytes(ctypes.byref(bad_drop)) == 0
     assert b"dropout" in lib.avf_last_error()
     assert lib.avf_gemm_workspace_bytes(A._lib.BF16, 1, 0, 1536, 512, 16384) > 0
-    # fp32: split-K slabs of the weight-gradient shapes (round 5: the fast fp32 form; optional - without a workspace avf_gemm runs
-    # the general kernel) and of skinny shapes; nothing for a shape whose tiles already fill the chip
+    # fp32: split-K slabs of the weight-gradient shapes (round 5; optional - without a workspace avf_gemm runs unsplit) and of
+    # skinny shapes; nothing for a shape whose tiles already fill the chip
     assert lib.avf_gemm_workspace_bytes(A._lib.F32, 1, 0, 1536, 512, 16384) % (1536 * 512 * 4) == 0
     assert lib.avf_gemm_workspace_bytes(A._lib.F32, 1, 0, 1536, 512, 16384) > 0
     assert lib.avf_gemm_workspace_bytes(A._lib.F32, 0, 1, 16384, 1536, 512) == 0

@@ -101,15 +101,14 @@ def test_gemm_f32_forms(ops, M, N, K, ta, tb):
 
 
 @pytest.mark.parametrize("M,N,K,ta,tb", [
-    (1536, 512, 4096, True, False),    # a weight gradient: 48 tiles of 128 x 128 -> split-K, both operands row-fast (TN)
-    (512, 1024, 2080, True, False),    # ... K % 32 == 0 but not a multiple of the split chunk (ragged last split)
-    (2048, 1024, 512, False, True),    # forward shape, k-fast operands (NT): 128 tiles, split 2 + fold with bias / residual
-    (2048, 1024, 768, False, False),   # dX shape: A k-fast, B row-fast (NN)
+    (1536, 512, 4096, True, False),    # a weight gradient: 192 tiles of 64 x 64 -> split-K (f32_split64), both operands row-fast (TN)
+    (500, 1000, 2080, True, False),    # ... ragged tiles, K not a multiple of the split chunk
+    (512, 1024, 4096, False, True),    # k-fast operands (NT) with a long reduction: the fold applies bias + residual
+    (2048, 1024, 768, False, False),   # dX shape (NN), short reduction: unsplit
 ])
-def test_gemm_f32_fast_form(ops, M, N, K, ta, tb):
-    """the fp32 kernel with 128 x 128 tiles and 16-byte accesses (gemm_f32_fast_kernel, round 5: the parity mode's weight
-    gradients), every operand orientation it takes, against fp64; with and without its split-K slabs (ops.gemm allocates the
-    workspace avf_gemm_workspace_bytes asks for, which is what selects the split)"""
+def test_gemm_f32_split64(ops, M, N, K, ta, tb):
+    """the parity mode's weight-gradient-shaped GEMMs (round 5): few 64 x 64 tiles, long reduction -> split-K slabs + fold
+    (ops.gemm allocates the workspace avf_gemm_workspace_bytes asks for, which is what enables the split), against fp64"""
     g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
     a = torch.randn((K, M) if ta else (M, K), generator=g)
     b = torch.randn((N, K) if tb else (K, N), generator=g)
