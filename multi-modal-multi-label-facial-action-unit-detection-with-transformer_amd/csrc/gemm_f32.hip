@@ -11,7 +11,8 @@ namespace avf {
 
 namespace {
 
-// K-step: 16 for the general configuration, 32 for the small one (half the barriers per FLOP)
+// K-step: 8 for the general configuration (round 5, back to back at 4096^3 / on the QKV shape of C2: K-step 4: 63 / 68 TFLOP/s, 8: 92 / 87,
+// 16: 89.6 / 83, 32: 73 / 67 - short steps keep the staging registers few and more workgroups resident), 32 for the small one
 // block tile (32 T) x (32 T): 2 x 2 waves of (16 T) x (16 T) each.  T = 2 (64 x 64) is the general configuration; T = 1
 // (32 x 32) serves the small GEMMs around the stacks - the 12-way projection of AU_former on a batch of a few dozen clips,
 // the AU logits - where 64 x 64 tiles would leave most of the chip without a workgroup.
@@ -36,7 +37,7 @@ struct F32GemmParams {
 
 template <int EPI, int T, bool SPLIT = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(F32GemmParams p) {
-  constexpr int BM = 32 * T, BN = 32 * T, BK = T == 1 ? 32 : 16;
+  constexpr int BM = 32 * T, BN = 32 * T, BK = T == 1 ? 32 : 8;
   constexpr int AS_LD = BK + 1;   // As[m][k] rows
   constexpr int BS_LD = BN + 16;  // Bs[k][n] rows (k -> +16 banks)
   __shared__ float As[BM * AS_LD];
