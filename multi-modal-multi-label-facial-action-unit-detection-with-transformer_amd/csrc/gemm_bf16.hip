@@ -291,7 +291,7 @@ int launch_nt_glds_any(const NtParams& p, hipStream_t s, int* part_rows, TimingS
     }
   }
   switch (tile) {
-    case 6: return launch_nt_glds<EPI, CT, 1, 4, 2, 1, 6>(p, s, part_rows, ts);  // 72 KiB: two workgroups per CU
+    case 6: return launch_nt_glds<EPI, CT, 1, 4, 2, 1, 3>(p, s, part_rows, ts);  // 36 KiB: four workgroups per CU
     case 0: return launch_nt_glds<EPI, CT, 2, 2, 4, 4, 2>(p, s, part_rows, ts);
     case 1: return launch_nt_glds<EPI, CT, 2, 2, 2, 4, 2>(p, s, part_rows, ts);
     case 3: return launch_nt_glds<EPI, CT, 2, 2, 3, 4, 2>(p, s, part_rows, ts);

@@ -637,8 +637,10 @@ int pick_nt_tile(int64_t M, int64_t N, int64_t K) {
 
 // bf16 NT kernel only: problems with few token rows (the reference's 12- / 17-token stacks at batch 64: ~1 k rows) put a few
 // dozen 96 x 128 tiles on 256 CUs, and with one stage of look-ahead every K-step of such a lone workgroup pays a full memory
-// round trip (measured: 10.9 us for 1088 x 512 x 512).  Tile 6 = 32 x 64, four waves, a 6-slot ring of 12 KiB stages (two
-// workgroups per CU): eight times the workgroups, five K-steps of a workgroup in flight at once.
+// round trip (measured: 10.9 us for 1088 x 512 x 512).  Tile 6 = 32 x 64, four waves, a ring of 12 KiB stages: eight times the
+// workgroups.  Round 5: THREE slots (36 KiB, four workgroups per CU) instead of six (72 KiB, two per CU) - the wide shapes of a
+// 1088-row layer (816 workgroups at N = 1536) then fit the chip's slots in one round, and co-resident workgroups hide a round trip as
+// well as ring depth does: TFormer (17 tokens, d = 512, B = 64) 144 -> 133 us per layer replayed (2 slots 146, 4 slots 134).
 int pick_nt_tile_bf16(int64_t M, int64_t N, int64_t K) {
   static const int small_on = [] {
     const char* e = tuning_env("AVF_NT_SMALL_M");  // A/B aid: 0 = the large tiles for every shape
