@@ -992,7 +992,9 @@ static bool tn_group_big(const TnGroupArgs& a) {
   if (forced >= 0) return forced != 0;
   int64_t tiles = 0;
   for (int i = 0; i < a.count; ++i) tiles += ceil_div(a.M[i], TBM) * ceil_div(a.N[i], TB);
-  return tiles >= 32 && a.K >= 2048;
+  // (round 5: also a FEW tiles under a very long reduction - ResFormer's token section, 16 tiles over 50 176 token rows: 921 -> 895 us
+  //  per layer with the split count filling the chip)
+  return (tiles >= 32 && a.K >= 2048) || (tiles >= 8 && a.K >= 16384);
 }
 static int tn_group_tiles(const TnGroupArgs& a, bool big) {
   int tiles = 0;
