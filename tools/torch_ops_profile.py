@@ -7,10 +7,10 @@ from torch.profiler import profile, ProfilerActivity  # noqa: E402
 
 B, Tv, Ta, D = 32, 196, 128, 512
 torch.manual_seed(123)
-model = A.SyntheticAVFormer(D, 6, 8, 64, 1024, Tv, Ta, task="AU", compute_dtype="bf16").cuda()
+model = A.SyntheticAVFormer(D, 6, 8, 64, 1024, Tv, Ta, task="AU", compute_dtype="bf16", residual_dtype="bf16").cuda()
 batch = {"clip": torch.randn(B, Tv, D, device="cuda"), "audio_features": torch.randn(B, Ta, D, device="cuda")}
 labels = (torch.rand(B, 12, device="cuda") > 0.5).float()
-opt = torch.optim.Adam(model.parameters(), lr=5e-4, weight_decay=5e-5, fused=True)
+opt = A.optim.FusedAdam(model, lr=5e-4, weight_decay=5e-5)
 
 
 def step():
