@@ -464,6 +464,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    # AVF_BENCH_ONE_DEVICE=1 + AVF_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow (launcher, rendezvous, collective
+    # decisions of the untimed loops, data-parallel report) on a ONE-GPU box - every rank on cuda:0, the collectives through gloo
+    # (RCCL refuses two ranks on one device).  Its numbers mean nothing; what it shows is that the multi-rank path runs to its line.
+    if os.environ.get("AVF_BENCH_ONE_DEVICE") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     A._lib.load()  # no fallback: fails here if the HIP library is missing
@@ -475,7 +480,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("AVF_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     events = not args.no_kernel_events
     mk = lambda name, dtype, dist_on: Region(A, torch, dist, name, dtype, args, dev, rank, world, dist_on)

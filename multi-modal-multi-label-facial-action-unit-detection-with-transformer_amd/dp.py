@@ -73,6 +73,8 @@ class DataParallel:
             self._owned.update(id(p) for p in st.flat_parameters())
         self._rest_params = [p for p in model.parameters() if id(p) not in self._owned]
         self._cuda = any(p.is_cuda for p in model.parameters())
+        # ncclAvg exists in RCCL only: a gloo group over GPU tensors (tests: two ranks on ONE GPU) pre-divides and sums
+        self._avg = self._cuda and str(dist.get_backend(process_group)).lower() == "nccl"
         self.stats_reset()
         self._pending: List = []
         self._held: List = []  # (layer, flat) handed over but not launched yet
@@ -147,7 +149,7 @@ class DataParallel:
         nb = flat.numel() * flat.element_size()
         self._stats["bytes_total"] += nb
         self._step_bytes.append(nb)
-        if self._cuda:
+        if self._avg:
             # Issued from the compute stream with async_op=True: the process group makes ITS communication stream wait for
             # what the compute stream has enqueued so far (the producing backward kernels), runs the collective there and
             # hands back a Work whose wait() makes the compute stream wait for it - the overlap with the remaining backward

@@ -124,11 +124,15 @@ def test_au_loss_sum_count_form_matches_mean_form():
     assert sc0.tolist() == [0.0, 0.0] and float(grad0.abs().sum()) == 0.0
 
 
-def _rccl_worker(rank, world, port, q):
+def _rccl_worker(rank, world, port, q, backend="nccl"):
     import avformer_amd as A
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    torch.cuda.set_device(rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:  # gloo over GPU tensors: every rank on cuda:0 (a one-GPU box); the collectives stage through the host
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.manual_seed(3 + rank)  # different init per rank: the wrapper broadcasts rank 0's
         kw = dict(dim=128, depth=3, heads=8, dim_head=32, mlp_dim=256, t_video=20, t_audio=13, compute_dtype="f32")
@@ -175,3 +179,52 @@ def test_dp_two_ranks_rccl_match_single_process():
         assert p.exitcode == 0
     for rank, worst in res:
         assert worst < 1e-4, (rank, worst)
+
+
+def test_dp_two_ranks_on_one_gpu_match_single_process():
+    """the same two-rank case on a ONE-GPU box: two processes, both on cuda:0, a gloo group over the GPU tensors (RCCL refuses
+    two ranks on one device).  Everything but the transport is the product path - HIP forward / backward per rank, the
+    per-layer hooks, bucket merging, the (sum, count) loss reduction, finish() - and the averaged gradients must equal the
+    single-process gradients on the concatenated batch, with unequal ignored rows per rank."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, port, q, "gloo")) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, worst in res:
+        assert worst < 1e-4, (rank, worst)
+
+
+def test_bench_two_rank_control_flow_rehearsal_on_one_gpu():
+    """`python bench.py --gpus 2` end to end on a ONE-GPU box: its own launcher starts two ranks, both on cuda:0, the collectives
+    through gloo (AVF_BENCH_ONE_DEVICE / AVF_BENCH_BACKEND: rehearsal switches of bench.py).  The numbers mean nothing (two ranks
+    share one GPU); what is checked is that the multi-rank control flow - rendezvous, rank assertion, the collectively decided
+    untimed loops, every timed region under the data-parallel wrapper, the data-parallel report - runs to ONE json line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AVF_BENCH_ONE_DEVICE="1", AVF_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-kernel-events"], capture_output=True, text=True, env=env, cwd=root, timeout=500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 64
+    dp = d["data_parallel"]
+    assert dp["rccl_ranks"] == 2 and dp["gradient_collectives_per_step"] >= 2 and dp["loss_collectives_per_step"] == 1
+    assert sum(dp["bucket_bytes"]) == dp["gradient_bytes_per_step"] > 50_000_000  # 12.6 M stack parameters + the head, fp32
+    assert d["launch"].startswith("eager") and d["value"] > 0
