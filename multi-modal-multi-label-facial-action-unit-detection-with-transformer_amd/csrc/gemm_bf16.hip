@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(NtParams p) {
 // LEAN: 0 = the general epilogue (run-time options), 1 = nt_epilogue_lean (every option fixed at compile time; the host has
 // checked nt_lean_ok), 2 = the same with column sums; + 4 = with the epilogue's dropout site
 template <int EPI, typename CT, int WM, int WN, int MI, int NI, int NS, int LEAN = 0>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(NtParams p, int tiles_n, int nwg) {
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(NtParams p, int tiles_n, int nwg, int wpf) {
   constexpr int WTM = 16 * MI, WTN = 16 * NI;  // per-wave output tile
   constexpr int BMT = WTM * WM, BNT = WTN * WN, NW = WM * WN;
   constexpr int A_BYTES = BMT * 128, B_BYTES = BNT * 128, STAGE = A_BYTES + B_BYTES;
@@ -149,6 +149,33 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(NtParam
     for (int j = 0; j < B_INS; ++j)
       if (B_TOT % NW == 0 || wave + j * NW < B_TOT) glds16(gb[j] + k0, sb + (wave + j * NW) * 1024);
   };
+
+  // Weight warm-up.  In the step a weight image was last touched a whole pass ago: it is in no cache, every workgroup walks K
+  // in the same order, and with one stage of look-ahead each K-step then exposes a full HBM round trip for the SAME few lines
+  // of B in all eight L2s (tools/diag/fresh_operand.py: 15.2 -> 21.2 us at K = 1024, 20.0 -> 30.2 at K = 1536 with nothing but
+  // the 1 - 1.5 MB weight out of cache).  So the workgroups dealt to one XCD (ids congruent mod 8 - a speed assumption only)
+  // split B between them and request ALL of it once, up front: one dword per 128-byte line, the value never used.  The
+  // destination registers stay live until after the K loop (the loads return in order: they are retired by the first counted
+  // wait, but hipcc cannot see that and must not re-use the registers while they are in flight).
+  constexpr int WPF = 2;
+  uint32_t wpf_sink[WPF];
+#pragma unroll
+  for (int i = 0; i < WPF; ++i) wpf_sink[i] = 0u;
+  if (wpf) {  // (host: B is dense, ldb == K)
+    const int nx = (nwg - (int)(blockIdx.x & 7) + 7) >> 3;  // workgroups of this XCD
+    const int lines = p.N * (p.K >> 6);
+    const int per = (lines + nx - 1) / nx;
+    const int lo = (int)(blockIdx.x >> 3) * per;
+    const int hi = (lo + per) < lines ? (lo + per) : lines;
+#pragma unroll
+    for (int i = 0; i < WPF; ++i) {
+      const int ln = lo + tid + i * NW * 64;
+      if (ln < hi) {
+        const bf16* src = p.B + (int64_t)ln * 64;
+        asm volatile("global_load_dword %0, %1, off" : "+v"(wpf_sink[i]) : "v"(src) : "memory");
+      }
+    }
+  }
 
   f32x4_t acc[MI][NI];
 #pragma unroll
@@ -224,6 +251,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(NtParam
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[1][j], fa[1][i], acc[i][j], 0, 0, 0);
     cur = (cur + 1 == NS) ? 0 : cur + 1;
   }
+#pragma unroll
+  for (int i = 0; i < WPF; ++i) asm volatile("" ::"v"(wpf_sink[i]));  // (end of the warm-up registers' live range)
 
   if constexpr (LEAN != 0)
     nt_epilogue_lean<EPI, CT, MI, NI, (LEAN & 3) == 2 ? 1 : 0, false, false, true, (LEAN & 4) != 0>(
@@ -256,8 +285,22 @@ int launch_nt_glds(const NtParams& p, hipStream_t s, int* part_rows, TimingScope
               EPI, 2.0 * p.M * p.N * p.K,
               2.0 * ((double)p.M * p.K + (double)p.N * p.K) + csz * p.M * p.N + epi_b);
   }
+  // Weight warm-up (see the kernel): on for launches that leave workgroup slots of the chip empty (C2: 432 workgroups on 512
+  // slots).  It turns stall time into MFMA-dense time, and the replayed step runs against the package power limit (amd-smi: PPT
+  // violation active during replay, shader clock 2.15 - 2.37 GHz of 2.4): on the full launches of C3 the tiled shapes ran 6 -
+  // 12 % shorter and the firmware lowered the clock of the WHOLE step by 6 % (2305 -> 2155 MHz) - C3 +3.0 %, C4 +0.5 %,
+  // C5 +0.3 % in wall time, C2 -1.9 ... -3.8 % (profiles/r05_weight_warmup.txt).
+  static const int wpf_env = [] {
+    const char* e = tuning_env("AVF_NT_WPF");  // A/B aid: 0 = never, 2 = every launch
+    return (e && *e) ? atoi(e) : 1;
+  }();
+  // the 8-wave tiles only: on the small-M tile (four workgroups of 8 K-steps per CU, the reference's 17-token layers) the warm-up
+  // loads queue in front of a short K loop's own - TFormer 133 -> 140 us per layer
+  constexpr int kSlots = (WM * WN == 8) ? 512 : 0;  // two 8-wave workgroups per CU, 256 CUs
+  const int wpf = (wpf_env && (wpf_env == 2 || nwg < kSlots) && p.ldb == p.K && p.K >= TK) ? 1 : 0;  // (K >= TK: the K loop's
+                                                                                                       //  first wait retires the loads)
   launch_in_scope(ts, gemm_bf16_nt_glds_kernel<EPI, CT, WM, WN, MI, NI, NS, LEAN>, dim3(nwg), dim3(WM * WN * 64), SMEM, s, p,
-                  tiles_n, nwg);
+                  tiles_n, nwg, wpf);
   return 0;
 }
 

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Diagnostic: does an NT GEMM run slower when its A operand was written by the kernel just before it (as in the step) than
+when the same buffer is re-read launch after launch (as in a standalone timing loop)?
+
+The per-shape tables of the step (profiles/r05_c2_shapes.csv) show the tiled kernel 20 - 25 % slower than the standalone loop
+of tools/vendor_yardstick.py on the same shapes, the persistent kernel not.  Three states of A for every shape:
+  resident  the loop re-reads one buffer (whatever cache level holds it keeps it)
+  fresh     a copy kernel rewrites A right before every GEMM launch (dirty lines of all eight L2s written back at its end)
+  cold      as fresh, then 1 GiB of other memory is written before the GEMM (nothing of A or W left in any cache)
+  coldW     the 1 GiB write first, then A rewritten: A as in fresh, the weight out of every cache (in the step a weight image
+            was last read a whole pass earlier)
+  coldA     A rewritten, the 1 GiB write, then the weight image read by two small kernels
+Run under rocprofv3 (tools/diag/fresh_operand.sh): kernel durations from the trace, median of 30 launches per shape and state.
+"""
+import os
+import statistics
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import avformer_amd as A  # noqa: E402
+
+ops = A.ops
+
+
+ITERS, WARM = 30, 5
+SHAPES = (("to_qkv (ws)", 1536, 512), ("d_o (ws)", 512, 512), ("net.0 (ws)", 1024, 512), ("dh2 (tiled)", 512, 1024),
+          ("dX of to_qkv (tiled)", 512, 1536))
+STATES = ("resident", "fresh", "cold", "coldW", "coldA")
+
+
+def run(R):
+    """the launches, in a fixed order: for every shape, for every state, WARM + ITERS x [state's writer kernels; GEMM]"""
+    flush = torch.empty(1 << 28, device="cuda", dtype=torch.float32)  # 1 GiB
+    for name, n, k in SHAPES:
+        src = torch.randn(R, k, device="cuda").bfloat16()
+        a = src.clone()
+        w = (torch.randn(n, k, device="cuda") / k ** 0.5).bfloat16()
+        if k == 512 and ops.gemm_ws_used(R, n, k):
+            wp = ops.pack_ws(w)
+            wt = wp
+            fn = lambda: ops.gemm_ws(a, wp, n, out_dtype=torch.bfloat16)
+        else:
+            wt = w
+            fn = lambda: ops.gemm(a, w, out_dtype=torch.bfloat16)
+        torch.cuda.synchronize()
+        for state in STATES:
+            for _ in range(WARM + ITERS):
+                if state == "coldW":
+                    flush.fill_(1.0)
+                if state != "resident":
+                    a.copy_(src)
+                if state in ("cold", "coldA"):
+                    flush.fill_(1.0)
+                if state == "coldA":
+                    wt.float().sum()  # two small kernels read the weight image again
+                fn()
+            torch.cuda.synchronize()
+
+
+def summarise(trace_csv, R):
+    """rocprofv3 --kernel-trace CSV of run(): the GEMM dispatches in start order are SHAPES x STATES x (WARM + ITERS)"""
+    import csv
+    rows = [r for r in csv.DictReader(open(trace_csv)) if "gemm_bf16_nt" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    per = WARM + ITERS
+    assert len(rows) == len(SHAPES) * len(STATES) * per, (len(rows), per)
+    print(f"{R} rows; kernel duration in us (rocprofv3 kernel trace, median of {ITERS} launches), by the state of the A operand")
+    i = 0
+    for name, n, k in SHAPES:
+        out = []
+        for state in STATES:
+            d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3 for r in rows[i + WARM:i + per]]
+            i += per
+            out.append(f"{state} {statistics.median(d):6.2f}")
+        print(f"  {name:24s} N={n:5d} K={k:5d}: " + "   ".join(out))
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--summarise":
+        summarise(sys.argv[2], int(sys.argv[3]))
+    else:
+        run(int(sys.argv[1]) if len(sys.argv) > 1 else 10368)
