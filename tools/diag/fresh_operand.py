@@ -10,6 +10,8 @@ of tools/vendor_yardstick.py on the same shapes, the persistent kernel not.  Thr
   coldW     the 1 GiB write first, then A rewritten: A as in fresh, the weight out of every cache (in the step a weight image
             was last read a whole pass earlier)
   coldA     A rewritten, the 1 GiB write, then the weight image read by two small kernels
+  coldW+touch  as coldW, then the weight image read by two small kernels before the GEMM: does a touch by an EARLIER kernel (the
+            lines then sit in the memory-side cache, not in the GEMM's L2s) remove the penalty?
 Run under rocprofv3 (tools/diag/fresh_operand.sh): kernel durations from the trace, median of 30 launches per shape and state.
 """
 import os
@@ -27,7 +29,7 @@ ops = A.ops
 ITERS, WARM = 30, 5
 SHAPES = (("to_qkv (ws)", 1536, 512), ("d_o (ws)", 512, 512), ("net.0 (ws)", 1024, 512), ("dh2 (tiled)", 512, 1024),
           ("dX of to_qkv (tiled)", 512, 1536))
-STATES = ("resident", "fresh", "cold", "coldW", "coldA")
+STATES = ("resident", "fresh", "cold", "coldW", "coldA", "coldW+touch")
 
 
 def run(R):
@@ -47,13 +49,13 @@ def run(R):
         torch.cuda.synchronize()
         for state in STATES:
             for _ in range(WARM + ITERS):
-                if state == "coldW":
+                if state in ("coldW", "coldW+touch"):
                     flush.fill_(1.0)
                 if state != "resident":
                     a.copy_(src)
                 if state in ("cold", "coldA"):
                     flush.fill_(1.0)
-                if state == "coldA":
+                if state in ("coldA", "coldW+touch"):
                     wt.float().sum()  # two small kernels read the weight image again
                 fn()
             torch.cuda.synchronize()
