@@ -79,7 +79,69 @@ def summarise(trace_csv, R):
         print(f"  {name:24s} N={n:5d} K={k:5d}: " + "   ".join(out))
 
 
+EPI_STATES = ("resident", "fresh", "coldX", "coldX+coldW")
+
+
+def run_epi(R):
+    """the epilogue forms whose EXTRA operand is cold in the step: dGELU reads the pre-activation u saved by the forward pass
+    (persistent kernel, aux staged by LDS-DMA); bias + residual reads a residual stream written a few launches earlier (tiled
+    kernel, K = 1024).  coldX: A rewritten, then the 1 GiB write with the extra operand out of cache, then A rewritten AGAIN and the
+    weight image touched - only the extra operand is cold."""
+    flush = torch.empty(1 << 28, device="cuda", dtype=torch.float32)
+    src = torch.randn(R, 512, device="cuda").bfloat16()
+    a = src.clone()
+    w = (torch.randn(1024, 512, device="cuda") / 512 ** 0.5).bfloat16()
+    wp = ops.pack_ws(w)
+    u = torch.randn(R, 1024, device="cuda").bfloat16()
+    src2 = torch.randn(R, 1024, device="cuda").bfloat16()
+    a2 = src2.clone()
+    w2 = (torch.randn(512, 1024, device="cuda") / 1024 ** 0.5).bfloat16()
+    res = torch.randn(R, 512, device="cuda").bfloat16()
+    bias = torch.zeros(512, device="cuda")
+    cases = (
+        (lambda: ops.gemm_ws(a, wp, 1024, out_dtype=torch.bfloat16, epilogue=A._lib.EPI_DGELU, aux=u, want_colsum=True), a, src, wp),
+        (lambda: ops.gemm(a2, w2, out_dtype=torch.bfloat16, epilogue=A._lib.EPI_BIAS_RES, bias=bias, residual=res), a2, src2, w2),
+    )
+    for fn, av, sv, wt in cases:
+        torch.cuda.synchronize()
+        for state in EPI_STATES:
+            for _ in range(WARM + ITERS):
+                if state != "resident":
+                    av.copy_(sv)
+                if state.startswith("coldX"):
+                    flush.fill_(1.0)
+                    av.copy_(sv)
+                    if state == "coldX":
+                        wt.float().sum()
+                fn()
+            torch.cuda.synchronize()
+
+
+def summarise_epi(trace_csv, R):
+    import csv
+    rows = [r for r in csv.DictReader(open(trace_csv)) if "gemm_bf16_nt" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    per = WARM + ITERS
+    names = ("dGELU (ws, N=1024 K=512, aux u)", "bias+res (tiled, N=512 K=1024, residual)")
+    assert len(rows) == len(names) * len(EPI_STATES) * per, (len(rows), per)
+    print(f"{R} rows; kernel duration in us (median of {ITERS} launches), by the state of the epilogue's extra operand (coldX: only it is cold)")
+    i = 0
+    for name in names:
+        out = []
+        for state in EPI_STATES:
+            d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3 for r in rows[i + WARM:i + per]]
+            i += per
+            out.append(f"{state} {statistics.median(d):6.2f}")
+        print(f"  {name:44s}: " + "   ".join(out))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--epi":
+        run_epi(int(sys.argv[2]))
+        sys.exit(0)
+    if len(sys.argv) > 3 and sys.argv[1] == "--summarise-epi":
+        summarise_epi(sys.argv[2], int(sys.argv[3]))
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[1] == "--summarise":
         summarise(sys.argv[2], int(sys.argv[3]))
     else:
