@@ -340,12 +340,52 @@ class Region:
             for m, k in zip(stacks, keep):
                 m.cache_weights = k
                 m.refresh_weights()
+        self._run = run
         self.steps = steps
         self.ms = dt / steps * 1e3
         self.clips_per_s = self.B * self.world * steps / dt
         self.loss = float(loss.item())
         self.tflops = 3.0 * stack_flops_fwd(self.c, self.B) / (self.ms * 1e-3) / 1e12
         self.frac = self.tflops / MFMA_PEAK_TFLOPS[self.dtype]
+
+    def clock_power(self, seconds=1.5):
+        """Shader clock and package power while the timed step keeps running (rocm-smi sampled from a thread, AFTER the timed
+        region; one rank, one GPU).  The step runs against the package power limit: `frac` is against
+        the NOMINAL roof at 2.4 GHz, this says what the box allowed.  None when rocm-smi is missing or prints something else."""
+        import re
+        import shutil
+        import statistics
+        import subprocess
+        import threading
+        if self.use_dist or shutil.which("rocm-smi") is None:
+            return None
+        stop, out = threading.Event(), []
+
+        def sample():
+            while not stop.is_set():
+                try:
+                    txt = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=5).stdout
+                    m = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", txt)
+                    w = re.search(r"Package Power \(W\): ([0-9.]+)", txt)
+                    if m and w:
+                        out.append((int(m.group(1)), float(w.group(1))))
+                except Exception:
+                    return
+                time.sleep(0.15)
+
+        th = threading.Thread(target=sample, daemon=True)
+        t0 = time.perf_counter()
+        th.start()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(20):
+                self._run()
+            self.torch.cuda.synchronize()
+        stop.set()
+        th.join(timeout=10)
+        if not out:
+            return None
+        return {"sclk_mhz": statistics.median(c for c, _ in out), "package_w": statistics.median(w for _, w in out),
+                "samples": len(out), "nominal_sclk_mhz": 2400, "how": "rocm-smi sampled while the timed step keeps replaying, after the timed region"}
 
     def instrumented(self, steps):
         """K more steps with a HIP-event pair ATTACHED to every hot-path dispatch (hipExtLaunchKernelGGL start/stop events =
@@ -501,6 +541,7 @@ def main():
     dp_graph_ok = (dp_graph_env != "0") if world == 1 else (dp_graph_env == "1" or args.launch == "graph")
     use_graph = ((args.graph or args.launch in ("auto", "graph")) and args.launch != "eager" and (not use_dist or dp_graph_ok))
     main_r.timed(args.steps, args.warmup, use_graph)
+    main_clock = main_r.clock_power() if (world == 1 and not args.no_extra) else None
     c, B = main_r.c, main_r.B
     Tv, Ta = c["t_video"], c["t_audio"]
     result = {
@@ -514,6 +555,8 @@ def main():
                    "global_batch": B * world, "seq_len": Tv + Ta, "parallelism": f"dp{world}",
                    "step": "zero_grad+fwd+AULoss+bwd" + ("+allreduce" if use_dist else "") + ("+adam" if main_r.optimizer else ""),
                    "optimizer": main_r.optimizer, "residual_stream": main_r.residual, "dropout": args.dropout, "loss": main_r.loss},
+        # what the box allowed while this step ran: the step is package-power-limited
+        "clock_power": main_clock,
         "untimed_steps_beyond_warmup": main_r.extra_warmup,  # until the caching allocator stopped growing (Region.timed)
         "launch": main_r.launch,
         # the same step launched eagerly from Python (None when `value` itself is the eager number)
@@ -539,6 +582,7 @@ def main():
     if not args.no_extra and args.config == "c2" and args.dtype == "bf16":
         c3_r = mk("c3", "bf16", use_dist)
         c3_r.timed(args.steps, args.warmup, use_graph)
+        c3_clock = c3_r.clock_power() if world == 1 else None
         if world == 1:
             f32_r = mk(args.config, "f32", False)
             f32_r.timed(max(2, min(20, args.steps // 6)), 1)
@@ -584,6 +628,7 @@ def main():
                 "clips_per_s": round(c3_r.clips_per_s, 2), "ms_per_step": round(c3_r.ms, 4),
                 "steps": args.steps, "warmup": args.warmup, "launch": c3_r.launch,
                 "eager_ms_per_step": None if c3_r.eager_ms is None else round(c3_r.eager_ms, 4),
+                "clock_power": c3_clock,
                 "stack_tflops_per_gpu": round(c3_r.tflops, 2),
                 "stack_frac_of_mfma_peak": round(c3_r.frac, 4),
                 "target_frac": 0.30, "kernel_classes": c3_r.classes if events else None}
