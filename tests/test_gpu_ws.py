@@ -170,6 +170,44 @@ def test_stack_with_and_without_the_persistent_kernel(tmp_path, dropout):
                 assert torch.equal(on[k], off[k]), k
 
 
+def test_weight_warmup_of_the_tiled_kernel_changes_no_bit(tmp_path):
+    """AVF_NT_WPF (gemm_bf16.hip): the tiled NT kernel's workgroups request the whole weight image up front in launches that
+    leave workgroup slots empty (default), never (0) or in every launch (2).  The loads feed nothing: three child processes
+    run the same GEMMs - both 8-wave tiles, partly filled and full grids, ragged M / N, a one-K-step problem, every lean
+    epilogue, the 2-layer stack at C2's token count - and every output must be bit-identical."""
+    import subprocess
+    import sys
+    code = (
+        "import os, torch, avformer_amd as A\n"
+        "ops = A.ops\n"
+        "torch.manual_seed(11)\n"
+        "d = {}\n"
+        "for i, (M, N, K) in enumerate(((10368, 512, 1024), (16384, 512, 1536), (4099, 520, 64), (2592, 384, 512), (20000, 1024, 192))):\n"
+        "    a = torch.randn(M, K, device='cuda').bfloat16(); w = (torch.randn(N, K, device='cuda') / K ** 0.5).bfloat16()\n"
+        "    bias = torch.randn(N, device='cuda'); res = torch.randn(M, N, device='cuda').bfloat16()\n"
+        "    d[f'plain{i}'] = ops.gemm(a, w, out_dtype=torch.bfloat16).float().cpu()\n"
+        "    d[f'res{i}'] = ops.gemm(a, w, out_dtype=torch.bfloat16, epilogue=A._lib.EPI_BIAS_RES, bias=bias, residual=res).float().cpu()\n"
+        "    d[f'f32{i}'] = ops.gemm(a, w, out_dtype=torch.float32).cpu()\n"
+        "m = A.Transformer(512, 2, 8, 64, 1024, 0.0, compute_dtype='bf16', residual_dtype='bf16').cuda().train()\n"
+        "x = torch.randn(8, 324, 512, device='cuda', requires_grad=True)\n"
+        "y = m(x); y.float().pow(2).mean().backward()\n"
+        "d['y'] = y.detach().float().cpu(); d['dx'] = x.grad.cpu()\n"
+        "d.update({n: p.grad.clone().cpu() for n, p in m.named_parameters()})\n"
+        "torch.save(d, os.environ['AVF_TEST_OUT'])\n")
+    outs = []
+    for wpf in ("0", "1", "2"):
+        path = str(tmp_path / f"wpf{wpf}.pt")
+        env = dict(os.environ, AVF_TUNING="1", AVF_NT_WPF=wpf, AVF_NT_WS="0", AVF_TEST_OUT=path)  # (every NT GEMM on the tiled kernel)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(torch.load(path))
+    for other in outs[1:]:
+        assert outs[0].keys() == other.keys()
+        for k in outs[0]:
+            assert torch.equal(outs[0][k], other[k]), k
+
+
 # ---------------------------------------------------------------------------------------------- against the ORACLE, >= 2048 rows
 # The B = 2 oracle tests of test_gpu_configs.py have 1024 token rows and therefore run the tiled kernel; these hold the
 # PERSISTENT kernel itself to the oracle's math (oracle/reference_math.py = /root/reference/models/heads.py:164-256), so that a
