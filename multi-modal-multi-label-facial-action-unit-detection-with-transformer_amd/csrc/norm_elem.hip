@@ -573,8 +573,11 @@ int fold_partials(const float* partial, int nb, int width, float* out, hipStream
 int fold_job(const FoldJob& j, hipStream_t s) { return launch_fold(j.partial, j.nb, j.width, j.o0, j.o1, j.o2, j.seg, s); }
 
 // LayerNorm backward on the all-bf16 streams (dy, x, the incoming residual gradient and dx in bf16; no dropout, no MX image):
-// the row8 layout of ln_fwd_row8_kernel.  A workgroup owns LNR_ROWS_PER_BLOCK = 4 waves x RU rows; the per-column sums stay in
-// registers and are combined through LDS in wave order, so the partial of a block - and the folded result - is deterministic.
+// the row8 layout of ln_fwd_row8_kernel.  A workgroup owns rpb rows = 4 waves x (rpb / 4 / RU) batches of RU rows; the per-column
+// sums stay in registers and are combined through LDS in wave order, so the partial of a block - and the folded result - is
+// deterministic.  rpb (lnr8_rows_per_block): 32 from 8192 rows up - two batches per wave halve the partial rows written here and
+// folded later and amortise the LDS combine (C2: 12.7 -> 11.6 us per launch and the layer's fold 12.0 -> 10.4; C3: 16.7 -> 14.2 and
+// 15.4 -> 12.2; 48 rows level with 32 at C2 and worse at C3, 64 and 8 worse) - 16 below (short inputs need the workgroups).
 // DROP (round 5): live dropout on the all-bf16 streams.  The row gradient leaves TWICE: dx_lo = the residual-gradient stream
 // (never masked: the next LayerNorm backward's dres) and dx_m = what the Linear behind the dropout site sees (masked, rescaled:
 // the GEMM operand; the column sums - that Linear's bias gradient - are those of the MASKED values, as ln_bwd_reg_kernel's).
@@ -585,11 +588,12 @@ __global__ __launch_bounds__(256) void ln_bwd_row8_kernel(const bf16* __restrict
                                                           bf16* __restrict__ dx_lo, float* __restrict__ partial, int64_t rows,
                                                           int D, int want_colsum, uint8_t* __restrict__ dxq = nullptr,
                                                           uint8_t* __restrict__ dxs = nullptr, float* __restrict__ dx = nullptr,
-                                                          DropCfg drop = kNoDrop, bf16* __restrict__ dx_m = nullptr) {
+                                                          DropCfg drop = kNoDrop, bf16* __restrict__ dx_m = nullptr,
+                                                          int rpb = LNR_ROWS_PER_BLOCK) {
   // dx (optional, wave-uniform): the fp32 copy of the row gradient (the bottom layer hands it to the caller)
+  // rpb: rows per workgroup, a multiple of 4 RU (host: lnr8_rows_per_block) - a wave's rows come in whole batches of RU
   uint64_t dkey = 0;
   if constexpr (DROP) dkey = drop_key(drop);
-  static_assert((LNR_ROWS_PER_BLOCK / 4) % RU == 0, "a wave's rows come in whole batches of RU");
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [4 waves][3][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float gm[NV8][8];
@@ -607,8 +611,8 @@ __global__ __launch_bounds__(256) void ln_bwd_row8_kernel(const bf16* __restrict
     for (int k = 0; k < 8; ++k) adg[i][k] = adb[i][k] = acs[i][k] = 0.f;
   const float invD = 1.0f / (float)D;
 #pragma unroll 1
-  for (int batch = 0; batch < LNR_ROWS_PER_BLOCK / 4 / RU; ++batch) {
-  const int64_t row0 = (int64_t)blockIdx.x * LNR_ROWS_PER_BLOCK + wave * (LNR_ROWS_PER_BLOCK / 4) + batch * RU;
+  for (int batch = 0; batch < rpb / 4 / RU; ++batch) {
+  const int64_t row0 = (int64_t)blockIdx.x * rpb + wave * (rpb / 4) + batch * RU;
   uint4 rd[RU][NV8], rx[RU][NV8], rr[RU][NV8];
   float mu[RU], rs[RU];
 #pragma unroll
@@ -717,6 +721,8 @@ __global__ __launch_bounds__(256) void ln_bwd_row8_kernel(const bf16* __restrict
 
 constexpr int64_t LNR_SHORT_ROWS = 4096;  // up to here the register-path backward runs 4 rows per workgroup
 static inline int lnr_rows_per_block(int64_t rows) { return rows <= LNR_SHORT_ROWS ? 4 : LNR_ROWS_PER_BLOCK; }
+constexpr int64_t LNR8_BIG_ROWS = 8192;  // from here the row8 backward runs two batches per wave (see the kernel)
+static inline int lnr8_rows_per_block(int64_t rows) { return rows >= LNR8_BIG_ROWS ? 2 * LNR_ROWS_PER_BLOCK : LNR_ROWS_PER_BLOCK; }
 size_t layernorm_bwd_ws(int64_t rows, int dim) {
   return (size_t)ceil_div(rows, lnr_rows_per_block(rows)) * 3 * dim * sizeof(float);  // LNR < LNB: covers both paths
 }
@@ -752,7 +758,7 @@ int layernorm_bwd(const void* dy, int dy_dtype, const void* xv, const float* gam
   if (fast) {
     const bool row8 = x_dtype == AVF_BF16 && dy_dtype == AVF_BF16 && (!dres || dres_dtype == AVF_BF16) && dx_lo &&
                       (!drop.thresh16 || dx_m) && (!mx_q || dim % 32 == 0) && dim % 8 == 0 && (ln_row8_on() || dx_m);
-    const int rpb = row8 ? LNR_ROWS_PER_BLOCK : lnr_rows_per_block(rows);
+    const int rpb = row8 ? lnr8_rows_per_block(rows) : lnr_rows_per_block(rows);
     nb = (int)ceil_div(rows, rpb);
     const size_t lds = (size_t)4 * 3 * dim * sizeof(float);
     const int nv = (dim + 255) / 256;
@@ -791,11 +797,11 @@ int layernorm_bwd(const void* dy, int dy_dtype, const void* xv, const float* gam
     if (dx_m)                                                                                                                \
       launch_in_scope(&ts, ln_bwd_row8_kernel<NVV, RU, true>, dim3(nb), dim3(256), (uint32_t)lds, s, (const bf16*)dy,        \
                       (const bf16*)xv, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx_lo, partial, rows, dim, wc,            \
-                      (uint8_t*)nullptr, (uint8_t*)nullptr, dx, drop, (bf16*)dx_m);                                          \
+                      (uint8_t*)nullptr, (uint8_t*)nullptr, dx, drop, (bf16*)dx_m, rpb);                                     \
     else                                                                                                                     \
       launch_in_scope(&ts, ln_bwd_row8_kernel<NVV, RU>, dim3(nb), dim3(256), (uint32_t)lds, s, (const bf16*)dy,              \
                       (const bf16*)xv, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx_lo, partial, rows, dim, wc,            \
-                      (uint8_t*)mx_q, (uint8_t*)mx_s, dx, kNoDrop, (bf16*)nullptr);                                          \
+                      (uint8_t*)mx_q, (uint8_t*)mx_s, dx, kNoDrop, (bf16*)nullptr, rpb);                                     \
   } while (0)
       switch ((dim + 511) / 512) {  // rows in flight per wave: what the register file allows at two waves per SIMD or more
         case 1: LAUNCH_R8(1, 4); break;
