@@ -451,6 +451,20 @@ bool gemm_bf16_nt_ws_preferred(const GemmArgs& a) {
     }();
     if (T / G < min_tiles) return false;
   }
+  // plain, N = dim (d_o in backward): the same prologue serves two column panels only - below three row tiles per workgroup the
+  // tiled kernel (whose launches at these sizes leave slots empty and warm their weights, gemm_bf16.hip) is ahead with the weight
+  // image cold as in the step: 10.4 against 12.2 us at C2's 10368 rows, 8.1 / 9.7 at 5184, 6.1 / 7.8 at 2048; N = 1536 stays
+  // here at every row count (tools/diag/ws_vs_tiled_small_m.py)
+  if (a.epilogue == AVF_EPI_NONE && a.N / WS_BN <= 2) {
+    const int64_t P = a.N / WS_BN, T = (a.M + 31) / 32;
+    int64_t G = ws_grid() / P;
+    G = G > T ? T : G;
+    static const int min_tiles0 = [] {
+      const char* e = tuning_env("AVF_NT_WS_PLAIN_TILES");  // tuning aid
+      return (e && *e) ? atoi(e) : 3;
+    }();
+    if (T < min_tiles0 * G) return false;
+  }
   return true;
 }
 

@@ -213,8 +213,10 @@ def test_weight_warmup_of_the_tiled_kernel_changes_no_bit(tmp_path):
 # PERSISTENT kernel itself to the oracle's math (oracle/reference_math.py = /root/reference/models/heads.py:164-256), so that a
 # divergence of the two kernels cannot hide behind their bit-identity tests.
 def test_stack_on_the_persistent_kernel_vs_oracle_2560_rows():
-    """d = 512, 2 layers, B = 5 x 512 tokens = 2560 rows: QKV (plain), MLP1 (bias + GELU), dGELU (+ column sums) and d_o
-    (plain) run on the persistent kernel; forward and every gradient against the oracle's autograd, both residual streams"""
+    """d = 512, 2 layers, B = 5 x 512 tokens = 2560 rows: QKV (plain), MLP1 (bias + GELU) and dGELU (+ column sums) run on the
+    persistent kernel (d_o - plain, N = 512 - only from three row tiles per persistent workgroup up, i.e. 12288 rows; its epilogue
+    form is held to the oracle by the 4128-row test below); forward and every gradient against the oracle's autograd, both
+    residual streams"""
     import oracle
     from gpu_util import check_rel, hip_transformer_run, oracle_transformer_run
     D, L, H, dh, M, B, N = 512, 2, 8, 64, 1024, 5, 512
