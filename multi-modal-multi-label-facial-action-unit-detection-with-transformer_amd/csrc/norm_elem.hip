@@ -1119,24 +1119,45 @@ template <typename OutT>  // float: float4 stores; bf16: the bf16 residual strea
 __global__ __launch_bounds__(256) void fuse_tokens_kernel(const float4* __restrict__ clip, const float4* __restrict__ audio,
                                                          const float4* __restrict__ pos, OutT* __restrict__ out, int Tv,
                                                          int Ta, int D4, int64_t rows) {
+  // the block's TOK_ROWS_PER_BLOCK x D4 quads are dealt to the 256 threads as one flat range (D4 = 128: two rows at a time,
+  // every thread busy; one row per pass left half of them idle)
   const int T = Tv + Ta;
-#pragma unroll
-  for (int rr = 0; rr < TOK_ROWS_PER_BLOCK; ++rr) {
-    const int64_t row = (int64_t)blockIdx.x * TOK_ROWS_PER_BLOCK + rr;
-    if (row >= rows) return;
+  const int64_t row0 = (int64_t)blockIdx.x * TOK_ROWS_PER_BLOCK;
+  if constexpr (sizeof(OutT) == 2) {
+    if ((D4 & 1) == 0 && ((uintptr_t)out & 15) == 0) {  // bf16 rows of a multiple of 8 columns: two quads in, ONE 16-byte store out (8-byte stores: 1.1 TB/s)
+      const int D8 = D4 >> 1;
+      for (int i = threadIdx.x; i < TOK_ROWS_PER_BLOCK * D8; i += 256) {
+        const int rr = i / D8, c = i - rr * D8;
+        const int64_t row = row0 + rr;
+        if (row >= rows) return;  // (rr grows with i)
+        const int64_t b = row / T;
+        const int t = (int)(row - b * T);
+        const float4* src = t < Tv ? clip + (b * Tv + t) * D4 : audio + (b * Ta + (t - Tv)) * D4;
+        float4 v0 = src[2 * c], v1 = src[2 * c + 1];
+        if (pos) {
+          const float4 p0 = pos[(int64_t)t * D4 + 2 * c], p1 = pos[(int64_t)t * D4 + 2 * c + 1];
+          v0.x += p0.x; v0.y += p0.y; v0.z += p0.z; v0.w += p0.w;
+          v1.x += p1.x; v1.y += p1.y; v1.z += p1.z; v1.w += p1.w;
+        }
+        const float o[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        *reinterpret_cast<uint4*>(out + (row * D4 + 2 * c) * 4) = pack8(o);
+      }
+      return;
+    }
+  }
+  for (int i = threadIdx.x; i < TOK_ROWS_PER_BLOCK * D4; i += 256) {
+    const int rr = i / D4, c = i - rr * D4;
+    const int64_t row = row0 + rr;
+    if (row >= rows) return;  // (rr grows with i)
     const int64_t b = row / T;
     const int t = (int)(row - b * T);
     const float4* src = t < Tv ? clip + (b * Tv + t) * D4 : audio + (b * Ta + (t - Tv)) * D4;
-    const float4* pr = pos ? pos + (int64_t)t * D4 : nullptr;
-    OutT* dst = out + row * D4 * 4;
-    for (int c = threadIdx.x; c < D4; c += 256) {
-      float4 v = src[c];
-      if (pr) {
-        const float4 p = pr[c];
-        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
-      }
-      store4<OutT>(dst + 4 * c, v);
+    float4 v = src[c];
+    if (pos) {
+      const float4 p = pos[(int64_t)t * D4 + c];
+      v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
     }
+    store4<OutT>(out + (row * D4 + c) * 4, v);
   }
 }
 
@@ -1179,28 +1200,49 @@ __global__ __launch_bounds__(256) void token_mean_fwd_kernel(const InT* __restri
 __global__ __launch_bounds__(256) void token_mean_bwd_kernel(const float4* __restrict__ g, float4* __restrict__ dy,
                                                             bf16* __restrict__ dy_lo, float* __restrict__ colsum, int B,
                                                             int T, int D4, int64_t rows, int main_blocks) {
-  if ((int)blockIdx.x >= main_blocks) {
-    const int d = ((int)blockIdx.x - main_blocks) * 256 + threadIdx.x;
+  // the column-sum blocks come FIRST in the grid (they are one dependent chain of B rows each and would otherwise be the tail of
+  // the launch), eight loads in flight; same summation order as before
+  const int extra = (int)gridDim.x - main_blocks;
+  if ((int)blockIdx.x < extra) {
+    const int d = (int)blockIdx.x * 256 + threadIdx.x;
     if (d < 4 * D4) {
       const float* gs = reinterpret_cast<const float*>(g);
       float a = 0.f;
-      for (int b = 0; b < B; ++b) a += gs[(int64_t)b * 4 * D4 + d];
+      int b = 0;
+      for (; b + 8 <= B; b += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = gs[(int64_t)(b + u) * 4 * D4 + d];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += v[u];
+      }
+      for (; b < B; ++b) a += gs[(int64_t)b * 4 * D4 + d];
       colsum[d] = a;
     }
     return;
   }
   const float inv = 1.0f / (float)T;
-#pragma unroll
-  for (int rr = 0; rr < TOK_ROWS_PER_BLOCK; ++rr) {
-    const int64_t row = (int64_t)blockIdx.x * TOK_ROWS_PER_BLOCK + rr;
-    if (row >= rows) return;
-    const float4* gr = g + (row / T) * D4;
-    for (int c = threadIdx.x; c < D4; c += 256) {
-      const float4 v = gr[c];
-      const float4 r = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
-      if (dy) dy[row * D4 + c] = r;
-      if (dy_lo) store4<bf16>(dy_lo + 4 * (row * D4 + c), r);
+  const int64_t row0 = (int64_t)((int)blockIdx.x - extra) * TOK_ROWS_PER_BLOCK;
+  if (!dy && (D4 & 1) == 0 && ((uintptr_t)dy_lo & 15) == 0) {  // the bf16 image alone (the bf16 gradient stream): 16-byte stores
+    const int D8 = D4 >> 1;
+    for (int i = threadIdx.x; i < TOK_ROWS_PER_BLOCK * D8; i += 256) {
+      const int rr = i / D8, c = i - rr * D8;
+      const int64_t row = row0 + rr;
+      if (row >= rows) return;
+      const float4 v0 = g[(row / T) * D4 + 2 * c], v1 = g[(row / T) * D4 + 2 * c + 1];
+      const float o[8] = {v0.x * inv, v0.y * inv, v0.z * inv, v0.w * inv, v1.x * inv, v1.y * inv, v1.z * inv, v1.w * inv};
+      *reinterpret_cast<uint4*>(dy_lo + 4 * (row * D4 + 2 * c)) = pack8(o);
     }
+    return;
+  }
+  for (int i = threadIdx.x; i < TOK_ROWS_PER_BLOCK * D4; i += 256) {  // (flat range, as fuse_tokens_kernel)
+    const int rr = i / D4, c = i - rr * D4;
+    const int64_t row = row0 + rr;
+    if (row >= rows) return;
+    const float4 v = g[(row / T) * D4 + c];
+    const float4 r = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+    if (dy) dy[row * D4 + c] = r;
+    if (dy_lo) store4<bf16>(dy_lo + 4 * (row * D4 + c), r);
   }
 }
 
