@@ -32,6 +32,10 @@ CONFIGS = {
     "c3_small_batch": (2, 512, 512, 6, 8, 64, 1024),
     "c4_model_short": (2, 200, 768, 2, 12, 64, 1536),
     "wide_tformer": (3, 17, 1536, 1, 8, 64, 1024),
+    # >= 8192 rows that are no multiple of 32: the row8 LayerNorm backward's two-batch form (32 rows per workgroup) with a ragged
+    # last workgroup, at one and at two 16-byte chunks per lane
+    "ragged_8748_rows": (27, 324, 512, 1, 8, 64, 1024),
+    "ragged_9009_rows_d1024": (9, 1001, 1024, 1, 8, 64, 1024),
 }
 
 
