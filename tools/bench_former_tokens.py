@@ -22,12 +22,23 @@ def bench(name, model, x, iters=100):
     model = model.to(dev).train()
     x = x.to(dev).requires_grad_(True)
 
+    # the upstream gradient is GIVEN (these sections sit in the middle of the reference's networks: ResNet stage 4 follows
+    # ResFormer's tokens, the AU head follows TFormer): y.backward(gy).  AVF_BENCH_OWN_LOSS=1 restores the harness of rounds
+    # 2 - 4, y.float().pow(2).mean().backward() - five torch elementwise / reduction kernels over the 51 MB output of
+    # ResFormerTokens, 92 of its 920 us per step (rocprofv3, round 5) that are the harness's, not the module's
+    own_loss = os.environ.get("AVF_BENCH_OWN_LOSS", "") == "1"
+    with torch.no_grad():
+        gy = torch.randn_like(model(x.detach())).float() * 1e-3
+
     def step():
         for p in model.parameters():
             p.grad = None
         x.grad = None
         y = model(x)
-        y.float().pow(2).mean().backward()
+        if own_loss:
+            y.float().pow(2).mean().backward()
+        else:
+            y.backward(gy.to(y.dtype))
 
     for _ in range(30):
         step()
