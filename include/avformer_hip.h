@@ -295,6 +295,12 @@ int avf_au_loss(const float* logits, int64_t ld_logits, const float* labels, int
 int avf_au_loss_sum(const float* logits, int64_t ld_logits, const float* labels, int64_t ld_labels,
                     const float* pos_weight, float ignore, int rows, int ncls, float* sum_count, float* grad_unit,
                     void* stream);
+/* Either of the two (sum_mode 0 / 1) with the gradient laid out as the model's OUTPUT row: grad_wide [rows, width] contiguous,
+ * columns 0..ncls-1 as grad_unit above, ncls..width-1 zero - the gradient of the reference's [B,21] row whose first 12 slots are
+ * the AU logits (train.py:136-138, loss on out[:, :12]: avformer.py get_au_loss), in the same launch instead of the fill + copy
+ * autograd's slice backward adds.  `loss`: one float (sum_mode 0) or the (sum, count) pair (sum_mode 1). */
+int avf_au_loss_wide(const float* logits, int64_t ld_logits, const float* labels, int64_t ld_labels, const float* pos_weight,
+                     float ignore, int rows, int ncls, int width, int sum_mode, float* loss, float* grad_wide, void* stream);
 
 /* ---- one transformer layer (heads.py:246-255), forward and backward ------------------------ */
 size_t avf_layer_saved_bytes(const avf_layer_cfg* cfg);     /* activations kept for backward        */

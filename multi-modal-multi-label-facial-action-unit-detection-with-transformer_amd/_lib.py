@@ -91,6 +91,7 @@ SIGNATURES = {
     "avf_linear_pad_bwd": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _vp]),
     "avf_au_loss": (_int, [_vp, _i64, _vp, _i64, _vp, _f, _int, _int, _vp, _vp, _vp]),
     "avf_au_loss_sum": (_int, [_vp, _i64, _vp, _i64, _vp, _f, _int, _int, _vp, _vp, _vp]),
+    "avf_au_loss_wide": (_int, [_vp, _i64, _vp, _i64, _vp, _f, _int, _int, _int, _int, _vp, _vp, _vp]),
     "avf_layer_saved_bytes": (_sz, [C.POINTER(LayerCfg)]),
     "avf_layer_lowp_bytes": (_sz, [C.POINTER(LayerCfg)]),
     "avf_layernorm_bwd_mx8": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp]),

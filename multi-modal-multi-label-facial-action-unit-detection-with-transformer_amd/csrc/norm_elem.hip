@@ -1062,7 +1062,10 @@ int prep_weight_bf16(const float* w, void* w_lo, void* w_t_lo, int rows, int col
 __global__ __launch_bounds__(256) void au_loss_kernel(const float* __restrict__ z, int64_t ldz,
                                                       const float* __restrict__ y, int64_t ldy,
                                                       const float* __restrict__ pw, float ignore, int rows, int ncls,
-                                                      float* __restrict__ loss, float* __restrict__ grad, int sum_mode) {
+                                                      float* __restrict__ loss, float* __restrict__ grad, int sum_mode,
+                                                      int gwidth) {
+  // gwidth >= ncls: rows of `grad` are gwidth wide, columns ncls .. gwidth-1 written as zeros (the gradient of the reference's
+  // [B,21] output row whose slots 0..11 are the AU logits: what autograd's slice backward would build with a fill and a copy)
   __shared__ float red[4];
   __shared__ int redc[4];
   float acc = 0.f;
@@ -1094,10 +1097,10 @@ __global__ __launch_bounds__(256) void au_loss_kernel(const float* __restrict__ 
     if (sum_mode) loss[1] = (float)nk;
   }
   const float inv = 1.0f / denom;
-  for (int i = threadIdx.x; i < rows * ncls; i += 256) {
-    const int r = i / ncls, c = i - r * ncls;
+  for (int i = threadIdx.x; i < rows * gwidth; i += 256) {
+    const int r = i / gwidth, c = i - r * gwidth;
     float g = 0.f;
-    if (y[(int64_t)r * ldy] != ignore) {
+    if (c < ncls && y[(int64_t)r * ldy] != ignore) {
       const float zz = z[(int64_t)r * ldz + c], yy = y[(int64_t)r * ldy + c], w = pw[c];
       const float sg = 1.0f / (1.0f + expf(-zz));
       g = (sg * (1.f - yy + w * yy) - w * yy) * inv;
@@ -1322,7 +1325,7 @@ extern "C" int avf_au_loss(const float* logits, int64_t ld_logits, const float* 
   using namespace avf;
   AVF_REQUIRE(rows > 0 && ncls > 0 && logits && labels && pos_weight && loss && grad_unit, "au_loss: bad arguments");
   au_loss_kernel<<<1, 256, 0, (hipStream_t)stream>>>(logits, ld_logits, labels, ld_labels, pos_weight, ignore, rows,
-                                                     ncls, loss, grad_unit, 0);
+                                                     ncls, loss, grad_unit, 0, ncls);
   return check_launch("au_loss_kernel");
 }
 
@@ -1332,6 +1335,17 @@ extern "C" int avf_au_loss_sum(const float* logits, int64_t ld_logits, const flo
   using namespace avf;
   AVF_REQUIRE(rows > 0 && ncls > 0 && logits && labels && pos_weight && sum_count && grad_unit, "au_loss_sum: bad arguments");
   au_loss_kernel<<<1, 256, 0, (hipStream_t)stream>>>(logits, ld_logits, labels, ld_labels, pos_weight, ignore, rows,
-                                                     ncls, sum_count, grad_unit, 1);
+                                                     ncls, sum_count, grad_unit, 1, ncls);
+  return check_launch("au_loss_kernel");
+}
+
+extern "C" int avf_au_loss_wide(const float* logits, int64_t ld_logits, const float* labels, int64_t ld_labels,
+                                const float* pos_weight, float ignore, int rows, int ncls, int width, int sum_mode,
+                                float* loss, float* grad_wide, void* stream) {
+  using namespace avf;
+  AVF_REQUIRE(rows > 0 && ncls > 0 && width >= ncls && logits && labels && pos_weight && loss && grad_wide,
+              "au_loss_wide: bad arguments");
+  au_loss_kernel<<<1, 256, 0, (hipStream_t)stream>>>(logits, ld_logits, labels, ld_labels, pos_weight, ignore, rows,
+                                                     ncls, loss, grad_wide, sum_mode ? 1 : 0, width);
   return check_launch("au_loss_kernel");
 }

@@ -60,6 +60,9 @@ class VisualFormer(nn.Module):
 
 class _TaskLossMixin:
     def get_au_loss(self, y_pred, y_true):
+        # loss on the AU slots 0..11 of the [B,21] row (train.py:136-138 / the reference models' get_au_loss)
+        if y_true.dim() == 2 and y_true.shape[1] == 12 and hasattr(self.loss_AU, "forward_rows"):
+            return self.loss_AU.forward_rows(y_pred, y_true)
         return self.loss_AU(y_pred[:, :12], y_true)
 
     def get_ex_loss(self, y_pred, y_true):

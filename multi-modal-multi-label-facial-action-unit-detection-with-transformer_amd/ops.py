@@ -575,6 +575,22 @@ def au_loss_sum(logits: torch.Tensor, labels: torch.Tensor, pos_weight: torch.Te
     return sc, grad
 
 
+def au_loss_wide(out: torch.Tensor, labels: torch.Tensor, pos_weight: torch.Tensor, ignore: float = -1.0, sum_mode: bool = False):
+    """AULoss on the first ``labels.shape[1]`` slots of the model's output rows ``out`` [rows, width] -> (loss scalar, or the
+    (sum, count) 2-vector with sum_mode; d / d out [rows, width], zero beyond the logits) - avf_au_loss_wide."""
+    _need_cuda(out, labels, pos_weight)
+    assert out.dim() == 2 and labels.dim() == 2 and out.shape[0] == labels.shape[0] and out.shape[1] >= labels.shape[1]
+    assert out.stride(1) == 1 and labels.stride(1) == 1 and out.dtype == torch.float32
+    labels = labels.to(torch.float32)
+    rows, width = out.shape
+    ncls = labels.shape[1]
+    loss = torch.empty(2 if sum_mode else (), dtype=torch.float32, device=out.device)
+    grad = torch.empty((rows, width), dtype=torch.float32, device=out.device)
+    _lib.check(_lib.load().avf_au_loss_wide(_ptr(out), out.stride(0), _ptr(labels), labels.stride(0), _ptr(pos_weight), float(ignore),
+                                            rows, ncls, width, 1 if sum_mode else 0, _ptr(loss), _ptr(grad), _stream()), "au_loss_wide")
+    return loss, grad
+
+
 def fuse_tokens(clip: torch.Tensor, audio: torch.Tensor, pos: Optional[torch.Tensor], out_bf16: bool = False) -> torch.Tensor:
     """[B,Tv,D] ++ [B,Ta,D] on the token axis, + pos[Tv+Ta, D] (nullable): one pass (avf_fuse_tokens); out_bf16: the
     result is written in bf16 (the storage type of a bf16 residual stream, avf_fuse_tokens_bf16)."""

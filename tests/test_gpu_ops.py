@@ -401,6 +401,33 @@ def test_au_loss_strided_and_all_ignored(ops):
     assert torch.isnan(crit(out.cuda()[:, :12], -torch.ones(9, 12).cuda()))
 
 
+def test_au_loss_on_output_rows_equals_the_sliced_form(ops):
+    """AULoss.forward_rows (avf_au_loss_wide: the loss on slots 0..11 of the model's [B,21] rows, the gradient written in that
+    layout by the loss kernel) against AULoss on the slice out[:, :12] - value and gradient bit-identical, the other slots' gradient
+    exactly zero; ignored rows, the (sum, count) form, every row ignored (NaN), and the fallback for a non-contiguous output"""
+    import avformer_amd as A
+    crit = A.AULoss().cuda()
+    g = torch.Generator().manual_seed(21)
+    out = torch.randn(11, 21, generator=g)
+    y = (torch.rand(11, 12, generator=g) > 0.5).float()
+    y[3] = -1
+    y[7] = -1
+    a = out.clone().cuda().requires_grad_(True)
+    b = out.clone().cuda().requires_grad_(True)
+    la = crit(a[:, :12], y.cuda())
+    lb = crit.forward_rows(b, y.cuda())
+    (3.0 * la).backward()
+    (3.0 * lb).backward()
+    assert torch.equal(la, lb) and torch.equal(a.grad, b.grad) and float(b.grad[:, 12:].abs().max()) == 0.0
+    _close(lb, oracle.au_loss(out[:, :12], y), atol=1e-6, rtol=1e-5)
+    sc_n, g_n = ops.au_loss_sum(out.cuda()[:, :12], y.cuda(), crit.pos_weight)
+    sc_w, g_w = ops.au_loss_wide(out.cuda(), y.cuda(), crit.pos_weight, sum_mode=True)
+    assert torch.equal(sc_n, sc_w) and torch.equal(g_n, g_w[:, :12]) and float(g_w[:, 12:].abs().max()) == 0.0
+    assert torch.isnan(crit.forward_rows(out.cuda(), -torch.ones(11, 12).cuda()))
+    wide = torch.randn(11, 42, generator=g).cuda()[:, ::2]  # not contiguous: the sliced form serves it
+    assert torch.equal(crit.forward_rows(wide, y.cuda()), crit(wide[:, :12], y.cuda()))
+
+
 @pytest.mark.parametrize("K,shapes", [
     (128, [(64, 64)]),                                               # one 128 x 128 tile, two K-steps
     (4096, [(1536, 512), (1024, 512), (512, 1024), (512, 512)]),     # a d=512 layer: the 256 x 128 kernel (64 tiles)
