@@ -904,13 +904,17 @@ int colsum(const void* in, int in_dtype, int64_t rows, int cols, int64_t ld, flo
   AVF_REQUIRE(rows > 0 && cols > 0 && ws && out, "colsum: bad arguments");
   const int ch = colsum_chunks(rows);
   dim3 grid((unsigned)ceil_div(cols, 256), ch);
+  // one row chunk (up to 64 rows - the batch sum behind d pos_embedding: 32 rows x 165 888 columns at C2): the kernel's "partial"
+  // row IS the result, written straight to `out`; the fold of one row was a 10 us copy launch
+  float* dst = ch == 1 ? out : (float*)ws;
   if (in_dtype == AVF_F32)
-    colsum_kernel<float><<<grid, 256, 0, s>>>((const float*)in, rows, cols, ld, (float*)ws);
+    colsum_kernel<float><<<grid, 256, 0, s>>>((const float*)in, rows, cols, ld, dst);
   else if (in_dtype == AVF_BF16)
-    colsum_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)in, rows, cols, ld, (float*)ws);
+    colsum_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)in, rows, cols, ld, dst);
   else
     AVF_REQUIRE(false, "colsum: bad dtype %d", in_dtype);
   AVF_TRY(check_launch("colsum_kernel"));
+  if (ch == 1) return 0;
   return launch_fold((const float*)ws, ch, cols, out, nullptr, nullptr, cols, s);
 }
 
