@@ -321,8 +321,8 @@ int avf_layer_adam_step(const avf_layer_cfg* cfg, const avf_layer_params* p, con
                         const avf_layer_grads* exp_avg, const avf_layer_grads* exp_avg_sq, void* lowp, float lr,
                         float beta1, float beta2, float eps, float weight_decay, const float* step, void* stream);
 
-/* the same for `layers` consecutive layers of one stack (arrays of `layers` structs, lowp[l] per layer): three layers per
- * launch */
+/* the same for `layers` consecutive layers of one stack (arrays of `layers` structs, lowp[l] per layer): thirteen layers per
+ * launch (the descriptor table is a 12.6 KB kernel argument) */
 int avf_stack_adam_step(const avf_layer_cfg* cfg, int layers, const avf_layer_params* p, const avf_layer_grads* g,
                         const avf_layer_grads* exp_avg, const avf_layer_grads* exp_avg_sq, void* const* lowp, float lr,
                         float beta1, float beta2, float eps, float weight_decay, const float* step, void* stream);
@@ -332,6 +332,14 @@ int avf_stack_adam_step(const avf_layer_cfg* cfg, int layers, const avf_layer_pa
 int avf_adam_step_tensors(int count, float* const* p, const float* const* g, float* const* exp_avg,
                           float* const* exp_avg_sq, const int64_t* numel, float lr, float beta1, float beta2, float eps,
                           float weight_decay, const float* step, void* stream);
+
+/* One optimizer step's launches, collected (torch.optim.Adam.step() over all parameters, train.py:237): between _begin and _end
+ * on the calling thread, avf_layer_adam_step / avf_stack_adam_step / avf_adam_step_tensors append to one descriptor table
+ * instead of launching; the table is launched when it is full (143 tensors), when the hyper-parameters, the step pointer or the
+ * stream of a call differ from the pending ones, and by _end.  The reference's real model has five small stacks and a dozen
+ * loose tensors: one launch instead of six.  Every pointer handed over must stay valid until _end returns. */
+int avf_adam_batch_begin(void);
+int avf_adam_batch_end(void);
 
 /* x_out = layer(x_in); x_in, x_out [B*N, D] (may not alias): fp32, or bf16 when cfg.resid_bf16 is set. */
 int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p, const void* lowp, const void* x_in,

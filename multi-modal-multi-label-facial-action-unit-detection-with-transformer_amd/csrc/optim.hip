@@ -40,7 +40,10 @@ struct AdamDesc {
   int tile0, tiles_c;  // first work item of this tensor, tiles per row of tiles (matrices)
 };
 
-constexpr int ADAM_MAX = 33;  // three layers per launch (the descriptor table travels as a kernel argument: < 4 KB)
+// Descriptors per launch.  The table travels as a kernel argument (12.6 KB: tools/diag/kernarg_probe.hip - this stack takes it);
+// rounds 1 - 4 kept it under 4 KB (33 = three layers), which made every small stack of the reference's real model its own 13 us
+// launch.  13 layers per launch; avf_adam_batch_begin / _end collect the stacks and loose tensors of one optimizer step.
+constexpr int ADAM_MAX = 143;
 
 struct AdamBatch {
   AdamDesc d[ADAM_MAX];
@@ -65,9 +68,15 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, con
 __global__ __launch_bounds__(256) void adam_layer_kernel(AdamBatch b) {
   __shared__ float tile[64][65];
   int di = 0;
+  {  // the last descriptor whose first work item is <= this one (tile0 ascends): binary search over up to ADAM_MAX entries
+    int hi = b.count - 1;
 #pragma unroll 1
-  for (int i = 1; i < b.count; ++i)
-    if ((int)blockIdx.x >= b.d[i].tile0) di = i;
+    while (di < hi) {
+      const int mid = (di + hi + 1) >> 1;
+      if ((int)blockIdx.x >= b.d[mid].tile0) di = mid;
+      else hi = mid - 1;
+    }
+  }
   const AdamDesc d = b.d[di];
   const int item = (int)blockIdx.x - d.tile0;
   const float step = b.step ? b.step[0] : 1.0f;
@@ -236,6 +245,59 @@ int adam_add_layer(AdamBatch& b, int& n, int& tiles, const avf_layer_cfg* cfg, c
 }  // namespace
 }  // namespace avf
 
+namespace avf {
+namespace {
+// One optimizer step's launches, collected (avf_adam_batch_begin ... avf_adam_batch_end on the calling thread): the stack and
+// tensor entry points append their descriptors here instead of launching; a full table, a change of hyper-parameters or the end
+// of the session launches what is pending.  Outside a session every call launches its own table, as before.
+struct AdamPending {
+  bool active = false;
+  AdamBatch b;
+  int n = 0, tiles = 0;
+  hipStream_t stream = nullptr;
+};
+thread_local AdamPending g_adam_pending;
+
+int adam_flush(AdamPending& P) {
+  if (P.n == 0) return 0;
+  P.b.count = P.n;
+  adam_layer_kernel<<<P.tiles, 256, 0, P.stream>>>(P.b);
+  P.n = 0;
+  P.tiles = 0;
+  return check_launch("adam_layer_kernel");
+}
+
+// the table the next descriptors go to: the session's (flushed first when the hyper-parameters or the stream change) or `local`
+AdamPending& adam_target(AdamPending& local, float lr, float b1, float b2, float eps, float wd, const float* step, hipStream_t s,
+                         int* rc) {
+  AdamPending& P = g_adam_pending.active ? g_adam_pending : local;
+  *rc = 0;
+  if (P.n > 0 && (P.b.lr != lr || P.b.b1 != b1 || P.b.b2 != b2 || P.b.eps != eps || P.b.wd != wd || P.b.step != step || P.stream != s))
+    *rc = adam_flush(P);
+  if (P.n == 0) memset(&P.b, 0, sizeof(P.b));
+  P.b.lr = lr; P.b.b1 = b1; P.b.b2 = b2; P.b.eps = eps; P.b.wd = wd; P.b.step = step;
+  P.stream = s;
+  return P;
+}
+}  // namespace
+}  // namespace avf
+
+extern "C" int avf_adam_batch_begin(void) {
+  using namespace avf;
+  AVF_REQUIRE(!g_adam_pending.active, "adam_batch_begin: a batch is already open on this thread");
+  g_adam_pending.active = true;
+  g_adam_pending.n = 0;
+  g_adam_pending.tiles = 0;
+  return 0;
+}
+
+extern "C" int avf_adam_batch_end(void) {
+  using namespace avf;
+  AVF_REQUIRE(g_adam_pending.active, "adam_batch_end: no batch is open on this thread");
+  g_adam_pending.active = false;
+  return adam_flush(g_adam_pending);
+}
+
 extern "C" int avf_stack_adam_step(const avf_layer_cfg* cfg, int layers, const avf_layer_params* p, const avf_layer_grads* g,
                                    const avf_layer_grads* exp_avg, const avf_layer_grads* exp_avg_sq, void* const* lowp,
                                    float lr, float beta1, float beta2, float eps, float weight_decay, const float* step,
@@ -246,19 +308,15 @@ extern "C" int avf_stack_adam_step(const avf_layer_cfg* cfg, int layers, const a
   AVF_REQUIRE(lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f,
               "stack_adam_step: bad hyper-parameters");
   AVF_REQUIRE(cfg->dtype == AVF_F32 || lowp, "stack_adam_step(bf16): lowp buffers missing");
-  constexpr int PER_LAUNCH = ADAM_MAX / 11;
-  for (int l0 = 0; l0 < layers; l0 += PER_LAUNCH) {
-    AdamBatch b;
-    memset(&b, 0, sizeof(b));
-    int n = 0, tiles = 0;
-    for (int l = l0; l < layers && l < l0 + PER_LAUNCH; ++l)
-      AVF_TRY(adam_add_layer(b, n, tiles, cfg, p + l, g + l, exp_avg + l, exp_avg_sq + l, lowp ? lowp[l] : nullptr));
-    if (n == 0) continue;
-    b.count = n;
-    b.lr = lr; b.b1 = beta1; b.b2 = beta2; b.eps = eps; b.wd = weight_decay; b.step = step;
-    adam_layer_kernel<<<tiles, 256, 0, (hipStream_t)stream>>>(b);
-    AVF_TRY(check_launch("adam_layer_kernel"));
+  AdamPending local;
+  int rc = 0;
+  AdamPending& P = adam_target(local, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream, &rc);
+  AVF_TRY(rc);
+  for (int l = 0; l < layers; ++l) {
+    if (P.n + 11 > ADAM_MAX) AVF_TRY(adam_flush(P));
+    AVF_TRY(adam_add_layer(P.b, P.n, P.tiles, cfg, p + l, g + l, exp_avg + l, exp_avg_sq + l, lowp ? lowp[l] : nullptr));
   }
+  if (&P == &local) AVF_TRY(adam_flush(P));
   return 0;
 }
 
@@ -277,23 +335,21 @@ extern "C" int avf_adam_step_tensors(int count, float* const* p, const float* co
   AVF_REQUIRE(count >= 0 && (count == 0 || (p && g && exp_avg && exp_avg_sq && numel)), "adam_step_tensors: null pointer");
   AVF_REQUIRE(lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f,
               "adam_step_tensors: bad hyper-parameters");
-  for (int base = 0; base < count; base += ADAM_MAX) {
-    AdamBatch b;
-    memset(&b, 0, sizeof(b));
-    int n = 0, tiles = 0;
-    for (int i = base; i < count && i < base + ADAM_MAX; ++i) {
-      if (!g[i] || numel[i] <= 0) continue;
-      AVF_REQUIRE(p[i] && exp_avg[i] && exp_avg_sq[i] && numel[i] < (1LL << 31), "adam_step_tensors: bad tensor %d", i);
-      AdamDesc& d = b.d[n++];
-      d.p = p[i]; d.g = g[i]; d.m = exp_avg[i]; d.v = exp_avg_sq[i]; d.R = 1; d.C = (int)numel[i];
-      d.tile0 = tiles; d.tiles_c = 1;
-      tiles += (int)((numel[i] + 4095) / 4096);
-    }
-    if (n == 0) continue;
-    b.count = n;
-    b.lr = lr; b.b1 = beta1; b.b2 = beta2; b.eps = eps; b.wd = weight_decay; b.step = step;
-    adam_layer_kernel<<<tiles, 256, 0, (hipStream_t)stream>>>(b);
-    AVF_TRY(check_launch("adam_layer_kernel(tensors)"));
+  AdamPending local;
+  int rc = 0;
+  AdamPending& P = adam_target(local, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream, &rc);
+  AVF_TRY(rc);
+  for (int i = 0; i < count; ++i) {
+    if (!g[i] || numel[i] <= 0) continue;
+    AVF_REQUIRE(p[i] && exp_avg[i] && exp_avg_sq[i] && numel[i] < (1LL << 31), "adam_step_tensors: bad tensor %d", i);
+    if (P.n + 1 > ADAM_MAX) AVF_TRY(adam_flush(P));
+    AdamDesc& d = P.b.d[P.n++];
+    memset(&d, 0, sizeof(d));
+    d.p = p[i]; d.g = g[i]; d.m = exp_avg[i]; d.v = exp_avg_sq[i]; d.R = 1; d.C = (int)numel[i];
+    d.lo_scale = 1.0f;
+    d.tile0 = P.tiles; d.tiles_c = 1;
+    P.tiles += (int)((numel[i] + 4095) / 4096);
   }
+  if (&P == &local) AVF_TRY(adam_flush(P));
   return 0;
 }
