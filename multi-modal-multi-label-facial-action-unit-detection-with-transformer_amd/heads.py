@@ -95,7 +95,7 @@ class _FrontFn(torch.autograd.Function):
         B = x.shape[0]
         dt = dtok.contiguous().view(B, 12 * E)
         dbias = ops.colsum(dt)                                   # [12 E]: the 12 bias gradients, concatenated
-        dpos = ops.colsum(dt).view(1, 12, E) if ctx.needs_input_grad[4] else None  # same sums, own storage (no aliased .grad)
+        dpos = dbias.clone().view(1, 12, E) if ctx.needs_input_grad[4] else None  # same sums, own storage (no aliased .grad)
         dW = ops.gemm(dt, y, trans_a=True, trans_b=False)        # [12 E, in]
         dy = ops.gemm(dt, W, trans_b=False)                      # [B, in]
         dx, dg, db = ops.bn1d_bwd(x, dy, bn_w, mean, invstd, ctx.training, need_dx=ctx.needs_input_grad[0])
