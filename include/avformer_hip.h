@@ -276,6 +276,10 @@ int avf_cat_features(const float* a, const float* v, const float* pos, float* ou
                      int emb_v, void* stream);
 int avf_transpose_add(const float* in, const float* pos, float* out, int batch, int rows, int cols, void* stream);
 int avf_zero_cols(float* out, int64_t ld, int rows, int c0, int c1, void* stream);
+/* counter[0] += 1; snapshot[0] = counter[0] (device int64 scalars, one launch, graph-capturable): the dropout seed of one forward
+ * of a stack (nn.Dropout at heads.py:194,196,216 draws fresh masks per call; the kernels of a forward and of its backward read
+ * the snapshot through cfg.seed_dev). */
+int avf_seed_advance(int64_t* counter, int64_t* snapshot, void* stream);
 /* a small nn.Linear on a few rows written into a zero-padded row - the AU logits of a pooled feature in the reference's [B,21]
  * layout (avformer.py:101-105): out[r, o] = x[r,:] . w[o,:] + bias[o] (o < out_features), 0 up to `width`; one launch.
  * Backward: dx = dout[:, :O] w, dw = dout[:, :O]^T x, db = column sums (any of them may be null); dout rows are ldd apart. */

@@ -87,6 +87,7 @@ SIGNATURES = {
     "avf_cat_features": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     "avf_transpose_add": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp]),
     "avf_zero_cols": (_int, [_vp, _i64, _int, _int, _int, _vp]),
+    "avf_seed_advance": (_int, [_vp, _vp, _vp]),
     "avf_linear_pad_fwd": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     "avf_linear_pad_bwd": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _vp]),
     "avf_au_loss": (_int, [_vp, _i64, _vp, _i64, _vp, _f, _int, _int, _vp, _vp, _vp]),

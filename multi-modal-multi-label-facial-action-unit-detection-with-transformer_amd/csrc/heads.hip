@@ -368,6 +368,22 @@ extern "C" int avf_transpose_add(const float* in, const float* pos, float* out, 
   return check_launch("transpose_add_kernel");
 }
 
+// counter += 1; snapshot = counter: the dropout seed of one forward of a stack (transformer.py: the kernels of that forward AND
+// of its backward read the snapshot; an in-place add and a clone were two launches per stack and step)
+__global__ void seed_advance_kernel(int64_t* __restrict__ counter, int64_t* __restrict__ snapshot) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const int64_t v = counter[0] + 1;
+    counter[0] = v;
+    snapshot[0] = v;
+  }
+}
+
+extern "C" int avf_seed_advance(int64_t* counter, int64_t* snapshot, void* stream) {
+  AVF_REQUIRE(counter && snapshot && counter != snapshot, "seed_advance: bad arguments");
+  seed_advance_kernel<<<1, 64, 0, (hipStream_t)stream>>>(counter, snapshot);
+  return check_launch("seed_advance_kernel");
+}
+
 extern "C" int avf_zero_cols(float* out, int64_t ld, int rows, int c0, int c1, void* stream) {
   AVF_REQUIRE(out && rows > 0 && c0 >= 0 && c1 >= c0 && ld >= c1, "zero_cols: bad arguments");
   if (c1 == c0) return 0;

@@ -412,8 +412,15 @@ class Transformer(nn.Module):
             host = (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._seed_salt * 0xD1B54A32D192ED03
                     + self.__dict__.get("_seed_rank", 0) * 0xA0761D6478BD642F) & 0x7FFFFFFFFFFFFFFF
             self._seed_dev = torch.tensor([host], dtype=torch.int64, device=dev)
-        self._seed_dev.add_(1)
-        self._last_seed_t = self._seed_dev.clone()
+        if dev.type != "cuda":  # (the counter's bookkeeping alone, tests/test_cabi_cpu.py: no kernel reads it there)
+            self._seed_dev.add_(1)
+            self._last_seed_t = self._seed_dev.clone()
+            return self._last_seed_t
+        # counter += 1 and the snapshot in ONE launch (an in-place add + a clone were two per stack and step)
+        self._last_seed_t = torch.empty_like(self._seed_dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().avf_seed_advance(self._seed_dev.data_ptr(), self._last_seed_t.data_ptr(),
+                                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)), "seed_advance")
         return self._last_seed_t
 
     @property
