@@ -118,6 +118,8 @@ SIGNATURES = {
     "avf_timing_enable": (_int, [_int]),
     "avf_timing_read": (_int, [_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                C.POINTER(C.c_double)]),
+    "avf_set_f32_arith": (_int, [_int]),
+    "avf_get_f32_arith": (_int, []),
     "avf_selftest_mfma_bf16": (_int, [_vp, _vp, _vp, _vp]),
     "avf_selftest_mfma_f32": (_int, [_vp, _vp, _vp, _vp]),
     "avf_selftest_tr16": (_int, [_vp, _vp, _vp]),
@@ -196,3 +198,18 @@ def check(rc: int, what: str = ""):
     if rc != 0:
         msg = load().avf_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"libavformer_hip: {what} failed (rc={rc}): {msg}")
+
+
+F32_ARITH = {"f32": 0, "bf16x3": 1}
+
+
+def set_f32_arithmetic(mode: str) -> str:
+    """Arithmetic of compute_dtype="f32" GEMMs and attention, process-wide: "bf16x3" (default: fp32 operands split in
+    three bf16 products on the bf16 matrix pipe, <= 1.1e-5 relative error per product) or "f32" (the f32-input MFMA).
+    Returns the previous mode's name."""
+    prev = load().avf_set_f32_arith(F32_ARITH[mode])
+    return "bf16x3" if prev else "f32"
+
+
+def get_f32_arithmetic() -> str:
+    return "bf16x3" if load().avf_get_f32_arith() else "f32"

@@ -399,6 +399,13 @@ extern "C" int avf_attn_bwd_qs(const void* qkv, const void* o, const void* d_o, 
                        dim_head, (hipStream_t)stream, true, w + (size_t)batch * tokens * heads);
 }
 
+extern "C" int avf_set_f32_arith(int mode) {
+  const int prev = get_f32_arith();
+  set_f32_arith(mode);
+  return prev;
+}
+extern "C" int avf_get_f32_arith(void) { return get_f32_arith(); }
+
 extern "C" int avf_selftest_mfma_bf16(const void* a, const void* b, float* c, void* stream) {
   selftest_mfma_bf16_kernel<<<1, 64, 0, (hipStream_t)stream>>>((const bf16*)a, (const bf16*)b, c);
   return check_launch("selftest_mfma_bf16");

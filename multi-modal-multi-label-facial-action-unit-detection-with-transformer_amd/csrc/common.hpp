@@ -471,6 +471,10 @@ size_t gemm_ws(int dtype, int transA, int transB, int64_t M, int64_t N, int64_t 
 int gemm(const GemmArgs& a, hipStream_t s);
 int gemm_f32(const GemmArgs& a, hipStream_t s);
 size_t gemm_f32_ws(int64_t M, int64_t N, int64_t K);  // split-K slabs of skinny shapes (0: no split)
+// arithmetic of the AVF_F32 mode (round 6): 1 = operands split in three bf16 products on the bf16 matrix pipe ("bf16x3", default),
+// 0 = the f32-input MFMA (v_mfma_f32_16x16x4_f32).  Process-wide; avf_set_f32_arith / avf_get_f32_arith.
+void set_f32_arith(int mode);
+int get_f32_arith();
 int gemm_bf16_nt(const GemmArgs& a, hipStream_t s);
 int gemm_bf16_tn(const GemmArgs& a, hipStream_t s);
 // MX-FP8 NT GEMM (gemm_mx8.hip): A, B are e4m3 byte images (lda, ldb in bytes), scales [rows][K/32] E8M0 bytes

@@ -190,13 +190,297 @@ int f32_split64(int64_t M, int64_t N, int64_t K, int epilogue) {
   return sp < 2 ? 1 : (int)sp;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 6: the same fp32 GEMM on the bf16 matrix pipe, operands split in three products ("bf16x3").
+//
+// gfx950 has no xf32 / tf32 MFMA: the f32-input MFMA above runs at 1/16 of the bf16 rate (157 TFLOP/s dense).  Here every fp32
+// operand x is split while it is staged into LDS:  x = hi + lo + r,  hi = bf16(x) (RNE),  lo = bf16(x - hi)  (x - hi is exact in
+// fp32: at most 16 significant bits remain), |r| <= 2^-18 |x|;  and  a b  ~  hi_a hi_b + hi_a lo_b + lo_a hi_b  on
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation (every bf16 x bf16 product is exact in fp32).  Dropped: lo_a lo_b and the two
+// residuals, each <= 2^-18 |a b|: a product carries <= 3 * 2^-18 = 1.1e-5 relative error (fp32: 6e-8), a K-long dot product
+// ~ 3e-6 rms of |a| |b| sqrt(K).  That is the precision class north_star's logits rtol 1e-3 asks for, at 3 bf16 MFMAs per
+// product: an effective roof of 2500 / 3 = 833 TFLOP/s against 157.  (models/heads.py:191-196, 212, 214-217 and their autograd.)
+//
+// 128 x 128 tile, 32-deep K-step, 4 waves of 64 x 64 (4 x 4 MFMA blocks each, 48 MFMAs per K-step and wave); global -> registers
+// (two K-steps of look-ahead) -> split -> LDS as four bf16 images [row][32 k] (64-byte rows, 16-byte chunks XOR-swizzled: fragment
+// reads and stores conflict-free), double-buffered: one barrier per K-step, 64 KB per workgroup, two workgroups per CU.  Either operand may be "k-fast"
+// (row-major along the reduction: 16-byte loads, K % 32 == 0) or "row-fast" (the transposed forms of dX / dW: lanes run along
+// the rows, one dword per k, ragged K allowed).  The accumulators are kept TRANSPOSED (the weight side is the MFMA's A operand)
+// so that a lane owns four consecutive columns of one row: 16-byte epilogue accesses.
+constexpr int SBM = 128, SBN = 128, SBK = 32;
+constexpr int SIMG = SBM * SBK;  // bf16 elements of one LDS image ([row][32 k], 64-byte rows, 16-byte chunks XOR-swizzled)
+
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  hi = pack_bf16x2(a, b);
+  lo = pack_bf16x2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
+// element offset of 16-byte chunk c (8 k) of row r.  ds_read_b128 is served in four groups of 16 lanes that are NOT contiguous
+// ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... - MI355X_MICROARCH.md, LDS): a group holds all 16 fragment rows, rows 0-3 and
+// 12-15 at k-chunk g, rows 4-11 at k-chunk g ^ 1, and rows r, r + 4, r + 8, r + 12 share the banks of a 256-byte line.  XORing
+// the chunk with 2 * bit 2 of the row makes the four chunks of such a quadruple distinct (conflict-free fragment reads); bit 1
+// of the row in the low bit makes the 16-byte stores of 8 consecutive rows (row-fast staging) conflict-free as well.
+__device__ __forceinline__ int sw_off(int r, int c) { return r * SBK + ((c ^ ((((r >> 2) & 1) << 1) | ((r >> 1) & 1))) << 3); }
+
+template <bool KF>
+struct SplitStage {
+  float v[16];  // fp32 values per thread and K-step
+  // element (row, k) of the operand at X[row * s_r + k * s_k]; rows clamped (their results are never stored), k >= kend -> 0
+  __device__ __forceinline__ void fetch(const float* X, int64_t s_r, int64_t s_k, int r0, int R, int k0, int kend) {
+    const int tid = threadIdx.x;
+    if constexpr (KF) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int idx = tid + 256 * e;
+        const int row = idx >> 3, kq = idx & 7;
+        int gr = r0 + row;
+        gr = gr < R ? gr : R - 1;
+        const float4 t = *reinterpret_cast<const float4*>(X + (int64_t)gr * s_r + k0 + kq * 4);
+        v[4 * e] = t.x; v[4 * e + 1] = t.y; v[4 * e + 2] = t.z; v[4 * e + 3] = t.w;
+      }
+    } else {
+      // lanes run along the rows; the k index is wave-uniform, so every load is (scalar row base) + (one 32-bit lane offset)
+      const int row = tid & 127, kh = __builtin_amdgcn_readfirstlane(tid >> 7);
+      int gr = r0 + row;
+      gr = gr < R ? gr : R - 1;
+      const float* base = X + (int64_t)(k0 + kh * 16) * s_k;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = (k0 + kh * 16 + e < kend) ? (base + (int64_t)e * s_k)[(uint32_t)gr] : 0.f;
+    }
+  }
+  __device__ __forceinline__ void commit(uint16_t* Xh, uint16_t* Xl) const {
+    const int tid = threadIdx.x;
+    if constexpr (KF) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int idx = tid + 256 * e;
+        const int row = idx >> 3, kq = idx & 7;
+        uint2 h, l;
+        split2(v[4 * e], v[4 * e + 1], h.x, l.x);
+        split2(v[4 * e + 2], v[4 * e + 3], h.y, l.y);
+        const int off = sw_off(row, kq >> 1) + (kq & 1) * 4;
+        *reinterpret_cast<uint2*>(Xh + off) = h;
+        *reinterpret_cast<uint2*>(Xl + off) = l;
+      }
+    } else {
+      const int row = tid & 127, kh = tid >> 7;
+      uint32_t h[8], l[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) split2(v[2 * e], v[2 * e + 1], h[e], l[e]);
+      const int o0 = sw_off(row, 2 * kh), o1 = sw_off(row, 2 * kh + 1);
+      *reinterpret_cast<uint4*>(Xh + o0) = make_uint4(h[0], h[1], h[2], h[3]);
+      *reinterpret_cast<uint4*>(Xh + o1) = make_uint4(h[4], h[5], h[6], h[7]);
+      *reinterpret_cast<uint4*>(Xl + o0) = make_uint4(l[0], l[1], l[2], l[3]);
+      *reinterpret_cast<uint4*>(Xl + o1) = make_uint4(l[4], l[5], l[6], l[7]);
+    }
+  }
+};
+
+template <bool AKF, bool BKF, int EPI, bool SPLIT>
+__global__ __launch_bounds__(256, 2) void gemm_f32x3_kernel(F32GemmParams p, int vec) {
+  // two buffers of four images (A hi, A lo, B hi, B lo): 64 KB, two workgroups per CU
+  __shared__ __attribute__((aligned(16))) uint16_t lds[2 * 4 * SIMG];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 15, lg = lane >> 4;
+  // XCD-aware tile order: workgroups go round-robin over the 8 XCDs (each with its own L2) in launch order, so the linear id is
+  // remapped to give every XCD a CONTIGUOUS run of tiles - the column tiles of one row panel (which share the A rows) and the
+  // neighbouring panels - instead of every eighth tile (cdna_hip_programming.md, T1)
+  int bx, by, bz;
+  {
+    const uint32_t gx = gridDim.x, gxy = gridDim.x * gridDim.y, total = gxy * gridDim.z;
+    const uint32_t id = blockIdx.x + gx * blockIdx.y + gxy * blockIdx.z;
+    const uint32_t xcd = id & 7, q = total >> 3, r = total & 7;
+    const uint32_t nid = xcd * q + (xcd < r ? xcd : r) + (id >> 3);
+    bz = nid / gxy;
+    const uint32_t rem = nid - bz * gxy;
+    by = rem / gx;
+    bx = rem - by * gx;
+  }
+  const int m0 = by * SBM, n0 = bx * SBN;
+  const int kbeg = SPLIT ? bz * p.kchunk : 0;
+  const int kend = SPLIT ? ((kbeg + p.kchunk) < p.K ? kbeg + p.kchunk : p.K) : p.K;
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // A: element (m, k) at A[m a_sm + k a_sk];  B: element (k, n) at B[k b_sk + n b_sn] (its tile rows are n)
+  SplitStage<AKF> sa0, sa1;
+  SplitStage<BKF> sb0, sb1;
+  auto fetch = [&](SplitStage<AKF>& sa, SplitStage<BKF>& sb, int k0) {
+    sa.fetch(p.A, p.a_sm, p.a_sk, m0, p.M, k0, kend);
+    sb.fetch(p.B, p.b_sn, p.b_sk, n0, p.N, k0, kend);
+  };
+  const int frag = sw_off(li, lg);  // this lane's 16-byte fragment inside a 16-row block (the swizzle depends on li only)
+  // one K-step: the MFMAs of the step staged in `cur`, while the NEXT step's registers are split into `nxt` and the loads of
+  // the step after the one in flight are issued - two K-steps of look-ahead on the global loads, one barrier per step
+  auto step = [&](SplitStage<AKF>& sa, SplitStage<BKF>& sb, const uint16_t* cur, uint16_t* nxt, int k0) {
+    if (k0 + SBK < kend) {
+      sa.commit(nxt, nxt + SIMG);
+      sb.commit(nxt + 2 * SIMG, nxt + 3 * SIMG);
+    }
+    if (k0 + 3 * SBK < kend) fetch(sa, sb, k0 + 3 * SBK);
+    bf16x8_t ah[4], al[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int off = (wm * 64 + i * 16) * SBK + frag;
+      ah[i] = *reinterpret_cast<const bf16x8_t*>(cur + off);
+      al[i] = *reinterpret_cast<const bf16x8_t*>(cur + SIMG + off);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int off = (wn * 64 + j * 16) * SBK + frag;
+      const bf16x8_t bh = *reinterpret_cast<const bf16x8_t*>(cur + 2 * SIMG + off);
+      const bf16x8_t bl = *reinterpret_cast<const bf16x8_t*>(cur + 3 * SIMG + off);
+      // D[n][m] += B-side rows (MFMA A operand) x A-side rows (MFMA B operand): the small terms first
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[i], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  };
+  uint16_t* buf0 = lds;
+  uint16_t* buf1 = lds + 4 * SIMG;
+  if (kbeg < kend) {
+    fetch(sa0, sb0, kbeg);
+    if (kbeg + SBK < kend) fetch(sa1, sb1, kbeg + SBK);
+    sa0.commit(buf0, buf0 + SIMG);
+    sb0.commit(buf0 + 2 * SIMG, buf0 + 3 * SIMG);
+    if (kbeg + 2 * SBK < kend) fetch(sa0, sb0, kbeg + 2 * SBK);
+    __syncthreads();
+  }
+  for (int k0 = kbeg; k0 < kend; k0 += 2 * SBK) {
+    step(sa1, sb1, buf0, buf1, k0);
+    if (k0 + SBK < kend) step(sa0, sb0, buf1, buf0, k0 + SBK);
+  }
+
+  // transposed accumulators: register r of lane (li, lg) of acc[i][j] = C[m0 + wm 64 + 16 i + li][n0 + wn 64 + 16 j + 4 lg + r]
+  const uint64_t dkey = (!SPLIT && p.drop.thresh16) ? drop_key(p.drop) : 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int gm = m0 + wm * 64 + i * 16 + li;
+    if (gm >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gn = n0 + wn * 64 + j * 16 + 4 * lg;
+      if (gn >= p.N) continue;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (SPLIT) {
+        float* dst = p.slabs + ((int64_t)bz * p.M + gm) * p.N + gn;
+        if (vec) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        else
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (gn + r < p.N) dst[r] = v[r];
+        continue;
+      }
+      if (vec) {  // N % 4 == 0 and every row pointer 16-byte aligned: gn + 3 < N
+        if (p.bias) {
+          const float4 b = *reinterpret_cast<const float4*>(p.bias + gn);
+          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        }
+        float4 df = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (p.drop.thresh16) df = drop_factor4(p.drop, dkey, (uint64_t)gm * p.N + gn);
+        const float dfv[4] = {df.x, df.y, df.z, df.w};
+        if (EPI == AVF_EPI_BIAS_RES) {
+          const float4 r4 = *reinterpret_cast<const float4*>(p.residual + (int64_t)gm * p.ldres + gn);
+          const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = v[r] * dfv[r] + rr[r];
+        } else if (EPI == AVF_EPI_BIAS_GELU) {
+          *reinterpret_cast<float4*>(p.aux + (int64_t)gm * p.ldaux + gn) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]) * dfv[r];
+        } else if (EPI == AVF_EPI_DGELU) {
+          const float4 u4 = *reinterpret_cast<const float4*>(p.aux + (int64_t)gm * p.ldaux + gn);
+          const float uu[4] = {u4.x, u4.y, u4.z, u4.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= dfv[r] * dgelu_tanh_f(uu[r]);
+        }
+        *reinterpret_cast<float4*>(p.C + (int64_t)gm * p.ldc + gn) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = gn + r;
+          if (n >= p.N) continue;
+          float x = v[r];
+          if (p.bias) x += p.bias[n];
+          const float df = p.drop.thresh16 ? drop_factor1(p.drop, dkey, (uint64_t)gm * p.N + n) : 1.0f;
+          if (EPI == AVF_EPI_BIAS_RES) {
+            x = x * df + p.residual[(int64_t)gm * p.ldres + n];
+          } else if (EPI == AVF_EPI_BIAS_GELU) {
+            p.aux[(int64_t)gm * p.ldaux + n] = x;
+            x = gelu_tanh_f(x) * df;
+          } else if (EPI == AVF_EPI_DGELU) {
+            x *= df * dgelu_tanh_f(p.aux[(int64_t)gm * p.ldaux + n]);
+          }
+          p.C[(int64_t)gm * p.ldc + n] = x;
+        }
+      }
+    }
+  }
+}
+
+// which arithmetic AVF_F32 GEMMs and attention run on: 1 = bf16x3 on the bf16 matrix pipe (default), 0 = the f32-input MFMA
+int g_f32_arith = 1;
+
+// shapes the bf16x3 kernel takes: tiles worth filling, one unit stride per operand, 16-byte loads where k is the fast axis
+bool f32x3_ok(const F32GemmParams& p) {
+  if (p.M < 64 || p.N < 64 || p.K < 32) return false;
+  const bool akf = p.a_sk == 1, bkf = p.b_sk == 1;
+  if (!akf && p.a_sm != 1) return false;
+  if (!bkf && p.b_sn != 1) return false;
+  if (akf && (p.K % 32 != 0 || p.a_sm % 4 != 0 || ((uintptr_t)p.A & 15))) return false;
+  if (bkf && (p.K % 32 != 0 || p.b_sn % 4 != 0 || ((uintptr_t)p.B & 15))) return false;
+  return true;
+}
+// split count over K for the 128 x 128 tiles: fill ~2 workgroups per CU, at least 8 K-steps per split
+int f32x3_splits(int64_t M, int64_t N, int64_t K, int epilogue) {
+  if (epilogue != AVF_EPI_NONE && epilogue != AVF_EPI_BIAS_RES) return 1;
+  const int64_t tiles = ceil_div(M, SBM) * ceil_div(N, SBN);
+  if (tiles >= 256 || K < 512) return 1;
+  int64_t sp = ceil_div(512, tiles);
+  if (sp > K / 256) sp = K / 256;
+  if (sp > 16) sp = 16;
+  return sp < 2 ? 1 : (int)sp;
+}
+
+template <bool AKF, bool BKF>
+int launch_f32x3(const F32GemmParams& p, int epilogue, int S, int vec, hipStream_t s) {
+  dim3 grid((unsigned)ceil_div(p.N, SBN), (unsigned)ceil_div(p.M, SBM), (unsigned)S);
+  if (S > 1) {
+    gemm_f32x3_kernel<AKF, BKF, AVF_EPI_NONE, true><<<grid, 256, 0, s>>>(p, vec);
+    return check_launch("gemm_f32x3_kernel(split)");
+  }
+  switch (epilogue) {
+    case AVF_EPI_NONE: gemm_f32x3_kernel<AKF, BKF, AVF_EPI_NONE, false><<<grid, 256, 0, s>>>(p, vec); break;
+    case AVF_EPI_BIAS_RES: gemm_f32x3_kernel<AKF, BKF, AVF_EPI_BIAS_RES, false><<<grid, 256, 0, s>>>(p, vec); break;
+    case AVF_EPI_BIAS_GELU: gemm_f32x3_kernel<AKF, BKF, AVF_EPI_BIAS_GELU, false><<<grid, 256, 0, s>>>(p, vec); break;
+    case AVF_EPI_DGELU: gemm_f32x3_kernel<AKF, BKF, AVF_EPI_DGELU, false><<<grid, 256, 0, s>>>(p, vec); break;
+    default: AVF_REQUIRE(false, "gemm_f32x3: bad epilogue %d", epilogue);
+  }
+  return check_launch("gemm_f32x3_kernel");
+}
+
 }  // namespace
 
 size_t gemm_f32_ws(int64_t M, int64_t N, int64_t K) {
   int sp = f32_splits(M, N, K, AVF_EPI_NONE);
   if (sp == 1) sp = f32_split64(M, N, K, AVF_EPI_NONE);
+  const int sx = (M >= 64 && N >= 64) ? f32x3_splits(M, N, K, AVF_EPI_NONE) : 1;  // the bf16x3 form of the same call
+  if (sx > sp) sp = sx;
   return sp > 1 ? (size_t)sp * M * N * sizeof(float) : 0;
 }
+
+void set_f32_arith(int mode) { g_f32_arith = mode ? 1 : 0; }
+int get_f32_arith() { return g_f32_arith; }
 
 int gemm_f32(const GemmArgs& a, hipStream_t s) {
   AVF_REQUIRE(a.c_dtype == AVF_F32, "gemm_f32: C must be fp32");
@@ -219,6 +503,37 @@ int gemm_f32(const GemmArgs& a, hipStream_t s) {
   p.M = (int)a.M; p.N = (int)a.N; p.K = (int)a.K;
   p.drop = a.drop;
   p.kchunk = 0; p.slabs = nullptr;
+  if (g_f32_arith == 1 && f32x3_ok(p)) {  // bf16x3 on the bf16 matrix pipe (round 6)
+    AVF_REQUIRE(a.epilogue != AVF_EPI_BIAS_RES || a.residual, "gemm_f32: residual missing");
+    AVF_REQUIRE((a.epilogue != AVF_EPI_BIAS_GELU && a.epilogue != AVF_EPI_DGELU) || a.aux, "gemm_f32: aux missing");
+    const int S0 = a.workspace ? f32x3_splits(a.M, a.N, a.K, a.epilogue) : 1;
+    int S = 1;
+    if (S0 > 1) {
+      p.slabs = (float*)a.workspace;
+      p.kchunk = (int)(ceil_div(ceil_div(a.K, S0), SBK) * SBK);
+      S = (int)ceil_div(a.K, p.kchunk);
+    }
+    auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    int vec = (p.N % 4 == 0);
+    if (S > 1) vec = vec && al16(p.slabs);
+    else
+      vec = vec && p.ldc % 4 == 0 && al16(p.C) && (!p.bias || al16(p.bias)) &&
+            (a.epilogue != AVF_EPI_BIAS_RES || (p.ldres % 4 == 0 && al16(p.residual))) &&
+            ((a.epilogue != AVF_EPI_BIAS_GELU && a.epilogue != AVF_EPI_DGELU) || (p.ldaux % 4 == 0 && al16(p.aux)));
+    AVF_REQUIRE(ceil_div(p.M, SBM) < 65536, "gemm_f32: M too large for grid");
+    const bool akf = p.a_sk == 1, bkf = p.b_sk == 1;
+    int rc;
+    if (akf && bkf) rc = launch_f32x3<true, true>(p, a.epilogue, S, vec, s);
+    else if (akf) rc = launch_f32x3<true, false>(p, a.epilogue, S, vec, s);
+    else if (bkf) rc = launch_f32x3<false, true>(p, a.epilogue, S, vec, s);
+    else rc = launch_f32x3<false, false>(p, a.epilogue, S, vec, s);
+    AVF_TRY(rc);
+    if (S > 1) {
+      gemm_f32_fold_kernel<<<(unsigned)ceil_div(a.M * a.N, 256), 256, 0, s>>>(p, S, a.epilogue == AVF_EPI_BIAS_RES ? 1 : 0);
+      return check_launch("gemm_f32_fold_kernel");
+    }
+    return 0;
+  }
   // skinny GEMMs with a long reduction (the heads' projections on a few dozen clips): split K over the grid, raw partials
   // into the caller's workspace, one fold launch with the epilogue - deterministic (no atomics)
   const int sp = a.workspace ? f32_splits(a.M, a.N, a.K, a.epilogue) : 1;
