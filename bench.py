@@ -346,7 +346,10 @@ class Region:
         self.clips_per_s = self.B * self.world * steps / dt
         self.loss = float(loss.item())
         self.tflops = 3.0 * stack_flops_fwd(self.c, self.B) / (self.ms * 1e-3) / 1e12
-        self.frac = self.tflops / MFMA_PEAK_TFLOPS[self.dtype]
+        self.peak = MFMA_PEAK_TFLOPS[self.dtype]
+        if self.dtype == "f32" and self.A._lib.get_f32_arithmetic() == "bf16x3":
+            self.peak = MFMA_PEAK_TFLOPS["bf16"] / 3.0  # three bf16 MFMA products per fp32 product
+        self.frac = self.tflops / self.peak
 
     def clock_power(self, seconds=1.5):
         """Shader clock and package power while the timed step keeps running (rocm-smi sampled from a thread, AFTER the timed
@@ -401,7 +404,7 @@ class Region:
         self.ms_events = (time.perf_counter() - t1) / steps * 1e3
         tm = A._lib.timing_read()
         A._lib.timing_enable(False)
-        peak = MFMA_PEAK_TFLOPS[self.dtype]
+        peak = self.peak
         self.timing = tm
         self.classes = {
             k: {"ms_per_step": round(v["ms"] / steps, 4), "launches_per_step": v["launches"] / steps,
@@ -568,7 +571,7 @@ def main():
     }
     if use_dist:
         result["data_parallel"] = dp_report(torch, dist, main_r, dev, world)
-    c3_r = f32_r = r32_r = None
+    c3_r = f32_r = f32m_r = r32_r = None
     if not args.no_extra and args.dtype != "f32" and args.residual == "bf16":
         # the same workload with the fp32 forward residual stream (the round-1/2 default): reported beside `value`
         keep = args.residual
@@ -584,10 +587,19 @@ def main():
         c3_r.timed(args.steps, args.warmup, use_graph)
         c3_clock = c3_r.clock_power() if world == 1 else None
         if world == 1:
+            # the parity mode (compute_dtype "f32"), in its default arithmetic (bf16x3: three bf16 products per fp32 product on the
+            # bf16 matrix pipe) and, beside it, on the f32-input MFMA (avf_set_f32_arith(0)) - same weights, same inputs
             f32_r = mk(args.config, "f32", False)
             f32_r.timed(max(2, min(20, args.steps // 6)), 1)
             f32_steps = f32_r.steps
             f32_r.model = f32_r.opt = f32_r.step = None  # free it before the instrumented passes
+            prev_arith = A._lib.set_f32_arithmetic("f32")
+            try:
+                f32m_r = mk(args.config, "f32", False)
+                f32m_r.timed(max(2, min(10, args.steps // 12)), 1)
+                f32m_r.model = f32m_r.opt = f32m_r.step = None
+            finally:
+                A._lib.set_f32_arithmetic(prev_arith)
     # ---- then the instrumented passes (per-kernel-class HIP events) of the regions that report classes
     if events:
         main_r.instrumented(args.steps)
@@ -606,7 +618,7 @@ def main():
             d = mfma[dom]
             if d["launches"] > 0 and d["ms"] > 0:
                 ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-                peak = MX8_PEAK_TFLOPS if dom == "gemm_mx8_nt" else MFMA_PEAK_TFLOPS[args.dtype]
+                peak = MX8_PEAK_TFLOPS if dom == "gemm_mx8_nt" else main_r.peak
                 traffic, note = pmc_traffic(dom, args.config)
                 result["roofline"] = {
                     "kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
@@ -634,10 +646,23 @@ def main():
                 "target_frac": 0.30, "kernel_classes": c3_r.classes if events else None}
         if f32_r is not None:
             result["f32_parity_clips_per_s"] = round(f32_r.clips_per_s, 2)
+            x3 = A._lib.get_f32_arithmetic() == "bf16x3"
+            # bf16x3 executes three bf16 MFMA products per algorithmic product: its roof is the bf16 MFMA peak / 3
+            roof = MFMA_PEAK_TFLOPS["bf16"] / 3.0 if x3 else MFMA_PEAK_TFLOPS["f32"]
             result["f32_parity"] = {"ms_per_step": round(f32_r.ms, 3), "steps": f32_steps,
+                                    "arithmetic": A._lib.get_f32_arithmetic(),
                                     "stack_tflops_per_gpu": round(f32_r.tflops, 2),
-                                    "peak": MFMA_PEAK_TFLOPS["f32"],
-                                    "note": "compute_dtype='f32' (fp32 MFMA + fp32 attention): the mode held to logits rtol 1e-3"}
+                                    "peak": round(roof, 1),
+                                    "peak_is": ("dense bf16 MFMA peak 2500 TFLOP/s / 3 products per fp32 product" if x3
+                                                else "dense f32-input MFMA peak"),
+                                    "frac": round(f32_r.tflops / roof, 4),
+                                    "executed_bf16_mfma_tflops": round(3.0 * f32_r.tflops, 1) if x3 else None,
+                                    "f32_mfma_ab": None if f32m_r is None else {
+                                        "ms_per_step": round(f32m_r.ms, 3), "clips_per_s": round(f32m_r.clips_per_s, 2),
+                                        "steps": f32m_r.steps, "peak": MFMA_PEAK_TFLOPS["f32"],
+                                        "frac": round(f32m_r.tflops / MFMA_PEAK_TFLOPS["f32"], 4),
+                                        "note": "the same step with avf_set_f32_arith(0): v_mfma_f32_16x16x4_f32 GEMMs and attention"},
+                                    "note": "compute_dtype='f32': the mode held to logits rtol 1e-3 against the fp32 CPU reference"}
         if world == 1 and not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, 16)
             try:

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBNAME = "libavformer_hip.so"
-SOURCES = ["api.hip", "norm_elem.hip", "gemm_f32.hip", "attn_f32.hip", "attn_f32_mfma.hip", "gemm_bf16.hip", "gemm_ws.hip", "gemm_mx8.hip", "attn_bf16.hip", "attn_bwd_merged.hip", "layer.hip", "optim.hip", "layer_small.hip", "heads.hip"]
+SOURCES = ["api.hip", "norm_elem.hip", "gemm_f32.hip", "attn_f32.hip", "attn_f32_mfma.hip", "attn_f32x3.hip", "gemm_bf16.hip", "gemm_ws.hip", "gemm_mx8.hip", "attn_bf16.hip", "attn_bwd_merged.hip", "layer.hip", "optim.hip", "layer_small.hip", "heads.hip"]
 HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "gemm_nt.hpp"), os.path.join(os.path.dirname(HERE), "include", "avformer_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # per-source extra flags.  attn_bwd_merged.hip: MFMA results in architectural VGPRs (the kernel pins its long-lived
@@ -19,7 +19,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # stream a packed instruction gets 42 % of its issue rate, a scalar one 77-88 % (tools/diag/mfma_valu_overlap.hip), and in
 # that kernel ONE wave per SIMD issues both streams.  C3: -0.8 % of the step (profiles/ab/r04_attn_bwd_unpacked.json).  The
 # feature is passed to both compilation passes; the host pass answers "not a recognized feature for this target (ignoring)".
-EXTRA_FLAGS = {"gemm_f32.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "attn_f32_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+EXTRA_FLAGS = {"gemm_f32.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "attn_f32_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "attn_f32x3.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                "attn_bwd_merged.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]}
 
 

@@ -1,0 +1,392 @@
+// attn_f32x3.hip - parity-mode attention core on the bf16 matrix pipe with three-product operands ("bf16x3"), round 6.
+//
+// Reference: models/heads.py:222-237 (dots = q k^T * dh^-0.5 ; softmax(dim=-1) ; out = attn v) and its autograd.
+//
+// Same arithmetic contract as gemm_f32.hip's bf16x3 GEMM: every fp32 operand of a matrix product is split x = hi + lo (two bf16,
+// RNE; x - hi is exact in fp32) and a b ~ hi hi + hi lo + lo hi on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: <= 1.1e-5
+// relative error per product, 3 MFMAs of 16 cycles where the f32-input MFMA kernels of attn_f32_mfma.hip spend 8 of 32.  The
+// softmax statistics, exp2 and every elementwise step stay fp32; P and dS are split like any other operand.  fp32 storage, no
+// token mask, dim_head 64, q not pre-scaled (the masked / bf16-storage / dim_head 32 calls stay on the f32 kernels).
+//
+// One workgroup = 4 wavefronts = 64 queries (forward, dQ) or 64 keys (dK/dV) of one (clip, head); the opposite operand streams
+// through LDS in tiles of 32 rows, split while it is staged.  As in attn_f32_mfma.hip everything is computed TRANSPOSED, so the row
+// a lane's statistics belong to sits on the lane index:  S^T = K Q^T -> register r of lane (li, lg) = S[query li][key 4 lg + r].
+// The second product needs P (or dS) as the MFMA's B operand: lane (query li, group lg) supplies 8 consecutive k-slots.  The
+// reduction index of an MFMA may be permuted freely as long as both operands agree, so k-slot (lg, e) is DEFINED as key
+// 16 (e >> 2) + 4 lg + (e & 3): the lane's eight accumulator registers of the two 16-key blocks ARE its B operand - no shuffle,
+// no LDS round trip.  The other operand (V^T, K^T, Q^T, dO^T) is staged as a transposed image [d][k-slot] in that slot order.
+// LDS images (bf16, hi and lo): "row" [32][64] (128-byte rows, fragment = 16 bytes of one row) and "transposed" [64][32]
+// (64-byte rows); 16-byte chunks XOR-swizzled for ds_read_b128's four non-contiguous 16-lane groups (MI355X_MICROARCH.md, LDS).
+#include "common.hpp"
+
+namespace avf {
+
+namespace {
+
+constexpr int XT = 32;   // rows of the streamed operand per tile
+constexpr int XD = 64;   // dim_head
+constexpr float kLog2e = 1.4426950408889634f;
+
+#define AVF_MFMA_X3(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ void x_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  hi = pack_bf16x2(a, b);
+  lo = pack_bf16x2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
+struct Frag2 {  // one MFMA operand fragment (8 k) as hi / lo
+  bf16x8_t h, l;
+};
+__device__ __forceinline__ Frag2 x_split8(const float (&v)[8]) {
+  uint32_t h[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) x_split2(v[2 * i], v[2 * i + 1], h[i], l[i]);
+  Frag2 f;
+  f.h = __builtin_bit_cast(bf16x8_t, make_uint4(h[0], h[1], h[2], h[3]));
+  f.l = __builtin_bit_cast(bf16x8_t, make_uint4(l[0], l[1], l[2], l[3]));
+  return f;
+}
+// acc += a b with the three products, small terms first
+__device__ __forceinline__ f32x4_t x_mma(const Frag2& a, const Frag2& b, f32x4_t acc) {
+  acc = AVF_MFMA_X3(a.l, b.h, acc);
+  acc = AVF_MFMA_X3(a.h, b.l, acc);
+  return AVF_MFMA_X3(a.h, b.h, acc);
+}
+
+// row image [XT][64]: element offset of 16-byte chunk c8 (8 d) of row r.  Two rows share a 256-byte bank line; a ds_read_b128 group
+// holds the 16 rows of a block at chunk g (rows 0-3, 12-15) or g ^ 1 (rows 4-11): XOR with (r >> 1) ^ [4 <= r < 12] gives the eight
+// rows of one parity eight distinct chunks
+__device__ __forceinline__ int x_row_off(int r, int c8) {
+  const int q = r & 15;
+  return r * XD + ((c8 ^ ((q >> 1) ^ (((q + 4) >> 3) & 1))) << 3);
+}
+// transposed image [64][XT]: chunk c4 (8 k-slots) of row d (64-byte rows: four rows per bank line; as gemm_f32.hip's sw_off)
+__device__ __forceinline__ int x_tr_off(int d, int c4) { return d * XT + ((c4 ^ ((((d >> 2) & 1) << 1) | ((d >> 1) & 1))) << 3); }
+
+// One tile of a streamed operand: XT rows x 64 floats of a row-major matrix (row stride ld).  A thread owns two adjacent rows
+// (2 kp, 2 kp + 1) x four columns: 64-byte row segments per four lanes in the global loads, (row, row + 1) pairs = adjacent k-slots
+// of the transposed image.
+struct TileRegs {
+  float4 v0, v1;
+};
+__device__ __forceinline__ TileRegs x_fetch(const float* src, int64_t ld, int row0, int nvalid) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int kp = lane >> 2, d0 = 16 * w + 4 * (lane & 3);
+  TileRegs t;
+  t.v0 = t.v1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (2 * kp < nvalid) t.v0 = *reinterpret_cast<const float4*>(src + (int64_t)(row0 + 2 * kp) * ld + d0);
+  if (2 * kp + 1 < nvalid) t.v1 = *reinterpret_cast<const float4*>(src + (int64_t)(row0 + 2 * kp + 1) * ld + d0);
+  return t;
+}
+template <bool ROWIMG, bool TRIMG>
+__device__ __forceinline__ void x_commit(const TileRegs& t, uint16_t* Rh, uint16_t* Rl, uint16_t* Th, uint16_t* Tl) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int kp = lane >> 2, d0 = 16 * w + 4 * (lane & 3);
+  if constexpr (ROWIMG) {
+    uint2 h, l;
+    x_split2(t.v0.x, t.v0.y, h.x, l.x);
+    x_split2(t.v0.z, t.v0.w, h.y, l.y);
+    int off = x_row_off(2 * kp, d0 >> 3) + (d0 & 7);
+    *reinterpret_cast<uint2*>(Rh + off) = h;
+    *reinterpret_cast<uint2*>(Rl + off) = l;
+    x_split2(t.v1.x, t.v1.y, h.x, l.x);
+    x_split2(t.v1.z, t.v1.w, h.y, l.y);
+    off = x_row_off(2 * kp + 1, d0 >> 3) + (d0 & 7);
+    *reinterpret_cast<uint2*>(Rh + off) = h;
+    *reinterpret_cast<uint2*>(Rl + off) = l;
+  }
+  if constexpr (TRIMG) {
+    // rows 2 kp, 2 kp + 1 -> k-slots: block kb = row >> 4, lane group (row & 15) >> 2, register r = row & 3 (0 or 2 here)
+    const int kb = kp >> 3, g = (kp & 7) >> 1, r = 2 * (kp & 1);
+    const float a[4] = {t.v0.x, t.v0.y, t.v0.z, t.v0.w}, b[4] = {t.v1.x, t.v1.y, t.v1.z, t.v1.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t h, l;
+      x_split2(a[i], b[i], h, l);
+      const int off = x_tr_off(d0 + i, g) + 4 * kb + r;
+      *reinterpret_cast<uint32_t*>(Th + off) = h;
+      *reinterpret_cast<uint32_t*>(Tl + off) = l;
+    }
+  }
+}
+
+// this lane's two fragments (d = 0..31, 32..63) of one row kept in registers for the whole kernel: f[c] = x[row][32 c + 8 lg ..] * scale
+__device__ __forceinline__ void x_row_frags(Frag2 (&f)[2], const float* row, bool valid, int lg, float scale) {
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (valid) {
+      const float4 a = *reinterpret_cast<const float4*>(row + 32 * c + 8 * lg);
+      const float4 b = *reinterpret_cast<const float4*>(row + 32 * c + 8 * lg + 4);
+      v[0] = a.x * scale; v[1] = a.y * scale; v[2] = a.z * scale; v[3] = a.w * scale;
+      v[4] = b.x * scale; v[5] = b.y * scale; v[6] = b.z * scale; v[7] = b.w * scale;
+    }
+    f[c] = x_split8(v);
+  }
+}
+// acc[b] (transposed: register r of lane (li, lg) = sum_d img[16 b + 4 lg + r][d] * f[lane's row li][d]) for the two 16-row blocks of
+// a staged row image
+__device__ __forceinline__ void x_tile_dot(f32x4_t (&acc)[2], const uint16_t* Rh, const uint16_t* Rl, const Frag2 (&f)[2], int li,
+                                           int lg) {
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    acc[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int off = x_row_off(16 * b + li, 4 * c + lg);
+      Frag2 a;
+      a.h = *reinterpret_cast<const bf16x8_t*>(Rh + off);
+      a.l = *reinterpret_cast<const bf16x8_t*>(Rl + off);
+      acc[b] = x_mma(a, f[c], acc[b]);
+    }
+  }
+}
+// out[db] (transposed: register r of lane (li, lg) = column 16 db + 4 lg + r of this lane's row li) += sum over the tile's 32 rows of
+// img^T[column][row] * w[row][lane's row li]; w = the lane's eight accumulator registers of the two blocks, used as they stand
+__device__ __forceinline__ void x_tile_acc(f32x4_t (&out)[4], const uint16_t* Th, const uint16_t* Tl, const f32x4_t (&w)[2], int li,
+                                           int lg) {
+  const float v[8] = {w[0][0], w[0][1], w[0][2], w[0][3], w[1][0], w[1][1], w[1][2], w[1][3]};
+  const Frag2 b = x_split8(v);
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+    const int off = x_tr_off(16 * db + li, lg);
+    Frag2 a;
+    a.h = *reinterpret_cast<const bf16x8_t*>(Th + off);
+    a.l = *reinterpret_cast<const bf16x8_t*>(Tl + off);
+    out[db] = x_mma(a, b, out[db]);
+  }
+}
+
+__device__ __forceinline__ float x_max_groups(float v) {  // over the four lane groups (lanes li, li + 16, + 32, + 48)
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float x_sum_groups(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+constexpr int IMG = XT * XD;  // bf16 elements of one image (4 KiB)
+
+// ---------------------------------------------------------------------------------------------- forward
+__global__ __launch_bounds__(256) void attn_fwd_x3_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+                                                          float* __restrict__ lse2, int N, int H) {
+  __shared__ __attribute__((aligned(16))) uint16_t lds[4 * IMG];  // K row hi / lo, V^T hi / lo
+  uint16_t *Kh = lds, *Kl = lds + IMG, *Vh = lds + 2 * IMG, *Vl = lds + 3 * IMG;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  const int I = H * XD;
+  const int64_t ld = 3 * (int64_t)I;
+  const float* base = qkv + (int64_t)b * N * ld + h * XD;
+  const int qi = blockIdx.x * 64 + wave * 16 + li;
+  const bool valid = qi < N;
+  Frag2 qf[2];
+  x_row_frags(qf, base + (int64_t)qi * ld, valid, lg, kLog2e / sqrtf((float)XD));
+  f32x4_t acc[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) acc[db] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, l = 0.f;  // l: this lane group's share of the row sum; summed over the groups at the end
+  TileRegs kr = x_fetch(base + I, ld, 0, N < XT ? N : XT), vr = x_fetch(base + 2 * I, ld, 0, N < XT ? N : XT);
+  for (int kt = 0; kt < N; kt += XT) {
+    const int nk = (N - kt) < XT ? (N - kt) : XT;
+    __syncthreads();
+    x_commit<true, false>(kr, Kh, Kl, nullptr, nullptr);
+    x_commit<false, true>(vr, nullptr, nullptr, Vh, Vl);
+    __syncthreads();
+    if (kt + XT < N) {  // the next tile's loads fly during this tile's arithmetic
+      const int nn = (N - kt - XT) < XT ? (N - kt - XT) : XT;
+      kr = x_fetch(base + I, ld, kt + XT, nn);
+      vr = x_fetch(base + 2 * I, ld, kt + XT, nn);
+    }
+    f32x4_t s[2];
+    x_tile_dot(s, Kh, Kl, qf, li, lg);  // s[kb][r] = S[query li][key kt + 16 kb + 4 lg + r] (log2 domain)
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (16 * kb + 4 * lg + r >= nk) s[kb][r] = -INFINITY;
+        tmax = fmaxf(tmax, s[kb][r]);
+      }
+    tmax = x_max_groups(tmax);
+    const float mn = fmaxf(m, tmax);
+    const float alpha = exp2f(m - mn);
+    m = mn;
+    l *= alpha;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      acc[db][0] *= alpha; acc[db][1] *= alpha; acc[db][2] *= alpha; acc[db][3] *= alpha;
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s[kb][r] = exp2f(s[kb][r] - mn);
+        l += s[kb][r];
+      }
+    x_tile_acc(acc, Vh, Vl, s, li, lg);  // O^T += V^T P
+  }
+  l = x_sum_groups(l);
+  if (valid) {
+    const float inv = 1.0f / l;
+    float* orow = o + ((int64_t)b * N + qi) * I + h * XD;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+      *reinterpret_cast<float4*>(orow + 16 * db + 4 * lg) =
+          make_float4(acc[db][0] * inv, acc[db][1] * inv, acc[db][2] * inv, acc[db][3] * inv);
+    if (lg == 0) lse2[(int64_t)bh * N + qi] = m + log2f(l);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- dQ
+// dS = P o (dP - delta),  dq = dS k * dh^-0.5   (64 queries per workgroup, keys streamed)
+__global__ __launch_bounds__(256) void attn_dq_x3_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
+                                                         const float* __restrict__ lse2, const float* __restrict__ delta,
+                                                         float* __restrict__ dqkv, int N, int H) {
+  __shared__ __attribute__((aligned(16))) uint16_t lds[6 * IMG];  // K row, K^T, V row (hi / lo each)
+  uint16_t *Kh = lds, *Kl = lds + IMG, *Kth = lds + 2 * IMG, *Ktl = lds + 3 * IMG, *Vh = lds + 4 * IMG, *Vl = lds + 5 * IMG;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  const int I = H * XD;
+  const int64_t ld = 3 * (int64_t)I;
+  const float* base = qkv + (int64_t)b * N * ld + h * XD;
+  const int qi = blockIdx.x * 64 + wave * 16 + li;
+  const bool valid = qi < N;
+  const float scale = 1.0f / sqrtf((float)XD);
+  Frag2 qf[2], gf[2];
+  x_row_frags(qf, base + (int64_t)qi * ld, valid, lg, kLog2e * scale);
+  x_row_frags(gf, d_o + ((int64_t)b * N + qi) * I + h * XD, valid, lg, 1.0f);
+  const float L = valid ? lse2[(int64_t)bh * N + qi] : INFINITY;  // rows past the end: P = 2^(s - inf) = 0
+  const float dl = valid ? delta[(int64_t)bh * N + qi] : 0.f;
+  f32x4_t dq[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) dq[db] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  TileRegs kr = x_fetch(base + I, ld, 0, N < XT ? N : XT), vr = x_fetch(base + 2 * I, ld, 0, N < XT ? N : XT);
+  for (int kt = 0; kt < N; kt += XT) {
+    const int nk = (N - kt) < XT ? (N - kt) : XT;
+    __syncthreads();
+    x_commit<true, true>(kr, Kh, Kl, Kth, Ktl);
+    x_commit<true, false>(vr, Vh, Vl, nullptr, nullptr);
+    __syncthreads();
+    if (kt + XT < N) {
+      const int nn = (N - kt - XT) < XT ? (N - kt - XT) : XT;
+      kr = x_fetch(base + I, ld, kt + XT, nn);
+      vr = x_fetch(base + 2 * I, ld, kt + XT, nn);
+    }
+    f32x4_t s[2], dp[2];
+    x_tile_dot(s, Kh, Kl, qf, li, lg);
+    x_tile_dot(dp, Vh, Vl, gf, li, lg);  // dP[query li][key] = dO[q] . V[key]
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool live = 16 * kb + 4 * lg + r < nk;
+        const float p = live ? exp2f(s[kb][r] - L) : 0.f;
+        s[kb][r] = p * (dp[kb][r] - dl);
+      }
+    x_tile_acc(dq, Kth, Ktl, s, li, lg);  // dQ^T += K^T dS^T
+  }
+  if (valid) {
+    float* out = dqkv + ((int64_t)b * N + qi) * ld + h * XD;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+      *reinterpret_cast<float4*>(out + 16 * db + 4 * lg) =
+          make_float4(dq[db][0] * scale, dq[db][1] * scale, dq[db][2] * scale, dq[db][3] * scale);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- dK, dV
+// dv = P^T dO,  dk = dS^T q * dh^-0.5   (64 keys per workgroup, queries streamed; one recomputation of P serves both)
+__global__ __launch_bounds__(256) void attn_dkv_x3_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
+                                                          const float* __restrict__ lse2, const float* __restrict__ delta,
+                                                          float* __restrict__ dqkv, int N, int H) {
+  __shared__ __attribute__((aligned(16))) uint16_t lds[8 * IMG];  // Q row, Q^T, dO row, dO^T (hi / lo each)
+  __shared__ __attribute__((aligned(16))) float Ls[XT];
+  __shared__ __attribute__((aligned(16))) float Ds[XT];
+  uint16_t *Qh = lds, *Ql = lds + IMG, *Qth = lds + 2 * IMG, *Qtl = lds + 3 * IMG;
+  uint16_t *Gh = lds + 4 * IMG, *Gl = lds + 5 * IMG, *Gth = lds + 6 * IMG, *Gtl = lds + 7 * IMG;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  const int I = H * XD;
+  const int64_t ld = 3 * (int64_t)I;
+  const float* base = qkv + (int64_t)b * N * ld + h * XD;
+  const float* gbase = d_o + (int64_t)b * N * I + h * XD;
+  const int ki = blockIdx.x * 64 + wave * 16 + li;
+  const bool valid = ki < N;
+  const float scale = 1.0f / sqrtf((float)XD);
+  Frag2 kf[2], vf[2];
+  x_row_frags(kf, base + I + (int64_t)ki * ld, valid, lg, kLog2e * scale);
+  x_row_frags(vf, base + 2 * I + (int64_t)ki * ld, valid, lg, 1.0f);
+  f32x4_t dk[4], dv[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) dk[db] = dv[db] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  TileRegs qr = x_fetch(base, ld, 0, N < XT ? N : XT), gr = x_fetch(gbase, I, 0, N < XT ? N : XT);
+  for (int qt = 0; qt < N; qt += XT) {
+    const int nq = (N - qt) < XT ? (N - qt) : XT;
+    __syncthreads();
+    x_commit<true, true>(qr, Qh, Ql, Qth, Qtl);
+    x_commit<true, true>(gr, Gh, Gl, Gth, Gtl);
+    if (threadIdx.x < XT) {
+      const bool ok = (int)threadIdx.x < nq;
+      Ls[threadIdx.x] = ok ? lse2[(int64_t)bh * N + qt + threadIdx.x] : INFINITY;  // 2^(s - inf) = 0
+      Ds[threadIdx.x] = ok ? delta[(int64_t)bh * N + qt + threadIdx.x] : 0.f;
+    }
+    __syncthreads();
+    if (qt + XT < N) {
+      const int nn = (N - qt - XT) < XT ? (N - qt - XT) : XT;
+      qr = x_fetch(base, ld, qt + XT, nn);
+      gr = x_fetch(gbase, I, qt + XT, nn);
+    }
+    f32x4_t s[2], dp[2];
+    x_tile_dot(s, Qh, Ql, kf, li, lg);   // s[qb][r] = S[query qt + 16 qb + 4 lg + r][key li]
+    x_tile_dot(dp, Gh, Gl, vf, li, lg);  // dP[query][key li] = dO[q] . V[key]
+    f32x4_t pt[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const float4 Lq = *reinterpret_cast<const float4*>(Ls + 16 * qb + 4 * lg);
+      const float4 Dq = *reinterpret_cast<const float4*>(Ds + 16 * qb + 4 * lg);
+      const float Lr[4] = {Lq.x, Lq.y, Lq.z, Lq.w}, Dr[4] = {Dq.x, Dq.y, Dq.z, Dq.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = exp2f(s[qb][r] - Lr[r]);
+        pt[qb][r] = p;
+        s[qb][r] = p * (dp[qb][r] - Dr[r]);
+      }
+    }
+    x_tile_acc(dv, Gth, Gtl, pt, li, lg);  // dV^T += dO^T P
+    x_tile_acc(dk, Qth, Qtl, s, li, lg);   // dK^T += Q^T dS
+  }
+  if (valid) {
+    float* outk = dqkv + ((int64_t)b * N + ki) * ld + I + h * XD;
+    float* outv = outk + I;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      *reinterpret_cast<float4*>(outk + 16 * db + 4 * lg) =
+          make_float4(dk[db][0] * scale, dk[db][1] * scale, dk[db][2] * scale, dk[db][3] * scale);
+      *reinterpret_cast<float4*>(outv + 16 * db + 4 * lg) = make_float4(dv[db][0], dv[db][1], dv[db][2], dv[db][3]);
+    }
+  }
+}
+
+}  // namespace
+
+// shapes these kernels take: the bf16x3 arithmetic selected, fp32 storage, no token mask, dim_head 64, q not pre-scaled, 16-byte rows
+bool attn_f32x3_ok(int dtype, int dh, const void* keep, int H, const void* qkv, const void* other, bool q_prescaled) {
+  return get_f32_arith() == 1 && dtype == AVF_F32 && !keep && !q_prescaled && dh == XD && ((uintptr_t)qkv & 15) == 0 &&
+         ((uintptr_t)other & 15) == 0;
+}
+
+int attn_fwd_f32x3(const float* qkv, float* o, float* lse2, int B, int N, int H, hipStream_t s) {
+  dim3 grid((unsigned)ceil_div(N, 64), (unsigned)(B * H));
+  attn_fwd_x3_kernel<<<grid, 256, 0, s>>>(qkv, o, lse2, N, H);
+  return check_launch("attn_fwd_x3_kernel");
+}
+
+int attn_bwd_f32x3(const float* qkv, const float* d_o, const float* lse2, const float* delta, float* dqkv, int B, int N, int H,
+                   hipStream_t s) {
+  dim3 grid((unsigned)ceil_div(N, 64), (unsigned)(B * H));
+  attn_dq_x3_kernel<<<grid, 256, 0, s>>>(qkv, d_o, lse2, delta, dqkv, N, H);
+  attn_dkv_x3_kernel<<<grid, 256, 0, s>>>(qkv, d_o, lse2, delta, dqkv, N, H);
+  return check_launch("attn_bwd_x3 kernels");
+}
+
+}  // namespace avf

@@ -433,7 +433,7 @@ int g_f32_arith = 1;
 
 // shapes the bf16x3 kernel takes: tiles worth filling, one unit stride per operand, 16-byte loads where k is the fast axis
 bool f32x3_ok(const F32GemmParams& p) {
-  if (p.M < 64 || p.N < 64 || p.K < 32) return false;
+  if (p.M < 96 || p.N < 96 || p.K < 32) return false;  // at least three quarters of a tile each way (smaller: the 32 / 64 tiles above)
   const bool akf = p.a_sk == 1, bkf = p.b_sk == 1;
   if (!akf && p.a_sm != 1) return false;
   if (!bkf && p.b_sn != 1) return false;
@@ -441,14 +441,16 @@ bool f32x3_ok(const F32GemmParams& p) {
   if (bkf && (p.K % 32 != 0 || p.b_sn % 4 != 0 || ((uintptr_t)p.B & 15))) return false;
   return true;
 }
-// split count over K for the 128 x 128 tiles: fill ~2 workgroups per CU, at least 8 K-steps per split
+// split count over K for the 128 x 128 tiles: as many splits as keep tiles x splits within ONE round of the chip's 512 workgroup
+// slots (two per CU) - 48 tiles x 11 splits = 528 workgroups ran a second, almost empty round (119 us; 10 splits: 85) - with at
+// least 8 K-steps per split
 int f32x3_splits(int64_t M, int64_t N, int64_t K, int epilogue) {
   if (epilogue != AVF_EPI_NONE && epilogue != AVF_EPI_BIAS_RES) return 1;
   const int64_t tiles = ceil_div(M, SBM) * ceil_div(N, SBN);
   if (tiles >= 256 || K < 512) return 1;
-  int64_t sp = ceil_div(512, tiles);
+  int64_t sp = 512 / tiles;
   if (sp > K / 256) sp = K / 256;
-  if (sp > 16) sp = 16;
+  if (sp > 32) sp = 32;
   return sp < 2 ? 1 : (int)sp;
 }
 
@@ -474,7 +476,7 @@ int launch_f32x3(const F32GemmParams& p, int epilogue, int S, int vec, hipStream
 size_t gemm_f32_ws(int64_t M, int64_t N, int64_t K) {
   int sp = f32_splits(M, N, K, AVF_EPI_NONE);
   if (sp == 1) sp = f32_split64(M, N, K, AVF_EPI_NONE);
-  const int sx = (M >= 64 && N >= 64) ? f32x3_splits(M, N, K, AVF_EPI_NONE) : 1;  // the bf16x3 form of the same call
+  const int sx = (M >= 96 && N >= 96) ? f32x3_splits(M, N, K, AVF_EPI_NONE) : 1;  // the bf16x3 form of the same call
   if (sx > sp) sp = sx;
   return sp > 1 ? (size_t)sp * M * N * sizeof(float) : 0;
 }

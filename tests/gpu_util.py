@@ -7,6 +7,24 @@ import oracle
 DEV = "cuda"
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def f32_arithmetic(mode):
+    """run a block with the parity mode's arithmetic set to "bf16x3" (default: three bf16 products per fp32 product on the
+    bf16 matrix pipe) or "f32" (the f32-input MFMA); avf_set_f32_arith is process-wide, so the previous mode is restored"""
+    from avformer_amd import _lib
+    prev = _lib.set_f32_arithmetic(mode)
+    try:
+        yield mode
+    finally:
+        _lib.set_f32_arithmetic(prev)
+
+
+F32_ARITHS = ("bf16x3", "f32")
+
+
 def rel_fro(a, b):
     a = a.detach().float().cpu()
     b = b.detach().float().cpu()

@@ -17,7 +17,8 @@ import torch
 
 import oracle
 from conftest import load_golden, split_golden
-from gpu_util import (DEV, check_abs, check_rel, hip_transformer_run, make_hip_transformer, oracle_transformer_run, rel_fro)
+from gpu_util import (DEV, F32_ARITHS, check_abs, check_rel, f32_arithmetic, hip_transformer_run, make_hip_transformer,
+                      oracle_transformer_run, rel_fro)
 
 pytestmark = pytest.mark.gpu
 
@@ -88,14 +89,18 @@ def test_config_vs_oracle_small_batch(cfg):
     sd, g = _state(D, L, H, dh, M, 900 + len(cfg) + N)
     x = torch.randn(B, N, D, generator=g)
     y_ref, dx_ref, g_ref = oracle_transformer_run(x, sd, L, H, SQ)
-    # parity mode: north_star's rtol 1e-3
-    t32 = make_hip_transformer(sd, D, L, H, dh, M, "f32")
-    y, dx, grads = hip_transformer_run(t32, x, SQ)
-    torch.testing.assert_close(y.cpu(), y_ref, rtol=1e-3, atol=5e-5)
-    torch.testing.assert_close(dx.cpu(), dx_ref, rtol=1e-3, atol=1e-6 if L <= 6 else 2e-6)
-    for k, v in g_ref.items():
-        check_rel(f"cfg_f32[{cfg}]:g.{k}", grads[k], v, 2e-3)
-    del t32
+    # parity mode: north_star's rtol 1e-3, in both of its arithmetics (three bf16 products per fp32 product - the default - and
+    # the f32-input MFMA); the same stated tolerances, each arithmetic held to 3 x its own calibrated measurement
+    for arith in F32_ARITHS:
+        with f32_arithmetic(arith):
+            t32 = make_hip_transformer(sd, D, L, H, dh, M, "f32")
+            y, dx, grads = hip_transformer_run(t32, x, SQ)
+        torch.testing.assert_close(y.cpu(), y_ref, rtol=1e-3, atol=5e-5)
+        torch.testing.assert_close(dx.cpu(), dx_ref, rtol=1e-3, atol=1e-6 if L <= 6 else 2e-6)
+        tag = "cfg_f32" if arith == "f32" else "cfg_f32x3"
+        for k, v in g_ref.items():
+            check_rel(f"{tag}[{cfg}]:g.{k}", grads[k], v, 2e-3)
+        del t32
     # throughput mode
     t = make_hip_transformer(sd, D, L, H, dh, M, mode)
     y, dx, grads = hip_transformer_run(t, x, SQ)

@@ -22,6 +22,16 @@ def ops():
     return A.ops
 
 
+@pytest.fixture(params=["bf16x3", "f32"])
+def f32_arith(request):
+    """the parity mode's two arithmetics (avf_set_f32_arith): three bf16 products per fp32 product on the bf16 matrix pipe
+    (the default) and the f32-input MFMA; every fp32 GEMM / attention test runs in both, at the same tolerances"""
+    from avformer_amd import _lib
+    prev = _lib.set_f32_arithmetic(request.param)
+    yield request.param
+    _lib.set_f32_arithmetic(prev)
+
+
 def _close(a, b, atol=2e-5, rtol=1e-4):
     if not torch.is_tensor(b):
         b = torch.tensor(b)
@@ -90,9 +100,9 @@ def _gemm_ref(a, b, ta, tb):
     return A_.double() @ B_.double()
 
 
-@pytest.mark.parametrize("M,N,K", [(5, 12, 8), (64, 64, 16), (130, 70, 52), (300, 256, 128), (257, 96, 260)])
+@pytest.mark.parametrize("M,N,K", [(5, 12, 8), (64, 64, 16), (130, 70, 52), (300, 256, 128), (257, 96, 260), (200, 102, 77)])
 @pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False)])
-def test_gemm_f32_forms(ops, M, N, K, ta, tb):
+def test_gemm_f32_forms(ops, f32_arith, M, N, K, ta, tb):
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
     a = torch.randn((K, M) if ta else (M, K), generator=g)
     b = torch.randn((N, K) if tb else (K, N), generator=g)
@@ -106,7 +116,7 @@ def test_gemm_f32_forms(ops, M, N, K, ta, tb):
     (512, 1024, 4096, False, True),    # k-fast operands (NT) with a long reduction: the fold applies bias + residual
     (2048, 1024, 768, False, False),   # dX shape (NN), short reduction: unsplit
 ])
-def test_gemm_f32_split64(ops, M, N, K, ta, tb):
+def test_gemm_f32_split64(ops, f32_arith, M, N, K, ta, tb):
     """the parity mode's weight-gradient-shaped GEMMs (round 5): few 64 x 64 tiles, long reduction -> split-K slabs + fold
     (ops.gemm allocates the workspace avf_gemm_workspace_bytes asks for, which is what enables the split), against fp64"""
     g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
@@ -116,7 +126,8 @@ def test_gemm_f32_split64(ops, M, N, K, ta, tb):
     c = ops.gemm(a.cuda(), b.cuda(), trans_a=ta, trans_b=tb)
     _close(c, ref.float(), atol=1e-4 * math.sqrt(K), rtol=1e-4)
     err = float((c.double().cpu() - ref).norm() / ref.norm())
-    assert err < 1e-6, err  # fp32 products, fp32 fmaf accumulation: the parity mode's precision class
+    # the precision class of each arithmetic: fp32 products in an fmaf chain / three bf16 products (<= 3 * 2^-18 per product)
+    assert err < (1e-6 if f32_arith == "f32" else 6e-6), err
     if not ta:  # the fused bias + residual epilogue rides in the fold of a split launch
         bias = torch.randn(N, generator=g)
         res = torch.randn(M, N, generator=g)
@@ -126,7 +137,9 @@ def test_gemm_f32_split64(ops, M, N, K, ta, tb):
 
 @pytest.mark.parametrize("dtype,M,N,K", [(torch.float32, 200, 136, 96), (torch.bfloat16, 200, 136, 96),
                                          (torch.bfloat16, 301, 260, 1088), (torch.bfloat16, 8200, 520, 64)])
-def test_gemm_epilogues(ops, dtype, M, N, K):
+def test_gemm_epilogues(ops, f32_arith, dtype, M, N, K):
+    if dtype != torch.float32 and f32_arith == "f32":
+        pytest.skip("the arithmetic switch only concerns fp32 operands")
     g = torch.Generator().manual_seed(11)
     a = torch.randn(M, K, generator=g).to(dtype)
     w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype)
@@ -216,7 +229,7 @@ def _attn_ref(qkv, B, N, H, dh, d_o=None):
 
 @pytest.mark.parametrize("B,N,H,dh", [(2, 7, 4, 8), (1, 64, 2, 32), (2, 49, 8, 32), (3, 17, 8, 64), (2, 130, 3, 64),
                                       (1, 324, 2, 64), (2, 12, 8, 16)])
-def test_attention_f32(ops, B, N, H, dh):
+def test_attention_f32(ops, f32_arith, B, N, H, dh):
     g = torch.Generator().manual_seed(B * 100 + N + dh)
     qkv = torch.randn(B * N, 3 * H * dh, generator=g)
     d_o = torch.randn(B * N, H * dh, generator=g)
