@@ -18,7 +18,7 @@ from typing import Optional, Tuple
 import torch
 from torch import nn
 
-from .heads import AU_former, ResFormerTokens, TFormer, tformer_AU_head
+from .heads import AU_former, ResFormerTokens, TFormer, VA_former, tformer_AU_head
 from .loss import AULoss
 from .models import _TaskLossMixin
 
@@ -62,14 +62,11 @@ class _FormerTask(nn.Module, _TaskLossMixin):
     def _config(self, modality, task):
         """``config_modality`` (sformer.py:384-391, same in vformer / tformer): RGB + mask -> the last 4 channels of the
         clip, mask only -> the last one, otherwise the 3 RGB channels (the caller's stem must take that many: the reference
-        rebuilds ``conv1`` there, which belongs to the backbone this package does not ship).  Tasks: AU and EX logits come out
-        of these entries as in the reference; its VA branch (``VA_former`` on the frame feature, sformer.py:378-380) is not
-        built - refuse it instead of silently returning the fc head's columns."""
+        rebuilds ``conv1`` there, which belongs to the backbone this package does not ship).  Tasks as in the reference: AU, EX
+        and VA columns come out of the fc head, with ``sformer`` overwriting the AU / VA columns by its ``AU_former`` /
+        ``VA_former`` heads (sformer.py:375-380); ``vformer`` and ``tformer`` have no VA head (their VA columns are the fc head's)."""
         if 'M' in modality:
             self.num_channels = 4 if 'V' in modality else 1
-        if task == 'VA':
-            raise NotImplementedError("task='VA' of the *former registry entries (VA_former head) is outside the hot path this "
-                                      "package builds (SURVEY.md section 8); use task='AU' or 'EX'")
 
     def _select(self, x):
         clip = x['clip']
@@ -89,6 +86,7 @@ class SpatialFormerModel(_FormerTask):
         self.task, self.modes = task, ["clip"]
         self.fc = _fc_head(512)
         self.au_head = AU_former(dropout=0.2, compute_dtype=compute_dtype)
+        self.va_head = VA_former(dropout=0.2, compute_dtype=compute_dtype)   # sformer.py:358
         # DEVIATION, on purpose: the reference's SpatialFormer trains AU with DiceAULoss (multi-label Dice + 5 x weighted BCE,
         # sformer.py:362, loss.py:149-176); this entry uses the AULoss of the path SURVEY.md section 8 scopes (loss.py:63-103,
         # what avformer / vformer / tformer use).  INTEGRATION.md section 4 says so.
@@ -100,6 +98,9 @@ class SpatialFormerModel(_FormerTask):
         if self.task == 'AU':
             au_out, _ = self.au_head(features)                 # sformer.py:382-384
             out = torch.cat([au_out[:, :12].to(out.dtype), out[:, 12:]], dim=1)
+        if self.task == 'VA':
+            va_out, _ = self.va_head(features)                 # sformer.py:378-380: out[:, -2:] = va_out
+            out = torch.cat([out[:, :-2], va_out.to(out.dtype)], dim=1)
         return out
 
 

@@ -3,6 +3,7 @@ reference classes (same constructor arguments, parameter names and return values
 HIP ``Transformer``:
 
 * ``AU_former``        - reference models/heads.py:258-339
+* ``VA_former``        - reference models/heads.py:341-372 (two valence / arousal tokens; SpatialFormer's ``va_head``)
 * ``tformer_AU_head``  - reference models/tformer.py:362-403; ``former_AU_head`` is the same structure and
                          stands in for the class models/avformer.py:19,87 imports but the reference never defines
 * ``TFormer``          - reference models/vformer.py:270-293 (= tformer.py:271-294)
@@ -69,11 +70,13 @@ class _FlatGroup:
 
 
 class _FrontFn(torch.autograd.Function):
-    """AU_former's front (heads.py:291-323): BatchNorm1d -> 12 x Linear(in, E) -> [B, 12, E] + pos_embedding"""
+    """the front of AU_former / VA_former (heads.py:291-323, 354-366): BatchNorm1d -> T x Linear(in, E) -> [B, T, E] +
+    pos_embedding  (T = 12 AU tokens, 2 VA tokens)"""
 
     @staticmethod
     def forward(ctx, x, mod, bn_w, bn_b, pos, *wb):
-        bn = mod.AU_BN1
+        bn = mod._front_bn()
+        T = mod.n_tokens
         training = bool(bn.training or bn.running_mean is None)
         x = x.detach().float().contiguous()
         B = x.shape[0]
@@ -81,45 +84,46 @@ class _FrontFn(torch.autograd.Function):
         y, mean, invstd = ops.bn1d_fwd(x, bn_w.detach(), bn_b.detach(), bn.running_mean, bn.running_var,
                                        bn.num_batches_tracked if bn.training else None, bn.eps,
                                        0.1 if bn.momentum is None else bn.momentum, training)
-        W = mod._proj_w.get().view(12 * E, -1)   # [12 E, in]: token i = rows i*E .. (i+1)*E (cat on dim 1, heads.py:318-319)
-        bias = mod._proj_b.get().view(12 * E)
-        tokens = ops.gemm(y, W, epilogue=ops.EPI_BIAS_RES, bias=bias, residual=pos.detach().reshape(12 * E), residual_ld=0)
+        W = mod._proj_w.get().view(T * E, -1)    # [T E, in]: token i = rows i*E .. (i+1)*E (cat on dim 1, heads.py:318-319)
+        bias = mod._proj_b.get().view(T * E)
+        tokens = ops.gemm(y, W, epilogue=ops.EPI_BIAS_RES, bias=bias, residual=pos.detach().reshape(T * E), residual_ld=0)
         ctx.save_for_backward(x, y, mean, invstd, bn_w.detach(), W)
-        ctx.training, ctx.E = training, E
-        return tokens.view(B, 12, E)
+        ctx.training, ctx.E, ctx.T = training, E, T
+        return tokens.view(B, T, E)
 
     @staticmethod
     def backward(ctx, dtok):
         x, y, mean, invstd, bn_w, W = ctx.saved_tensors
-        E = ctx.E
+        E, T = ctx.E, ctx.T
         B = x.shape[0]
-        dt = dtok.contiguous().view(B, 12 * E)
-        dbias = ops.colsum(dt)                                   # [12 E]: the 12 bias gradients, concatenated
-        dpos = dbias.clone().view(1, 12, E) if ctx.needs_input_grad[4] else None  # same sums, own storage (no aliased .grad)
-        dW = ops.gemm(dt, y, trans_a=True, trans_b=False)        # [12 E, in]
+        dt = dtok.contiguous().view(B, T * E)
+        dbias = ops.colsum(dt)                                   # [T E]: the T bias gradients, concatenated
+        dpos = dbias.clone().view(1, T, E) if ctx.needs_input_grad[4] else None  # same sums, own storage (no aliased .grad)
+        dW = ops.gemm(dt, y, trans_a=True, trans_b=False)        # [T E, in]
         dy = ops.gemm(dt, W, trans_b=False)                      # [B, in]
         dx, dg, db = ops.bn1d_bwd(x, dy, bn_w, mean, invstd, ctx.training, need_dx=ctx.needs_input_grad[0])
-        gw = [dW[i * E:(i + 1) * E] for i in range(12)]
-        gb = [dbias[i * E:(i + 1) * E] for i in range(12)]
+        gw = [dW[i * E:(i + 1) * E] for i in range(T)]
+        gb = [dbias[i * E:(i + 1) * E] for i in range(T)]
         return (dx, None, dg, db, dpos, *gw, *gb)
 
 
 class _DotsFn(torch.autograd.Function):
-    """the 12 per-token bias-free Linear(E, 1) heads (heads.py:325-337): logits[b, i] = tokens[b, i, :] . w_i, written into
-    a [B, pad_to] row (columns 12.. zero: the [B,21] layout)"""
+    """the T per-token bias-free Linear(E, 1) heads (heads.py:325-337, 367-369): logits[b, i] = tokens[b, i, :] . w_i, written
+    into a [B, pad_to] row (columns T.. zero: the [B,21] layout)"""
 
     @staticmethod
     def forward(ctx, tokens, mod, pad_to, *w):
         tokens = tokens.detach().float().contiguous()
-        W = mod._last_w.get().view(12, -1)
+        W = mod._last_w.get().view(mod.n_tokens, -1)
         ctx.save_for_backward(tokens, W)
+        ctx.T = mod.n_tokens
         return ops.token_dots_fwd(tokens, W, pad_to)
 
     @staticmethod
     def backward(ctx, dout):
         tokens, W = ctx.saved_tensors
         dtok, dw = ops.token_dots_bwd(dout, tokens, W, need_dtokens=ctx.needs_input_grad[0])
-        return (dtok, None, None, *[dw[i:i + 1] for i in range(12)])
+        return (dtok, None, None, *[dw[i:i + 1] for i in range(ctx.T)])
 
 
 class _AssembleFn(torch.autograd.Function):
@@ -206,13 +210,32 @@ class _TokensToMapFn(torch.autograd.Function):
 
 
 class _AUHeadBase(nn.Module):
+    prefix, n_tokens = "AU", 12   # parameter-name prefix and token count of the head (VA_former: "VA", 2)
+
+    def _front_bn(self):
+        return getattr(self, f"{self.prefix}_BN1")
+
+    def _make_front(self, input_dim, emb_dim):
+        """BatchNorm1d + the T projections Linear(input_dim, emb_dim) under the reference's names"""
+        T, px = self.n_tokens, self.prefix
+        setattr(self, f"{px}_BN1", nn.BatchNorm1d(input_dim))
+        for i in range(1, T + 1):
+            setattr(self, f"{px}_linear_p{i}", nn.Linear(input_dim, emb_dim))
+        self._proj_w = _FlatGroup([getattr(self, f"{px}_linear_p{i}") for i in range(1, T + 1)], "weight")
+        self._proj_b = _FlatGroup([getattr(self, f"{px}_linear_p{i}") for i in range(1, T + 1)], "bias")
+
     def _make_last(self, emb_dim):
-        for i in range(1, 13):
-            setattr(self, f"AU_linear_last{i}", nn.Linear(emb_dim, 1, bias=False))
-        self._last_w = _FlatGroup([getattr(self, f"AU_linear_last{i}") for i in range(1, 13)], "weight")
+        T, px = self.n_tokens, self.prefix
+        for i in range(1, T + 1):
+            setattr(self, f"{px}_linear_last{i}", nn.Linear(emb_dim, 1, bias=False))
+        self._last_w = _FlatGroup([getattr(self, f"{px}_linear_last{i}") for i in range(1, T + 1)], "weight")
+
+    def _front_tokens(self, emb):
+        bn = self._front_bn()
+        return _FrontFn.apply(emb, self, bn.weight, bn.bias, self.pos_embedding, *self._proj_w.params, *self._proj_b.params)
 
     def _last_logits(self, tokens, pad_to=None):
-        # token i -> bias-free Linear(emb,1) number i+1  == batched row-dot [B,12,E] . [12,E]
+        # token i -> bias-free Linear(emb,1) number i+1  == batched row-dot [B,T,E] . [T,E]
         return _DotsFn.apply(tokens, self, pad_to, *self._last_w.params)
 
 
@@ -220,25 +243,41 @@ class AU_former(_AUHeadBase):
     def __init__(self, input_dim=512, emb_dim=128, dropout=0.0, compute_dtype="bf16"):
         super().__init__()
         self.emb_dim = input_dim
-        self.AU_BN1 = nn.BatchNorm1d(self.emb_dim)
-        for i in range(1, 13):
-            setattr(self, f"AU_linear_p{i}", nn.Linear(self.emb_dim, emb_dim))
+        self._make_front(self.emb_dim, emb_dim)
         self.pos_embedding = nn.Parameter(torch.randn(1, 12, emb_dim))
         self.corr_transformer = Transformer(emb_dim, depth=2, heads=8, mlp_dim=256, dim_head=32, dropout=dropout,
                                             compute_dtype=compute_dtype)
         self._make_last(emb_dim)
-        self._proj_w = _FlatGroup([getattr(self, f"AU_linear_p{i}") for i in range(1, 13)], "weight")
-        self._proj_b = _FlatGroup([getattr(self, f"AU_linear_p{i}") for i in range(1, 13)], "bias")
 
     def tokens(self, emb):
         """the AU tokens [B, 12, E] after the correlation transformer (what avformer.py:96-99 keeps of this head)"""
         _need_gpu(emb, "AU_former")
-        bn = self.AU_BN1
-        tokens = _FrontFn.apply(emb, self, bn.weight, bn.bias, self.pos_embedding, *self._proj_w.params, *self._proj_b.params)
-        return self.corr_transformer(tokens)
+        return self.corr_transformer(self._front_tokens(emb))
 
     def forward(self, emb):
         out = self.tokens(emb)
+        return self._last_logits(out), out
+
+
+class VA_former(_AUHeadBase):
+    """reference models/heads.py:341-372: BatchNorm1d -> 2 x Linear(in, E) -> [B, 2, E] + pos_embedding ->
+    Transformer(E, depth 2, 8 heads of 32, mlp 128) -> one bias-free Linear(E, 1) per token -> (valence / arousal [B, 2], tokens).
+    Parameter names as the reference's (``VA_BN1``, ``VA_linear_p1/2``, ``pos_embedding``, ``corr_transformer.*``,
+    ``VA_linear_last1/2``).  Two tokens per clip: the single-launch small-token layer kernels (layer_small.hip)."""
+    prefix, n_tokens = "VA", 2
+
+    def __init__(self, input_dim=512, emb_dim=128, dropout=0.0, compute_dtype="bf16"):
+        super().__init__()
+        self.emb_dim = input_dim
+        self._make_front(self.emb_dim, emb_dim)
+        self.pos_embedding = nn.Parameter(torch.randn(1, 2, emb_dim))
+        self.corr_transformer = Transformer(emb_dim, depth=2, heads=8, mlp_dim=128, dim_head=32, dropout=dropout,
+                                            compute_dtype=compute_dtype)
+        self._make_last(emb_dim)
+
+    def forward(self, emb):
+        _need_gpu(emb, "VA_former")
+        out = self.corr_transformer(self._front_tokens(emb))
         return self._last_logits(out), out
 
 

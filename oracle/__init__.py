@@ -16,6 +16,7 @@ reference's own ``models/heads.py``, ``models/loss.py``, ``models/tformer.py`` a
 from .reference_math import (  # noqa: F401
     AU_POS_WEIGHT,
     au_former_forward,
+    va_former_forward,
     au_head_forward,
     au_loss,
     attention_forward,

@@ -191,6 +191,25 @@ def au_former_forward(emb: Tensor, sd: Dict[str, Tensor], prefix: str = "", trai
     return _last_linears(out, sd, prefix, 12, "AU_linear_last"), out
 
 
+def va_former_forward(emb: Tensor, sd: Dict[str, Tensor], prefix: str = "", training: bool = False,
+                      depth: int = 2, heads: int = 8, eps: float = 1e-5):
+    """models/heads.py:354-372 (``VA_former``): BatchNorm1d -> 2 Linear(in, E) -> cat / view [B, 2, E] -> +pos ->
+    Transformer -> one bias-free dot per token.  Returns (valence / arousal [B, 2], tokens [B, 2, E])."""
+    bs = emb.shape[0]
+    w, b = sd[f"{prefix}VA_BN1.weight"], sd[f"{prefix}VA_BN1.bias"]
+    if training:
+        mu = emb.mean(dim=0)
+        var = emb.var(dim=0, unbiased=False)
+    else:
+        mu, var = sd[f"{prefix}VA_BN1.running_mean"], sd[f"{prefix}VA_BN1.running_var"]
+    e = (emb - mu) / torch.sqrt(var + eps) * w + b
+    toks = [e @ sd[f"{prefix}VA_linear_p{i + 1}.weight"].t() + sd[f"{prefix}VA_linear_p{i + 1}.bias"] for i in range(2)]
+    tok = torch.cat(toks, dim=1).reshape(bs, 2, -1)  # heads.py:360-361
+    tok = tok + sd[f"{prefix}pos_embedding"][:, :2]
+    out = transformer_forward(tok, sd, depth, heads, prefix=f"{prefix}corr_transformer.")
+    return _last_linears(out, sd, prefix, 2, "VA_linear_last"), out
+
+
 def tformer_forward(x: Tensor, sd: Dict[str, Tensor], num_patches: int, dim: int, depth: int, heads: int,
                     prefix: str = "") -> Tensor:
     """models/vformer.py:279-293 (``TFormer``): view, prepend CLS, +pos, Transformer, take token 0."""

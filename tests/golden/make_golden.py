@@ -16,7 +16,8 @@ G4 transformer with inner != dim at N in {12, 17, 49}, G5 AU_former (eval), G6 t
 (emb 64), G7 TFormer, G8 AULoss with/without ignored rows, G9 tiny pipeline TFormer -> AU_former
 -> AULoss with gradients, G10 tanh-GELU on a grid, G11 the token section of ResFormer.forward, G12 the evaluation
 score of metrics/accf1.py (MultiLabelAccF1, the reference's own sklearn-backed implementation) on seeded batches, G13 the
-Transformer with a token mask (the branch heads.py:225-232), G14 the Transformer whose to_out is nn.Identity (heads.py:207).
+Transformer with a token mask (the branch heads.py:225-232), G14 the Transformer whose to_out is nn.Identity (heads.py:207),
+G15 VA_former (heads.py:341-372) in eval and in train mode.
 
     python tests/golden/make_golden.py --only g12        (re)generates just that fixture
 """
@@ -284,6 +285,22 @@ def identity_fixture():
          **module_io(tr, torch.randn(3, 10, 32), lambda y: y.pow(2).mean()))
 
 
+def va_former_fixture():
+    """G15: VA_former (models/heads.py:341-372; SpatialFormer's ``va_head``, sformer.py:358, 378-380): BatchNorm1d -> two
+    Linear(in, E) -> [B, 2, E] + pos_embedding -> Transformer(E, depth 2, 8 heads of 32, mlp 128) -> one bias-free Linear(E, 1)
+    per token.  Two cases at the reference's own emb_dim = 128 (input_dim 64 keeps the files small): eval mode with perturbed
+    running statistics, and train mode (batch statistics; dropout 0 so the outputs are deterministic)."""
+    heads, _, _, _ = load_reference()
+    sq = lambda y: y.pow(2).mean()
+    for tag, train in (("eval", False), ("train", True)):
+        torch.manual_seed(1500 + int(train))
+        m = heads.VA_former(input_dim=64, emb_dim=128)
+        m.VA_BN1.running_mean.normal_(0, 0.5)
+        m.VA_BN1.running_var.uniform_(0.5, 2.0)
+        m.train(train)
+        save(f"g15_va_former_{tag}", input_dim=64, emb_dim=128, training=int(train), **module_io(m, torch.randn(6, 64), sq))
+
+
 if __name__ == "__main__":
     only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
     if only == "g12":
@@ -292,8 +309,11 @@ if __name__ == "__main__":
         mask_fixture()
     elif only == "g14":
         identity_fixture()
+    elif only == "g15":
+        va_former_fixture()
     else:
         main()
         metric_fixture()
         mask_fixture()
         identity_fixture()
+        va_former_fixture()

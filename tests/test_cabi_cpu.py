@@ -84,6 +84,7 @@ def test_same_seed_same_init_as_reference_fixture():
 def test_head_schemas_match_reference_fixtures():
     for name, mod in (("g5_au_former", A.AU_former(input_dim=64, emb_dim=32)),
                       ("g6_au_head", A.tformer_AU_head(emb_dim=64)),
+                      ("g15_va_former_eval", A.VA_former(input_dim=64, emb_dim=128)),
                       ("g7_tformer", A.TFormer(16, 64, 2, 8, 128, 32))):
         p, _, _ = split_golden(load_golden(name))
         ref_keys = [k for k, v in p.items()]

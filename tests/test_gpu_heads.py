@@ -202,5 +202,27 @@ def test_former_registry_models_run_a_training_step(name):
     m.get_au_loss(out, y).backward()
     tok = m.base_model if name == "sformer" else m.video_model.s_former
     assert tok.pos_embedding.grad is not None and torch.isfinite(tok.pos_embedding.grad).all()
-    g = [p.grad for n, p in m.named_parameters() if "to_qkv" in n]
+    g = [p.grad for n, p in m.named_parameters() if "to_qkv" in n and not n.startswith("va_head.")]  # (VA head: task 'VA' only)
     assert g and all(t is not None and torch.isfinite(t).all() and float(t.abs().sum()) > 0 for t in g)
+
+
+def test_sformer_va_task_runs_va_former():
+    """registry entry ``sformer`` with task='VA' (sformer.py:358, 378-380): the last two columns of the [B,21] row come from
+    ``VA_former`` on the frame feature; the CCC loss of get_va_loss reaches its stack and the token section"""
+    import avformer_amd as A
+    torch.manual_seed(0)
+    m = A.models.build_model("sformer", task="VA").cuda()
+    B = 4
+    x = {"clip": torch.randn(B, 256, 7, 7, device="cuda")}
+    out = m(x)
+    assert out.shape == (B, 21) and torch.isfinite(out).all()
+    m.eval()                                                  # (dropout 0.2 is live in train mode: compare in eval mode)
+    out = m(x)
+    va, _ = m.va_head(m.base_model(x["clip"]))
+    assert torch.equal(out[:, 19:21], va.to(out.dtype))
+    m.train()
+    y = torch.rand(B, 2, device="cuda") * 2 - 1
+    m.get_va_loss(m(x), y).backward()
+    g = [p.grad for n, p in m.named_parameters() if n.startswith("va_head.") and "to_qkv" in n]
+    assert g and all(t is not None and torch.isfinite(t).all() and float(t.abs().sum()) > 0 for t in g)
+    assert m.base_model.pos_embedding.grad is not None

@@ -248,6 +248,37 @@ def test_au_former_golden_f32():
         _close(got[k].grad, v, atol=2e-6, rtol=2e-3)
 
 
+@pytest.mark.parametrize("tag", ["eval", "train"])
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_va_former_golden(tag, mode):
+    """G15: VA_former (reference models/heads.py:341-372) through the HIP path - the 2-token front (BatchNorm1d with running /
+    batch statistics, two projections as one GEMM, positional add), the two-layer stack on the small-token kernels, the two
+    per-token dots - against the reference's own outputs and gradients"""
+    import avformer_amd as A
+    p, g, r = split_golden(load_golden(f"g15_va_former_{tag}"))
+    train = bool(int(r["training"]))
+    m = _load_into(A.VA_former(input_dim=int(r["input_dim"]), emb_dim=int(r["emb_dim"]), compute_dtype=mode), p).train(train)
+    x = r["x"].to(DEV).requires_grad_(True)
+    va, tokens = m(x)
+    assert va.shape == (x.shape[0], 2) and tokens.shape == (x.shape[0], 2, int(r["emb_dim"]))
+    if mode == "f32":
+        _close(va, r["y"])
+        _close(tokens, r["y_extra0"])
+        va.float().pow(2).mean().backward()
+        _close(x.grad, r["dx"], atol=1e-6)
+        got = dict(m.named_parameters())
+        for k, v in g.items():
+            _close(got[k].grad, v, atol=2e-6, rtol=2e-3)
+    else:
+        check_rel(f"g15_bf16[{tag}]:va", va, r["y"], 2e-2)
+        check_rel(f"g15_bf16[{tag}]:tokens", tokens, r["y_extra0"], 1.5e-2)
+        va.float().pow(2).mean().backward()
+        check_rel(f"g15_bf16[{tag}]:dx", x.grad, r["dx"], 5e-2)
+        got = dict(m.named_parameters())
+        for k, v in g.items():
+            check_rel(f"g15_bf16[{tag}]:g.{k}", got[k].grad, v, 6e-2)
+
+
 def test_au_head_golden_f32():
     import avformer_amd as A
     p, g, r = split_golden(load_golden("g6_au_head"))

@@ -95,6 +95,18 @@ def test_g5_au_former():
     check_grads(ps, g)
 
 
+@pytest.mark.parametrize("tag", ["eval", "train"])
+def test_g15_va_former(tag):
+    p, g, r = split_golden(load_golden(f"g15_va_former_{tag}"))
+    train = bool(int(r["training"]))
+    x, ps, (va, tokens) = run_with_grads(lambda x, ps: oracle.va_former_forward(x, ps, training=train), r["x"], p)
+    close(va, r["y"])
+    close(tokens, r["y_extra0"])
+    va.pow(2).mean().backward()
+    close(x.grad, r["dx"])
+    check_grads(ps, g)
+
+
 def test_g6_au_head():
     p, g, r = split_golden(load_golden("g6_au_head"))
     x, ps, y = run_with_grads(lambda x, ps: oracle.au_head_forward(x, ps), r["x"], p)
