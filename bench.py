@@ -161,6 +161,7 @@ class Region:
 
     def __init__(self, A, torch, dist, name, dtype, args, dev, rank, world, use_dist):
         self.A, self.torch, self.dist, self.use_dist, self.world, self.dtype = A, torch, dist, use_dist, world, dtype
+        self.rank = rank
         c = dict(CONFIGS[name])
         if args.batch and name == args.config:
             c["batch"] = args.batch
@@ -260,6 +261,27 @@ class Region:
         run = self.step
         self.launch = "eager"
         self.eager_ms = None
+        # graph == "auto_dp" (the multi-rank default, --launch auto): FIRST the K eager steps, timed like any region - a valid
+        # measurement whatever happens next; THEN the captured step is attempted under a watchdog.  It becomes `value` only if
+        # every rank captured, the first replay's loss is finite, the same on every rank and within 10 % of the last eager
+        # loss; otherwise the eager measurement stands.  A replay that never returns (a multi-rank capture has never run on
+        # this build's hardware) is ended by the watchdog: rank 0 prints the eager line, every rank exits - nothing re-execs.
+        auto_dp = graph == "auto_dp"
+        eager_dt = None
+        watchdog = None
+        if auto_dp:
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss = self.step()
+            self.fence()
+            te = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=self.dev)
+            if self.use_dist:
+                self.dist.all_reduce(te, op=self.dist.ReduceOp.MAX)
+            eager_dt = te.item()
+            self.eager_ms = eager_dt / steps * 1e3
+            eager_loss = float(loss.item())
+            watchdog = self._arm_watchdog(float(os.environ.get("AVF_BENCH_GRAPH_WATCHDOG_S", "90")), steps)
+            graph, eager_too = True, False
         if graph and eager_too:
             # the same K steps launched from Python, timed the same way: reported beside the graph-replay number so that the
             # N = 1 line can be compared like for like with lines that cannot replay a graph
@@ -295,7 +317,22 @@ class Region:
             ok = torch.tensor([0.0 if err else 1.0], device=self.dev)
             if self.use_dist:
                 self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN)
-            if ok.item() > 0.5:
+            why = None if ok.item() > 0.5 else f"graph capture failed: {err or 'on another rank'}"
+            if why is None and auto_dp:
+                # validate the first replay before trusting it with `value`
+                gr.replay()
+                self.fence()
+                lv = static_loss.detach().float().reshape(1).clone()
+                lo, hi = lv.clone(), lv.clone()
+                if self.use_dist:
+                    self.dist.all_reduce(lo, op=self.dist.ReduceOp.MIN)
+                    self.dist.all_reduce(hi, op=self.dist.ReduceOp.MAX)
+                l0, l1 = float(lo.item()), float(hi.item())
+                good = (l0 == l0 and l1 == l1 and abs(l1 - l0) <= 1e-6 * max(1.0, abs(l1))
+                        and abs(l1 - eager_loss) <= 0.1 * max(abs(eager_loss), 1e-3))
+                if not good:
+                    why = f"first replayed loss {l0:.6g}..{l1:.6g} over the ranks against the eager loss {eager_loss:.6g}"
+            if why is None:
                 run = lambda: (gr.replay(), static_loss)[1]
                 for _ in range(3):
                     run()
@@ -303,10 +340,20 @@ class Region:
                 self.launch = "hipGraph replay" + (" (RCCL all-reduces captured)" if self.dp is not None else "")
             else:
                 run = self.step
-                self.launch = f"eager (graph capture failed: {err or 'on another rank'})"
+                self.launch = f"eager ({why})"
                 for _ in range(2):
                     self.step()
                 self.fence()
+        if watchdog is not None and run is self.step:
+            # the attempt fell back to eager launches: the eager region timed above IS the measurement
+            watchdog.cancel()
+            self.steps, self.ms = steps, eager_dt / steps * 1e3
+            self.clips_per_s = self.B * self.world * steps / eager_dt
+            self.loss = eager_loss
+            self._run = run
+            self._finish_timed()
+            self.fwd_bwd_ms = None
+            return
         t0 = time.perf_counter()
         for _ in range(steps):
             loss = run()
@@ -316,6 +363,8 @@ class Region:
         if self.use_dist:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         dt = t.item()
+        if watchdog is not None:
+            watchdog.cancel()
         # forward + loss + backward (+ the gradient all-reduces) alone - what the metric names; the step above also clears the
         # gradients and applies Adam.  Eager launches, same fences (the step is GPU-bound either way: `eager_ms_per_step`).
         self.fwd_bwd_ms = None
@@ -345,11 +394,37 @@ class Region:
         self.ms = dt / steps * 1e3
         self.clips_per_s = self.B * self.world * steps / dt
         self.loss = float(loss.item())
+        self._finish_timed()
+
+    def _finish_timed(self):
         self.tflops = 3.0 * stack_flops_fwd(self.c, self.B) / (self.ms * 1e-3) / 1e12
         self.peak = MFMA_PEAK_TFLOPS[self.dtype]
         if self.dtype == "f32" and self.A._lib.get_f32_arithmetic() == "bf16x3":
             self.peak = MFMA_PEAK_TFLOPS["bf16"] / 3.0  # three bf16 MFMA products per fp32 product
         self.frac = self.tflops / self.peak
+
+    def _arm_watchdog(self, seconds, steps):
+        """A timer thread for the multi-rank graph attempt: if capture / validation / the replayed region has not finished after
+        `seconds`, the replay is taken for hung (a collective waiting for a peer that will never issue it).  The eager
+        measurement taken before the attempt is then the result: rank 0 prints the contract's line from it (self.hang_line,
+        set by main()), every rank leaves with os._exit - no re-exec, no second attempt."""
+        import threading
+
+        def fire():
+            try:
+                if self.rank == 0 and getattr(self, "hang_line", None) is not None:
+                    line = self.hang_line(self.eager_ms, steps)
+                    os.write(_REAL_STDOUT, (json.dumps(line) + "\n").encode())
+                sys.stderr.write(f"bench.py rank {self.rank}: graph replay did not finish within {seconds:.0f} s - "
+                                 f"reported the eager measurement, leaving\n")
+                sys.stderr.flush()
+            finally:
+                os._exit(0 if getattr(self, "hang_line", None) is not None or self.rank != 0 else 3)
+
+        t = threading.Timer(seconds, fire)
+        t.daemon = True
+        t.start()
+        return t
 
     def clock_power(self, seconds=1.5):
         """Shader clock and package power while the timed step keeps running (rocm-smi sampled from a thread, AFTER the timed
@@ -428,10 +503,13 @@ def dp_report(torch, dist, region, dev, world):
         raise SystemExit(f"bench.py: a rank saw {seen} ranks in the process group, expected {world}")
     dp = region.dp
     dp.stats_reset()
-    region.step()
+    region.step()  # ONE EAGER step: bucket_bytes is published by the wrapper's Python finish(), which a graph replay bypasses
     torch.cuda.synchronize()
     st = dp.stats()
     sizes = st["bucket_bytes"]
+    if not (len(sizes) == st["collectives"] > 0):
+        raise SystemExit(f"bench.py: the data-parallel step published {len(sizes)} bucket sizes for {st['collectives']} "
+                         f"collectives - the step did not go through DataParallel.finish()")
     bufs = [torch.zeros(max(1, b // 4), device=dev) for b in sizes]
     for b in bufs:
         dist.all_reduce(b)
@@ -543,7 +621,25 @@ def main():
     dp_graph_env = os.environ.get("AVF_BENCH_DP_GRAPH", "")
     dp_graph_ok = (dp_graph_env != "0") if world == 1 else (dp_graph_env == "1" or args.launch == "graph")
     use_graph = ((args.graph or args.launch in ("auto", "graph")) and args.launch != "eager" and (not use_dist or dp_graph_ok))
-    main_r.timed(args.steps, args.warmup, use_graph)
+    # --launch auto with more than one rank: eager steps first (the safe measurement), then the captured step under a watchdog
+    # and only if its first replay validates (Region.timed, "auto_dp"); the other regions of a multi-rank run stay eager
+    main_graph = use_graph
+    # (AVF_BENCH_AUTO_DP=1: take that path with ONE rank too - with AVF_BENCH_FORCE_DP=1 the rehearsal of its success branch on a
+    # one-GPU box: eager region, capture with the 1-rank RCCL all-reduces, validated first replay, replayed region)
+    if (use_dist and (world > 1 or os.environ.get("AVF_BENCH_AUTO_DP") == "1") and args.launch == "auto" and not args.graph
+            and dp_graph_env not in ("0", "1")):
+        main_graph = "auto_dp"
+        B0, c0 = main_r.B, main_r.c
+        main_r.hang_line = lambda ms, k: {
+            "metric": "clips/sec (fwd+bwd) on synthetic (B,T,d) AV sequences", "value": round(B0 * world / (ms * 1e-3), 2),
+            "unit": "clips/s", "n_gpus": world, "steps": k, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[{'1' if args.config == 'c2' else args.config}]: avformer transformer "
+                                   f"stack d={c0['dim']} L={c0['depth']}, B={B0}/GPU", "global_batch": B0 * world,
+                       "seq_len": c0["t_video"] + c0["t_audio"], "parallelism": f"dp{world}"},
+            "launch": "eager (the captured data-parallel step did not return: watchdog; this is the eager region timed before the attempt)",
+            "roofline": None, "cpu_baseline": None}
+    main_r.timed(args.steps, args.warmup, main_graph)
     main_clock = main_r.clock_power() if (world == 1 and not args.no_extra) else None
     c, B = main_r.c, main_r.B
     Tv, Ta = c["t_video"], c["t_audio"]

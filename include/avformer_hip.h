@@ -341,9 +341,16 @@ int avf_adam_step_tensors(int count, float* const* p, const float* const* g, flo
  * on the calling thread, avf_layer_adam_step / avf_stack_adam_step / avf_adam_step_tensors append to one descriptor table
  * instead of launching; the table is launched when it is full (143 tensors), when the hyper-parameters, the step pointer or the
  * stream of a call differ from the pending ones, and by _end.  The reference's real model has five small stacks and a dozen
- * loose tensors: one launch instead of six.  Every pointer handed over must stay valid until _end returns. */
+ * loose tensors: one launch instead of six.  Every pointer handed over must stay valid until _end returns.
+ * The session is THREAD-LOCAL: _begin, every step call and _end / _abort must come from the same thread, with the same device
+ * current (the table is launched on the stream of the calls it collected).  _abort closes the session without launching the
+ * pending table (the caller failed while collecting the step); tables that were already launched stay launched.
+ * The table is a ~12.6 KB by-value kernel argument: avf_selftest_adam_table() launches a full one (143 descriptors, one element
+ * each) and checks every element - run it once per process where kernel arguments above 4 KB are in doubt. */
 int avf_adam_batch_begin(void);
 int avf_adam_batch_end(void);
+int avf_adam_batch_abort(void);
+int avf_selftest_adam_table(void* stream);
 
 /* x_out = layer(x_in); x_in, x_out [B*N, D] (may not alias): fp32, or bf16 when cfg.resid_bf16 is set. */
 int avf_layer_fwd(const avf_layer_cfg* cfg, const avf_layer_params* p, const void* lowp, const void* x_in,

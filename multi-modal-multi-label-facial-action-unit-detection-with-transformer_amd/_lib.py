@@ -114,6 +114,8 @@ SIGNATURES = {
     "avf_adam_step_tensors": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _vp, _vp]),
     "avf_adam_batch_begin": (_int, []),
     "avf_adam_batch_end": (_int, []),
+    "avf_adam_batch_abort": (_int, []),
+    "avf_selftest_adam_table": (_int, [_vp]),
     "avf_dropout_factors": (_int, [C.c_uint32, C.c_uint32, _int, _int, _f, _i64, _int, _vp, _vp]),
     "avf_timing_enable": (_int, [_int]),
     "avf_timing_read": (_int, [_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),

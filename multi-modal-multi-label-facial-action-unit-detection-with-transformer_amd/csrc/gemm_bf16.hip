@@ -155,8 +155,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(NtParam
   // of B in all eight L2s (tools/diag/fresh_operand.py: 15.2 -> 21.2 us at K = 1024, 20.0 -> 30.2 at K = 1536 with nothing but
   // the 1 - 1.5 MB weight out of cache).  So the workgroups dealt to one XCD (ids congruent mod 8 - a speed assumption only)
   // split B between them and request ALL of it once, up front: one dword per 128-byte line, the value never used.  The
-  // destination registers stay live until after the K loop (the loads return in order: they are retired by the first counted
-  // wait, but hipcc cannot see that and must not re-use the registers while they are in flight).
+  // loads are PLAIN C++ loads (round 6; rounds 4-5 issued them through inline asm into "+v" registers, whose flight the
+  // compiler's wait-count and liveness tracking could not see): hipcc owns the destination registers for the whole flight, the
+  // empty asm after the K loop is the values' only use (hipcc puts an s_waitcnt vmcnt(0) in front of it, free there), and the
+  // "memory" clobbers of the LDS-DMA statements keep the loads in front of the K loop.  They return in order, so the loop's own
+  // counted waits (which count the DMA instructions issued AFTER them) retire them first, as before.
   constexpr int WPF = 2;
   uint32_t wpf_sink[WPF];
 #pragma unroll
@@ -172,10 +175,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_nt_glds_kernel(NtParam
       const int ln = lo + tid + i * NW * 64;
       if (ln < hi) {
         const bf16* src = p.B + (int64_t)ln * 64;
-        asm volatile("global_load_dword %0, %1, off" : "+v"(wpf_sink[i]) : "v"(src) : "memory");
+        wpf_sink[i] = *reinterpret_cast<const uint32_t*>(src);
       }
     }
   }
+  asm volatile("" ::: "memory");  // nothing of the warm-up moves below this point
 
   f32x4_t acc[MI][NI];
 #pragma unroll

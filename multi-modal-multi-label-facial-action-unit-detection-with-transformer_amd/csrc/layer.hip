@@ -58,6 +58,10 @@ int make_dims(const avf_layer_cfg* c, Dims* d) {
   AVF_REQUIRE(c->dropout_p >= 0.0f && c->dropout_p < 1.0f, "layer: dropout_p=%g out of range", (double)c->dropout_p);
   AVF_REQUIRE(c->dropout_p == 0.0f || (c->dim % 4 == 0 && c->dim <= 1536 && c->mlp_dim % 4 == 0),
               "layer: dropout needs dim %% 4 == 0, dim <= 1536");
+  // the masks compare 16-bit uniforms with round(p * 65536): a p that rounds to 0 would leave "dropout_p > 0" (which selects the
+  // masked gradient images of the bf16 streams) and the kernels' own predicate (thresh16 != 0) in disagreement - refuse it
+  AVF_REQUIRE(c->dropout_p == 0.0f || make_drop(c->dropout_p, 0, 0, 0).thresh16 != 0,
+              "layer: dropout_p=%g is below the mask resolution (2^-17): pass 0", (double)c->dropout_p);
   // nn.Identity to_out (heads == 1 && dim_head == dim, heads.py:207; never instantiated by the reference): the caller passes the
   // identity matrix as w_out and zeros as b_out (x 1.0 and + 0.0 are exact in fp32 and in bf16 with fp32 accumulation, so the
   // projection GEMM returns the attention output bit for bit) and the library drops the dropout site that nn.Identity lacks

@@ -298,6 +298,17 @@ extern "C" int avf_adam_batch_end(void) {
   return adam_flush(g_adam_pending);
 }
 
+// close the session WITHOUT launching what is pending (the caller failed half-way through collecting the step: a table that
+// holds part of the model must not run).  Tables already launched - full ones, or flushed by a change of hyper-parameters -
+// stay launched.  No-op when no session is open.
+extern "C" int avf_adam_batch_abort(void) {
+  using namespace avf;
+  g_adam_pending.active = false;
+  g_adam_pending.n = 0;
+  g_adam_pending.tiles = 0;
+  return 0;
+}
+
 extern "C" int avf_stack_adam_step(const avf_layer_cfg* cfg, int layers, const avf_layer_params* p, const avf_layer_grads* g,
                                    const avf_layer_grads* exp_avg, const avf_layer_grads* exp_avg_sq, void* const* lowp,
                                    float lr, float beta1, float beta2, float eps, float weight_decay, const float* step,
@@ -351,5 +362,32 @@ extern "C" int avf_adam_step_tensors(int count, float* const* p, const float* co
     P.tiles += (int)((numel[i] + 4095) / 4096);
   }
   if (&P == &local) AVF_TRY(adam_flush(P));
+  return 0;
+}
+
+// A full descriptor table (ADAM_MAX one-element tensors) through the real kernel, every element checked on the host: the
+// table is a ~12.6 KB by-value kernel argument, which this ROCm stack takes (tools/diag/kernarg_probe.hip) - a runtime that
+// truncated it would update only the first tensors.  Allocates and frees its own scratch; synchronises the stream.
+extern "C" int avf_selftest_adam_table(void* stream) {
+  using namespace avf;
+  AVF_REQUIRE(!g_adam_pending.active, "selftest_adam_table: a batch is open on this thread");
+  hipStream_t s = (hipStream_t)stream;
+  constexpr int n = ADAM_MAX;
+  float* buf = nullptr;  // p | g | m | v | step
+  AVF_REQUIRE(hipMalloc((void**)&buf, (4 * n + 1) * sizeof(float)) == hipSuccess, "selftest_adam_table: hipMalloc failed");
+  float host[4 * n + 1];
+  for (int i = 0; i < n; ++i) { host[i] = 1.0f + i; host[n + i] = 1.0f; host[2 * n + i] = 0.f; host[3 * n + i] = 0.f; }
+  host[4 * n] = 1.0f;
+  int rc = hipMemcpyAsync(buf, host, sizeof(host), hipMemcpyHostToDevice, s) == hipSuccess ? 0 : 1;
+  float* p[n]; const float* g[n]; float* m[n]; float* v[n]; int64_t numel[n];
+  for (int i = 0; i < n; ++i) { p[i] = buf + i; g[i] = buf + n + i; m[i] = buf + 2 * n + i; v[i] = buf + 3 * n + i; numel[i] = 1; }
+  if (!rc) rc = avf_adam_step_tensors(n, p, g, m, v, numel, 0.5f, 0.9f, 0.999f, 0.f, 0.f, buf + 4 * n, stream);
+  if (!rc) rc = hipMemcpyAsync(host, buf, n * sizeof(float), hipMemcpyDeviceToHost, s) == hipSuccess ? 0 : 1;
+  if (!rc) rc = hipStreamSynchronize(s) == hipSuccess ? 0 : 1;
+  (void)hipFree(buf);
+  AVF_REQUIRE(rc == 0, "selftest_adam_table: launch or copy failed");
+  // first step, g = 1, eps = 0: m_hat / sqrt(v_hat) = 1, so every p moved by exactly lr
+  for (int i = 0; i < n; ++i)
+    AVF_REQUIRE(fabsf(host[i] - (0.5f + i)) < 1e-4f, "selftest_adam_table: tensor %d of %d not updated (%g)", i, n, (double)host[i]);
   return 0;
 }

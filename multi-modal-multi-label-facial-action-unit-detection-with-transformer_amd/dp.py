@@ -141,7 +141,10 @@ class DataParallel:
         self._step_bytes = []
 
     def stats(self):
-        """collectives issued since stats_reset(): gradient all-reduces (count, bytes of each) and loss reductions"""
+        """``collectives`` / ``loss_collectives`` / ``bytes_total``: counters since stats_reset().  ``bucket_bytes``: the sizes of
+        the gradient collectives of the LAST step that went through ``finish()`` - empty until one has, and unchanged by steps
+        that bypass the Python ``finish()`` (a replayed hipGraph issues the same collectives without touching this object).
+        A caller that sizes something from it must have run one eager step since stats_reset() (bench.py::dp_report asserts)."""
         return {k: (list(v) if isinstance(v, list) else v) for k, v in self._stats.items()}
 
     def _launch(self, flat: torch.Tensor):

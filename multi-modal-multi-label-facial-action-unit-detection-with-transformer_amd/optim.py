@@ -91,16 +91,22 @@ class FusedAdam(torch.optim.Optimizer):
             raise RuntimeError("FusedAdam: the model must be on the GPU (no CPU fallback)")
         if self._step_dev is None or self._step_dev.device != dev:
             self._step_dev = torch.full((1,), getattr(self, "_loaded_step", 0.0), dtype=torch.float32, device=dev)
-        self._step_dev.add_(1.0)  # device-side counter: the kernels read it at run time (graph-capturable)
         # every stack and every loose tensor of this step in ONE descriptor table (avf_adam_batch_begin / _end): the per-stack
-        # launches of the reference's real model (five small stacks + the head's tensors) were 80 us of a 650 us step
-        _lib.check(lib.avf_adam_batch_begin(), "adam_batch_begin")
-        keep = None
-        try:
-            keep = self._step_body(lib, hip_group, dev)  # (converted gradients: alive until the table has been launched)
-        finally:
+        # launches of the reference's real model (five small stacks + the head's tensors) were 80 us of a 650 us step.
+        # The whole session runs with the model's device current (the table is launched by _end, which must see the device its
+        # pointers live on), and a failure while the table is being collected ABORTS the session: a half-built table is never
+        # launched, the step counter is not advanced, and the original exception propagates.
+        with torch.cuda.device(dev):
+            _lib.check(lib.avf_adam_batch_begin(), "adam_batch_begin")
+            self._step_dev.add_(1.0)  # device-side counter: the kernels read it at run time (graph-capturable)
+            try:
+                keep = self._step_body(lib, hip_group, dev)  # (converted gradients: alive until the table has been launched)
+            except BaseException:
+                lib.avf_adam_batch_abort()
+                self._step_dev.sub_(1.0)
+                raise
             _lib.check(lib.avf_adam_batch_end(), "adam_batch_end")
-        del keep
+            del keep
         return loss
 
     def _step_body(self, lib, hip_group, dev):

@@ -25,11 +25,10 @@ def dgelu(u):
     return u.grad.float()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--cases", type=int, default=300)
-    ap.add_argument("--seed", type=int, default=0)
-    args = ap.parse_args()
+def run(cases=300, seed=0):
+    """`cases` random NT GEMM cases from `seed`; returns worst error / tolerance, raises AssertionError on the first failing case
+    (tests/test_gpu_fuzz.py runs a fixed budget of these under pytest -m gpu)"""
+    args = argparse.Namespace(cases=cases, seed=seed)
     rnd = random.Random(args.seed)
     ops = A.ops
     worst = 0.0
@@ -90,9 +89,20 @@ def main():
                 deq = oracle.mx8_dequant(outs[2], outs[3])
                 ok = ok and (deq - c).abs().max().item() / scale < 0.13  # 2^-4 rounding, 12 % in the saturating corner (449..511 -> 448)
         worst = max(worst, err / tol)
-        if not ok:
-            print(f"FAIL case {case}: mx={mx} M={M} N={N} K={K} epi={epi} out={od} err={err:.3g} tol={tol}")
-            sys.exit(1)
+        assert ok, f"FAIL case {case} (seed {args.seed}): mx={mx} M={M} N={N} K={K} epi={epi} out={od} err={err:.3g} tol={tol}"
+    return worst
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=300)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    try:
+        worst = run(args.cases, args.seed)
+    except AssertionError as e:
+        print(e)
+        sys.exit(1)
     print(f"{args.cases} cases ok; worst error / tolerance = {worst:.2f}")
 
 

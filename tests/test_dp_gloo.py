@@ -114,6 +114,70 @@ def test_dp_two_ranks_match_single_process(bucket_layers):
         assert ncoll == (3 if bucket_layers == 1 else 2), ncoll
 
 
+def _worker_byte_rule(rank, world, port, out, depth, layers_per_bucket_bytes):
+    """the byte rule of the bucket merger on a `depth`-layer stack: bucket_bytes = layers_per_bucket_bytes x (one layer's bytes)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100)
+
+        class Deep(TinyModel):
+            def __init__(self):
+                torch.nn.Module.__init__(self)
+                self.pos = torch.nn.Parameter(torch.randn(1, 6, D) * 0.1)
+                self.stack = OracleStack(D, depth, H, DH, M)
+                self.fc = torch.nn.Linear(D, 12)
+
+        model = Deep()
+        layer_bytes = 4 * sum(p.numel() for p in model.stack.layer_parameters(0))
+        dp = A.dp.DataParallel(model, bucket_bytes=int(layers_per_bucket_bytes * layer_bytes))
+        launched = []
+        real_launch = dp._launch
+        dp._launch = lambda t: (launched.append(t.numel() * 4), real_launch(t))[1]
+        g = torch.Generator().manual_seed(7)
+        x = torch.randn(8, 6, D, generator=g)
+        y = (torch.rand(8, 12, generator=g) > 0.5).float()
+        ref = Deep()
+        ref.load_state_dict(model.state_dict())
+        oracle.au_loss(ref(x), y).backward()
+        sl = slice(rank * 4, rank * 4 + 4)
+        oracle.au_loss(model(x[sl]), y[sl]).backward()
+        model.stack.emulate_backward_hooks()
+        dp.finish()
+        worst = max((p.grad - q.grad).abs().max().item() / (q.grad.abs().max().item() + 1e-12)
+                    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()))
+        out.put((rank, worst, launched, layer_bytes))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("depth,ratio,expect_layers", [
+    (3, 0.85, [1, 1, 1]),     # BASELINE config 4's case: one layer (18.9 MB at d = 768) EXCEEDS the 16 MiB rule -> one collective per layer
+    (4, 1.9, [2, 2]),         # configs 2 / 3 / 5: two layers of 8.4 MB per 16 MiB bucket
+    (5, 1.9, [2, 2, 1]),      # an odd layer count: the bottom layer (layer 0) flushes what is held
+    (3, 100.0, [3]),          # a whole small stack (the 12-token heads) in one collective
+])
+def test_dp_bucket_byte_rule(depth, ratio, expect_layers):
+    """the merger's byte rule (dp.DataParallel, bucket_bytes): which layers share a collective when a layer is larger than the
+    rule (C4), when two fit (C2 / C3 / C5), with a remainder, and when the whole stack fits - and the averaged gradients equal the
+    single-process ones in every case"""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_byte_rule, args=(r, 2, port, out, depth, ratio)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, worst, launched, layer_bytes in res:
+        assert worst < 1e-5, (rank, worst)
+        stack_colls, rest = launched[:-1], launched[-1]      # the last collective carries the parameters outside the stack
+        assert [b // layer_bytes for b in stack_colls] == expect_layers and all(b % layer_bytes == 0 for b in stack_colls), launched
+        assert 0 < rest < layer_bytes
+
+
 class OracleAULoss(torch.nn.Module):
     """CPU stand-in for loss.AULoss with the same data-parallel protocol: when the wrapper has set ``global_mean`` it hands
     over (sum over kept rows of the row mean, kept rows) instead of dividing locally"""

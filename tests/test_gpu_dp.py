@@ -227,4 +227,29 @@ def test_bench_two_rank_control_flow_rehearsal_on_one_gpu():
     dp = d["data_parallel"]
     assert dp["rccl_ranks"] == 2 and dp["gradient_collectives_per_step"] >= 2 and dp["loss_collectives_per_step"] == 1
     assert sum(dp["bucket_bytes"]) == dp["gradient_bytes_per_step"] > 50_000_000  # 12.6 M stack parameters + the head, fp32
-    assert d["launch"].startswith("eager") and d["value"] > 0
+    # --launch auto with two ranks: the eager region is timed first, then the captured step is ATTEMPTED; gloo's collectives
+    # cannot be recorded into a hipGraph, so the attempt must fail cleanly on both ranks and the eager measurement stand
+    assert d["launch"].startswith("eager (graph capture failed") and d["value"] > 0
+    assert d["eager_ms_per_step"] is not None and abs(d["eager_ms_per_step"] - d["ms_per_step"]) < 1e-6
+
+
+def test_bench_launch_auto_success_branch_on_one_rank_rccl():
+    """the multi-rank default launch mode (--launch auto: eager region first, then the captured data-parallel step under a
+    watchdog, adopted only if its first replay validates against the eager loss) with its SUCCESS branch forced on one rank:
+    process group over RCCL with world size 1, all-reduces captured into the hipGraph, `value` from the replayed region and
+    the eager region's number beside it"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AVF_BENCH_FORCE_DP="1", AVF_BENCH_AUTO_DP="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT="29533")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
+                        "--no-kernel-events", "--no-extra"], capture_output=True, text=True, env=env, cwd=root, timeout=500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["launch"].startswith("hipGraph replay"), d["launch"]
+    assert d["eager_ms_per_step"] is not None and d["ms_per_step"] > 0 and d["data_parallel"]["rccl_ranks"] == 1

@@ -133,3 +133,12 @@ def test_avformer_model_trains_with_its_reference_dropout():
     loss.backward()
     assert torch.isfinite(loss)
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+def test_dropout_p_below_mask_resolution_is_refused():
+    """0 < p < 2^-17 rounds to a dead mask (thresh16 == 0) while still selecting the live-dropout buffers: the library refuses
+    the configuration instead of running with the two predicates in disagreement"""
+    import avformer_amd as A
+    t = A.Transformer(128, 1, 8, 32, 256, dropout=1e-6).cuda().train()
+    with pytest.raises(RuntimeError, match="below the mask resolution"):
+        t(torch.randn(2, 12, 128, device="cuda"))

@@ -234,3 +234,34 @@ def test_inplace_weight_edit_after_fused_step_is_not_ignored():
     with torch.no_grad():
         y_fresh = ma(batch)
     assert torch.equal(y_zeroed, y_fresh)
+
+
+def test_adam_descriptor_table_selftest_and_abort():
+    """the ~12.6 KB by-value descriptor table reaches the kernel whole (143 one-element tensors, each checked), and an aborted
+    session launches nothing: avf_adam_batch_abort leaves parameters untouched and a later session works"""
+    import ctypes as C
+    import avformer_amd as A
+    from avformer_amd import _lib
+    lib = _lib.load()
+    _lib.check(lib.avf_selftest_adam_table(C.c_void_p(torch.cuda.current_stream().cuda_stream)), "selftest_adam_table")
+    torch.manual_seed(0)
+    t = A.Transformer(128, 1, 8, 32, 256).cuda()
+    opt = A.optim.FusedAdam(t, lr=1e-2)
+    x = torch.randn(2, 12, 128, device="cuda")
+    t(x).float().pow(2).mean().backward()
+    before = [p.detach().clone() for p in t.parameters()]
+    step_before = None if opt._step_dev is None else float(opt._step_dev)
+    orig = opt._step_body
+    def boom(*a, **k):
+        orig(*a, **k)              # the table has been collected ...
+        raise RuntimeError("boom")  # ... and the caller fails before _end
+    opt._step_body = boom
+    with pytest.raises(RuntimeError, match="boom"):
+        opt.step()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, p.detach()) for a, p in zip(before, t.parameters())), "an aborted session launched its table"
+    assert float(opt._step_dev) == (0.0 if step_before is None else step_before)
+    opt._step_body = orig
+    opt.step()                     # the session machinery is usable again
+    torch.cuda.synchronize()
+    assert any(not torch.equal(a, p.detach()) for a, p in zip(before, t.parameters()))

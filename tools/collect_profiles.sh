@@ -10,6 +10,11 @@ TAG=${1:-r05}
 R=$PWD
 O=$R/gpurun_out/final
 mkdir -p $O
+# the plain bench line of THIS box first (no profiler attached), stored beside the tables: profiles/<tag>_bench_line_same_box.json,
+# so that roofline.frac of the line and the fractions of the rocprof tables can be compared on one box (boxes of the pool differ
+# by up to 12 % in what their power management allows)
+( cd $R && AVF_BENCH_SETTLE_S= python bench.py --no-cpu-baseline > $O/bench_line_same_box.json 2> $O/bench_line_same_box.err && cp $O/bench_line_same_box.json profiles/${TAG}_bench_line_same_box.json ) || echo "bench line of this box: FAILED (see $O/bench_line_same_box.err)"
+echo "bench line of this box done"
 cd /tmp
 export TMPDIR=/tmp
 # every traced pass runs WITHOUT the per-dispatch event pass (--no-kernel-events): a third of the launches averaged in the
