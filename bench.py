@@ -296,22 +296,43 @@ class Region:
             # of host time per 2.3 ms step; under data parallelism 1.7-2.65 ms).  The collectives are stream operations of
             # torch's process group and are recorded like kernels.
             err = None
+            side = torch.cuda.Stream()
+            cap = torch.cuda.Stream()          # the capture stream (ours, so that a failed capture can be closed by hand)
+            home = torch.cuda.current_stream()
+            backend = str(self.dist.get_backend()).lower() if self.use_dist else "none"
             try:
+                if self.use_dist and backend != "nccl":
+                    # only RCCL's collectives are stream operations that a hipGraph can record (gloo synchronises the host)
+                    raise RuntimeError(f"the {backend} backend's collectives cannot be recorded into a hipGraph")
                 if self.opt is not None:
                     for gdict in self.opt.param_groups:
                         gdict["capturable"] = True
                     self.step()
                 gr = torch.cuda.CUDAGraph()
-                side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     self.step()
                 torch.cuda.current_stream().wait_stream(side)
-                with torch.cuda.graph(gr):
+                with torch.cuda.graph(gr, stream=cap):
+                    if os.environ.get("AVF_BENCH_FAIL_CAPTURE") == "1":  # test aid: an operation no capture can record
+                        torch.cuda.synchronize()
                     static_loss = self.step()
             except Exception as e:  # capture is an optimisation of the launch path, never a requirement
                 err = f"{type(e).__name__}: {str(e)[:120]}"
-                torch.cuda.synchronize()
+                # A failed capture can leave three things behind: torch's current stream still pointing at the capture stream
+                # (torch.cuda.graph.__exit__ raises before it restores it), the capture itself still open in the invalidated
+                # state, and the runtime's sticky last-error - each of which would fail the next, unrelated HIP call.
+                import ctypes as _C
+                torch.cuda.set_stream(home)
+                for st in (cap, side, home):
+                    try:
+                        self.A._lib.load().avf_hip_error_reset(_C.c_void_p(st.cuda_stream))
+                    except Exception:
+                        pass
+                try:
+                    torch.cuda.synchronize()
+                except Exception:
+                    self.A._lib.load().avf_hip_error_reset(_C.c_void_p(home.cuda_stream))
             # Recording executes nothing, so the ranks are still in step here.  They must also AGREE on the launch mode before
             # the first replay: a rank that failed to capture would issue eager collectives against its peers' replayed ones.
             ok = torch.tensor([0.0 if err else 1.0], device=self.dev)

@@ -383,6 +383,11 @@ int avf_dropout_factors(uint32_t seed_lo, uint32_t seed_hi, int layer_index, int
 int avf_set_f32_arith(int mode);
 int avf_get_f32_arith(void);
 
+/* After a FAILED hipGraph capture of a step (something that cannot be recorded was issued while `stream` was capturing - e.g. a
+ * host-synchronising collective): ends a capture still open on `stream`, discards its graph and clears the runtime's sticky
+ * last-error so that the caller can continue with eager launches.  Returns the HIP error code that was pending (0: none). */
+int avf_hip_error_reset(void* stream);
+
 /* ---- optional HIP-event timing per kernel class (bench.py's roofline line) --------------------------
  * classes: 0 gemm_bf16_nt, 1 gemm_bf16_tn(+fold), 2 gemm_f32, 3 attn_fwd, 4 attn_bwd, 5 layernorm, 6 other, 7 gemm_mx8_nt.
  * enable(1) resets the records; read() synchronises the recorded events and sums them.  Every class but 2 and 6

@@ -399,6 +399,26 @@ extern "C" int avf_attn_bwd_qs(const void* qkv, const void* o, const void* d_o, 
                        dim_head, (hipStream_t)stream, true, w + (size_t)batch * tokens * heads);
 }
 
+// After a FAILED stream capture (an operation that cannot be recorded was issued while capturing): end a capture that is still
+// open on `stream` (discarding its graph) and clear the runtime's sticky last-error, which would otherwise surface at the
+// caller's next, unrelated HIP call.  Returns the error code that was pending (0: none).
+extern "C" int avf_hip_error_reset(void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
+    hipGraph_t g = nullptr;
+    (void)hipStreamEndCapture(s, &g);
+    if (g) (void)hipGraphDestroy(g);
+  }
+  int first = 0;
+  for (int i = 0; i < 8; ++i) {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) break;
+    if (!first) first = (int)e;
+  }
+  return first;
+}
+
 extern "C" int avf_set_f32_arith(int mode) {
   const int prev = get_f32_arith();
   set_f32_arith(mode);

@@ -242,7 +242,7 @@ def test_bench_launch_auto_success_branch_on_one_rank_rccl():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, AVF_BENCH_FORCE_DP="1", AVF_BENCH_AUTO_DP="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT="29533")
+    env = dict(os.environ, AVF_BENCH_FORCE_DP="1", AVF_BENCH_AUTO_DP="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(_free_tcp_port()))
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
@@ -253,3 +253,36 @@ def test_bench_launch_auto_success_branch_on_one_rank_rccl():
     d = json.loads(lines[0])
     assert d["launch"].startswith("hipGraph replay"), d["launch"]
     assert d["eager_ms_per_step"] is not None and d["ms_per_step"] > 0 and d["data_parallel"]["rccl_ranks"] == 1
+
+
+def test_bench_recovers_from_a_failed_capture():
+    """a capture that fails half-way (AVF_BENCH_FAIL_CAPTURE=1 issues a device synchronisation while the step is being recorded -
+    the kind of error a collective that cannot be recorded raises) must leave the process usable: the current stream restored,
+    the invalidated capture closed, the sticky HIP error cleared (avf_hip_error_reset) - the eager measurement stands and every
+    later part of the run (data-parallel report, other regions) still works"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AVF_BENCH_FORCE_DP="1", AVF_BENCH_AUTO_DP="1", AVF_BENCH_FAIL_CAPTURE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(_free_tcp_port()))
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
+                        "--no-kernel-events", "--no-extra"], capture_output=True, text=True, env=env, cwd=root, timeout=500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["launch"].startswith("eager (graph capture failed"), d["launch"]
+    assert d["value"] > 0 and abs(d["eager_ms_per_step"] - d["ms_per_step"]) < 1e-6
+    assert d["data_parallel"]["rccl_ranks"] == 1 and d["data_parallel"]["gradient_collectives_per_step"] >= 2
+
+
+def _free_tcp_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
