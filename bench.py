@@ -267,6 +267,7 @@ class Region:
         # loss; otherwise the eager measurement stands.  A replay that never returns (a multi-rank capture has never run on
         # this build's hardware) is ended by the watchdog: rank 0 prints the eager line, every rank exits - nothing re-execs.
         auto_dp = graph == "auto_dp"
+        crash_armed = False
         eager_dt = None
         watchdog = None
         if auto_dp:
@@ -280,7 +281,24 @@ class Region:
             eager_dt = te.item()
             self.eager_ms = eager_dt / steps * 1e3
             eager_loss = float(loss.item())
+            del loss  # a live loss keeps the last eager step's autograd graph (its AccumulateGrad nodes, bound to the stream they
+            #           were created on) alive into the capture: torch warns "may break CUDA graph capture" - here it segfaults
+            #           in capture_end
             watchdog = self._arm_watchdog(float(os.environ.get("AVF_BENCH_GRAPH_WATCHDOG_S", "90")), steps)
+            # ... and a crash INSIDE the runtime during the attempt (capture_end / instantiate of a multi-rank graph has never run
+            # on this build's hardware; a stale autograd graph made it segfault on one rank during development) cannot be caught
+            # as an exception: while the attempt runs, a fatal signal writes the eager line (rank 0) and leaves with _exit(0)
+            crash_armed = False
+            try:
+                line = b""
+                if self.rank == 0 and getattr(self, "hang_line", None) is not None:
+                    d = self.hang_line(self.eager_ms, steps)
+                    d["launch"] = "eager (the captured data-parallel step crashed inside the runtime; this is the eager region timed before the attempt)"
+                    line = (json.dumps(d) + "\n").encode()
+                self.A._lib.check(self.A._lib.load().avf_crash_line_arm(line, _REAL_STDOUT if line else -1), "crash_line_arm")
+                crash_armed = True
+            except Exception:
+                pass
             graph, eager_too = True, False
         if graph and eager_too:
             # the same K steps launched from Python, timed the same way: reported beside the graph-replay number so that the
@@ -316,6 +334,9 @@ class Region:
                 with torch.cuda.graph(gr, stream=cap):
                     if os.environ.get("AVF_BENCH_FAIL_CAPTURE") == "1":  # test aid: an operation no capture can record
                         torch.cuda.synchronize()
+                    if os.environ.get("AVF_BENCH_FAIL_CAPTURE") == "segv":  # test aid: the process dies inside the attempt
+                        import signal
+                        os.kill(os.getpid(), signal.SIGSEGV)
                     static_loss = self.step()
             except Exception as e:  # capture is an optimisation of the launch path, never a requirement
                 err = f"{type(e).__name__}: {str(e)[:120]}"
@@ -365,9 +386,12 @@ class Region:
                 for _ in range(2):
                     self.step()
                 self.fence()
-        if watchdog is not None and run is self.step:
+        if auto_dp and crash_armed and run is self.step:
+            self.A._lib.load().avf_crash_line_disarm()
+        if auto_dp and run is self.step:
             # the attempt fell back to eager launches: the eager region timed above IS the measurement
-            watchdog.cancel()
+            if watchdog is not None:
+                watchdog.cancel()
             self.steps, self.ms = steps, eager_dt / steps * 1e3
             self.clips_per_s = self.B * self.world * steps / eager_dt
             self.loss = eager_loss
@@ -386,6 +410,8 @@ class Region:
         dt = t.item()
         if watchdog is not None:
             watchdog.cancel()
+        if auto_dp and crash_armed:
+            self.A._lib.load().avf_crash_line_disarm()
         # forward + loss + backward (+ the gradient all-reduces) alone - what the metric names; the step above also clears the
         # gradients and applies Adam.  Eager launches, same fences (the step is GPU-bound either way: `eager_ms_per_step`).
         self.fwd_bwd_ms = None
@@ -430,6 +456,8 @@ class Region:
         measurement taken before the attempt is then the result: rank 0 prints the contract's line from it (self.hang_line,
         set by main()), every rank leaves with os._exit - no re-exec, no second attempt."""
         import threading
+        if seconds <= 0:   # AVF_BENCH_GRAPH_WATCHDOG_S=0: no watchdog
+            return None
 
         def fire():
             try:

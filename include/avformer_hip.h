@@ -388,6 +388,12 @@ int avf_get_f32_arith(void);
  * last-error so that the caller can continue with eager launches.  Returns the HIP error code that was pending (0: none). */
 int avf_hip_error_reset(void* stream);
 
+/* A last line for a process that may die inside an OPTIONAL step (bench.py's multi-rank hipGraph attempt, which follows a completed
+ * eager measurement): while armed, SIGSEGV / SIGBUS / SIGABRT / SIGFPE / SIGILL write `line` to `fd` (write(2); fd < 0: nothing) and
+ * leave with _exit(0).  _disarm restores the previous handlers.  Process-wide; not for product code paths. */
+int avf_crash_line_arm(const char* line, int fd);
+int avf_crash_line_disarm(void);
+
 /* ---- optional HIP-event timing per kernel class (bench.py's roofline line) --------------------------
  * classes: 0 gemm_bf16_nt, 1 gemm_bf16_tn(+fold), 2 gemm_f32, 3 attn_fwd, 4 attn_bwd, 5 layernorm, 6 other, 7 gemm_mx8_nt.
  * enable(1) resets the records; read() synchronises the recorded events and sums them.  Every class but 2 and 6

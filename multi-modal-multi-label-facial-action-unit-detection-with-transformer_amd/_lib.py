@@ -121,6 +121,8 @@ SIGNATURES = {
     "avf_timing_read": (_int, [_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                C.POINTER(C.c_double)]),
     "avf_hip_error_reset": (_int, [_vp]),
+    "avf_crash_line_arm": (_int, [C.c_char_p, _int]),
+    "avf_crash_line_disarm": (_int, []),
     "avf_set_f32_arith": (_int, [_int]),
     "avf_get_f32_arith": (_int, []),
     "avf_selftest_mfma_bf16": (_int, [_vp, _vp, _vp, _vp]),

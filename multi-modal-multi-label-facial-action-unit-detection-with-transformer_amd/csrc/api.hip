@@ -419,6 +419,50 @@ extern "C" int avf_hip_error_reset(void* stream) {
   return first;
 }
 
+// A last line for a process that may die inside an OPTIONAL step (bench.py: the multi-rank hipGraph attempt that follows a completed
+// eager measurement).  While armed, a fatal signal (SIGSEGV, SIGBUS, SIGABRT, SIGFPE, SIGILL - a crash inside the runtime's capture /
+// instantiate path cannot be caught as an exception) writes `line` to `fd` with write(2) and leaves with _exit(0): the measurement
+// that was already taken is reported, nothing is retried.  fd < 0 or an empty line: just leave.  Disarm restores the handlers.
+#include <signal.h>
+#include <unistd.h>
+namespace {
+char g_crash_line[16384];
+int g_crash_len = 0, g_crash_fd = -1;
+struct sigaction g_crash_old[5];
+const int g_crash_sigs[5] = {SIGSEGV, SIGBUS, SIGABRT, SIGFPE, SIGILL};
+bool g_crash_armed = false;
+void crash_line_handler(int) {
+  if (g_crash_fd >= 0 && g_crash_len > 0) {
+    ssize_t w = write(g_crash_fd, g_crash_line, (size_t)g_crash_len);
+    (void)w;
+  }
+  _exit(0);
+}
+}  // namespace
+extern "C" int avf_crash_line_arm(const char* line, int fd) {
+  AVF_REQUIRE(!g_crash_armed, "crash_line_arm: already armed");
+  const size_t n = line ? strlen(line) : 0;
+  AVF_REQUIRE(n < sizeof(g_crash_line), "crash_line_arm: line too long");
+  if (n) memcpy(g_crash_line, line, n);
+  g_crash_len = (int)n;
+  g_crash_fd = fd;
+  struct sigaction sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.sa_handler = crash_line_handler;
+  sigemptyset(&sa.sa_mask);
+  for (int i = 0; i < 5; ++i) sigaction(g_crash_sigs[i], &sa, &g_crash_old[i]);
+  g_crash_armed = true;
+  return 0;
+}
+extern "C" int avf_crash_line_disarm(void) {
+  if (!g_crash_armed) return 0;
+  for (int i = 0; i < 5; ++i) sigaction(g_crash_sigs[i], &g_crash_old[i], nullptr);
+  g_crash_armed = false;
+  g_crash_len = 0;
+  g_crash_fd = -1;
+  return 0;
+}
+
 extern "C" int avf_set_f32_arith(int mode) {
   const int prev = get_f32_arith();
   set_f32_arith(mode);

@@ -279,6 +279,27 @@ def test_bench_recovers_from_a_failed_capture():
     assert d["data_parallel"]["rccl_ranks"] == 1 and d["data_parallel"]["gradient_collectives_per_step"] >= 2
 
 
+def test_bench_reports_the_eager_measurement_when_the_graph_attempt_crashes():
+    """a crash INSIDE the runtime during the optional graph attempt (AVF_BENCH_FAIL_CAPTURE=segv raises SIGSEGV in the middle of
+    the capture) cannot be handled as an exception: the armed crash line (avf_crash_line_arm) prints the eager measurement taken
+    before the attempt and the process leaves with status 0 - one JSON line, `launch` says what happened"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AVF_BENCH_FORCE_DP="1", AVF_BENCH_AUTO_DP="1", AVF_BENCH_FAIL_CAPTURE="segv",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(_free_tcp_port()))
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
+                        "--no-kernel-events", "--no-extra"], capture_output=True, text=True, env=env, cwd=root, timeout=500)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert "crashed inside the runtime" in d["launch"] and d["value"] > 0 and d["n_gpus"] == 1
+
+
 def _free_tcp_port():
     import socket
     s = socket.socket()

@@ -86,7 +86,8 @@ def test_mask_replay_against_oracle(cfg):
     check_rel(tag + ":eval_y", ye, y_nodrop, caps[0])
 
 
-@pytest.mark.parametrize("cfg", [(3, 77, 128, 2, 8, 32, 256), (2, 100, 64, 3, 2, 16, 96), (4, 12, 128, 2, 8, 32, 256)])
+@pytest.mark.parametrize("cfg", [(3, 77, 128, 2, 8, 32, 256), (2, 100, 64, 3, 2, 16, 96), (4, 12, 128, 2, 8, 32, 256),
+                                 (2, 324, 256, 2, 4, 64, 512)])  # round 6: dim_head 64, 648 rows - the three-product GEMM and attention kernels
 def test_mask_replay_against_oracle_fp32_mode(cfg):
     """the fp32 parity mode with live dropout (round 2): the same counter-based masks ride in the fp32 GEMM epilogues and in
     fp32 masked copies of the two gradients a Linear behind a dropout site sees; replayed through the oracle the whole
