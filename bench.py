@@ -642,6 +642,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     A._lib.load()  # no fallback: fails here if the HIP library is missing
+    if os.environ.get("AVF_F32_ARITH"):  # "bf16x3" (the library's default) / "f32": the parity mode's arithmetic for this run
+        A._lib.set_f32_arithmetic(os.environ["AVF_F32_ARITH"])
     # AVF_BENCH_FORCE_DP=1: take the multi-GPU code path (process group, data-parallel wrapper, barriers) even with one
     # rank - the only way to rehearse it on a one-GPU box
     use_dist = world > 1 or os.environ.get("AVF_BENCH_FORCE_DP") == "1"

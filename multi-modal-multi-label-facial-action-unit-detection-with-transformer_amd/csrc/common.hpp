@@ -503,6 +503,10 @@ struct TnGroupArgs {
 bool gemm_bf16_tn_group_ok(const TnGroupArgs& a);
 size_t gemm_bf16_tn_group_ws(const TnGroupArgs& a);
 int gemm_bf16_tn_group(const TnGroupArgs& a, hipStream_t s, const FoldList* extra_folds = nullptr);
+// the same group for fp32 operands in the parity mode's bf16x3 arithmetic (gemm_f32.hip, round 6): one launch + one fold
+bool gemm_f32x3_tn_group_ok(const TnGroupArgs& a);
+size_t gemm_f32x3_tn_group_ws(const TnGroupArgs& a);
+int gemm_f32x3_tn_group(const TnGroupArgs& a, hipStream_t s);
 
 int attn_fwd_f32(const float* qkv, float* o, float* lse2, int B, int N, int H, int dh, hipStream_t s);
 // fp32-arithmetic attention on fp32 / bf16 storage with the optional token mask keep [B, N] (bytes, 1 = kept; heads.py:225-232)

@@ -276,28 +276,21 @@ struct SplitStage {
   }
 };
 
+// XCD-aware tile order: workgroups go round-robin over the 8 XCDs (each with its own L2) in launch order, so the linear id is
+// remapped to give every XCD a CONTIGUOUS run of tiles - the column tiles of one row panel (which share the A rows) and the
+// neighbouring panels - instead of every eighth tile (cdna_hip_programming.md, T1)
+__device__ __forceinline__ uint32_t xcd_contiguous(uint32_t id, uint32_t total) {
+  const uint32_t xcd = id & 7, q = total >> 3, r = total & 7;
+  return xcd * q + (xcd < r ? xcd : r) + (id >> 3);
+}
+
+// one 128 x 128 tile (bx, by) of C, K range bz (SPLIT): the whole kernel body; lds = 2 x 4 images (64 KB, two workgroups per CU)
 template <bool AKF, bool BKF, int EPI, bool SPLIT>
-__global__ __launch_bounds__(256, 2) void gemm_f32x3_kernel(F32GemmParams p, int vec) {
-  // two buffers of four images (A hi, A lo, B hi, B lo): 64 KB, two workgroups per CU
-  __shared__ __attribute__((aligned(16))) uint16_t lds[2 * 4 * SIMG];
+__device__ __forceinline__ void f32x3_tile(const F32GemmParams& p, int vec, int bx, int by, int bz, uint16_t* lds) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 15, lg = lane >> 4;
-  // XCD-aware tile order: workgroups go round-robin over the 8 XCDs (each with its own L2) in launch order, so the linear id is
-  // remapped to give every XCD a CONTIGUOUS run of tiles - the column tiles of one row panel (which share the A rows) and the
-  // neighbouring panels - instead of every eighth tile (cdna_hip_programming.md, T1)
-  int bx, by, bz;
-  {
-    const uint32_t gx = gridDim.x, gxy = gridDim.x * gridDim.y, total = gxy * gridDim.z;
-    const uint32_t id = blockIdx.x + gx * blockIdx.y + gxy * blockIdx.z;
-    const uint32_t xcd = id & 7, q = total >> 3, r = total & 7;
-    const uint32_t nid = xcd * q + (xcd < r ? xcd : r) + (id >> 3);
-    bz = nid / gxy;
-    const uint32_t rem = nid - bz * gxy;
-    by = rem / gx;
-    bx = rem - by * gx;
-  }
   const int m0 = by * SBM, n0 = bx * SBN;
   const int kbeg = SPLIT ? bz * p.kchunk : 0;
   const int kend = SPLIT ? ((kbeg + p.kchunk) < p.K ? kbeg + p.kchunk : p.K) : p.K;
@@ -428,6 +421,62 @@ __global__ __launch_bounds__(256, 2) void gemm_f32x3_kernel(F32GemmParams p, int
   }
 }
 
+
+template <bool AKF, bool BKF, int EPI, bool SPLIT>
+__global__ __launch_bounds__(256, 2) void gemm_f32x3_kernel(F32GemmParams p, int vec) {
+  __shared__ __attribute__((aligned(16))) uint16_t lds[2 * 4 * SIMG];
+  const uint32_t gx = gridDim.x, gxy = gridDim.x * gridDim.y;
+  const uint32_t nid = xcd_contiguous(blockIdx.x + gx * blockIdx.y + gxy * blockIdx.z, gxy * gridDim.z);
+  const int bz = nid / gxy;
+  const uint32_t rem = nid - bz * gxy;
+  const int by = rem / gx;
+  f32x3_tile<AKF, BKF, EPI, SPLIT>(p, vec, rem - by * gx, by, bz, lds);
+}
+
+// The weight gradients of one layer (up to four C_i[M_i, N_i] = A_i[K, M_i]^T B_i[K, N_i] sharing the token reduction K) as ONE
+// launch: the tiles of all problems in one list, every tile split S ways over K, tiles x S = one round of the chip's workgroup slots.
+// Four separate launches each chose their own split count to fill the chip (10 / 32 / 16 / 16 at C2) and wrote 130 MB of slabs per
+// layer where this writes 34, and each ended in its own under-filled tail and its own fold launch.
+struct F32GroupParams {
+  F32GemmParams p[4];
+  int tile0[5];   // first tile of problem i in the list (tile0[count] = all tiles)
+  int64_t el0[5]; // first C element of problem i in the concatenated fold index space
+  int count, S, vec;
+};
+__global__ __launch_bounds__(256, 2) void gemm_f32x3_group_kernel(F32GroupParams g) {
+  __shared__ __attribute__((aligned(16))) uint16_t lds[2 * 4 * SIMG];
+  const uint32_t tiles = g.tile0[g.count];
+  const uint32_t nid = xcd_contiguous(blockIdx.x, tiles * g.S);
+  const int bz = nid / tiles;
+  const int t = nid - bz * tiles;
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < 4; ++k)
+    if (k < g.count && t >= g.tile0[k]) i = k;
+  const int local = t - g.tile0[i];
+  const int gxi = (g.p[i].N + SBN - 1) / SBN;
+  const int by = local / gxi;
+  f32x3_tile<false, false, AVF_EPI_NONE, true>(g.p[i], g.vec, local - by * gxi, by, bz, lds);
+}
+// C_i = sum over the S slabs of problem i, 16 bytes per thread (every M_i N_i is a multiple of 4)
+__global__ __launch_bounds__(256) void gemm_f32x3_group_fold_kernel(F32GroupParams g) {
+  const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e >= g.el0[g.count]) return;
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < 4; ++k)
+    if (k < g.count && e >= g.el0[k]) i = k;
+  const int64_t le = e - g.el0[i], mn = (int64_t)g.p[i].M * g.p[i].N;
+  const float* sl = g.p[i].slabs + le;
+  float4 v = *reinterpret_cast<const float4*>(sl);
+  for (int z = 1; z < g.S; ++z) {
+    const float4 t = *reinterpret_cast<const float4*>(sl + (int64_t)z * mn);
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  }
+  const int m = (int)(le / g.p[i].N), n = (int)(le - (int64_t)m * g.p[i].N);  // (ldc may exceed N)
+  *reinterpret_cast<float4*>(g.p[i].C + (int64_t)m * g.p[i].ldc + n) = v;
+}
+
 // which arithmetic AVF_F32 GEMMs and attention run on: 1 = bf16x3 on the bf16 matrix pipe (default), 0 = the f32-input MFMA
 int g_f32_arith = 1;
 
@@ -483,6 +532,69 @@ size_t gemm_f32_ws(int64_t M, int64_t N, int64_t K) {
 
 void set_f32_arith(int mode) { g_f32_arith = mode ? 1 : 0; }
 int get_f32_arith() { return g_f32_arith; }
+
+// ---- the grouped weight-gradient launch of the parity mode (bf16x3 arithmetic) ---------------------------------------------------
+namespace {
+int f32x3_group_setup(const TnGroupArgs& a, F32GroupParams* g) {
+  if (g_f32_arith != 1 || a.count < 2 || a.count > 4 || a.K < 512 || a.K >= (1LL << 31)) return 0;
+  int tiles = 0;
+  int64_t el = 0;
+  for (int i = 0; i < a.count; ++i) {
+    if (a.M[i] < 96 || a.N[i] < 96 || a.N[i] % 4 != 0 || a.M[i] >= (1LL << 31) || a.N[i] >= (1LL << 31)) return 0;
+    if (a.A[i] && (((uintptr_t)a.A[i] | (uintptr_t)a.B[i] | (uintptr_t)a.C[i]) & 15)) return 0;
+    F32GemmParams& p = g->p[i];
+    memset(&p, 0, sizeof(p));
+    p.A = (const float*)a.A[i]; p.a_sm = 1; p.a_sk = a.lda[i];   // A_i [K, M_i]: element (m, k) at A[k lda + m]
+    p.B = (const float*)a.B[i]; p.b_sk = a.ldb[i]; p.b_sn = 1;   // B_i [K, N_i]
+    p.C = a.C[i]; p.ldc = a.N[i];
+    p.M = (int)a.M[i]; p.N = (int)a.N[i]; p.K = (int)a.K;
+    p.drop = kNoDrop;
+    g->tile0[i] = tiles;
+    g->el0[i] = el;
+    tiles += (int)(ceil_div(a.M[i], SBM) * ceil_div(a.N[i], SBN));
+    el += a.M[i] * a.N[i];
+  }
+  g->tile0[a.count] = tiles;
+  g->el0[a.count] = el;
+  g->count = a.count;
+  g->vec = 1;
+  int64_t sp = 512 / tiles;   // tiles x splits within one round of the 512 workgroup slots, at least 8 K-steps per split
+  if (sp > a.K / 256) sp = a.K / 256;
+  if (sp > 32) sp = 32;
+  if (sp < 2) return 0;       // enough tiles to fill the chip unsplit: the per-problem launches serve that case
+  const int kchunk = (int)(ceil_div(ceil_div(a.K, sp), SBK) * SBK);
+  g->S = (int)ceil_div(a.K, kchunk);
+  for (int i = 0; i < a.count; ++i) g->p[i].kchunk = kchunk;
+  return 1;
+}
+}  // namespace
+
+bool gemm_f32x3_tn_group_ok(const TnGroupArgs& a) {
+  F32GroupParams g;
+  return f32x3_group_setup(a, &g) != 0;
+}
+size_t gemm_f32x3_tn_group_ws(const TnGroupArgs& a) {
+  F32GroupParams g;
+  if (!f32x3_group_setup(a, &g)) return 0;
+  return (size_t)g.S * (size_t)g.el0[g.count] * sizeof(float);
+}
+int gemm_f32x3_tn_group(const TnGroupArgs& a, hipStream_t s) {
+  F32GroupParams g;
+  AVF_REQUIRE(f32x3_group_setup(a, &g), "gemm_f32x3_tn_group: shapes not eligible (ask gemm_f32x3_tn_group_ok first)");
+  AVF_REQUIRE(a.workspace && ((uintptr_t)a.workspace & 15) == 0, "gemm_f32x3_tn_group: workspace missing");
+  double fl = 0, by = 0;
+  for (int i = 0; i < a.count; ++i) {
+    AVF_REQUIRE(a.A[i] && a.B[i] && a.C[i], "gemm_f32x3_tn_group: null operand %d", i);
+    g.p[i].slabs = (float*)a.workspace + (size_t)g.S * (size_t)g.el0[i];
+    fl += 2.0 * a.M[i] * a.N[i] * a.K;
+    by += 4.0 * (a.K * (a.M[i] + a.N[i]) + a.M[i] * a.N[i]);
+  }
+  TimingScope ts(KC_GEMM_F32, fl, by, s);
+  gemm_f32x3_group_kernel<<<(unsigned)(g.tile0[g.count] * g.S), 256, 0, s>>>(g);
+  AVF_TRY(check_launch("gemm_f32x3_group_kernel"));
+  gemm_f32x3_group_fold_kernel<<<(unsigned)ceil_div(g.el0[g.count] / 4, 256), 256, 0, s>>>(g);
+  return check_launch("gemm_f32x3_group_fold_kernel");
+}
 
 int gemm_f32(const GemmArgs& a, hipStream_t s) {
   AVF_REQUIRE(a.c_dtype == AVF_F32, "gemm_f32: C must be fp32");

@@ -243,6 +243,9 @@ size_t carve_work(const Dims& d, void* base, Work* w) {
     g = a > b ? a : b;
     g = g > e ? g : e;
     g = g > f ? g : f;
+    TnGroupArgs ga = dw_group(d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    const size_t gg = gemm_f32x3_tn_group_ws(ga);   // (0 in the f32-MFMA arithmetic; the buffer serves either)
+    g = g > gg ? g : gg;
   }
   t.gemm_ws = c.take(g);
   t.small_part = (float*)c.take(small_layer_ok(d.dt, d.N, d.D, d.H, d.dh, d.M) ? small_bwd_partial_floats(d.B, d.D, d.M) * 4 : 0);
@@ -589,7 +592,10 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   // alive in the workspace), when the shapes allow the LDS-DMA kernel
   TnGroupArgs grp = dw_group(d, gy, sv.g, w.du, sv.h2, gm, sv.o, w.dqkv, sv.h1, g);
   grp.workspace = w.gemm_ws;
-  const bool grouped = lo && gemm_bf16_tn_group_ok(grp);
+  // parity mode, bf16x3 arithmetic (round 6): the four fp32 weight gradients likewise as one launch + one fold, issued right after
+  // the attention backward - the last point where every operand exists and dx_out (which dx_in may alias) is still intact
+  const bool grouped32 = !lo && !small_bwd && gemm_f32x3_tn_group_ok(grp);
+  const bool grouped = lo && gemm_bf16_tn_group_ok(grp);   // (also defers the column folds of the layer to the grouped fold)
   FoldList folds;
   memset(&folds, 0, sizeof(folds));
   folds.count = 3;
@@ -663,7 +669,7 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
       AVF_TRY(colsum(gy, AVF_BF16, d.R, d.D, d.D, g->b2, w.cs_ws, s));
     }
   }
-  if (!grouped) AVF_TRY(linear_dw(d, gy, d.D, sv.g, d.M, g->w2, w.gemm_ws, s));
+  if (!grouped && !grouped32) AVF_TRY(linear_dw(d, gy, d.D, sv.g, d.M, g->w2, w.gemm_ws, s));
   // config 5, backward half: the three dX GEMMs whose A operand leaves a row-wise producer (LayerNorm backward of this /
   // the next layer, the dGELU epilogue) read MX-FP8 images written by that producer; dqkv -> dh1 (A produced per head by the
   // attention backward) and the four weight-gradient GEMMs (reduction over tokens, not features) stay bf16
@@ -722,10 +728,10 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
     AVF_TRY(layernorm_bwd(w.dh, d.dt, sv.x_mid, p->ln2_w, sv.mean2, sv.rstd2, dx_out, w.dx_mid,
                           lo ? w.dx_mid_lo : nullptr, g->ln2_w, g->ln2_b, g->b_out, w.ln_ws, d.R, d.D, s, dr0,
                           grouped ? &folds.job[1] : nullptr, AVF_F32, d.xdt, w.mq, w.ms));
-  if (!grouped) AVF_TRY(linear_dw(d, w.du, d.M, sv.h2, d.D, g->w1, w.gemm_ws, s));
+  if (!grouped && !grouped32) AVF_TRY(linear_dw(d, w.du, d.M, sv.h2, d.D, g->w1, w.gemm_ws, s));
   // ---- attention half ----------------------------------------------------------------------
   if (f32_drop0) AVF_TRY(mask_copy_f32(w.dx_mid, w.gm_m, d.R * d.D, s, dr0));  // to_out sees dx_mid through its site-0 mask
-  if (!grouped) AVF_TRY(linear_dw(d, gm, d.D, sv.o, d.I, g->w_out, w.gemm_ws, s));
+  if (!grouped && !grouped32) AVF_TRY(linear_dw(d, gm, d.D, sv.o, d.I, g->w_out, w.gemm_ws, s));
   if (d.mxb)
     AVF_TRY(linear_dx_mx(d, w.mq, w.ms, d.D, l.wot_q, l.wot_s, d.I, w.d_o, AVF_EPI_NONE, nullptr, s, nullptr, nullptr, kNoDrop,
                          nullptr));
@@ -753,6 +759,7 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   else
     AVF_TRY(attn_bwd_f32((const float*)sv.qkv, (const float*)sv.o, (const float*)w.d_o, sv.lse2, (float*)w.dqkv,
                          w.delta, d.B, d.N, d.H, d.dh, s));
+  if (grouped32) AVF_TRY(gemm_f32x3_tn_group(grp, s));
   if (dq_mx)  // dh1 = dqkv Wqkv on MX-FP8 operands: the image of dqkv left the attention backward's epilogue
     AVF_TRY(linear_dx_mx(d, w.dqq, w.dqs, 3 * d.I, l.wqkvt_q, l.wqkvt_s, d.D, w.dh, AVF_EPI_NONE, nullptr, s, nullptr, nullptr,
                          kNoDrop, nullptr));
@@ -767,7 +774,7 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
     AVF_TRY(layernorm_bwd(w.dh, d.dt, x_in, p->ln1_w, sv.mean1, sv.rstd1, w.dx_mid, dx_in, lo ? dx_in_lo : nullptr,
                           g->ln1_w, g->ln1_b, dx_in_colsum, w.ln_ws1, d.R, d.D, s, dr_prev2,
                           grouped ? &folds.job[2] : nullptr, AVF_F32, d.xdt, inq, ins));
-  if (!grouped) AVF_TRY(linear_dw(d, w.dqkv, 3 * d.I, sv.h1, d.D, g->w_qkv, w.gemm_ws, s));
+  if (!grouped && !grouped32) AVF_TRY(linear_dw(d, w.dqkv, 3 * d.I, sv.h1, d.D, g->w_qkv, w.gemm_ws, s));
   // one launch folds the split-K slabs of the four weight gradients and the three deferred column folds
   // (db1; dgamma2/dbeta2/dbo; dgamma1/dbeta1/previous layer's db2)
   if (grouped) {

@@ -10,7 +10,7 @@ import oracle
 
 
 def rel(a, b):
-    a, b = a.double().cpu(), b.double().cpu()
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 

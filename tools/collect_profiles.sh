@@ -13,7 +13,7 @@ mkdir -p $O
 # the plain bench line of THIS box first (no profiler attached), stored beside the tables: profiles/<tag>_bench_line_same_box.json,
 # so that roofline.frac of the line and the fractions of the rocprof tables can be compared on one box (boxes of the pool differ
 # by up to 12 % in what their power management allows)
-( cd $R && AVF_BENCH_SETTLE_S= python bench.py --no-cpu-baseline > $O/bench_line_same_box.json 2> $O/bench_line_same_box.err && cp $O/bench_line_same_box.json profiles/${TAG}_bench_line_same_box.json ) || echo "bench line of this box: FAILED (see $O/bench_line_same_box.err)"
+( cd $R && AVF_BENCH_SETTLE_S=0.3 python bench.py --no-cpu-baseline > $O/bench_line_same_box.json 2> $O/bench_line_same_box.err && cp $O/bench_line_same_box.json profiles/${TAG}_bench_line_same_box.json ) || echo "bench line of this box: FAILED (see $O/bench_line_same_box.err)"
 echo "bench line of this box done"
 cd /tmp
 export TMPDIR=/tmp
@@ -52,7 +52,14 @@ B5="python $R/bench.py --config c5 --steps 3 --warmup 2 --no-cpu-baseline --no-k
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_c5b -o f -- $B5 > /dev/null 2> $O/fetch_c5b.err
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_c5b -o w -- $B5 > /dev/null 2> $O/write_c5b.err
 echo "c5 (bf16) stats + shape log + traffic done"
+# round 6: the parity mode (compute_dtype f32) in its two arithmetics: three bf16 products per fp32 product (default) and the
+# f32-input MFMA (AVF_F32_ARITH=f32 is read by bench.py only, it calls avf_set_f32_arith)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_f32x3 -o s -- python $R/bench.py --dtype f32 --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-events --no-extra > $O/stats_f32x3.json 2> $O/stats_f32x3.err
+AVF_F32_ARITH=f32 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_f32m -o s -- python $R/bench.py --dtype f32 --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-events --no-extra > $O/stats_f32m.json 2> $O/stats_f32m.err
+echo "f32 parity stats done"
 cd $R
+cp $O/stats_f32x3/s_kernel_stats.csv profiles/${TAG}_f32_bf16x3_kernel_stats.csv
+cp $O/stats_f32m/s_kernel_stats.csv profiles/${TAG}_f32_mfma_kernel_stats.csv
 python tools/pmc_traffic.py $O/stats_c2/s_kernel_stats.csv $O/fetch_c2/f_counter_collection.csv $O/write_c2/w_counter_collection.csv $TAG c2
 python tools/pmc_traffic.py $O/stats_c3/s_kernel_stats.csv $O/fetch_c3/f_counter_collection.csv $O/write_c3/w_counter_collection.csv ${TAG}_c3 c3
 python tools/pmc_traffic.py $O/stats_c4/s_kernel_stats.csv $O/fetch_c4/f_counter_collection.csv $O/write_c4/w_counter_collection.csv ${TAG}_c4 c4
