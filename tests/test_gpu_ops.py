@@ -135,6 +135,32 @@ def test_gemm_f32_split64(ops, f32_arith, M, N, K, ta, tb):
         _close(c2, (ref + bias.double() + res.double()).float(), atol=1e-4 * math.sqrt(K), rtol=1e-4)
 
 
+@pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False)])
+def test_gemm_f32_bf16x3_error_bound_elementwise(ops, ta, tb):
+    """the stated contract of the bf16x3 arithmetic, element by element: |C - A B| <= 3 * 2^-18 * sum_k |a_k| |b_k| (+ the fp32
+    accumulation's own K * 2^-24) - on operands whose magnitudes span eight decades inside every row, where a norm-wise check
+    would hide a badly rounded small term behind the large ones"""
+    from avformer_amd import _lib
+    M, N, K = 384, 256, 1024
+    g = torch.Generator().manual_seed(77 + int(ta) + 2 * int(tb))
+    def wide(shape):
+        return torch.randn(shape, generator=g) * torch.pow(10.0, torch.rand(shape, generator=g) * 8 - 4)
+    a = wide((K, M) if ta else (M, K))
+    b = wide((N, K) if tb else (K, N))
+    A_ = (a.t() if ta else a).double()
+    B_ = (b.t() if tb else b).double()
+    ref = A_ @ B_
+    mag = A_.abs() @ B_.abs()
+    prev = _lib.set_f32_arithmetic("bf16x3")
+    try:
+        c = ops.gemm(a.cuda(), b.cuda(), trans_a=ta, trans_b=tb).double().cpu()
+    finally:
+        _lib.set_f32_arithmetic(prev)
+    bound = (3 * 2.0 ** -18 + K * 2.0 ** -24) * mag
+    worst = float(((c - ref).abs() / bound).max())
+    assert worst <= 1.0, worst
+
+
 @pytest.mark.parametrize("dtype,M,N,K", [(torch.float32, 200, 136, 96), (torch.bfloat16, 200, 136, 96),
                                          (torch.bfloat16, 301, 260, 1088), (torch.bfloat16, 8200, 520, 64)])
 def test_gemm_epilogues(ops, f32_arith, dtype, M, N, K):
