@@ -222,7 +222,9 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t&
 // of the row in the low bit makes the 16-byte stores of 8 consecutive rows (row-fast staging) conflict-free as well.
 __device__ __forceinline__ int sw_off(int r, int c) { return r * SBK + ((c ^ ((((r >> 2) & 1) << 1) | ((r >> 1) & 1))) << 3); }
 
-template <bool KF>
+// KTAIL: the K range may end inside a K-step (both operands row-fast: the token reduction of a weight gradient); with a k-fast
+// operand in the product K % 32 == 0 holds (f32x3_ok) and the row-fast side loads unconditionally
+template <bool KF, bool KTAIL = true>
 struct SplitStage {
   float v[16];  // fp32 values per thread and K-step
   // element (row, k) of the operand at X[row * s_r + k * s_k]; rows clamped (their results are never stored), k >= kend -> 0
@@ -244,8 +246,14 @@ struct SplitStage {
       int gr = r0 + row;
       gr = gr < R ? gr : R - 1;
       const float* base = X + (int64_t)(k0 + kh * 16) * s_k;
+      if (!KTAIL || k0 + kh * 16 + 16 <= kend) {  // wave-uniform: every K-step but (possibly) the last loads unconditionally -
+        // 16 predicated loads cost the mixed (NN) form 8 % and sit in 16 basic blocks
 #pragma unroll
-      for (int e = 0; e < 16; ++e) v[e] = (k0 + kh * 16 + e < kend) ? (base + (int64_t)e * s_k)[(uint32_t)gr] : 0.f;
+        for (int e = 0; e < 16; ++e) v[e] = (base + (int64_t)e * s_k)[(uint32_t)gr];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = (k0 + kh * 16 + e < kend) ? (base + (int64_t)e * s_k)[(uint32_t)gr] : 0.f;
+      }
     }
   }
   __device__ __forceinline__ void commit(uint16_t* Xh, uint16_t* Xl) const {
@@ -302,16 +310,19 @@ __device__ __forceinline__ void f32x3_tile(const F32GemmParams& p, int vec, int 
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   // A: element (m, k) at A[m a_sm + k a_sk];  B: element (k, n) at B[k b_sk + n b_sn] (its tile rows are n)
-  SplitStage<AKF> sa0, sa1;
-  SplitStage<BKF> sb0, sb1;
-  auto fetch = [&](SplitStage<AKF>& sa, SplitStage<BKF>& sb, int k0) {
+  constexpr bool KTAIL = !AKF && !BKF;
+  using StageA = SplitStage<AKF, KTAIL>;
+  using StageB = SplitStage<BKF, KTAIL>;
+  StageA sa0, sa1;
+  StageB sb0, sb1;
+  auto fetch = [&](StageA& sa, StageB& sb, int k0) {
     sa.fetch(p.A, p.a_sm, p.a_sk, m0, p.M, k0, kend);
     sb.fetch(p.B, p.b_sn, p.b_sk, n0, p.N, k0, kend);
   };
   const int frag = sw_off(li, lg);  // this lane's 16-byte fragment inside a 16-row block (the swizzle depends on li only)
   // one K-step: the MFMAs of the step staged in `cur`, while the NEXT step's registers are split into `nxt` and the loads of
   // the step after the one in flight are issued - two K-steps of look-ahead on the global loads, one barrier per step
-  auto step = [&](SplitStage<AKF>& sa, SplitStage<BKF>& sb, const uint16_t* cur, uint16_t* nxt, int k0) {
+  auto step = [&](StageA& sa, StageB& sb, const uint16_t* cur, uint16_t* nxt, int k0) {
     if (k0 + SBK < kend) {
       sa.commit(nxt, nxt + SIMG);
       sb.commit(nxt + 2 * SIMG, nxt + 3 * SIMG);
