@@ -369,6 +369,7 @@ struct FoldList {
 // aligned partials.  (Round 4: 32 columns x 32 row groups with four loads in flight put 48 blocks on the 1536 columns of a
 // LayerNorm fold, each walking 1024 partial rows with 16 KiB in flight - latency-bound at ~8 GB/s per CU, 12 of the 19.5 us of
 // the layer's fold launch at C3.  Half the columns per block and twice the loads in flight: four times the bytes in flight.)
+int fold_list(const FoldList& fl, hipStream_t s);  // the (up to three) jobs of a list in one launch
 constexpr int FOLD_COLS = 16, FOLD_RG = 64;
 __device__ __forceinline__ void fold_columns_vec(const FoldJob& j, int colgroup, float4 (*red)[FOLD_COLS / 4]) {
   const int cq = threadIdx.x & (FOLD_COLS / 4 - 1), grp = threadIdx.x / (FOLD_COLS / 4);

@@ -727,7 +727,7 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   else
     AVF_TRY(layernorm_bwd(w.dh, d.dt, sv.x_mid, p->ln2_w, sv.mean2, sv.rstd2, dx_out, w.dx_mid,
                           lo ? w.dx_mid_lo : nullptr, g->ln2_w, g->ln2_b, g->b_out, w.ln_ws, d.R, d.D, s, dr0,
-                          grouped ? &folds.job[1] : nullptr, AVF_F32, d.xdt, w.mq, w.ms));
+                          (grouped || grouped32) ? &folds.job[1] : nullptr, AVF_F32, d.xdt, w.mq, w.ms));
   if (!grouped && !grouped32) AVF_TRY(linear_dw(d, w.du, d.M, sv.h2, d.D, g->w1, w.gemm_ws, s));
   // ---- attention half ----------------------------------------------------------------------
   if (f32_drop0) AVF_TRY(mask_copy_f32(w.dx_mid, w.gm_m, d.R * d.D, s, dr0));  // to_out sees dx_mid through its site-0 mask
@@ -773,12 +773,13 @@ extern "C" int avf_layer_bwd(const avf_layer_cfg* cfg, const avf_layer_params* p
   else
     AVF_TRY(layernorm_bwd(w.dh, d.dt, x_in, p->ln1_w, sv.mean1, sv.rstd1, w.dx_mid, dx_in, lo ? dx_in_lo : nullptr,
                           g->ln1_w, g->ln1_b, dx_in_colsum, w.ln_ws1, d.R, d.D, s, dr_prev2,
-                          grouped ? &folds.job[2] : nullptr, AVF_F32, d.xdt, inq, ins));
+                          (grouped || grouped32) ? &folds.job[2] : nullptr, AVF_F32, d.xdt, inq, ins));
   if (!grouped && !grouped32) AVF_TRY(linear_dw(d, w.dqkv, 3 * d.I, sv.h1, d.D, g->w_qkv, w.gemm_ws, s));
   // one launch folds the split-K slabs of the four weight gradients and the three deferred column folds
   // (db1; dgamma2/dbeta2/dbo; dgamma1/dbeta1/previous layer's db2)
   if (grouped) {
     AVF_TRY(gemm_bf16_tn_group(grp, s, &folds));
   }
+  if (grouped32) AVF_TRY(fold_list(folds, s));  // the two LayerNorm column folds of the layer in one launch (job 0 stays empty)
   return 0;
 }

@@ -572,6 +572,35 @@ int fold_partials(const float* partial, int nb, int width, float* out, hipStream
 
 int fold_job(const FoldJob& j, hipStream_t s) { return launch_fold(j.partial, j.nb, j.width, j.o0, j.o1, j.o2, j.seg, s); }
 
+// every job of a list in ONE launch (the parity mode's layer backward: its LayerNorm column folds were a launch each - 19 tiny
+// launches per C2 step); jobs with a null partial are skipped.  Falls back to one launch per job for unaligned / odd widths.
+__global__ __launch_bounds__(256) void fold_list_kernel(FoldList fl, int g0, int g1, int g2) {
+  __shared__ float4 red[FOLD_RG][FOLD_COLS / 4];
+  const int b = blockIdx.x;
+  const int j = b < g0 ? 0 : (b < g0 + g1 ? 1 : 2);
+  const int local = b - (j == 0 ? 0 : (j == 1 ? g0 : g0 + g1));
+  (void)g2;
+  fold_columns_vec(fl.job[j], local, red);
+}
+int fold_list(const FoldList& fl, hipStream_t s) {
+  int g[3] = {0, 0, 0};
+  bool vec = true;
+  for (int j = 0; j < 3; ++j) {
+    const FoldJob& job = fl.job[j];
+    if (j >= fl.count || !job.partial) continue;
+    g[j] = (int)ceil_div(job.width, FOLD_COLS);
+    vec = vec && job.width % 4 == 0 && (((uintptr_t)job.partial) & 15) == 0;
+  }
+  if (g[0] + g[1] + g[2] == 0) return 0;
+  if (!vec) {
+    for (int j = 0; j < fl.count && j < 3; ++j)
+      if (fl.job[j].partial) AVF_TRY(fold_job(fl.job[j], s));
+    return 0;
+  }
+  fold_list_kernel<<<(unsigned)(g[0] + g[1] + g[2]), 256, 0, s>>>(fl, g[0], g[1], g[2]);
+  return check_launch("fold_list_kernel");
+}
+
 // LayerNorm backward on the all-bf16 streams (dy, x, the incoming residual gradient and dx in bf16; no dropout, no MX image):
 // the row8 layout of ln_fwd_row8_kernel.  A workgroup owns rpb rows = 4 waves x (rpb / 4 / RU) batches of RU rows; the per-column
 // sums stay in registers and are combined through LDS in wave order, so the partial of a block - and the folded result - is
