@@ -14,7 +14,8 @@ ops (``torch.stft`` runs on rocFFT on the GPU) - device-agnostic glue either sid
   * (x - mean) / std with mean = -14.8, std = 19.895                                         (aff2compdataset.py:67-68)
 
 Parity: unpinned by the reference (its transform cannot be imported here); checked against an independent numpy
-restatement (oracle/audio_front_end.py, tests/test_audio_cpu.py).
+restatement (oracle/audio_front_end.py) and against a third-party implementation of the same published transform
+(transformers.audio_utils; tests/test_audio_cpu.py).
 """
 from __future__ import annotations
 

@@ -54,3 +54,28 @@ def test_two_dimensional_batch_is_clamped_per_clip_too():
     assert np.abs(y[1].numpy() - mel_features(b.numpy())).max() < 2e-3
     assert torch.equal(y[1], fe(b[None])[0])    # the same clip alone
     assert torch.equal(fe(a), y[0])             # and a bare [samples] clip
+
+
+def test_mel_power_against_a_third_party_implementation():
+    """The reference's transform is torchaudio.transforms.MelSpectrogram (torchaudio 0.6, README.md:12), which this image does not
+    hold - so no fixture can come from the reference itself and the front-end stays 'parity unpinned'.  What CAN be checked here:
+    an implementation written by somebody else.  `transformers.audio_utils` (Hugging Face, an installed third-party package that
+    documents its `spectrogram` / `mel_filter_bank` as reproducing torchaudio's MelSpectrogram with mel_scale='htk', norm=None)
+    computes the same mel power spectrogram from the same parameters (aff2compdataset.py:48-65): n_fft 1024, win 882 (periodic
+    Hann, centred in the frame), hop 441, reflect padding, power 2, 64 HTK mel filters over 0 .. 22050 Hz."""
+    tau = __import__("pytest").importorskip("transformers.audio_utils")
+    fe = A.audio.MelFrontEnd()
+    x = _wave(2.0, 7)
+    ours = fe.mel_power(x).double().numpy()                     # [64, frames]
+    window = tau.window_function(fe.win_length, "hann", periodic=True, frame_length=fe.n_fft)
+    filters = tau.mel_filter_bank(fe.n_fft // 2 + 1, fe.n_mels, 0.0, 22050.0, fe.sample_rate, norm=None, mel_scale="htk")
+    theirs = tau.spectrogram(x.double().numpy(), window, frame_length=fe.n_fft, hop_length=fe.hop_length, fft_length=fe.n_fft,
+                             power=2.0, center=True, pad_mode="reflect", onesided=True, mel_filters=filters, mel_floor=0.0)
+    assert theirs.shape == ours.shape
+    assert np.allclose(filters.T, fe.fb.double().numpy().T, atol=1e-6)          # the filterbank itself, filter by filter
+    scale = np.abs(theirs).max()
+    assert np.abs(ours - theirs).max() / scale < 2e-5            # fp32 STFT against float64
+    # ... and on the dB scale the network sees (10 log10, floor 1e-10)
+    db_o, db_t = 10 * np.log10(np.maximum(ours, 1e-10)), 10 * np.log10(np.maximum(theirs, 1e-10))
+    keep = theirs > 1e-6 * scale                                 # (bins at the numerical floor differ in their noise, not in dB that matter)
+    assert np.abs(db_o - db_t)[keep].max() < 0.02
