@@ -690,7 +690,10 @@ def main():
                        "seq_len": c0["t_video"] + c0["t_audio"], "parallelism": f"dp{world}"},
             "launch": "eager (the captured data-parallel step did not return: watchdog; this is the eager region timed before the attempt)",
             "roofline": None, "cpu_baseline": None}
-    main_r.timed(args.steps, args.warmup, main_graph)
+    try:
+        main_r.timed(args.steps, args.warmup, main_graph)
+    finally:
+        A._lib.load().avf_crash_line_disarm()  # (armed only around the multi-rank graph attempt; never past this region)
     main_clock = main_r.clock_power() if (world == 1 and not args.no_extra) else None
     c, B = main_r.c, main_r.B
     Tv, Ta = c["t_video"], c["t_audio"]

@@ -547,8 +547,8 @@ int get_f32_arith() { return g_f32_arith; }
 
 // ---- the grouped weight-gradient launch of the parity mode (bf16x3 arithmetic) ---------------------------------------------------
 namespace {
-int f32x3_group_setup(const TnGroupArgs& a, F32GroupParams* g) {
-  if (g_f32_arith != 1 || a.count < 2 || a.count > 4 || a.K < 512 || a.K >= (1LL << 31)) return 0;
+int f32x3_group_setup(const TnGroupArgs& a, F32GroupParams* g, bool any_arith = false) {
+  if ((g_f32_arith != 1 && !any_arith) || a.count < 2 || a.count > 4 || a.K < 512 || a.K >= (1LL << 31)) return 0;
   int tiles = 0;
   int64_t el = 0;
   for (int i = 0; i < a.count; ++i) {
@@ -585,9 +585,9 @@ bool gemm_f32x3_tn_group_ok(const TnGroupArgs& a) {
   F32GroupParams g;
   return f32x3_group_setup(a, &g) != 0;
 }
-size_t gemm_f32x3_tn_group_ws(const TnGroupArgs& a) {
+size_t gemm_f32x3_tn_group_ws(const TnGroupArgs& a) {  // (whatever arithmetic is selected NOW: a buffer sized under one serves both)
   F32GroupParams g;
-  if (!f32x3_group_setup(a, &g)) return 0;
+  if (!f32x3_group_setup(a, &g, true)) return 0;
   return (size_t)g.S * (size_t)g.el0[g.count] * sizeof(float);
 }
 int gemm_f32x3_tn_group(const TnGroupArgs& a, hipStream_t s) {

@@ -244,7 +244,7 @@ size_t carve_work(const Dims& d, void* base, Work* w) {
     g = g > e ? g : e;
     g = g > f ? g : f;
     TnGroupArgs ga = dw_group(d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-    const size_t gg = gemm_f32x3_tn_group_ws(ga);   // (0 in the f32-MFMA arithmetic; the buffer serves either)
+    const size_t gg = gemm_f32x3_tn_group_ws(ga);   // (independent of the arithmetic selected now: the buffer serves either)
     g = g > gg ? g : gg;
   }
   t.gemm_ws = c.take(g);
