@@ -3,8 +3,8 @@
 // Reference: models/heads.py:222-237 (dots = q k^T * dh^-0.5 ; softmax(dim=-1) ; out = attn v) and its autograd.
 //
 // Same arithmetic contract as gemm_f32.hip's bf16x3 GEMM: every fp32 operand of a matrix product is split x = hi + lo (two bf16,
-// RNE; x - hi is exact in fp32) and a b ~ hi hi + hi lo + lo hi on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: <= 1.1e-5
-// relative error per product, 3 MFMAs of 16 cycles where the f32-input MFMA kernels of attn_f32_mfma.hip spend 8 of 32.  The
+// RNE; x - hi is exact in fp32) and a b ~ hi hi + hi lo + lo hi on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: <= 3 * 2^-16 = 4.6e-5
+// relative error per product in the worst case (4e-6 typical), 3 MFMAs of 16 cycles where the f32-input MFMA kernels of attn_f32_mfma.hip spend 8 of 32.  The
 // softmax statistics, exp2 and every elementwise step stay fp32; P and dS are split like any other operand.  fp32 storage, no
 // token mask, dim_head 64, q not pre-scaled (the masked / bf16-storage / dim_head 32 calls stay on the f32 kernels).
 //

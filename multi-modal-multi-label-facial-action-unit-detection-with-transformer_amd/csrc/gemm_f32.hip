@@ -196,11 +196,13 @@ int f32_split64(int64_t M, int64_t N, int64_t K, int epilogue) {
 //
 // gfx950 has no xf32 / tf32 MFMA: the f32-input MFMA above runs at 1/16 of the bf16 rate (157 TFLOP/s dense).  Here every fp32
 // operand x is split while it is staged into LDS:  x = hi + lo + r,  hi = bf16(x) (RNE),  lo = bf16(x - hi)  (x - hi is exact in
-// fp32: at most 16 significant bits remain), |r| <= 2^-18 |x|;  and  a b  ~  hi_a hi_b + hi_a lo_b + lo_a hi_b  on
-// v_mfma_f32_16x16x32_bf16 with fp32 accumulation (every bf16 x bf16 product is exact in fp32).  Dropped: lo_a lo_b and the two
-// residuals, each <= 2^-18 |a b|: a product carries <= 3 * 2^-18 = 1.1e-5 relative error (fp32: 6e-8), a K-long dot product
-// ~ 3e-6 rms of |a| |b| sqrt(K).  That is the precision class north_star's logits rtol 1e-3 asks for, at 3 bf16 MFMAs per
-// product: an effective roof of 2500 / 3 = 833 TFLOP/s against 157.  (models/heads.py:191-196, 212, 214-217 and their autograd.)
+// fp32: at most 16 significant bits remain); bf16 rounds to 8 significant bits (unit roundoff u = 2^-8), so |x - hi| <= u |x| and
+// |r| <= u^2 |x| = 2^-16 |x|;  and  a b  ~  hi_a hi_b + hi_a lo_b + lo_a hi_b  on v_mfma_f32_16x16x32_bf16 with fp32 accumulation
+// (every bf16 x bf16 product is exact in fp32).  Dropped: lo_a lo_b and the two residuals, each <= 2^-16 |a b|: a product carries
+// <= 3 * 2^-16 = 4.6e-5 relative error in the worst case, ~4e-6 typically (measured: 4.4e-6 relative Frobenius on K = 512 ... 10368
+// GEMMs; fp32: 4e-7) - oracle/bf16x3.py emulates exactly this arithmetic and the tests hold the kernel to it at 6e-7.  That is well
+// inside north_star's logits rtol 1e-3, at 3 bf16 MFMAs per product: an effective roof of 2500 / 3 = 833 TFLOP/s against 157.
+// (models/heads.py:191-196, 212, 214-217 and their autograd.)
 //
 // 128 x 128 tile, 32-deep K-step, 4 waves of 64 x 64 (4 x 4 MFMA blocks each, 48 MFMAs per K-step and wave); global -> registers
 // (two K-steps of look-ahead) -> split -> LDS as four bf16 images [row][32 k] (64-byte rows, 16-byte chunks XOR-swizzled: fragment

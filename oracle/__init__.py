@@ -31,3 +31,4 @@ from .reference_math import (  # noqa: F401
     init_transformer_state,
 )
 from .mx8 import mx8_dequant, mx8_quant  # noqa: F401,E402
+from . import bf16x3  # noqa: F401,E402

@@ -126,7 +126,7 @@ def test_gemm_f32_split64(ops, f32_arith, M, N, K, ta, tb):
     c = ops.gemm(a.cuda(), b.cuda(), trans_a=ta, trans_b=tb)
     _close(c, ref.float(), atol=1e-4 * math.sqrt(K), rtol=1e-4)
     err = float((c.double().cpu() - ref).norm() / ref.norm())
-    # the precision class of each arithmetic: fp32 products in an fmaf chain / three bf16 products (<= 3 * 2^-18 per product)
+    # the precision class of each arithmetic: fp32 products in an fmaf chain / three bf16 products (<= 3 * 2^-16 per product in the worst case, ~4e-6 typical)
     assert err < (1e-6 if f32_arith == "f32" else 6e-6), err
     if not ta:  # the fused bias + residual epilogue rides in the fold of a split launch
         bias = torch.randn(N, generator=g)
@@ -137,7 +137,7 @@ def test_gemm_f32_split64(ops, f32_arith, M, N, K, ta, tb):
 
 @pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False)])
 def test_gemm_f32_bf16x3_error_bound_elementwise(ops, ta, tb):
-    """the stated contract of the bf16x3 arithmetic, element by element: |C - A B| <= 3 * 2^-18 * sum_k |a_k| |b_k| (+ the fp32
+    """the stated contract of the bf16x3 arithmetic, element by element: |C - A B| <= 3 * 2^-16 * sum_k |a_k| |b_k| (+ the fp32
     accumulation's own K * 2^-24) - on operands whose magnitudes span eight decades inside every row, where a norm-wise check
     would hide a badly rounded small term behind the large ones"""
     from avformer_amd import _lib
@@ -156,9 +156,33 @@ def test_gemm_f32_bf16x3_error_bound_elementwise(ops, ta, tb):
         c = ops.gemm(a.cuda(), b.cuda(), trans_a=ta, trans_b=tb).double().cpu()
     finally:
         _lib.set_f32_arithmetic(prev)
-    bound = (3 * 2.0 ** -18 + K * 2.0 ** -24) * mag
+    bound = (oracle.bf16x3.PER_PRODUCT_BOUND + K * 2.0 ** -24) * mag
     worst = float(((c - ref).abs() / bound).max())
     assert worst <= 1.0, worst
+
+
+@pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False)])
+def test_gemm_f32_bf16x3_kernel_implements_the_emulated_arithmetic(ops, ta, tb):
+    """the three-product kernel against the CPU emulation of ITS arithmetic (oracle/bf16x3.py): what is left between them is the
+    fp32 accumulation order - 1e-6 - where the exact product is 4e-6 away.  A kernel that lost a cross term, or split by
+    truncation instead of rounding, stays within 1e-3 of the exact product and fails this by an order of magnitude."""
+    from avformer_amd import _lib
+    M, N, K = 384, 256, 1024
+    g = torch.Generator().manual_seed(91 + int(ta) + 2 * int(tb))
+    a = torch.randn((K, M) if ta else (M, K), generator=g)
+    b = torch.randn((N, K) if tb else (K, N), generator=g)
+    A_, B_ = (a.t() if ta else a), (b.t() if tb else b)
+    emu = oracle.bf16x3.matmul(A_, B_)
+    exact = A_.double() @ B_.double()
+    prev = _lib.set_f32_arithmetic("bf16x3")
+    try:
+        c = ops.gemm(a.cuda(), b.cuda(), trans_a=ta, trans_b=tb).double().cpu()
+    finally:
+        _lib.set_f32_arithmetic(prev)
+    to_emu = float((c - emu).norm() / emu.norm())
+    to_exact = float((c - exact).norm() / exact.norm())
+    assert to_emu < 6e-7, (to_emu, to_exact)
+    assert 2e-6 < to_exact < 8e-6, (to_emu, to_exact)
 
 
 @pytest.mark.parametrize("dtype,M,N,K", [(torch.float32, 200, 136, 96), (torch.bfloat16, 200, 136, 96),
