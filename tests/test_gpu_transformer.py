@@ -147,14 +147,21 @@ def test_full_c2_vs_oracle_bf16_and_f32():
     logits_ref = y.mean(1) @ sd["au_fc.weight"].t() + sd["au_fc.bias"]
     loss_ref = oracle.au_loss(logits_ref, labels)
     batch = {"clip": clip.to(DEV), "audio_features": aud.to(DEV)}
+    from gpu_util import F32_ARITHS, f32_arithmetic
     with torch.no_grad():
-        out32 = m32(batch)
         out16 = m16(batch)
-        l32 = m32.get_au_loss(out32, labels.to(DEV))
         l16 = m16.get_au_loss(out16, labels.to(DEV))
-    torch.testing.assert_close(out32[:, :12].cpu(), logits_ref, rtol=1e-3, atol=1e-4)
-    torch.testing.assert_close(l32.cpu(), loss_ref, rtol=1e-4, atol=1e-5)
-    assert torch.all(out32[:, 12:] == 0)
+    # parity mode: north_star's logits rtol 1e-3, in BOTH arithmetics (three bf16 products per fp32 product - the default - and
+    # the f32-input MFMA); the measured relative error of the logits is recorded per arithmetic (calibrated tags)
+    for arith in F32_ARITHS:
+        with f32_arithmetic(arith), torch.no_grad():
+            out32 = m32(batch)
+            l32 = m32.get_au_loss(out32, labels.to(DEV))
+        torch.testing.assert_close(out32[:, :12].cpu(), logits_ref, rtol=1e-3, atol=1e-4)
+        torch.testing.assert_close(l32.cpu(), loss_ref, rtol=1e-4, atol=1e-5)
+        assert torch.all(out32[:, 12:] == 0)
+        check_rel(f"c2_full:logits_parity[{arith}]", out32[:, :12], logits_ref, 1e-4)
+        check_abs(f"c2_full:logits_parity_maxabs[{arith}]", out32[:, :12], logits_ref, 1e-4, floor=1e-6)
     # throughput mode: stated tolerance
     check_abs("c2_full:logits_maxabs", out16[:, :12], logits_ref, 2e-2)
     check_rel("c2_full:logits", out16[:, :12], logits_ref, 1.5e-2)
