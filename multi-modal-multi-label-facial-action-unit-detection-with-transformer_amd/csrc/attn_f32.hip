@@ -338,9 +338,9 @@ int attn_bwd_vec(int dtype, const void* qkv, const void* o, const void* d_o, con
   AVF_REQUIRE((int64_t)B * H < 65536, "attn_bwd_f32: batch*heads too large for grid");
   AVF_REQUIRE(dtype == AVF_F32 || dtype == AVF_BF16, "attn_bwd_f32: bad dtype %d", dtype);
   TimingScope ts(KC_ATTN_BWD, 10.0 * B * H * (double)N * N * dh, 4.0 * 8.0 * B * N * H * dh, s);
+  if (attn_f32x3_ok(dtype, dh, keep, H, qkv, d_o, q_prescaled) && ((uintptr_t)dqkv & 15) == 0 && ((uintptr_t)o & 15) == 0)
+    return attn_bwd_f32x3((const float*)qkv, (const float*)o, (const float*)d_o, lse2, delta, (float*)dqkv, B, N, H, s);
   AVF_TRY(attn_delta(dtype, o, d_o, delta, B, N, H, dh, s));
-  if (attn_f32x3_ok(dtype, dh, keep, H, qkv, d_o, q_prescaled) && ((uintptr_t)dqkv & 15) == 0)
-    return attn_bwd_f32x3((const float*)qkv, (const float*)d_o, lse2, delta, (float*)dqkv, B, N, H, s);
   if (attn_f32_mfma_ok(dtype, dh, keep, H, qkv, d_o) && ((uintptr_t)dqkv & 15) == 0)
     return attn_bwd_f32_mfma((const float*)qkv, (const float*)d_o, lse2, delta, (float*)dqkv, B, N, H, dh, s, q_prescaled);
   dim3 grid((unsigned)ceil_div(N, 64), (unsigned)(B * H));

@@ -239,9 +239,11 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(const float* __restric
 
 // ---------------------------------------------------------------------------------------------- dQ
 // dS = P o (dP - delta),  dq = dS k * dh^-0.5   (64 queries per workgroup, keys streamed)
-__global__ __launch_bounds__(256) void attn_dq_x3_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
-                                                         const float* __restrict__ lse2, const float* __restrict__ delta,
-                                                         float* __restrict__ dqkv, int N, int H) {
+// Also produces delta[q] = sum_d O[q, d] dO[q, d] for its rows (fp32, from the rows it loads anyway) and writes it for the dK / dV
+// kernel that follows on the stream - no separate delta launch on this path (6 launches of 10 us per C2 step).
+__global__ __launch_bounds__(256) void attn_dq_x3_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
+                                                         const float* __restrict__ d_o, const float* __restrict__ lse2,
+                                                         float* __restrict__ delta, float* __restrict__ dqkv, int N, int H) {
   __shared__ __attribute__((aligned(16))) uint16_t lds[6 * IMG];  // K row, K^T, V row (hi / lo each)
   uint16_t *Kh = lds, *Kl = lds + IMG, *Kth = lds + 2 * IMG, *Ktl = lds + 3 * IMG, *Vh = lds + 4 * IMG, *Vl = lds + 5 * IMG;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
@@ -256,7 +258,21 @@ __global__ __launch_bounds__(256) void attn_dq_x3_kernel(const float* __restrict
   x_row_frags(qf, base + (int64_t)qi * ld, valid, lg, kLog2e * scale);
   x_row_frags(gf, d_o + ((int64_t)b * N + qi) * I + h * XD, valid, lg, 1.0f);
   const float L = valid ? lse2[(int64_t)bh * N + qi] : INFINITY;  // rows past the end: P = 2^(s - inf) = 0
-  const float dl = valid ? delta[(int64_t)bh * N + qi] : 0.f;
+  float dl = 0.f;  // this lane's 16 of the row's 64 products, then the sum over the four lane groups
+  if (valid) {
+    const float* gr = d_o + ((int64_t)b * N + qi) * I + h * XD;
+    const float* orow = o + ((int64_t)b * N + qi) * I + h * XD;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int hlf = 0; hlf < 2; ++hlf) {
+        const float4 gv = *reinterpret_cast<const float4*>(gr + 32 * c + 8 * lg + 4 * hlf);
+        const float4 ov = *reinterpret_cast<const float4*>(orow + 32 * c + 8 * lg + 4 * hlf);
+        dl = fmaf(gv.x, ov.x, dl); dl = fmaf(gv.y, ov.y, dl); dl = fmaf(gv.z, ov.z, dl); dl = fmaf(gv.w, ov.w, dl);
+      }
+  }
+  dl = x_sum_groups(dl);
+  if (valid && lg == 0) delta[(int64_t)bh * N + qi] = dl;
   f32x4_t dq[4];
 #pragma unroll
   for (int db = 0; db < 4; ++db) dq[db] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -381,10 +397,10 @@ int attn_fwd_f32x3(const float* qkv, float* o, float* lse2, int B, int N, int H,
   return check_launch("attn_fwd_x3_kernel");
 }
 
-int attn_bwd_f32x3(const float* qkv, const float* d_o, const float* lse2, const float* delta, float* dqkv, int B, int N, int H,
-                   hipStream_t s) {
+int attn_bwd_f32x3(const float* qkv, const float* o, const float* d_o, const float* lse2, float* delta, float* dqkv, int B, int N,
+                   int H, hipStream_t s) {
   dim3 grid((unsigned)ceil_div(N, 64), (unsigned)(B * H));
-  attn_dq_x3_kernel<<<grid, 256, 0, s>>>(qkv, d_o, lse2, delta, dqkv, N, H);
+  attn_dq_x3_kernel<<<grid, 256, 0, s>>>(qkv, o, d_o, lse2, delta, dqkv, N, H);
   attn_dkv_x3_kernel<<<grid, 256, 0, s>>>(qkv, d_o, lse2, delta, dqkv, N, H);
   return check_launch("attn_bwd_x3 kernels");
 }

@@ -519,8 +519,8 @@ int attn_bwd_f32_mfma(const float* qkv, const float* d_o, const float* lse2, con
 // parity-mode attention with three bf16 products per fp32 product (attn_f32x3.hip): fp32 storage, no mask, dim_head 64, raw q
 bool attn_f32x3_ok(int dtype, int dh, const void* keep, int H, const void* qkv, const void* other, bool q_prescaled);
 int attn_fwd_f32x3(const float* qkv, float* o, float* lse2, int B, int N, int H, hipStream_t s);
-int attn_bwd_f32x3(const float* qkv, const float* d_o, const float* lse2, const float* delta, float* dqkv, int B, int N, int H,
-                   hipStream_t s);
+int attn_bwd_f32x3(const float* qkv, const float* o, const float* d_o, const float* lse2, float* delta, float* dqkv, int B, int N,
+                   int H, hipStream_t s);  // (computes delta itself: no attn_delta launch in front of it)
 int attn_fwd_vec(int dtype, const void* qkv, void* o, float* lse2, int B, int N, int H, int dh, hipStream_t s, const void* keep,
                  bool q_prescaled);
 int attn_bwd_vec(int dtype, const void* qkv, const void* o, const void* d_o, const float* lse2, void* dqkv, float* delta,
