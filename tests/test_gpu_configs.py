@@ -286,3 +286,32 @@ def test_g10_gelu_fixture_through_hip_epilogues(dtype):
                  aux=auxin.to(DEV))
     torch.testing.assert_close(d[:, 0].cpu()[keep], g["dy_du"][keep], **(dict(atol=2e-6, rtol=2e-6) if dtype == torch.float32
                                                                           else dict(atol=5e-6, rtol=5e-5)))
+
+
+def test_g10_gelu_fixture_through_the_bf16x3_epilogues():
+    """G10 through the fused GELU / dGELU epilogues of the parity mode's DEFAULT kernel (gemm_f32x3_kernel takes problems of at
+    least 96 x 96: the 8-column problem of the test above runs the f32-MFMA kernel and its tanhf).  Here the grid enters a
+    128-column problem; the operand split leaves acc = u (1 - 2^-16 at worst), and the epilogue evaluates the exp2 / rcp forms of
+    common.hpp: agreement with the reference's 9-op GELU and its derivative at 5e-5 relative - the class of the arithmetic."""
+    import avformer_amd as A
+    from gpu_util import f32_arithmetic
+    ops = A.ops
+    g = load_golden("g10_gelu")
+    u = g["u"]
+    n = u.numel()
+    rows = ((n + 127) // 128) * 128
+    a = torch.zeros(rows, 32)
+    a[:n, 0] = u
+    w = torch.zeros(128, 32)
+    w[0, 0] = 1.0
+    with f32_arithmetic("bf16x3"):
+        out, aux = ops.gemm(a.to(DEV), w.to(DEV), epilogue=ops.EPI_BIAS_GELU, bias=torch.zeros(128, device=DEV))
+        torch.testing.assert_close(aux[:n, 0].cpu(), u, atol=1e-30, rtol=3e-5)
+        torch.testing.assert_close(out[:n, 0].cpu(), g["y"], atol=5e-6, rtol=5e-5)
+        assert float(out[:, 1:].abs().max()) == 0.0 and float(aux[:, 1:].abs().max()) == 0.0
+        ones = torch.zeros(rows, 32)
+        ones[:, 0] = 1.0
+        auxin = torch.zeros(rows, 128)
+        auxin[:n, 0] = u
+        d = ops.gemm(ones.to(DEV), w.to(DEV), epilogue=ops.EPI_DGELU, aux=auxin.to(DEV))
+        torch.testing.assert_close(d[:n, 0].cpu(), g["dy_du"], atol=5e-6, rtol=5e-5)
